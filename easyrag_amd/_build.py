@@ -1,0 +1,84 @@
+"""Build libeasyrag_hip.so in-tree with hipcc for gfx950 (no JIT cache: the built .so travels with the tree)."""
+from __future__ import annotations
+
+import hashlib
+import os
+import shutil
+import subprocess
+from pathlib import Path
+
+PKG_DIR = Path(__file__).resolve().parent
+CSRC = PKG_DIR / "csrc"
+INCLUDE = PKG_DIR.parent / "include"
+LIB_PATH = PKG_DIR / "libeasyrag_hip.so"
+STAMP = PKG_DIR / ".libeasyrag_hip.stamp"
+
+SOURCES = ["api.hip", "dense_scan.hip", "select.hip", "bm25.hip", "fuse.hip"]
+HEADERS = ["common.h", "kernels.h"]
+
+HIPCC_FLAGS = [
+    "--offload-arch=gfx950",
+    "-O3",
+    "-std=c++17",
+    "-fPIC",
+    "-ffp-contract=off",      # bit parity: no fused multiply-add unless written as one
+    "-fno-fast-math",
+    "-Wall",
+    "-Wno-unused-function",
+]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (need ROCm >= 7.0 to build libeasyrag_hip.so)")
+
+
+def _digest() -> str:
+    h = hashlib.sha256()
+    for name in SOURCES + HEADERS:
+        h.update((CSRC / name).read_bytes())
+    h.update((INCLUDE / "easyrag_hip.h").read_bytes())
+    h.update(" ".join(HIPCC_FLAGS).encode())
+    return h.hexdigest()
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    """Compile every HIP translation unit for gfx950 and link the shared library. Idempotent."""
+    dig = _digest()
+    if not force and LIB_PATH.exists() and STAMP.exists() and STAMP.read_text().strip() == dig:
+        return LIB_PATH
+    hipcc = _hipcc()
+    obj_dir = PKG_DIR / "build"
+    obj_dir.mkdir(exist_ok=True)
+    objs = []
+    procs = []
+    for src in SOURCES:
+        obj = obj_dir / (src.replace(".hip", ".o"))
+        cmd = [hipcc, *HIPCC_FLAGS, "-I", str(INCLUDE), "-I", str(CSRC), "-c", str(CSRC / src), "-o", str(obj)]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        objs.append(str(obj))
+    failed = []
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            failed.append(f"--- {src} ---\n{out}")
+        elif verbose and out.strip():
+            print(out)
+    if failed:
+        raise RuntimeError("hipcc failed:\n" + "\n".join(failed))
+    tmp = str(LIB_PATH) + ".tmp"
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp, *objs]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n" + r.stdout)
+    os.replace(tmp, LIB_PATH)
+    STAMP.write_text(dig)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in os.sys.argv, verbose=True))

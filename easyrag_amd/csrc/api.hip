@@ -1,0 +1,790 @@
+// C ABI of libeasyrag_hip.so (see include/easyrag_hip.h): handle, device state, work space, stage
+// orchestration on the caller's HIP stream, event-based kernel timing.  No CPU compute path lives here.
+#include "../../include/easyrag_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        // grow geometrically so that alternating batch sizes do not reallocate every call
+        size_t want = std::max(bytes, cap + cap / 2);
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { p = nullptr; return e; }
+        cap = want;
+        return hipSuccess;
+    }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; cap = 0; } }
+    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct EvPair { hipEvent_t a, b; int cls; };
+
+}  // namespace
+
+struct erh_handle {
+    int device = 0;
+    std::string err;
+    // dense state
+    DevBuf X;
+    int64_t N = 0;
+    int d = 0;
+    float xnorm_max = 0.f;
+    // bm25 state
+    int variant = -1;
+    int64_t V = 0, Nb = 0, nnz = 0;
+    DevBuf indptr, doc_ids, payload, tile_off;
+    std::vector<int64_t> host_indptr;     // host copy: query validation + algorithmic-byte accounting
+    int n_tiles = 0, tile_docs = 0;
+    // metadata
+    int64_t Nmeta = 0;
+    DevBuf content_id, dir_id;
+    bool has_content = false, has_dir = false;
+    // work space
+    DevBuf qin, Q16, qnorm, tau, S0, cand, cand_cnt, flags, filt;
+    DevBuf o_ids, o_sc, o_len;              // staging for host outputs
+    DevBuf qptr, qtok, part_sc, part_ids, part_len;
+    DevBuf hy_sids, hy_ssc, hy_slen, hy_dids, hy_dsc, hy_dlen;
+    DevBuf fa_ids, fa_sc, fa_len, fb_ids, fb_sc, fb_len;
+    DevBuf scores_tmp, scores_wide;
+    // options
+    int64_t opt_n0 = 32768, opt_n1 = 262144;
+    // profiling
+    bool prof = false;
+    std::vector<EvPair> pending;
+    std::vector<EvPair> pool;
+    double ms[ERH_K_COUNT] = {0};
+    int64_t launches[ERH_K_COUNT] = {0};
+    double work_bytes[ERH_K_COUNT] = {0};
+    double work_flops[ERH_K_COUNT] = {0};
+    // diag of the last dense call
+    double diag_maxerr = 0, diag_margin = 0;
+    int32_t diag_uncert = 0;
+
+    int fail(int code, const char *what, hipError_t e = hipSuccess) {
+        char buf[512];
+        if (e != hipSuccess)
+            snprintf(buf, sizeof buf, "%s: %s (%s)", erh_status_str(code), what, hipGetErrorString(e));
+        else
+            snprintf(buf, sizeof buf, "%s: %s", erh_status_str(code), what);
+        err = buf;
+        return code;
+    }
+};
+
+#define HIPCHK(h, call)                                                     \
+    do {                                                                    \
+        hipError_t e_ = (call);                                             \
+        if (e_ != hipSuccess) return (h)->fail(e_ == hipErrorOutOfMemory ? ERH_ERR_NOMEM : ERH_ERR_HIP, #call, e_); \
+    } while (0)
+
+namespace {
+
+struct ProfScope {
+    erh_handle *h;
+    hipStream_t st;
+    EvPair ev;
+    bool on;
+    ProfScope(erh_handle *h_, hipStream_t st_, int cls, double bytes, double flops) : h(h_), st(st_), on(h_->prof) {
+        if (!on) return;
+        if (!h->pool.empty()) { ev = h->pool.back(); h->pool.pop_back(); }
+        else {
+            if (hipEventCreate(&ev.a) != hipSuccess || hipEventCreate(&ev.b) != hipSuccess) { on = false; return; }
+        }
+        ev.cls = cls;
+        h->work_bytes[cls] += bytes;
+        h->work_flops[cls] += flops;
+        (void)hipEventRecord(ev.a, st);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        (void)hipEventRecord(ev.b, st);
+        h->pending.push_back(ev);
+    }
+};
+
+void drain_events(erh_handle *h) {
+    for (auto &ev : h->pending) {
+        if (hipEventSynchronize(ev.b) == hipSuccess) {
+            float t = 0.f;
+            if (hipEventElapsedTime(&t, ev.a, ev.b) == hipSuccess) { h->ms[ev.cls] += t; h->launches[ev.cls] += 1; }
+        }
+        h->pool.push_back(ev);
+    }
+    h->pending.clear();
+}
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// ---- dense pipeline on device buffers ------------------------------------------------------------
+int dense_topk_dev(erh_handle *h, const void *q_dev, int q_dtype, int normalize_q, int B, int k,
+                   const int16_t *filter_dev, int mode, int32_t *d_ids, double *d_sc, int32_t *d_len, hipStream_t st) {
+    const int QT = erh::dense_scan_q_tile();
+    const int Bpad = round_up(B, QT);
+    const int d = h->d;
+    const int64_t N = h->N;
+    const int cap = erh::kDenseCapMax;
+    HIPCHK(h, h->Q16.ensure((size_t)Bpad * d * 2));
+    HIPCHK(h, h->qnorm.ensure((size_t)Bpad * 4));
+    HIPCHK(h, h->tau.ensure((size_t)Bpad * 4));
+    HIPCHK(h, h->cand.ensure((size_t)B * cap * sizeof(ErhCand)));
+    HIPCHK(h, h->cand_cnt.ensure((size_t)B * 4));
+    HIPCHK(h, h->flags.ensure(64));
+    int64_t n0 = std::min<int64_t>(std::min<int64_t>(h->opt_n0, erh::kDenseN0Max), N);
+    if (n0 < 1) n0 = 1;
+    const int ld = round_up((int)n0, 256);
+    HIPCHK(h, h->S0.ensure((size_t)Bpad * ld * 4));
+    uint32_t *flags = h->flags.as<uint32_t>();   // [0] overflow, [1] maxerr (float bits), [2] uncertified
+    HIPCHK(h, hipMemsetAsync(flags, 0, 64, st));
+
+    { ProfScope ps(h, st, ERH_K_DENSE_SELECT, 0, 0);
+      HIPCHK(h, erh::launch_prep_queries(q_dev, q_dtype, normalize_q, B, Bpad, d, h->Q16.as<_Float16>(),
+                                         h->qnorm.as<float>(), st)); }
+    const _Float16 *X = h->X.as<_Float16>();
+    const _Float16 *Q16 = h->Q16.as<_Float16>();
+    const int16_t *dir = h->has_dir ? h->dir_id.as<int16_t>() : nullptr;
+    auto scan_work = [&](int64_t rows, double *bytes, double *flops) {
+        *bytes = (double)rows * d * 2.0 + (double)Bpad * d * 2.0;
+        *flops = 2.0 * (double)rows * (double)Bpad * (double)d;
+    };
+    double wb, wf;
+    // stage A: score the seed prefix densely, k-th best -> pruning threshold
+    scan_work(n0, &wb, &wf);
+    { ProfScope ps(h, st, ERH_K_DENSE_SCAN, wb, wf);
+      HIPCHK(h, erh::launch_dense_scan_store(Q16, Bpad, X, N, d, 0, (int)n0, h->S0.as<float>(), ld, st)); }
+    { ProfScope ps(h, st, ERH_K_DENSE_SELECT, 0, 0);
+      HIPCHK(h, erh::launch_seed_select(h->S0.as<float>(), ld, (int)n0, 0, B, k, h->qnorm.as<float>(), h->xnorm_max, d,
+                                        filter_dev, dir, h->tau.as<float>(), h->cand.as<ErhCand>(),
+                                        h->cand_cnt.as<uint32_t>(), cap, flags, st)); }
+    if (N > n0) {
+        int64_t n1 = h->opt_n1;
+        if (n1 <= n0 || n1 >= N) n1 = 0;
+        const int64_t b_end = n1 ? n1 : N;
+        scan_work(b_end - n0, &wb, &wf);
+        { ProfScope ps(h, st, ERH_K_DENSE_SCAN, wb, wf);
+          HIPCHK(h, erh::launch_dense_scan_append(X, N, d, n0, b_end, Q16, Bpad, B, h->tau.as<float>(), filter_dev, dir,
+                                                  h->cand.as<ErhCand>(), h->cand_cnt.as<uint32_t>(), cap, flags, st)); }
+        if (n1) {
+            { ProfScope ps(h, st, ERH_K_DENSE_SELECT, 0, 0);
+              HIPCHK(h, erh::launch_cand_refine(B, k, h->qnorm.as<float>(), h->xnorm_max, d, h->tau.as<float>(),
+                                                h->cand.as<ErhCand>(), h->cand_cnt.as<uint32_t>(), cap, st)); }
+            scan_work(N - n1, &wb, &wf);
+            { ProfScope ps(h, st, ERH_K_DENSE_SCAN, wb, wf);
+              HIPCHK(h, erh::launch_dense_scan_append(X, N, d, n1, N, Q16, Bpad, B, h->tau.as<float>(), filter_dev, dir,
+                                                      h->cand.as<ErhCand>(), h->cand_cnt.as<uint32_t>(), cap, flags, st)); }
+        }
+    }
+    { ProfScope ps(h, st, ERH_K_DENSE_SELECT, 0, 0);
+      HIPCHK(h, erh::launch_dense_finalize(B, k, mode, h->qnorm.as<float>(), h->xnorm_max, d, X, Q16,
+                                           h->cand.as<ErhCand>(), h->cand_cnt.as<uint32_t>(), cap, d_ids, d_sc, d_len,
+                                           reinterpret_cast<float *>(flags + 1), flags + 2, st)); }
+    return ERH_OK;
+}
+
+// Read the flag words of the last dense call (synchronises the stream).
+int dense_check_flags(erh_handle *h, hipStream_t st) {
+    uint32_t f[4] = {0, 0, 0, 0};
+    HIPCHK(h, hipMemcpyAsync(f, h->flags.p, sizeof f, hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    float me;
+    memcpy(&me, &f[1], 4);
+    h->diag_maxerr = me;
+    h->diag_uncert = (int32_t)f[2];
+    h->diag_margin = 2.0 * (double)h->d * 1.1920929e-7 * (double)h->xnorm_max;   // for a unit-norm query
+    if (f[0]) return h->fail(ERH_ERR_OVERFLOW, "dense candidate list overflowed (too many near-threshold chunks)");
+    return ERH_OK;
+}
+
+int bm25_topk_dev(erh_handle *h, const int32_t *qptr_dev, const int32_t *qtok_dev, int B, int k,
+                  const int16_t *filter_dev, int32_t *d_ids, double *d_sc, int32_t *d_len, double postings_bytes,
+                  hipStream_t st) {
+    int segs = (512 + B - 1) / B;
+    segs = std::max(1, std::min(segs, h->n_tiles));
+    while (segs > 1 && (int64_t)segs * k > 8192) --segs;
+    const int16_t *dir = h->has_dir ? h->dir_id.as<int16_t>() : nullptr;
+    if (segs == 1) {
+        ProfScope ps(h, st, ERH_K_BM25_SCAN, postings_bytes, 0);
+        HIPCHK(h, erh::launch_bm25_scan(h->variant, h->indptr.as<int64_t>(), h->doc_ids.as<int32_t>(), h->payload.p,
+                                        h->tile_off.as<int32_t>(), h->n_tiles, h->Nb, qptr_dev, qtok_dev, B, k, 1,
+                                        filter_dev, dir, d_sc, d_ids, d_len, st));
+        return ERH_OK;
+    }
+    HIPCHK(h, h->part_sc.ensure((size_t)B * segs * k * 8));
+    HIPCHK(h, h->part_ids.ensure((size_t)B * segs * k * 4));
+    HIPCHK(h, h->part_len.ensure((size_t)B * segs * 4));
+    { ProfScope ps(h, st, ERH_K_BM25_SCAN, postings_bytes, 0);
+      HIPCHK(h, erh::launch_bm25_scan(h->variant, h->indptr.as<int64_t>(), h->doc_ids.as<int32_t>(), h->payload.p,
+                                      h->tile_off.as<int32_t>(), h->n_tiles, h->Nb, qptr_dev, qtok_dev, B, k, segs,
+                                      filter_dev, dir, h->part_sc.as<double>(), h->part_ids.as<int32_t>(),
+                                      h->part_len.as<int32_t>(), st)); }
+    { ProfScope ps(h, st, ERH_K_BM25_MERGE, 0, 0);
+      HIPCHK(h, erh::launch_bm25_merge(B, k, segs, h->part_sc.as<double>(), h->part_ids.as<int32_t>(),
+                                       h->part_len.as<int32_t>(), d_ids, d_sc, d_len, st)); }
+    return ERH_OK;
+}
+
+// Upload the query CSR; returns the algorithmic posting bytes of the batch in *bytes (0 if an id is bad -> error).
+int upload_bm25_queries(erh_handle *h, const int32_t *q_indptr, const int32_t *q_tok, int B, hipStream_t st,
+                        const std::vector<int64_t> &host_indptr, double *bytes) {
+    if (q_indptr[0] != 0) return h->fail(ERH_ERR_INVALID, "q_indptr[0] must be 0");
+    for (int b = 0; b < B; ++b)
+        if (q_indptr[b + 1] < q_indptr[b]) return h->fail(ERH_ERR_INVALID, "q_indptr must be non-decreasing");
+    const int nt = q_indptr[B];
+    const size_t per = (h->variant == ERH_BM25_OKAPI) ? 12 : 8;
+    double total = 0;
+    for (int i = 0; i < nt; ++i) {
+        const int32_t t = q_tok[i];
+        if (t < 0 || t >= h->V) return h->fail(ERH_ERR_INVALID, "query term id out of range");
+        total += (double)(host_indptr[t + 1] - host_indptr[t]) * per;
+    }
+    *bytes = total;
+    HIPCHK(h, h->qptr.ensure((size_t)(B + 1) * 4));
+    HIPCHK(h, h->qtok.ensure((size_t)std::max(nt, 1) * 4));
+    HIPCHK(h, hipMemcpyAsync(h->qptr.p, q_indptr, (size_t)(B + 1) * 4, hipMemcpyHostToDevice, st));
+    if (nt) HIPCHK(h, hipMemcpyAsync(h->qtok.p, q_tok, (size_t)nt * 4, hipMemcpyHostToDevice, st));
+    return ERH_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int erh_version(void) { return 100; }
+
+const char *erh_status_str(int s) {
+    switch (s) {
+        case ERH_OK: return "ok";
+        case ERH_ERR_INVALID: return "invalid argument";
+        case ERH_ERR_NO_DEVICE: return "no usable gfx950 device";
+        case ERH_ERR_HIP: return "HIP error";
+        case ERH_ERR_STATE: return "state not set";
+        case ERH_ERR_UNSUPPORTED: return "unsupported shape";
+        case ERH_ERR_OVERFLOW: return "candidate overflow";
+        case ERH_ERR_NOMEM: return "out of device memory";
+        default: return "unknown status";
+    }
+}
+
+int erh_create(int device, erh_handle **out) {
+    if (!out) return ERH_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return ERH_ERR_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return ERH_ERR_NO_DEVICE;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return ERH_ERR_NO_DEVICE;   // kernels are built for gfx950 only
+    if (hipSetDevice(device) != hipSuccess) return ERH_ERR_NO_DEVICE;
+    erh_handle *h = new (std::nothrow) erh_handle();
+    if (!h) return ERH_ERR_NOMEM;
+    h->device = device;
+    if (erh::dense_scan_init() != hipSuccess || erh::select_init() != hipSuccess || erh::bm25_init() != hipSuccess) {
+        delete h;
+        return ERH_ERR_HIP;
+    }
+    *out = h;
+    return ERH_OK;
+}
+
+int erh_destroy(erh_handle *h) {
+    if (!h) return ERH_ERR_INVALID;
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+    drain_events(h);
+    for (auto &ev : h->pool) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
+    DevBuf *bufs[] = {&h->X, &h->indptr, &h->doc_ids, &h->payload, &h->tile_off, &h->content_id, &h->dir_id,
+                      &h->qin, &h->Q16, &h->qnorm, &h->tau, &h->S0, &h->cand, &h->cand_cnt, &h->flags, &h->filt,
+                      &h->o_ids, &h->o_sc, &h->o_len, &h->qptr, &h->qtok, &h->part_sc, &h->part_ids, &h->part_len,
+                      &h->hy_sids, &h->hy_ssc, &h->hy_slen, &h->hy_dids, &h->hy_dsc, &h->hy_dlen,
+                      &h->fa_ids, &h->fa_sc, &h->fa_len, &h->fb_ids, &h->fb_sc, &h->fb_len,
+                      &h->scores_tmp, &h->scores_wide};
+    for (DevBuf *b : bufs) b->release();
+    delete h;
+    return ERH_OK;
+}
+
+const char *erh_last_error(erh_handle *h) { return h ? h->err.c_str() : "null handle"; }
+
+int erh_sync(erh_handle *h, void *stream) {
+    if (!h) return ERH_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
+    return ERH_OK;
+}
+
+int erh_set_option(erh_handle *h, const char *name, int64_t value) {
+    if (!h || !name) return ERH_ERR_INVALID;
+    if (!strcmp(name, "dense_n0")) { if (value < 1) return h->fail(ERH_ERR_INVALID, "dense_n0 < 1"); h->opt_n0 = value; return ERH_OK; }
+    if (!strcmp(name, "dense_n1")) { if (value < 0) return h->fail(ERH_ERR_INVALID, "dense_n1 < 0"); h->opt_n1 = value; return ERH_OK; }
+    return h->fail(ERH_ERR_INVALID, "unknown option");
+}
+
+int erh_set_profiling(erh_handle *h, int enable) {
+    if (!h) return ERH_ERR_INVALID;
+    h->prof = enable != 0;
+    return ERH_OK;
+}
+
+int erh_get_kernel_time(erh_handle *h, int cls, double *total_ms, int64_t *launches) {
+    if (!h || cls < 0 || cls >= ERH_K_COUNT) return ERH_ERR_INVALID;
+    (void)hipSetDevice(h->device);
+    drain_events(h);
+    if (total_ms) *total_ms = h->ms[cls];
+    if (launches) *launches = h->launches[cls];
+    return ERH_OK;
+}
+
+int erh_get_kernel_work(erh_handle *h, int cls, double *bytes, double *flops) {
+    if (!h || cls < 0 || cls >= ERH_K_COUNT) return ERH_ERR_INVALID;
+    if (bytes) *bytes = h->work_bytes[cls];
+    if (flops) *flops = h->work_flops[cls];
+    return ERH_OK;
+}
+
+int erh_reset_kernel_time(erh_handle *h) {
+    if (!h) return ERH_ERR_INVALID;
+    (void)hipSetDevice(h->device);
+    drain_events(h);
+    for (int i = 0; i < ERH_K_COUNT; ++i) { h->ms[i] = 0; h->launches[i] = 0; h->work_bytes[i] = 0; h->work_flops[i] = 0; }
+    return ERH_OK;
+}
+
+int erh_dense_check(erh_handle *h, void *stream) {
+    if (!h) return ERH_ERR_INVALID;
+    if (!h->flags.p) return ERH_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    return dense_check_flags(h, (hipStream_t)stream);
+}
+
+int erh_dense_diag(erh_handle *h, double *max_abs_err, double *margin, int32_t *uncertified) {
+    if (!h) return ERH_ERR_INVALID;
+    if (max_abs_err) *max_abs_err = h->diag_maxerr;
+    if (margin) *margin = h->diag_margin;
+    if (uncertified) *uncertified = h->diag_uncert;
+    return ERH_OK;
+}
+
+// ---- corpus state ------------------------------------------------------------------------------------
+
+int erh_set_dense(erh_handle *h, const void *x, int64_t n, int d, int dtype, int is_device_ptr, int normalize) {
+    if (!h) return ERH_ERR_INVALID;
+    if (!x || n <= 0 || d <= 0) return h->fail(ERH_ERR_INVALID, "erh_set_dense: null matrix or non-positive shape");
+    if (d % 64 != 0) return h->fail(ERH_ERR_UNSUPPORTED, "erh_set_dense: d must be a multiple of 64");
+    if (n > 2147483647LL) return h->fail(ERH_ERR_UNSUPPORTED, "erh_set_dense: n must fit int32 document ids");
+    if (dtype != ERH_F16 && dtype != ERH_F32) return h->fail(ERH_ERR_INVALID, "erh_set_dense: dtype");
+    if (dtype == ERH_F16 && normalize)
+        return h->fail(ERH_ERR_UNSUPPORTED, "erh_set_dense: normalize=1 needs fp32 rows (fp16 rows are taken as stored)");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t st = nullptr;
+    HIPCHK(h, h->X.ensure((size_t)n * d * 2));
+    const hipMemcpyKind kind = is_device_ptr ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    if (dtype == ERH_F16) {
+        HIPCHK(h, hipMemcpyAsync(h->X.p, x, (size_t)n * d * 2, kind, st));
+    } else {
+        // fp32 rows -> (optionally normalised) fp16 on the device, in slabs so that a 1M x 1024 fp32 host matrix
+        // never needs 4 GB of staging
+        const int64_t slab = std::max<int64_t>(1, (int64_t)(256u << 20) / ((int64_t)d * 4));
+        HIPCHK(h, h->qin.ensure((size_t)std::min<int64_t>(slab, n) * d * 4));
+        for (int64_t r0 = 0; r0 < n; r0 += slab) {
+            const int64_t rows = std::min<int64_t>(slab, n - r0);
+            HIPCHK(h, hipMemcpyAsync(h->qin.p, (const float *)x + r0 * d, (size_t)rows * d * 4, kind, st));
+            HIPCHK(h, erh::launch_convert_rows(h->qin.as<float>(), rows, d, normalize, h->X.as<_Float16>() + r0 * d, st));
+            HIPCHK(h, hipStreamSynchronize(st));
+        }
+    }
+    HIPCHK(h, h->flags.ensure(64));
+    HIPCHK(h, erh::launch_row_norm_max(h->X.as<_Float16>(), n, d, reinterpret_cast<float *>(h->flags.p), st));
+    float xn = 0.f;
+    HIPCHK(h, hipMemcpyAsync(&xn, h->flags.p, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    h->xnorm_max = xn;
+    h->N = n;
+    h->d = d;
+    return ERH_OK;
+}
+
+static int bm25_common_upload(erh_handle *h, int variant, int64_t V, int64_t N, int64_t nnz,
+                              const int64_t *indptr, const int32_t *doc_ids) {
+    if (variant != ERH_BM25_OKAPI && variant != ERH_BM25_BM25S) return h->fail(ERH_ERR_INVALID, "bm25 variant");
+    if (V <= 0 || N <= 0 || nnz < 0 || !indptr || (nnz > 0 && !doc_ids)) return h->fail(ERH_ERR_INVALID, "bm25 csr: null or non-positive shape");
+    if (N > 2147483647LL) return h->fail(ERH_ERR_UNSUPPORTED, "bm25 csr: N must fit int32 document ids");
+    if (indptr[0] != 0 || indptr[V] != nnz) return h->fail(ERH_ERR_INVALID, "bm25 csr: indptr[0] != 0 or indptr[V] != nnz");
+    for (int64_t t = 0; t < V; ++t) {
+        if (indptr[t + 1] < indptr[t]) return h->fail(ERH_ERR_INVALID, "bm25 csr: indptr must be non-decreasing");
+        for (int64_t p = indptr[t]; p < indptr[t + 1]; ++p) {
+            const int32_t dd = doc_ids[p];
+            if (dd < 0 || dd >= N) return h->fail(ERH_ERR_INVALID, "bm25 csr: document id out of range");
+            if (p > indptr[t] && doc_ids[p - 1] >= dd)
+                return h->fail(ERH_ERR_INVALID, "bm25 csr: document ids must be strictly ascending inside a term");
+        }
+    }
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t st = nullptr;
+    HIPCHK(h, h->indptr.ensure((size_t)(V + 1) * 8));
+    HIPCHK(h, h->doc_ids.ensure((size_t)std::max<int64_t>(nnz, 1) * 4));
+    HIPCHK(h, hipMemcpyAsync(h->indptr.p, indptr, (size_t)(V + 1) * 8, hipMemcpyHostToDevice, st));
+    if (nnz) HIPCHK(h, hipMemcpyAsync(h->doc_ids.p, doc_ids, (size_t)nnz * 4, hipMemcpyHostToDevice, st));
+    h->tile_docs = (variant == ERH_BM25_OKAPI) ? erh::kBm25TileF64 : erh::kBm25TileF32;
+    h->n_tiles = (int)((N + h->tile_docs - 1) / h->tile_docs);
+    HIPCHK(h, h->tile_off.ensure((size_t)V * (h->n_tiles + 1) * 4));
+    HIPCHK(h, erh::launch_bm25_tile_off(h->indptr.as<int64_t>(), h->doc_ids.as<int32_t>(), V, h->tile_docs, h->n_tiles,
+                                        h->tile_off.as<int32_t>(), st));
+    h->host_indptr.assign(indptr, indptr + V + 1);
+    h->variant = variant;
+    h->V = V;
+    h->Nb = N;
+    h->nnz = nnz;
+    return ERH_OK;
+}
+
+int erh_set_bm25_csr(erh_handle *h, int variant, int64_t V, int64_t N, int64_t nnz,
+                     const int64_t *indptr, const int32_t *doc_ids, const void *payload) {
+    if (!h) return ERH_ERR_INVALID;
+    if (nnz > 0 && !payload) return h->fail(ERH_ERR_INVALID, "bm25 csr: null payload");
+    h->variant = -1;
+    int rc = bm25_common_upload(h, variant, V, N, nnz, indptr, doc_ids);
+    if (rc != ERH_OK) { h->variant = -1; return rc; }
+    const size_t es = (variant == ERH_BM25_OKAPI) ? 8 : 4;
+    HIPCHK(h, h->payload.ensure((size_t)std::max<int64_t>(nnz, 1) * es));
+    if (nnz) HIPCHK(h, hipMemcpyAsync(h->payload.p, payload, (size_t)nnz * es, hipMemcpyHostToDevice, nullptr));
+    HIPCHK(h, hipStreamSynchronize(nullptr));
+    return ERH_OK;
+}
+
+int erh_set_bm25_tf(erh_handle *h, int variant, int64_t V, int64_t N, int64_t nnz,
+                    const int64_t *indptr, const int32_t *doc_ids, const int32_t *tf,
+                    const int32_t *doc_len, const void *idf, double avgdl, double k1, double b) {
+    if (!h) return ERH_ERR_INVALID;
+    if (!tf || !doc_len || !idf || !(avgdl > 0)) return h->fail(ERH_ERR_INVALID, "bm25 tf: null input or avgdl <= 0");
+    h->variant = -1;
+    int rc = bm25_common_upload(h, variant, V, N, nnz, indptr, doc_ids);
+    if (rc != ERH_OK) { h->variant = -1; return rc; }
+    const size_t es = (variant == ERH_BM25_OKAPI) ? 8 : 4;
+    hipStream_t st = nullptr;
+    HIPCHK(h, h->payload.ensure((size_t)std::max<int64_t>(nnz, 1) * es));
+    DevBuf d_tf, d_dl, d_idf;
+    auto cleanup = [&]() { d_tf.release(); d_dl.release(); d_idf.release(); };
+    hipError_t e = d_tf.ensure((size_t)std::max<int64_t>(nnz, 1) * 4);
+    if (e == hipSuccess) e = d_dl.ensure((size_t)N * 4);
+    if (e == hipSuccess) e = d_idf.ensure((size_t)V * es);
+    if (e == hipSuccess && nnz) e = hipMemcpyAsync(d_tf.p, tf, (size_t)nnz * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_dl.p, doc_len, (size_t)N * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_idf.p, idf, (size_t)V * es, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess)
+        e = erh::launch_bm25_payload(variant, V, nnz, h->indptr.as<int64_t>(), h->doc_ids.as<int32_t>(), d_tf.as<int32_t>(),
+                                     d_dl.as<int32_t>(), d_idf.p, avgdl, k1, b, h->payload.p, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    cleanup();
+    if (e != hipSuccess) { h->variant = -1; return h->fail(ERH_ERR_HIP, "erh_set_bm25_tf", e); }
+    return ERH_OK;
+}
+
+int erh_get_bm25_payload(erh_handle *h, void *out_payload) {
+    if (!h || !out_payload) return ERH_ERR_INVALID;
+    if (h->variant < 0) return h->fail(ERH_ERR_STATE, "bm25 index not set");
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t es = (h->variant == ERH_BM25_OKAPI) ? 8 : 4;
+    if (h->nnz) HIPCHK(h, hipMemcpy(out_payload, h->payload.p, (size_t)h->nnz * es, hipMemcpyDeviceToHost));
+    return ERH_OK;
+}
+
+int erh_set_doc_meta(erh_handle *h, int64_t N, const int32_t *content_id, const int16_t *dir_id) {
+    if (!h) return ERH_ERR_INVALID;
+    if (N <= 0) return h->fail(ERH_ERR_INVALID, "erh_set_doc_meta: N <= 0");
+    HIPCHK(h, hipSetDevice(h->device));
+    if (content_id) {
+        for (int64_t i = 0; i < N; ++i)
+            if (content_id[i] < 0) return h->fail(ERH_ERR_INVALID, "erh_set_doc_meta: negative content id");
+        HIPCHK(h, h->content_id.ensure((size_t)N * 4));
+        HIPCHK(h, hipMemcpy(h->content_id.p, content_id, (size_t)N * 4, hipMemcpyHostToDevice));
+    }
+    if (dir_id) {
+        HIPCHK(h, h->dir_id.ensure((size_t)N * 2));
+        HIPCHK(h, hipMemcpy(h->dir_id.p, dir_id, (size_t)N * 2, hipMemcpyHostToDevice));
+    }
+    h->has_content = content_id != nullptr;
+    h->has_dir = dir_id != nullptr;
+    h->Nmeta = N;
+    return ERH_OK;
+}
+
+// ---- queries ---------------------------------------------------------------------------------------
+
+static int stage_filter(erh_handle *h, const int16_t *filter_dir, int B, int64_t n_docs, hipStream_t st, const int16_t **dev) {
+    *dev = nullptr;
+    if (!filter_dir) return ERH_OK;
+    bool any = false;
+    for (int b = 0; b < B; ++b) any = any || filter_dir[b] >= 0;
+    if (!any) return ERH_OK;
+    if (!h->has_dir || h->Nmeta < n_docs) return h->fail(ERH_ERR_STATE, "filter given but erh_set_doc_meta(dir_id) not set for all documents");
+    HIPCHK(h, h->filt.ensure((size_t)B * 2));
+    HIPCHK(h, hipMemcpyAsync(h->filt.p, filter_dir, (size_t)B * 2, hipMemcpyHostToDevice, st));
+    *dev = h->filt.as<int16_t>();
+    return ERH_OK;
+}
+
+static int stage_query_block(erh_handle *h, const void *q, int q_dtype, int q_is_device, int B, hipStream_t st, const void **dev) {
+    if (q_is_device) { *dev = q; return ERH_OK; }
+    const size_t bytes = (size_t)B * h->d * (q_dtype == ERH_F16 ? 2 : 4);
+    HIPCHK(h, h->qin.ensure(bytes));
+    HIPCHK(h, hipMemcpyAsync(h->qin.p, q, bytes, hipMemcpyHostToDevice, st));
+    *dev = h->qin.p;
+    return ERH_OK;
+}
+
+static int copy_out(erh_handle *h, int B, int k, const int32_t *d_ids, const double *d_sc, const int32_t *d_len,
+                    int32_t *out_ids, double *out_scores, int32_t *out_len, hipStream_t st) {
+    HIPCHK(h, hipMemcpyAsync(out_ids, d_ids, (size_t)B * k * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipMemcpyAsync(out_scores, d_sc, (size_t)B * k * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipMemcpyAsync(out_len, d_len, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    return ERH_OK;
+}
+
+int erh_dense_topk(erh_handle *h, const void *q, int q_dtype, int q_is_device, int normalize_q,
+                   int B, int k, const int16_t *filter_dir, int mode,
+                   int32_t *out_ids, double *out_scores, int32_t *out_len, int out_is_device, void *stream) {
+    if (!h) return ERH_ERR_INVALID;
+    if (!h->X.p || h->N <= 0) return h->fail(ERH_ERR_STATE, "erh_dense_topk before erh_set_dense");
+    if (!q || !out_ids || !out_scores || !out_len || B <= 0 || k <= 0) return h->fail(ERH_ERR_INVALID, "erh_dense_topk: null pointer or non-positive B/k");
+    if (q_dtype != ERH_F16 && q_dtype != ERH_F32) return h->fail(ERH_ERR_INVALID, "erh_dense_topk: q_dtype");
+    if (mode != ERH_DENSE_EXACT && mode != ERH_DENSE_FAST) return h->fail(ERH_ERR_INVALID, "erh_dense_topk: mode");
+    if (k > 768) return h->fail(ERH_ERR_UNSUPPORTED, "erh_dense_topk: k > 768");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int16_t *filt = nullptr;
+    int rc = stage_filter(h, filter_dir, B, h->N, st, &filt);
+    if (rc != ERH_OK) return rc;
+    const void *qd = nullptr;
+    rc = stage_query_block(h, q, q_dtype, q_is_device, B, st, &qd);
+    if (rc != ERH_OK) return rc;
+    int32_t *d_ids = out_ids; double *d_sc = out_scores; int32_t *d_len = out_len;
+    if (!out_is_device) {
+        HIPCHK(h, h->o_ids.ensure((size_t)B * k * 4));
+        HIPCHK(h, h->o_sc.ensure((size_t)B * k * 8));
+        HIPCHK(h, h->o_len.ensure((size_t)B * 4));
+        d_ids = h->o_ids.as<int32_t>(); d_sc = h->o_sc.as<double>(); d_len = h->o_len.as<int32_t>();
+    }
+    rc = dense_topk_dev(h, qd, q_dtype, normalize_q, B, k, filt, mode, d_ids, d_sc, d_len, st);
+    if (rc != ERH_OK) return rc;
+    if (!out_is_device) {
+        rc = copy_out(h, B, k, d_ids, d_sc, d_len, out_ids, out_scores, out_len, st);
+        if (rc != ERH_OK) return rc;
+        return dense_check_flags(h, st);
+    }
+    return ERH_OK;
+}
+
+int erh_bm25_topk(erh_handle *h, const int32_t *q_indptr, const int32_t *q_tok, int B, int k,
+                  const int16_t *filter_dir,
+                  int32_t *out_ids, double *out_scores, int32_t *out_len, int out_is_device, void *stream) {
+    if (!h) return ERH_ERR_INVALID;
+    if (h->variant < 0) return h->fail(ERH_ERR_STATE, "erh_bm25_topk before erh_set_bm25_*");
+    if (!q_indptr || !out_ids || !out_scores || !out_len || B <= 0 || k <= 0) return h->fail(ERH_ERR_INVALID, "erh_bm25_topk: null pointer or non-positive B/k");
+    if (q_indptr[B] > 0 && !q_tok) return h->fail(ERH_ERR_INVALID, "erh_bm25_topk: null q_tok");
+    if (k > 1024) return h->fail(ERH_ERR_UNSUPPORTED, "erh_bm25_topk: k > 1024");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int16_t *filt = nullptr;
+    int rc = stage_filter(h, filter_dir, B, h->Nb, st, &filt);
+    if (rc != ERH_OK) return rc;
+    double bytes = 0;
+    rc = upload_bm25_queries(h, q_indptr, q_tok, B, st, h->host_indptr, &bytes);
+    if (rc != ERH_OK) return rc;
+    int32_t *d_ids = out_ids; double *d_sc = out_scores; int32_t *d_len = out_len;
+    if (!out_is_device) {
+        HIPCHK(h, h->o_ids.ensure((size_t)B * k * 4));
+        HIPCHK(h, h->o_sc.ensure((size_t)B * k * 8));
+        HIPCHK(h, h->o_len.ensure((size_t)B * 4));
+        d_ids = h->o_ids.as<int32_t>(); d_sc = h->o_sc.as<double>(); d_len = h->o_len.as<int32_t>();
+    }
+    rc = bm25_topk_dev(h, h->qptr.as<int32_t>(), h->qtok.as<int32_t>(), B, k, filt, d_ids, d_sc, d_len, bytes, st);
+    if (rc != ERH_OK) return rc;
+    if (!out_is_device) return copy_out(h, B, k, d_ids, d_sc, d_len, out_ids, out_scores, out_len, st);
+    return ERH_OK;
+}
+
+int erh_bm25_scores(erh_handle *h, const int32_t *q_tok, int n_tok, double *out_scores) {
+    if (!h) return ERH_ERR_INVALID;
+    if (h->variant < 0) return h->fail(ERH_ERR_STATE, "erh_bm25_scores before erh_set_bm25_*");
+    if (!out_scores || n_tok < 0 || (n_tok > 0 && !q_tok)) return h->fail(ERH_ERR_INVALID, "erh_bm25_scores: null pointer");
+    for (int i = 0; i < n_tok; ++i)
+        if (q_tok[i] < 0 || q_tok[i] >= h->V) return h->fail(ERH_ERR_INVALID, "erh_bm25_scores: term id out of range");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t st = nullptr;
+    const size_t es = (h->variant == ERH_BM25_OKAPI) ? 8 : 4;
+    HIPCHK(h, h->scores_tmp.ensure((size_t)h->Nb * es));
+    HIPCHK(h, hipMemsetAsync(h->scores_tmp.p, 0, (size_t)h->Nb * es, st));
+    for (int i = 0; i < n_tok; ++i)
+        HIPCHK(h, erh::launch_bm25_add_term(h->variant, h->indptr.as<int64_t>(), h->doc_ids.as<int32_t>(), h->payload.p,
+                                            q_tok[i], h->scores_tmp.p, st));
+    const double *src = h->scores_tmp.as<double>();
+    if (h->variant == ERH_BM25_BM25S) {
+        HIPCHK(h, h->scores_wide.ensure((size_t)h->Nb * 8));
+        HIPCHK(h, erh::launch_widen_f32(h->scores_tmp.as<float>(), h->Nb, h->scores_wide.as<double>(), st));
+        src = h->scores_wide.as<double>();
+    }
+    HIPCHK(h, hipMemcpyAsync(out_scores, src, (size_t)h->Nb * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    return ERH_OK;
+}
+
+static int fuse_common(erh_handle *h, bool rrf, const int32_t *ids_a, const double *sc_a, const int32_t *len_a, int depth_a,
+                       const int32_t *ids_b, const double *sc_b, const int32_t *len_b, int depth_b, int B, int K, int topk,
+                       int32_t *out_ids, double *out_scores, int32_t *out_len, int io_is_device, hipStream_t st) {
+    if (!ids_a || !ids_b || !out_ids || !out_scores || !out_len || B <= 0 || topk <= 0 || depth_a < 0 || depth_b < 0)
+        return h->fail(ERH_ERR_INVALID, "fusion: null pointer or non-positive B/topk");
+    if (!rrf && (!sc_a || !sc_b)) return h->fail(ERH_ERR_INVALID, "fusion: null scores");
+    if (depth_a + depth_b > erh::kFuseMaxItems) return h->fail(ERH_ERR_UNSUPPORTED, "fusion: depth_a + depth_b > 2048");
+    if (depth_a + depth_b == 0) return h->fail(ERH_ERR_INVALID, "fusion: both lists empty by construction");
+    HIPCHK(h, hipSetDevice(h->device));
+    const int32_t *cid = h->has_content ? h->content_id.as<int32_t>() : nullptr;
+    const int32_t *da = ids_a, *db = ids_b, *dla = len_a, *dlb = len_b;
+    const double *dsa = sc_a, *dsb = sc_b;
+    int32_t *d_ids = out_ids; double *d_sc = out_scores; int32_t *d_len = out_len;
+    if (!io_is_device) {
+        HIPCHK(h, h->fa_ids.ensure((size_t)B * std::max(depth_a, 1) * 4));
+        HIPCHK(h, h->fb_ids.ensure((size_t)B * std::max(depth_b, 1) * 4));
+        HIPCHK(h, hipMemcpyAsync(h->fa_ids.p, ids_a, (size_t)B * depth_a * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(h, hipMemcpyAsync(h->fb_ids.p, ids_b, (size_t)B * depth_b * 4, hipMemcpyHostToDevice, st));
+        da = h->fa_ids.as<int32_t>(); db = h->fb_ids.as<int32_t>();
+        if (len_a) { HIPCHK(h, h->fa_len.ensure((size_t)B * 4)); HIPCHK(h, hipMemcpyAsync(h->fa_len.p, len_a, (size_t)B * 4, hipMemcpyHostToDevice, st)); dla = h->fa_len.as<int32_t>(); }
+        if (len_b) { HIPCHK(h, h->fb_len.ensure((size_t)B * 4)); HIPCHK(h, hipMemcpyAsync(h->fb_len.p, len_b, (size_t)B * 4, hipMemcpyHostToDevice, st)); dlb = h->fb_len.as<int32_t>(); }
+        if (!rrf) {
+            HIPCHK(h, h->fa_sc.ensure((size_t)B * std::max(depth_a, 1) * 8));
+            HIPCHK(h, h->fb_sc.ensure((size_t)B * std::max(depth_b, 1) * 8));
+            HIPCHK(h, hipMemcpyAsync(h->fa_sc.p, sc_a, (size_t)B * depth_a * 8, hipMemcpyHostToDevice, st));
+            HIPCHK(h, hipMemcpyAsync(h->fb_sc.p, sc_b, (size_t)B * depth_b * 8, hipMemcpyHostToDevice, st));
+            dsa = h->fa_sc.as<double>(); dsb = h->fb_sc.as<double>();
+        }
+        HIPCHK(h, h->o_ids.ensure((size_t)B * topk * 4));
+        HIPCHK(h, h->o_sc.ensure((size_t)B * topk * 8));
+        HIPCHK(h, h->o_len.ensure((size_t)B * 4));
+        d_ids = h->o_ids.as<int32_t>(); d_sc = h->o_sc.as<double>(); d_len = h->o_len.as<int32_t>();
+    }
+    { ProfScope ps(h, st, ERH_K_FUSE, 0, 0);
+      if (rrf) HIPCHK(h, erh::launch_rrf(da, dla, depth_a, db, dlb, depth_b, cid, B, K, topk, d_ids, d_sc, d_len, st));
+      else HIPCHK(h, erh::launch_fusion(da, dsa, dla, depth_a, db, dsb, dlb, depth_b, cid, B, topk, d_ids, d_sc, d_len, st)); }
+    if (!io_is_device) return copy_out(h, B, topk, d_ids, d_sc, d_len, out_ids, out_scores, out_len, st);
+    return ERH_OK;
+}
+
+int erh_rrf(erh_handle *h, const int32_t *ids_a, const int32_t *len_a, int depth_a,
+            const int32_t *ids_b, const int32_t *len_b, int depth_b, int B, int K, int topk,
+            int32_t *out_ids, double *out_scores, int32_t *out_len, int io_is_device, void *stream) {
+    if (!h) return ERH_ERR_INVALID;
+    if (K < 0) return h->fail(ERH_ERR_INVALID, "erh_rrf: K < 0");
+    return fuse_common(h, true, ids_a, nullptr, len_a, depth_a, ids_b, nullptr, len_b, depth_b, B, K, topk,
+                       out_ids, out_scores, out_len, io_is_device, (hipStream_t)stream);
+}
+
+int erh_fusion(erh_handle *h, const int32_t *ids_a, const double *scores_a, const int32_t *len_a, int depth_a,
+               const int32_t *ids_b, const double *scores_b, const int32_t *len_b, int depth_b, int B, int topk,
+               int32_t *out_ids, double *out_scores, int32_t *out_len, int io_is_device, void *stream) {
+    if (!h) return ERH_ERR_INVALID;
+    return fuse_common(h, false, ids_a, scores_a, len_a, depth_a, ids_b, scores_b, len_b, depth_b, B, 0, topk,
+                       out_ids, out_scores, out_len, io_is_device, (hipStream_t)stream);
+}
+
+int erh_hybrid_topk(erh_handle *h, const void *q, int q_dtype, int q_is_device, int normalize_q,
+                    const int32_t *q_indptr, const int32_t *q_tok, int B,
+                    int k_dense, int k_sparse, int K, int topk, const int16_t *filter_dir,
+                    int32_t *out_ids, double *out_scores, int32_t *out_len, int out_is_device, void *stream) {
+    if (!h) return ERH_ERR_INVALID;
+    if (!h->X.p || h->N <= 0) return h->fail(ERH_ERR_STATE, "erh_hybrid_topk before erh_set_dense");
+    if (h->variant < 0) return h->fail(ERH_ERR_STATE, "erh_hybrid_topk before erh_set_bm25_*");
+    if (h->Nb != h->N) return h->fail(ERH_ERR_STATE, "erh_hybrid_topk: dense and bm25 corpora differ in size");
+    if (!q || !q_indptr || !out_ids || !out_scores || !out_len || B <= 0 || k_dense <= 0 || k_sparse <= 0 || topk <= 0 || K < 0)
+        return h->fail(ERH_ERR_INVALID, "erh_hybrid_topk: null pointer or non-positive size");
+    if (q_dtype != ERH_F16 && q_dtype != ERH_F32) return h->fail(ERH_ERR_INVALID, "erh_hybrid_topk: q_dtype");
+    if (k_dense > 768 || k_sparse > 1024 || k_dense + k_sparse > erh::kFuseMaxItems)
+        return h->fail(ERH_ERR_UNSUPPORTED, "erh_hybrid_topk: k_dense > 768 or k_sparse > 1024");
+    if (q_indptr[B] > 0 && !q_tok) return h->fail(ERH_ERR_INVALID, "erh_hybrid_topk: null q_tok");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int16_t *filt = nullptr;
+    int rc = stage_filter(h, filter_dir, B, h->N, st, &filt);
+    if (rc != ERH_OK) return rc;
+    double bytes = 0;
+    rc = upload_bm25_queries(h, q_indptr, q_tok, B, st, h->host_indptr, &bytes);
+    if (rc != ERH_OK) return rc;
+    const void *qd = nullptr;
+    rc = stage_query_block(h, q, q_dtype, q_is_device, B, st, &qd);
+    if (rc != ERH_OK) return rc;
+    HIPCHK(h, h->hy_sids.ensure((size_t)B * k_sparse * 4));
+    HIPCHK(h, h->hy_ssc.ensure((size_t)B * k_sparse * 8));
+    HIPCHK(h, h->hy_slen.ensure((size_t)B * 4));
+    HIPCHK(h, h->hy_dids.ensure((size_t)B * k_dense * 4));
+    HIPCHK(h, h->hy_dsc.ensure((size_t)B * k_dense * 8));
+    HIPCHK(h, h->hy_dlen.ensure((size_t)B * 4));
+    // sparse route (list a), dense route (list b), fusion -- all on the caller's stream, no host round trip
+    rc = bm25_topk_dev(h, h->qptr.as<int32_t>(), h->qtok.as<int32_t>(), B, k_sparse, filt, h->hy_sids.as<int32_t>(),
+                       h->hy_ssc.as<double>(), h->hy_slen.as<int32_t>(), bytes, st);
+    if (rc != ERH_OK) return rc;
+    rc = dense_topk_dev(h, qd, q_dtype, normalize_q, B, k_dense, filt, ERH_DENSE_EXACT, h->hy_dids.as<int32_t>(),
+                        h->hy_dsc.as<double>(), h->hy_dlen.as<int32_t>(), st);
+    if (rc != ERH_OK) return rc;
+    int32_t *d_ids = out_ids; double *d_sc = out_scores; int32_t *d_len = out_len;
+    if (!out_is_device) {
+        HIPCHK(h, h->o_ids.ensure((size_t)B * topk * 4));
+        HIPCHK(h, h->o_sc.ensure((size_t)B * topk * 8));
+        HIPCHK(h, h->o_len.ensure((size_t)B * 4));
+        d_ids = h->o_ids.as<int32_t>(); d_sc = h->o_sc.as<double>(); d_len = h->o_len.as<int32_t>();
+    }
+    const int32_t *cid = h->has_content ? h->content_id.as<int32_t>() : nullptr;
+    { ProfScope ps(h, st, ERH_K_FUSE, 0, 0);
+      HIPCHK(h, erh::launch_rrf(h->hy_sids.as<int32_t>(), h->hy_slen.as<int32_t>(), k_sparse,
+                                h->hy_dids.as<int32_t>(), h->hy_dlen.as<int32_t>(), k_dense, cid, B, K, topk,
+                                d_ids, d_sc, d_len, st)); }
+    if (!out_is_device) {
+        rc = copy_out(h, B, topk, d_ids, d_sc, d_len, out_ids, out_scores, out_len, st);
+        if (rc != ERH_OK) return rc;
+        return dense_check_flags(h, st);
+    }
+    return ERH_OK;
+}
+
+int erh_debug_dense_scores(erh_handle *h, const void *q_f16_host, int B, int64_t row0, int rows, int use_mfma, float *out) {
+    if (!h) return ERH_ERR_INVALID;
+    if (!h->X.p) return h->fail(ERH_ERR_STATE, "erh_debug_dense_scores before erh_set_dense");
+    if (!q_f16_host || !out || B <= 0 || rows <= 0 || row0 < 0 || row0 + rows > h->N) return h->fail(ERH_ERR_INVALID, "erh_debug_dense_scores: bad range");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t st = nullptr;
+    const int QT = erh::dense_scan_q_tile();
+    const int Bpad = round_up(B, QT);
+    const int d = h->d;
+    HIPCHK(h, h->qin.ensure((size_t)B * d * 2));
+    HIPCHK(h, hipMemcpyAsync(h->qin.p, q_f16_host, (size_t)B * d * 2, hipMemcpyHostToDevice, st));
+    HIPCHK(h, h->Q16.ensure((size_t)Bpad * d * 2));
+    HIPCHK(h, h->qnorm.ensure((size_t)Bpad * 4));
+    HIPCHK(h, erh::launch_prep_queries(h->qin.p, ERH_F16, 0, B, Bpad, d, h->Q16.as<_Float16>(), h->qnorm.as<float>(), st));
+    if (use_mfma) {
+        const int ld = round_up(rows, 256);
+        HIPCHK(h, h->S0.ensure((size_t)Bpad * ld * 4));
+        HIPCHK(h, erh::launch_dense_scan_store(h->Q16.as<_Float16>(), Bpad, h->X.as<_Float16>(), h->N, d, row0, rows,
+                                               h->S0.as<float>(), ld, st));
+        HIPCHK(h, hipMemcpy2DAsync(out, (size_t)rows * 4, h->S0.p, (size_t)ld * 4, (size_t)rows * 4, B, hipMemcpyDeviceToHost, st));
+    } else {
+        HIPCHK(h, h->S0.ensure((size_t)B * rows * 4));
+        HIPCHK(h, erh::launch_dense_naive(h->Q16.as<_Float16>(), B, h->X.as<_Float16>(), row0, rows, d, h->S0.as<float>(), st));
+        HIPCHK(h, hipMemcpyAsync(out, h->S0.p, (size_t)B * rows * 4, hipMemcpyDeviceToHost, st));
+    }
+    HIPCHK(h, hipStreamSynchronize(st));
+    return ERH_OK;
+}
+
+}  // extern "C"

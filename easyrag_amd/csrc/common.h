@@ -1,0 +1,90 @@
+// Shared device helpers for the gfx950 retrieval kernels (wave64, LDS-resident selection).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define ERH_WAVE 64
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define ERH_LDS_PTR(p) ((__attribute__((address_space(3))) void *)(p))
+
+// Dense candidate record written by the scan epilogue: fp32 MFMA score + document index.
+struct __attribute__((aligned(8))) ErhCand {
+    float s;
+    int32_t idx;
+};
+
+// ---- order-preserving float <-> uint32 (total order, -inf lowest among real numbers) --------
+__device__ __forceinline__ uint32_t erh_f2ord(float f) {
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float erh_ord2f(uint32_t o) {
+    uint32_t u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+    return __uint_as_float(u);
+}
+// (score, idx) -> 64-bit key whose descending order is (score desc, idx asc). key 0 = "empty".
+__device__ __forceinline__ uint64_t erh_key32(float s, int32_t idx) {
+    return ((uint64_t)erh_f2ord(s) << 32) | (uint64_t)(0xffffffffu - (uint32_t)idx);
+}
+__device__ __forceinline__ float erh_key32_score(uint64_t k) { return erh_ord2f((uint32_t)(k >> 32)); }
+__device__ __forceinline__ int32_t erh_key32_idx(uint64_t k) { return (int32_t)(0xffffffffu - (uint32_t)k); }
+
+// ---- block-wide bitonic sort, descending, n a power of two, data in LDS -----------------------
+// Every thread of the block must call it (contains __syncthreads()).
+template <typename T>
+__device__ __forceinline__ void erh_bitonic_desc(T *a, int n) {
+    const int tid = threadIdx.x, nth = blockDim.x;
+    for (int k = 2; k <= n; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            __syncthreads();
+            for (int t = tid; t < (n >> 1); t += nth) {
+                // t-th compare-exchange pair of this (k, j) step
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int p = i | j;
+                const bool desc = ((i & k) == 0);
+                const T x = a[i], y = a[p];
+                const bool sw = desc ? (x < y) : (y < x);
+                if (sw) { a[i] = y; a[p] = x; }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// Two-array variant for (double score, int idx) records: order (score desc, idx asc).
+__device__ __forceinline__ bool erh_rec_before(double s1, int32_t i1, double s2, int32_t i2) {
+    return (s1 > s2) || (s1 == s2 && i1 < i2);
+}
+template <typename ST>
+__device__ __forceinline__ void erh_bitonic_rec_desc(ST *s, int32_t *ix, int n) {
+    const int tid = threadIdx.x, nth = blockDim.x;
+    for (int k = 2; k <= n; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            __syncthreads();
+            for (int t = tid; t < (n >> 1); t += nth) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int p = i | j;
+                const bool desc = ((i & k) == 0);
+                const ST sx = s[i], sy = s[p];
+                const int32_t ixx = ix[i], iyy = ix[p];
+                // "x before y" in the final descending order?
+                const bool x_first = (sx > sy) || (sx == sy && ixx < iyy);
+                const bool y_first = (sy > sx) || (sx == sy && iyy < ixx);
+                const bool sw = desc ? y_first : x_first;
+                if (sw) { s[i] = sy; s[p] = sx; ix[i] = iyy; ix[p] = ixx; }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ int erh_next_pow2(int v) {
+    int p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+__device__ __forceinline__ int erh_lane() { return (int)(threadIdx.x & 63); }

@@ -1,0 +1,129 @@
+// Fusion of the two rank lists, kernel K4.  Replaces HybridRetriever.reciprocal_rank_fusion and
+// HybridRetriever.fusion (/root/reference/src/easyrag/custom/retrievers.py:256-274 and 239-253).
+//
+// Items are the concatenation [list a | list b] (the reference passes [sparse, dense], retrievers.py:290).
+// The key is the node TEXT (get_content(), retrievers.py:245,263): content_id[doc] here.
+//   RRF     score(c) = sum over occurrences, in item order, of 1/(rank + K) in float64, rank 1-based inside
+//           its list; Python dict order = first-seen order, and the stable sort keeps it among equal
+//           scores; the node returned is the LAST one seen for the content (text_to_node[content] = item).
+//   fusion  first occurrence wins, ordered by its raw route score (stable).
+// Lists are tiny (<= 192 + 288 in the reference config), so one workgroup per query does the
+// quadratic leader / rank counting out of LDS; no host round trip between the routes and the fusion.
+#include "common.h"
+#include "kernels.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr int kFuseThreads = 256;
+
+struct FuseLds {
+    int32_t content[erh::kFuseMaxItems];
+    int32_t doc[erh::kFuseMaxItems];
+    int32_t out_doc[erh::kFuseMaxItems];
+    int32_t leader[erh::kFuseMaxItems];
+    double score[erh::kFuseMaxItems];
+    int n_leaders;
+};
+
+template <bool RRF>
+__global__ __launch_bounds__(kFuseThreads) void fuse_kernel(
+    const int32_t *__restrict__ ids_a, const double *__restrict__ sc_a, const int32_t *__restrict__ len_a, int depth_a,
+    const int32_t *__restrict__ ids_b, const double *__restrict__ sc_b, const int32_t *__restrict__ len_b, int depth_b,
+    const int32_t *__restrict__ content_id, int K, int topk,
+    int32_t *__restrict__ out_ids, double *__restrict__ out_scores, int32_t *__restrict__ out_len) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    FuseLds &L = *reinterpret_cast<FuseLds *>(smem);
+    const int q = blockIdx.x, tid = threadIdx.x;
+    int la = len_a ? len_a[q] : depth_a;
+    int lb = len_b ? len_b[q] : depth_b;
+    if (la > depth_a) la = depth_a;
+    if (lb > depth_b) lb = depth_b;
+    if (la < 0) la = 0;
+    if (lb < 0) lb = 0;
+    const int n = la + lb;
+    if (tid == 0) L.n_leaders = 0;
+    for (int i = tid; i < n; i += kFuseThreads) {
+        const int32_t id = (i < la) ? ids_a[(int64_t)q * depth_a + i] : ids_b[(int64_t)q * depth_b + (i - la)];
+        L.doc[i] = id;
+        L.content[i] = content_id ? content_id[id] : id;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += kFuseThreads) {
+        const int32_t c = L.content[i];
+        bool lead = true;
+        for (int j = 0; j < i; ++j) lead = lead && (L.content[j] != c);
+        L.leader[i] = lead ? 1 : 0;
+        if (lead) {
+            atomicAdd(&L.n_leaders, 1);
+            if (RRF) {
+                double s = 0.0;
+                int32_t last = L.doc[i];
+                for (int j = i; j < n; ++j) {
+                    if (L.content[j] == c) {
+                        const int rank = (j < la) ? (j + 1) : (j - la + 1);
+                        s = s + 1.0 / (double)(rank + K);
+                        last = L.doc[j];
+                    }
+                }
+                L.score[i] = s;
+                L.out_doc[i] = last;
+            } else {
+                L.score[i] = (i < la) ? sc_a[(int64_t)q * depth_a + i] : sc_b[(int64_t)q * depth_b + (i - la)];
+                L.out_doc[i] = L.doc[i];
+            }
+        }
+    }
+    __syncthreads();
+    const int nl = L.n_leaders;
+    const int kk = topk < nl ? topk : nl;
+    for (int i = tid; i < n; i += kFuseThreads) {
+        if (!L.leader[i]) continue;
+        const double s = L.score[i];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) {
+            if (L.leader[j]) {
+                const double sj = L.score[j];
+                rank += (sj > s || (sj == s && j < i)) ? 1 : 0;
+            }
+        }
+        if (rank < kk) {
+            out_ids[(int64_t)q * topk + rank] = L.out_doc[i];
+            out_scores[(int64_t)q * topk + rank] = s;
+        }
+    }
+    for (int i = kk + tid; i < topk; i += kFuseThreads) {
+        out_ids[(int64_t)q * topk + i] = -1;
+        out_scores[(int64_t)q * topk + i] = 0.0;
+    }
+    if (tid == 0) out_len[q] = kk;
+}
+
+}  // namespace
+
+namespace erh {
+
+hipError_t launch_rrf(const int32_t *ids_a, const int32_t *len_a, int depth_a,
+                      const int32_t *ids_b, const int32_t *len_b, int depth_b,
+                      const int32_t *content_id, int B, int K, int topk,
+                      int32_t *out_ids, double *out_scores, int32_t *out_len, hipStream_t st) {
+    if (B <= 0) return hipSuccess;
+    hipLaunchKernelGGL(fuse_kernel<true>, dim3(B), dim3(kFuseThreads), sizeof(FuseLds), st,
+                       ids_a, (const double *)nullptr, len_a, depth_a, ids_b, (const double *)nullptr, len_b, depth_b,
+                       content_id, K, topk, out_ids, out_scores, out_len);
+    return hipGetLastError();
+}
+
+hipError_t launch_fusion(const int32_t *ids_a, const double *sc_a, const int32_t *len_a, int depth_a,
+                         const int32_t *ids_b, const double *sc_b, const int32_t *len_b, int depth_b,
+                         const int32_t *content_id, int B, int topk,
+                         int32_t *out_ids, double *out_scores, int32_t *out_len, hipStream_t st) {
+    if (B <= 0) return hipSuccess;
+    hipLaunchKernelGGL(fuse_kernel<false>, dim3(B), dim3(kFuseThreads), sizeof(FuseLds), st,
+                       ids_a, sc_a, len_a, depth_a, ids_b, sc_b, len_b, depth_b,
+                       content_id, 0, topk, out_ids, out_scores, out_len);
+    return hipGetLastError();
+}
+
+}  // namespace erh

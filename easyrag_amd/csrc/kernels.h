@@ -1,0 +1,85 @@
+// Launcher prototypes shared between the kernel translation units and the C-ABI (api.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "common.h"
+
+namespace erh {
+
+// ---- dense_scan.hip --------------------------------------------------------------------------
+int dense_scan_lds_bytes();
+int dense_scan_q_tile();   // queries are padded to a multiple of this
+hipError_t dense_scan_init();
+hipError_t launch_dense_scan_store(const _Float16 *Q, int Bpad, const _Float16 *X, int64_t N, int d,
+                                   int64_t c0, int nc, float *S0, int ld_s0, hipStream_t st);
+hipError_t launch_dense_scan_append(const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1,
+                                    const _Float16 *Q, int Bpad, int B, const float *tau,
+                                    const int16_t *filter_dir, const int16_t *dir_id,
+                                    ErhCand *cand, uint32_t *cand_cnt, int cap, uint32_t *overflow, hipStream_t st);
+hipError_t launch_dense_naive(const _Float16 *Q, int B, const _Float16 *X, int64_t row0, int rows, int d,
+                              float *out, hipStream_t st);
+
+// ---- select.hip ------------------------------------------------------------------------------
+constexpr int kDenseN0Max = 32768;    // seed prefix: one fp32 score row must fit LDS for the k-th select
+constexpr int kDenseCapMax = 16384;   // candidates per query that the LDS sort can hold (64-bit keys)
+constexpr int kDenseRescoreMax = 1024;
+hipError_t select_init();
+// fp32/fp16 -> fp16 query block [Bpad x d] (+ fp32 norm of the fp16 row); rows >= B are zeroed.
+hipError_t launch_prep_queries(const void *q, int q_dtype, int normalize, int B, int Bpad, int d,
+                               _Float16 *Q16, float *qnorm, hipStream_t st);
+// rows fp32 -> fp16 (optionally L2-normalised) for erh_set_dense
+hipError_t launch_convert_rows(const float *x, int64_t n, int d, int normalize, _Float16 *out, hipStream_t st);
+// max L2 norm over fp16 rows -> *out (float, device)
+hipError_t launch_row_norm_max(const _Float16 *x, int64_t n, int d, float *out, hipStream_t st);
+// Seed stage: k-th best of S0[q][0..n0) (filter applied) -> tau[q] = kth - margin(q); candidates >= tau
+// are written to cand[q] and cand_cnt[q] is (re)initialised.
+hipError_t launch_seed_select(const float *S0, int ld_s0, int n0, int64_t c0, int B, int k,
+                              const float *qnorm, float xnorm_max, int d,
+                              const int16_t *filter_dir, const int16_t *dir_id,
+                              float *tau, ErhCand *cand, uint32_t *cand_cnt, int cap, uint32_t *overflow,
+                              hipStream_t st);
+// Refine: k-th best over the current candidates -> tighter tau; candidates below it are dropped.
+hipError_t launch_cand_refine(int B, int k, const float *qnorm, float xnorm_max, int d,
+                              float *tau, ErhCand *cand, uint32_t *cand_cnt, int cap, hipStream_t st);
+// Final: sort candidates, (EXACT) re-score the margin set in pinned fp64, rank, write top-k.
+hipError_t launch_dense_finalize(int B, int k, int mode, const float *qnorm, float xnorm_max, int d,
+                                 const _Float16 *X, const _Float16 *Q16,
+                                 const ErhCand *cand, const uint32_t *cand_cnt, int cap,
+                                 int32_t *out_ids, double *out_scores, int32_t *out_len,
+                                 float *diag_maxerr, uint32_t *diag_uncert, hipStream_t st);
+
+// ---- bm25.hip --------------------------------------------------------------------------------
+constexpr int kBm25TileF32 = 32768;   // documents per LDS accumulator tile (fp32 sums)
+constexpr int kBm25TileF64 = 16384;   // (fp64 sums)
+hipError_t bm25_init();
+hipError_t launch_bm25_tile_off(const int64_t *indptr, const int32_t *doc_ids, int64_t V, int tile_docs,
+                                int n_tiles, int32_t *tile_off, hipStream_t st);
+hipError_t launch_bm25_payload(int variant, int64_t V, int64_t nnz, const int64_t *indptr, const int32_t *doc_ids,
+                               const int32_t *tf, const int32_t *doc_len, const void *idf, double avgdl,
+                               double k1, double b, void *payload, hipStream_t st);
+// segs partial lists per query; partial_* are [B][segs][k]
+hipError_t launch_bm25_scan(int variant, const int64_t *indptr, const int32_t *doc_ids, const void *payload,
+                            const int32_t *tile_off, int n_tiles, int64_t N,
+                            const int32_t *q_indptr, const int32_t *q_tok, int B, int k, int segs,
+                            const int16_t *filter_dir, const int16_t *dir_id,
+                            double *part_scores, int32_t *part_ids, int32_t *part_len, hipStream_t st);
+hipError_t launch_bm25_merge(int B, int k, int segs, const double *part_scores, const int32_t *part_ids,
+                             const int32_t *part_len, int32_t *out_ids, double *out_scores, int32_t *out_len,
+                             hipStream_t st);
+// scores[doc] += payload for one term (launched once per query token, in order) -> get_scores parity
+hipError_t launch_bm25_add_term(int variant, const int64_t *indptr, const int32_t *doc_ids, const void *payload,
+                                int32_t term, void *scores, hipStream_t st);
+hipError_t launch_widen_f32(const float *in, int64_t n, double *out, hipStream_t st);
+
+// ---- fuse.hip --------------------------------------------------------------------------------
+constexpr int kFuseMaxItems = 2048;   // depth_a + depth_b
+hipError_t launch_rrf(const int32_t *ids_a, const int32_t *len_a, int depth_a,
+                      const int32_t *ids_b, const int32_t *len_b, int depth_b,
+                      const int32_t *content_id, int B, int K, int topk,
+                      int32_t *out_ids, double *out_scores, int32_t *out_len, hipStream_t st);
+hipError_t launch_fusion(const int32_t *ids_a, const double *sc_a, const int32_t *len_a, int depth_a,
+                         const int32_t *ids_b, const double *sc_b, const int32_t *len_b, int depth_b,
+                         const int32_t *content_id, int B, int topk,
+                         int32_t *out_ids, double *out_scores, int32_t *out_len, hipStream_t st);
+
+}  // namespace erh

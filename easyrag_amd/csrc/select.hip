@@ -1,0 +1,370 @@
+// Dense route, selection side: query preparation, threshold seeding, candidate refinement and the
+// final ranking with the order-pinned fp64 re-score.  Together with dense_scan.hip this replaces the
+// "argsort(scores)[::-1], walk, take `limit`" of Qdrant's exact COSINE search behind
+// QdrantRetriever (/root/reference/src/easyrag/custom/retrievers.py:37-52).
+//
+// Pruning is exact, not approximate: a chunk may be dropped only if its fp32 MFMA score is below
+// (a valid lower bound of the k-th best fp32 score) - margin, margin = 2*delta(q),
+// delta(q) = d * 2^-23 * ||q|| * max_i ||x_i|| >= |fp32 score - exact score| for any summation order.
+// Everything that survives is ranked by (fp64 score desc, index asc) in EXACT mode.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int kSelThreads = 1024;
+
+__device__ __forceinline__ float block_sum_256(float v, float *red) {
+    // blockDim.x == 256
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+__device__ __forceinline__ float margin_of(float qn, float xn, int d) {
+    // 2 * delta, delta = d * 2^-23 * |q| * max|x|  (2^-23: twice the unit round-off of fp32, to stay
+    // a bound whatever rounding the matrix core applies to its internal partial sums)
+    return 2.0f * ((float)d * 1.1920929e-7f * qn * xn) + 1e-30f;
+}
+
+// ---- query block preparation -----------------------------------------------------------------
+template <typename TIN>
+__global__ __launch_bounds__(256) void prep_queries_kernel(const TIN *__restrict__ q, int normalize, int B, int d,
+                                                          _Float16 *__restrict__ Q16, float *__restrict__ qnorm) {
+    __shared__ float red[4];
+    const int row = blockIdx.x;
+    _Float16 *out = Q16 + (int64_t)row * d;
+    if (row >= B) {
+        for (int i = threadIdx.x; i < d; i += 256) out[i] = (_Float16)0.f;
+        if (threadIdx.x == 0) qnorm[row] = 0.f;
+        return;
+    }
+    const TIN *in = q + (int64_t)row * d;
+    float inv = 1.f;
+    if (normalize) {
+        float ss = 0.f;
+        for (int i = threadIdx.x; i < d; i += 256) { const float v = (float)in[i]; ss += v * v; }
+        ss = block_sum_256(ss, red);
+        inv = ss > 0.f ? 1.0f / sqrtf(ss) : 0.f;
+    }
+    float s2 = 0.f;
+    for (int i = threadIdx.x; i < d; i += 256) {
+        const _Float16 hv = (_Float16)((float)in[i] * inv);
+        out[i] = hv;
+        const float f = (float)hv;
+        s2 += f * f;
+    }
+    s2 = block_sum_256(s2, red);
+    if (threadIdx.x == 0) qnorm[row] = sqrtf(s2) * 1.0001f;
+}
+
+__global__ __launch_bounds__(256) void convert_rows_kernel(const float *__restrict__ x, int64_t n, int d, int normalize,
+                                                          _Float16 *__restrict__ out) {
+    __shared__ float red[4];
+    for (int64_t row = blockIdx.x; row < n; row += gridDim.x) {
+        const float *in = x + row * d;
+        float inv = 1.f;
+        if (normalize) {
+            float ss = 0.f;
+            for (int i = threadIdx.x; i < d; i += 256) { const float v = in[i]; ss += v * v; }
+            ss = block_sum_256(ss, red);
+            inv = ss > 0.f ? 1.0f / sqrtf(ss) : 0.f;
+        }
+        for (int i = threadIdx.x; i < d; i += 256) out[row * d + i] = (_Float16)(in[i] * inv);
+    }
+}
+
+__global__ __launch_bounds__(256) void row_norm_max_kernel(const _Float16 *__restrict__ x, int64_t n, int d,
+                                                          float *__restrict__ out) {
+    __shared__ float red[4];
+    float best = 0.f;
+    for (int64_t row = blockIdx.x; row < n; row += gridDim.x) {
+        const _Float16 *in = x + row * d;
+        float ss = 0.f;
+        for (int i = threadIdx.x; i < d; i += 256) { const float v = (float)in[i]; ss += v * v; }
+        ss = block_sum_256(ss, red);
+        best = fmaxf(best, ss);
+    }
+    if (threadIdx.x == 0) atomicMax((unsigned int *)out, __float_as_uint(sqrtf(best) * 1.0001f));
+}
+
+// ---- seed stage: k-th best of the stored prefix scores ------------------------------------------
+// grid = B, block = 1024, dynamic LDS = np2 * 4 bytes.
+__global__ __launch_bounds__(kSelThreads) void seed_select_kernel(
+    const float *__restrict__ S0, int ld_s0, int n0, int np2, int64_t c0, int k,
+    const float *__restrict__ qnorm, float xnorm_max, int d,
+    const int16_t *__restrict__ filter_dir, const int16_t *__restrict__ dir_id,
+    float *__restrict__ tau, ErhCand *__restrict__ cand, uint32_t *__restrict__ cand_cnt, int cap,
+    uint32_t *__restrict__ overflow) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // all LDS lives in the dynamic region (a static __shared__ in front would misalign it): 64-byte header first
+    int &s_nvalid = *reinterpret_cast<int *>(smem);
+    int &s_cnt = *reinterpret_cast<int *>(smem + 4);
+    uint32_t *keys = reinterpret_cast<uint32_t *>(smem + 64);
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const float *row = S0 + (int64_t)q * ld_s0;
+    const int fd = filter_dir ? (int)filter_dir[q] : -1;
+    if (tid == 0) { s_nvalid = 0; s_cnt = 0; }
+    __syncthreads();
+    int myvalid = 0;
+    for (int i = tid; i < np2; i += kSelThreads) {
+        uint32_t key = 0;
+        if (i < n0) {
+            const float s = row[i];
+            bool ok = s > -INFINITY;                                  // chunks past N were stored as -inf
+            if (ok && fd >= 0) ok = ((int)dir_id[c0 + i] == fd);
+            if (ok) { key = erh_f2ord(s); ++myvalid; }
+        }
+        keys[i] = key;
+    }
+    for (int o = 32; o >= 1; o >>= 1) myvalid += __shfl_xor(myvalid, o);
+    if ((tid & 63) == 0 && myvalid) atomicAdd(&s_nvalid, myvalid);
+    erh_bitonic_desc<uint32_t>(keys, np2);   // begins and ends with a barrier
+    const int nv = s_nvalid;
+    float prune = -INFINITY;
+    if (nv >= k) prune = erh_ord2f(keys[k - 1]) - margin_of(qnorm[q], xnorm_max, d);
+    if (tid == 0) tau[q] = prune;
+    // every stored prefix score >= prune becomes a candidate
+    for (int i = tid; i < n0; i += kSelThreads) {
+        const float s = row[i];
+        bool ok = (s > -INFINITY) && (s >= prune);
+        if (ok && fd >= 0) ok = ((int)dir_id[c0 + i] == fd);
+        if (ok) {
+            const int pos = atomicAdd(&s_cnt, 1);
+            if (pos < cap) {
+                ErhCand c;
+                c.s = s;
+                c.idx = (int32_t)(c0 + i);
+                cand[(int64_t)q * cap + pos] = c;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const int c = s_cnt;
+        cand_cnt[q] = (uint32_t)(c < cap ? c : cap);
+        if (c > cap) atomicOr(overflow, 1u);
+    }
+}
+
+// ---- refine: tighten tau from the candidates gathered so far --------------------------------------
+// grid = B, block = 1024, dynamic LDS = cp2 * 8 bytes.
+__global__ __launch_bounds__(kSelThreads) void cand_refine_kernel(
+    int k, int cp2, const float *__restrict__ qnorm, float xnorm_max, int d,
+    float *__restrict__ tau, ErhCand *__restrict__ cand, uint32_t *__restrict__ cand_cnt, int cap) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int &s_keep = *reinterpret_cast<int *>(smem);
+    uint64_t *keys = reinterpret_cast<uint64_t *>(smem + 64);
+    const int q = blockIdx.x, tid = threadIdx.x;
+    int c = (int)cand_cnt[q];
+    if (c > cap) c = cap;
+    if (c < k) return;                                     // nothing to learn yet (uniform)
+    ErhCand *mine = cand + (int64_t)q * cap;
+    const int ns = erh_next_pow2(c < 2 ? 2 : c);           // sort only what is there (ns <= cp2)
+    for (int i = tid; i < ns; i += kSelThreads) {
+        uint64_t key = 0;
+        if (i < c) { const ErhCand e = mine[i]; key = erh_key32(e.s, e.idx); }
+        keys[i] = key;
+    }
+    if (tid == 0) s_keep = c;
+    erh_bitonic_desc<uint64_t>(keys, ns);
+    const float kth = erh_key32_score(keys[k - 1]);
+    float t_new = kth - margin_of(qnorm[q], xnorm_max, d);
+    const float t_old = tau[q];
+    if (t_old > t_new) t_new = t_old;
+    // survivors are a prefix of the sorted keys
+    for (int i = tid; i < c; i += kSelThreads) {
+        const bool keep_i = erh_key32_score(keys[i]) >= t_new;
+        const bool keep_n = (i + 1 < c) ? (erh_key32_score(keys[i + 1]) >= t_new) : false;
+        if (keep_i && !keep_n) s_keep = i + 1;
+    }
+    __syncthreads();
+    const int m = s_keep;
+    for (int i = tid; i < m; i += kSelThreads) {
+        ErhCand e;
+        e.s = erh_key32_score(keys[i]);
+        e.idx = erh_key32_idx(keys[i]);
+        mine[i] = e;
+    }
+    if (tid == 0) { cand_cnt[q] = (uint32_t)m; tau[q] = t_new; }
+}
+
+// ---- final: sort, pinned fp64 re-score of the margin set, rank, emit --------------------------------
+// grid = B, block = 1024, dynamic LDS = cp2 * 8 + kDenseRescoreMax * 16 bytes.
+__global__ __launch_bounds__(kSelThreads) void dense_finalize_kernel(
+    int k, int mode, int cp2, const float *__restrict__ qnorm, float xnorm_max, int d,
+    const _Float16 *__restrict__ X, const _Float16 *__restrict__ Q16,
+    const ErhCand *__restrict__ cand, const uint32_t *__restrict__ cand_cnt, int cap,
+    int32_t *__restrict__ out_ids, double *__restrict__ out_scores, int32_t *__restrict__ out_len,
+    float *__restrict__ diag_maxerr, uint32_t *__restrict__ diag_uncert) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int &s_m = *reinterpret_cast<int *>(smem);
+    unsigned int &s_maxerr = *reinterpret_cast<unsigned int *>(smem + 4);
+    uint64_t *keys = reinterpret_cast<uint64_t *>(smem + 64);
+    double *r_s64 = reinterpret_cast<double *>(smem + 64 + (size_t)cp2 * 8);
+    int32_t *r_idx = reinterpret_cast<int32_t *>(r_s64 + erh::kDenseRescoreMax);
+    float *r_s32 = reinterpret_cast<float *>(r_idx + erh::kDenseRescoreMax);
+    const int q = blockIdx.x, tid = threadIdx.x;
+    int c = (int)cand_cnt[q];
+    if (c > cap) c = cap;
+    const ErhCand *mine = cand + (int64_t)q * cap;
+    const int ns = erh_next_pow2(c < 2 ? 2 : c);           // sort only what is there (ns <= cp2)
+    for (int i = tid; i < ns; i += kSelThreads) {
+        uint64_t key = 0;
+        if (i < c) { const ErhCand e = mine[i]; key = erh_key32(e.s, e.idx); }
+        keys[i] = key;
+    }
+    if (tid == 0) { s_m = 0; s_maxerr = 0; }
+    erh_bitonic_desc<uint64_t>(keys, ns);
+    const int kk = k < c ? k : c;
+    int32_t *o_ids = out_ids + (int64_t)q * k;
+    double *o_sc = out_scores + (int64_t)q * k;
+    if (tid == 0) out_len[q] = kk;
+    for (int i = kk + tid; i < k; i += kSelThreads) { o_ids[i] = -1; o_sc[i] = 0.0; }
+    if (kk == 0) return;
+
+    if (mode == 1 /* ERH_DENSE_FAST */) {
+        for (int i = tid; i < kk; i += kSelThreads) {
+            o_ids[i] = erh_key32_idx(keys[i]);
+            o_sc[i] = (double)erh_key32_score(keys[i]);
+        }
+        return;
+    }
+
+    // EXACT: everything whose fp32 score is within the margin of the kk-th best can still be in the top kk
+    const float delta = 0.5f * margin_of(qnorm[q], xnorm_max, d);
+    const float thr = erh_key32_score(keys[kk - 1]) - 2.0f * delta;
+    for (int i = tid; i < c; i += kSelThreads) {
+        const bool in_i = erh_key32_score(keys[i]) >= thr;
+        const bool in_n = (i + 1 < c) ? (erh_key32_score(keys[i + 1]) >= thr) : false;
+        if (in_i && !in_n) s_m = i + 1;
+    }
+    __syncthreads();
+    int m = s_m;
+    bool uncertified = false;
+    if (m > erh::kDenseRescoreMax) { m = erh::kDenseRescoreMax; uncertified = true; }
+    for (int i = tid; i < m; i += kSelThreads) {
+        r_idx[i] = erh_key32_idx(keys[i]);
+        r_s32[i] = erh_key32_score(keys[i]);
+    }
+    __syncthreads();
+    // one wave per candidate: lane j accumulates elements 512*t + 8*j + e (e = 0..7) sequentially in fp64,
+    // then an xor butterfly 32,16,..,1.  Products of two fp16 values are exact in fp64, so the result
+    // depends only on this order -- which oracle/dense.py: dense_exact_scores reproduces.
+    const int lane = tid & 63, wave = tid >> 6;
+    const _Float16 *qrow = Q16 + (int64_t)q * d;
+    for (int e = wave; e < m; e += kSelThreads / 64) {
+        const _Float16 *xrow = X + (int64_t)r_idx[e] * d;
+        double acc = 0.0;
+        for (int off = 8 * lane; off < d; off += 512) {
+            const half8 xv = *reinterpret_cast<const half8 *>(xrow + off);
+            const half8 qv = *reinterpret_cast<const half8 *>(qrow + off);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = acc + (double)xv[u] * (double)qv[u];
+        }
+        for (int o = 32; o >= 1; o >>= 1) acc = acc + __shfl_xor(acc, o);
+        if (lane == 0) {
+            r_s64[e] = acc;
+            const float err = fabsf((float)(acc - (double)r_s32[e]));
+            atomicMax(&s_maxerr, __float_as_uint(err));
+        }
+    }
+    __syncthreads();
+    // rank by (fp64 desc, index asc) by counting; m <= 1024 = one element per thread
+    if (tid < m) {
+        const double s = r_s64[tid];
+        const int32_t ix = r_idx[tid];
+        int rank = 0;
+        for (int f = 0; f < m; ++f) {
+            const double sf = r_s64[f];
+            const int32_t jf = r_idx[f];
+            rank += (sf > s || (sf == s && jf < ix)) ? 1 : 0;
+        }
+        if (rank < kk) { o_ids[rank] = ix; o_sc[rank] = s; }
+    }
+    if (tid == 0) {
+        const float me = __uint_as_float(s_maxerr);
+        atomicMax((unsigned int *)diag_maxerr, __float_as_uint(me));
+        if (uncertified || me > delta) atomicAdd(diag_uncert, 1u);
+    }
+}
+
+}  // namespace
+
+namespace erh {
+
+static int pow2_ge(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+
+hipError_t select_init() {
+    hipError_t e;
+    e = hipFuncSetAttribute((const void *)seed_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kDenseN0Max * 4 + 64);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void *)cand_refine_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kDenseCapMax * 8 + 64);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute((const void *)dense_finalize_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               kDenseCapMax * 8 + kDenseRescoreMax * 16 + 64);
+}
+
+hipError_t launch_prep_queries(const void *q, int q_dtype, int normalize, int B, int Bpad, int d,
+                               _Float16 *Q16, float *qnorm, hipStream_t st) {
+    if (q_dtype == 0)
+        hipLaunchKernelGGL(prep_queries_kernel<_Float16>, dim3(Bpad), dim3(256), 0, st,
+                           (const _Float16 *)q, normalize, B, d, Q16, qnorm);
+    else
+        hipLaunchKernelGGL(prep_queries_kernel<float>, dim3(Bpad), dim3(256), 0, st,
+                           (const float *)q, normalize, B, d, Q16, qnorm);
+    return hipGetLastError();
+}
+
+hipError_t launch_convert_rows(const float *x, int64_t n, int d, int normalize, _Float16 *out, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    const unsigned grid = (unsigned)(n < 65536 ? n : 65536);
+    hipLaunchKernelGGL(convert_rows_kernel, dim3(grid), dim3(256), 0, st, x, n, d, normalize, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_row_norm_max(const _Float16 *x, int64_t n, int d, float *out, hipStream_t st) {
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(float), st);
+    if (e != hipSuccess || n <= 0) return e;
+    const unsigned grid = (unsigned)(n < 8192 ? n : 8192);
+    hipLaunchKernelGGL(row_norm_max_kernel, dim3(grid), dim3(256), 0, st, x, n, d, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_seed_select(const float *S0, int ld_s0, int n0, int64_t c0, int B, int k,
+                              const float *qnorm, float xnorm_max, int d,
+                              const int16_t *filter_dir, const int16_t *dir_id,
+                              float *tau, ErhCand *cand, uint32_t *cand_cnt, int cap, uint32_t *overflow,
+                              hipStream_t st) {
+    const int np2 = pow2_ge(n0 < 2 ? 2 : n0);
+    hipLaunchKernelGGL(seed_select_kernel, dim3(B), dim3(kSelThreads), (size_t)np2 * 4 + 64, st,
+                       S0, ld_s0, n0, np2, c0, k, qnorm, xnorm_max, d, filter_dir, dir_id, tau, cand, cand_cnt, cap,
+                       overflow);
+    return hipGetLastError();
+}
+
+hipError_t launch_cand_refine(int B, int k, const float *qnorm, float xnorm_max, int d,
+                              float *tau, ErhCand *cand, uint32_t *cand_cnt, int cap, hipStream_t st) {
+    const int cp2 = pow2_ge(cap);
+    hipLaunchKernelGGL(cand_refine_kernel, dim3(B), dim3(kSelThreads), (size_t)cp2 * 8 + 64, st,
+                       k, cp2, qnorm, xnorm_max, d, tau, cand, cand_cnt, cap);
+    return hipGetLastError();
+}
+
+hipError_t launch_dense_finalize(int B, int k, int mode, const float *qnorm, float xnorm_max, int d,
+                                 const _Float16 *X, const _Float16 *Q16,
+                                 const ErhCand *cand, const uint32_t *cand_cnt, int cap,
+                                 int32_t *out_ids, double *out_scores, int32_t *out_len,
+                                 float *diag_maxerr, uint32_t *diag_uncert, hipStream_t st) {
+    const int cp2 = pow2_ge(cap);
+    hipLaunchKernelGGL(dense_finalize_kernel, dim3(B), dim3(kSelThreads),
+                       (size_t)cp2 * 8 + (size_t)kDenseRescoreMax * 16 + 64, st,
+                       k, mode, cp2, qnorm, xnorm_max, d, X, Q16, cand, cand_cnt, cap,
+                       out_ids, out_scores, out_len, diag_maxerr, diag_uncert);
+    return hipGetLastError();
+}
+
+}  // namespace erh

@@ -1,0 +1,288 @@
+"""RetrievalEngine: thin, typed wrapper over one libeasyrag_hip handle (one GPU).
+
+It only marshals: numpy arrays / torch tensors -> pointers, status codes -> exceptions.  All
+retrieval arithmetic runs in the HIP kernels; nothing here computes a score.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from .index import BM25Index, BM25S, OKAPI
+
+
+def _is_torch(x) -> bool:
+    return type(x).__module__.split(".")[0] == "torch"
+
+
+def _ptr(a) -> int:
+    if a is None:
+        return 0
+    if _is_torch(a):
+        return int(a.data_ptr())
+    return int(a.ctypes.data)
+
+
+def _np(a, dtype) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def queries_to_csr(queries: Sequence[Sequence[int]]) -> Tuple[np.ndarray, np.ndarray]:
+    """List of term-id sequences -> (q_indptr int32[B+1], q_tok int32[sum])."""
+    lens = np.fromiter((len(q) for q in queries), dtype=np.int64, count=len(queries))
+    indptr = np.zeros(len(queries) + 1, np.int32)
+    np.cumsum(lens, out=indptr[1:])
+    tok = np.empty(int(indptr[-1]), np.int32)
+    for i, q in enumerate(queries):
+        tok[indptr[i]:indptr[i + 1]] = q
+    return indptr, tok
+
+
+class RetrievalEngine:
+    """One handle = one GPU's replica of the corpus state (chunk matrix, postings, metadata)."""
+
+    def __init__(self, device: int = 0):
+        self._lib = _lib.load()
+        h = C.c_void_p()
+        rc = self._lib.erh_create(int(device), C.byref(h))
+        if rc != 0:
+            raise _lib.ErhError(rc, self._lib.erh_status_str(rc).decode() +
+                                " (libeasyrag_hip needs a gfx950 GPU; there is no CPU fallback)")
+        self._h = h
+        self.device = int(device)
+        self.n_dense = 0
+        self.d = 0
+        self.bm25: Optional[BM25Index] = None
+        self.n_meta = 0
+
+    # -- lifetime ---------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.erh_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc != 0:
+            raise _lib.ErhError(rc, self._lib.erh_last_error(self._h).decode())
+
+    # -- corpus state ---------------------------------------------------------------------------
+    def set_dense(self, x, normalize: bool = False):
+        """x: [N, d] float16 or float32, numpy array or (ROCm) torch tensor."""
+        if _is_torch(x):
+            import torch
+            x = x.contiguous()
+            is_dev = 1 if x.is_cuda else 0
+            if x.dtype == torch.float16:
+                dt = _lib.ERH_F16
+            elif x.dtype == torch.float32:
+                dt = _lib.ERH_F32
+            else:
+                raise TypeError("dense matrix must be float16 or float32")
+            n, d = int(x.shape[0]), int(x.shape[1])
+            if is_dev:
+                torch.cuda.current_stream(x.device).synchronize()
+        else:
+            x = np.ascontiguousarray(x)
+            if x.dtype == np.float16:
+                dt = _lib.ERH_F16
+            elif x.dtype == np.float32:
+                dt = _lib.ERH_F32
+            else:
+                raise TypeError("dense matrix must be float16 or float32")
+            is_dev = 0
+            n, d = x.shape
+        self._check(self._lib.erh_set_dense(self._h, _ptr(x), n, d, dt, is_dev, 1 if normalize else 0))
+        self.n_dense, self.d = int(n), int(d)
+
+    def set_bm25(self, index: BM25Index, payload_on_device: bool = False):
+        """Upload CSR postings.  payload_on_device=True lets the GPU evaluate IDF*TF/(TF+k1*lenNorm)."""
+        indptr = _np(index.indptr, np.int64)
+        doc_ids = _np(index.doc_ids, np.int32)
+        if payload_on_device:
+            tf = _np(index.tf, np.int32)
+            dl = _np(index.doc_len, np.int32)
+            idf = _np(index.idf, np.float64 if index.variant == OKAPI else np.float32)
+            rc = self._lib.erh_set_bm25_tf(self._h, index.variant, index.n_vocab, index.n_docs, index.nnz,
+                                           _ptr(indptr), _ptr(doc_ids), _ptr(tf), _ptr(dl), _ptr(idf),
+                                           float(index.avgdl), float(index.k1), float(index.b))
+        else:
+            pay = _np(index.payload, np.float64 if index.variant == OKAPI else np.float32)
+            if pay.shape[0] != index.nnz:
+                raise ValueError("index has no host payload; build with compute_payload=True")
+            rc = self._lib.erh_set_bm25_csr(self._h, index.variant, index.n_vocab, index.n_docs, index.nnz,
+                                            _ptr(indptr), _ptr(doc_ids), _ptr(pay))
+        self._check(rc)
+        self.bm25 = index
+
+    def get_bm25_payload(self) -> np.ndarray:
+        assert self.bm25 is not None
+        out = np.empty(self.bm25.nnz, np.float64 if self.bm25.variant == OKAPI else np.float32)
+        self._check(self._lib.erh_get_bm25_payload(self._h, _ptr(out)))
+        return out
+
+    def set_doc_meta(self, n_docs: int, content_id=None, dir_id=None):
+        cid = None if content_id is None else _np(content_id, np.int32)
+        did = None if dir_id is None else _np(dir_id, np.int16)
+        self._check(self._lib.erh_set_doc_meta(self._h, int(n_docs), _ptr(cid), _ptr(did)))
+        self.n_meta = int(n_docs)
+
+    # -- helpers ------------------------------------------------------------------------------
+    @staticmethod
+    def _q_desc(q):
+        if _is_torch(q):
+            import torch
+            q = q.contiguous()
+            dt = {torch.float16: _lib.ERH_F16, torch.float32: _lib.ERH_F32}.get(q.dtype)
+            if dt is None:
+                raise TypeError("queries must be float16 or float32")
+            return q, dt, (1 if q.is_cuda else 0), int(q.shape[0])
+        q = np.ascontiguousarray(q)
+        if q.ndim == 1:
+            q = q[None, :]
+        if q.dtype == np.float16:
+            dt = _lib.ERH_F16
+        else:
+            q = np.ascontiguousarray(q, dtype=np.float32)
+            dt = _lib.ERH_F32
+        return q, dt, 0, int(q.shape[0])
+
+    @staticmethod
+    def _filter(filter_dir, B):
+        if filter_dir is None:
+            return None
+        f = _np(filter_dir, np.int16)
+        if f.shape[0] != B:
+            raise ValueError("filter_dir must have one entry per query")
+        return f
+
+    @staticmethod
+    def _outs(B, k, device_out):
+        if device_out:
+            import torch
+            dev = torch.device("cuda", torch.cuda.current_device())
+            return (torch.empty((B, k), dtype=torch.int32, device=dev),
+                    torch.empty((B, k), dtype=torch.float64, device=dev),
+                    torch.empty((B,), dtype=torch.int32, device=dev))
+        return np.empty((B, k), np.int32), np.empty((B, k), np.float64), np.empty((B,), np.int32)
+
+    @staticmethod
+    def _stream(stream):
+        if stream is None:
+            return 0
+        if hasattr(stream, "cuda_stream"):
+            return int(stream.cuda_stream)
+        return int(stream)
+
+    # -- queries --------------------------------------------------------------------------------
+    def dense_topk(self, q, k: int, filter_dir=None, mode: int = _lib.ERH_DENSE_EXACT, normalize_q: bool = False,
+                   device_out: bool = False, stream=None):
+        q, dt, is_dev, B = self._q_desc(q)
+        f = self._filter(filter_dir, B)
+        ids, sc, ln = self._outs(B, k, device_out)
+        self._check(self._lib.erh_dense_topk(self._h, _ptr(q), dt, is_dev, 1 if normalize_q else 0, B, int(k),
+                                             _ptr(f), int(mode), _ptr(ids), _ptr(sc), _ptr(ln),
+                                             1 if device_out else 0, self._stream(stream)))
+        return ids, sc, ln
+
+    def bm25_topk(self, q_indptr, q_tok, k: int, filter_dir=None, device_out: bool = False, stream=None):
+        q_indptr = _np(q_indptr, np.int32)
+        q_tok = _np(q_tok, np.int32)
+        B = q_indptr.shape[0] - 1
+        f = self._filter(filter_dir, B)
+        ids, sc, ln = self._outs(B, k, device_out)
+        self._check(self._lib.erh_bm25_topk(self._h, _ptr(q_indptr), _ptr(q_tok), B, int(k), _ptr(f),
+                                            _ptr(ids), _ptr(sc), _ptr(ln), 1 if device_out else 0,
+                                            self._stream(stream)))
+        return ids, sc, ln
+
+    def bm25_scores(self, q_tok) -> np.ndarray:
+        assert self.bm25 is not None
+        q_tok = _np(q_tok, np.int32)
+        out = np.empty(self.bm25.n_docs, np.float64)
+        self._check(self._lib.erh_bm25_scores(self._h, _ptr(q_tok), int(q_tok.shape[0]), _ptr(out)))
+        return out
+
+    def rrf(self, ids_a, len_a, ids_b, len_b, K: int = 60, topk: int = 256):
+        ids_a = _np(ids_a, np.int32)
+        ids_b = _np(ids_b, np.int32)
+        B = ids_a.shape[0]
+        la = None if len_a is None else _np(len_a, np.int32)
+        lb = None if len_b is None else _np(len_b, np.int32)
+        ids, sc, ln = self._outs(B, topk, False)
+        self._check(self._lib.erh_rrf(self._h, _ptr(ids_a), _ptr(la), ids_a.shape[1], _ptr(ids_b), _ptr(lb),
+                                      ids_b.shape[1], B, int(K), int(topk), _ptr(ids), _ptr(sc), _ptr(ln), 0, 0))
+        return ids, sc, ln
+
+    def fusion(self, ids_a, sc_a, len_a, ids_b, sc_b, len_b, topk: int = 256):
+        ids_a = _np(ids_a, np.int32)
+        ids_b = _np(ids_b, np.int32)
+        sc_a = _np(sc_a, np.float64)
+        sc_b = _np(sc_b, np.float64)
+        B = ids_a.shape[0]
+        la = None if len_a is None else _np(len_a, np.int32)
+        lb = None if len_b is None else _np(len_b, np.int32)
+        ids, sc, ln = self._outs(B, topk, False)
+        self._check(self._lib.erh_fusion(self._h, _ptr(ids_a), _ptr(sc_a), _ptr(la), ids_a.shape[1],
+                                         _ptr(ids_b), _ptr(sc_b), _ptr(lb), ids_b.shape[1], B, int(topk),
+                                         _ptr(ids), _ptr(sc), _ptr(ln), 0, 0))
+        return ids, sc, ln
+
+    def hybrid_topk(self, q, q_indptr, q_tok, k_dense: int = 288, k_sparse: int = 192, K: int = 60, topk: int = 256,
+                    filter_dir=None, normalize_q: bool = False, device_out: bool = False, stream=None):
+        q, dt, is_dev, B = self._q_desc(q)
+        q_indptr = _np(q_indptr, np.int32)
+        q_tok = _np(q_tok, np.int32)
+        if q_indptr.shape[0] - 1 != B:
+            raise ValueError("dense and sparse query batches differ in size")
+        f = self._filter(filter_dir, B)
+        ids, sc, ln = self._outs(B, topk, device_out)
+        self._check(self._lib.erh_hybrid_topk(self._h, _ptr(q), dt, is_dev, 1 if normalize_q else 0,
+                                              _ptr(q_indptr), _ptr(q_tok), B, int(k_dense), int(k_sparse), int(K),
+                                              int(topk), _ptr(f), _ptr(ids), _ptr(sc), _ptr(ln),
+                                              1 if device_out else 0, self._stream(stream)))
+        return ids, sc, ln
+
+    # -- measurement ------------------------------------------------------------------------------
+    def sync(self, stream=None):
+        self._check(self._lib.erh_sync(self._h, self._stream(stream)))
+
+    def dense_check(self, stream=None):
+        self._check(self._lib.erh_dense_check(self._h, self._stream(stream)))
+
+    def set_profiling(self, on: bool):
+        self._check(self._lib.erh_set_profiling(self._h, 1 if on else 0))
+
+    def reset_kernel_time(self):
+        self._check(self._lib.erh_reset_kernel_time(self._h))
+
+    def kernel_time(self, cls: int):
+        ms, n = C.c_double(), C.c_int64()
+        self._check(self._lib.erh_get_kernel_time(self._h, cls, C.byref(ms), C.byref(n)))
+        by, fl = C.c_double(), C.c_double()
+        self._check(self._lib.erh_get_kernel_work(self._h, cls, C.byref(by), C.byref(fl)))
+        return {"ms": ms.value, "launches": n.value, "bytes": by.value, "flops": fl.value}
+
+    def set_option(self, name: str, value: int):
+        self._check(self._lib.erh_set_option(self._h, name.encode(), int(value)))
+
+    def dense_diag(self):
+        e, m, u = C.c_double(), C.c_double(), C.c_int()
+        self._check(self._lib.erh_dense_diag(self._h, C.byref(e), C.byref(m), C.byref(u)))
+        return {"max_abs_err": e.value, "margin": m.value, "uncertified": u.value}
+
+    def debug_dense_scores(self, q16: np.ndarray, row0: int, rows: int, use_mfma: bool) -> np.ndarray:
+        q16 = np.ascontiguousarray(q16, dtype=np.float16)
+        B = q16.shape[0]
+        out = np.empty((B, rows), np.float32)
+        self._check(self._lib.erh_debug_dense_scores(self._h, _ptr(q16), B, int(row0), int(rows),
+                                                     1 if use_mfma else 0, _ptr(out)))
+        return out

@@ -1,0 +1,418 @@
+"""Drop-in retrievers with the reference's class names, constructor kwargs, methods and return
+conventions, backed by libeasyrag_hip.so (MI355X).  Mirrors
+/root/reference/src/easyrag/custom/retrievers.py:
+
+  QdrantRetriever(vector_store, embed_model, similarity_top_k=2, filters=None)      ref :23-69
+  tokenize_and_remove_stopwords(tokenizer, text, stopwords)                          ref :72-76
+  BM25Retriever(nodes, tokenizer, similarity_top_k, ..., stopwords, embed_type, bm25_type)
+      .get_scores(query, docs=None) / .from_defaults(...) / .filter(scores) / ._retrieve   ref :80-220
+  HybridRetriever(dense_retriever, sparse_retriever, retrieval_type=1, topk=256)
+      .fusion(lists, topk) / .reciprocal_rank_fusion(lists, K, topk) / ._aretrieve     ref :223-305
+
+What differs, deliberately: nodes are addressed by their integer position in the caller's node list
+(the pipeline keeps the same map, pipeline.py:221-223); the Qdrant collection is replaced by
+HipVectorStore (the fp16 chunk matrix resident in HBM); equal scores are ordered by node index
+(numpy's argsort()[::-1] tie order is implementation-defined); and every retriever also offers a
+batched entry point (retrieve_batch) because the GPU path is built for batches.  Scores, cut-offs,
+filters, fusion keys and list order follow the reference.
+
+No retrieval arithmetic happens in this file except BM25Retriever.filter(scores), which the reference
+exposes as a host-side helper over a caller-supplied score vector; _retrieve does not use it.
+"""
+from __future__ import annotations
+
+import asyncio
+import logging
+from typing import Any, Callable, Dict, Hashable, List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from .engine import RetrievalEngine, queries_to_csr
+from .index import BM25Index, build_bm25_index
+from .schema import NodeWithScore, QueryBundle
+
+logger = logging.getLogger(__name__)
+
+DEFAULT_SIMILARITY_TOP_K = 2   # llama_index.core.constants.DEFAULT_SIMILARITY_TOP_K
+
+
+# ---------------------------------------------------------------------------------------------------
+# text variants and tokenisation (host side, as in the reference)
+def get_node_content(node, embed_type: int = 0) -> str:
+    """Text fed to a route, by embed_type (ref: src/easyrag/pipeline/ingestion.py:34-76).
+    0 raw text; 1 '###\\n<file_path>\\n\\n<text>'; 2 same with know_path; 3 image captions expanded;
+    4 file_path only; 5 know_path only.  (6 = 3 plus a table-header merge that needs node
+    relationships; it degrades to 3 here.)"""
+    text = node.get_content()
+    meta = node.metadata
+    if embed_type == 1 and "file_path" in meta:
+        return "###\n" + meta["file_path"] + "\n\n" + text
+    if embed_type == 2 and "know_path" in meta:
+        return "###\n" + meta["know_path"] + "\n\n" + text
+    if embed_type in (3, 6):
+        for img in meta.get("imgobjs") or []:
+            text = text.replace(f"{img['cap']} {img['title']}\n", f"{img['cap']}.{img['title']}:{img['content']}\n")
+        return text
+    if embed_type == 4:
+        return meta.get("file_path", "")
+    if embed_type == 5:
+        return meta.get("know_path", "")
+    return text
+
+
+def tokenize_and_remove_stopwords(tokenizer, text, stopwords):
+    """``tokenizer.cut(text)`` minus stop-words and single spaces (ref retrievers.py:72-76)."""
+    return [w for w in tokenizer.cut(text) if w not in stopwords and w != " "]
+
+
+def _as_bundle(q) -> QueryBundle:
+    return q if isinstance(q, QueryBundle) else QueryBundle(query_str=str(q))
+
+
+class _MetaClasses:
+    """Per-document class ids for an equality filter over a fixed set of metadata keys."""
+
+    def __init__(self, nodes, keys: Sequence[str]):
+        self.keys = tuple(keys)
+        self.values: Dict[tuple, int] = {}
+        ids = np.empty(len(nodes), np.int16)
+        for i, n in enumerate(nodes):
+            v = tuple(n.metadata.get(k) for k in self.keys)
+            j = self.values.get(v)
+            if j is None:
+                j = len(self.values)
+                if j >= 32000:
+                    raise ValueError("too many distinct filter values")
+                self.values[v] = j
+            ids[i] = j
+        self.ids = ids
+
+    def class_of(self, filter_dict: Dict[str, Any]) -> int:
+        v = tuple(filter_dict.get(k) for k in self.keys)
+        return self.values.get(v, 32767)          # 32767 matches no document
+
+
+def _filter_to_dict(filters) -> Optional[Dict[str, Any]]:
+    """Accept None, a {key: value} dict, or a qdrant-style Filter(must=[FieldCondition(key, match=MatchValue(value))])
+    (what build_qdrant_filters returns, ref ingestion.py:207-216)."""
+    if filters is None:
+        return None
+    if isinstance(filters, dict):
+        return dict(filters) or None
+    must = getattr(filters, "must", None)
+    if must:
+        out = {}
+        for cond in must:
+            out[getattr(cond, "key")] = getattr(getattr(cond, "match"), "value")
+        return out or None
+    raise TypeError(f"unsupported filter object: {filters!r}")
+
+
+class _FilteredCorpus:
+    """Shared bookkeeping: one engine, one node list, the content ids and the active filter column."""
+
+    def __init__(self, nodes, engine: Optional[RetrievalEngine]):
+        self.nodes = list(nodes)
+        self.engine = engine if engine is not None else RetrievalEngine()
+        self._classes: Optional[_MetaClasses] = None
+        seen: Dict[Hashable, int] = {}
+        cid = np.empty(len(self.nodes), np.int32)
+        for i, n in enumerate(self.nodes):
+            cid[i] = seen.setdefault(n.get_content(), i)      # smallest index with identical text
+        self.content_id = cid
+        self._push_meta()
+
+    def _push_meta(self):
+        self.engine.set_doc_meta(len(self.nodes), self.content_id, None if self._classes is None else self._classes.ids)
+
+    def filter_class(self, filter_dict: Optional[Dict[str, Any]]) -> int:
+        if not filter_dict:
+            return -1
+        keys = tuple(sorted(filter_dict))
+        if self._classes is None or self._classes.keys != keys:
+            self._classes = _MetaClasses(self.nodes, keys)
+            self._push_meta()
+        return self._classes.class_of(filter_dict)
+
+
+_CORPORA: Dict[int, _FilteredCorpus] = {}
+
+
+def _corpus_for(nodes, engine: Optional[RetrievalEngine]) -> _FilteredCorpus:
+    """Retrievers built over the same engine share one _FilteredCorpus (and so one metadata upload)."""
+    if engine is not None and id(engine) in _CORPORA and len(_CORPORA[id(engine)].nodes) == len(nodes):
+        return _CORPORA[id(engine)]
+    c = _FilteredCorpus(nodes, engine)
+    _CORPORA[id(c.engine)] = c
+    return c
+
+
+# ---------------------------------------------------------------------------------------------------
+class HipVectorStore:
+    """Stand-in for the Qdrant collection (Distance.COSINE, ref ingestion.py:155-191): the chunk embeddings
+    live as one fp16 matrix in HBM.  `embeddings` is [N, d] (numpy or torch, fp16/fp32), row i belongs to
+    nodes[i]; normalize=True applies Qdrant's insert-time L2 normalisation."""
+
+    def __init__(self, nodes, embeddings, engine: Optional[RetrievalEngine] = None, normalize: bool = True):
+        self.corpus = _corpus_for(nodes, engine)
+        self.engine = self.corpus.engine
+        is_f16 = str(getattr(embeddings, "dtype", "")).endswith("float16")
+        self.engine.set_dense(embeddings, normalize=normalize and not is_f16)
+
+    @property
+    def nodes(self):
+        return self.corpus.nodes
+
+    def query_batch(self, query_embeddings, similarity_top_k: int, filters=None, mode: int = _lib.ERH_DENSE_EXACT):
+        fd = _filter_to_dict(filters)
+        q = np.asarray(query_embeddings, dtype=np.float32)
+        if q.ndim == 1:
+            q = q[None, :]
+        cls = self.corpus.filter_class(fd)
+        filt = None if cls < 0 else np.full(q.shape[0], cls, np.int16)
+        return self.engine.dense_topk(q, similarity_top_k, filter_dir=filt, mode=mode, normalize_q=True)
+
+    def query(self, query_embedding, similarity_top_k: int, filters=None):
+        ids, sc, ln = self.query_batch(query_embedding, similarity_top_k, filters)
+        n = int(ln[0])
+        return [self.corpus.nodes[i] for i in ids[0, :n]], [float(s) for s in sc[0, :n]]
+
+
+class _RetrieverBase:
+    """The slice of llama_index's BaseRetriever the pipeline uses: retrieve / aretrieve accept str or QueryBundle."""
+
+    def retrieve(self, str_or_query_bundle) -> List[NodeWithScore]:
+        return self._retrieve(_as_bundle(str_or_query_bundle))
+
+    async def aretrieve(self, str_or_query_bundle) -> List[NodeWithScore]:
+        return await self._aretrieve(_as_bundle(str_or_query_bundle))
+
+    async def _aretrieve(self, query_bundle: QueryBundle) -> List[NodeWithScore]:
+        return self._retrieve(query_bundle)
+
+
+class QdrantRetriever(_RetrieverBase):
+    def __init__(self, vector_store: HipVectorStore, embed_model, similarity_top_k: int = 2, filters=None) -> None:
+        self._vector_store = vector_store
+        self._embed_model = embed_model
+        self._similarity_top_k = similarity_top_k
+        self.filters = filters
+
+    def _retrieve(self, query_bundle: QueryBundle) -> List[NodeWithScore]:
+        emb = self._embed_model.get_query_embedding(query_bundle.query_str)
+        nodes, sims = self._vector_store.query(emb, self._similarity_top_k, self.filters)
+        return [NodeWithScore(node=n, score=s) for n, s in zip(nodes, sims)]
+
+    def retrieve_batch(self, queries: Sequence[str]) -> List[List[NodeWithScore]]:
+        embs = np.asarray([self._embed_model.get_query_embedding(q) for q in queries], dtype=np.float32)
+        ids, sc, ln = self._vector_store.query_batch(embs, self._similarity_top_k, self.filters)
+        nodes = self._vector_store.nodes
+        return [[NodeWithScore(node=nodes[i], score=float(s)) for i, s in zip(ids[b, :ln[b]], sc[b, :ln[b]])]
+                for b in range(len(queries))]
+
+
+class BM25Retriever(_RetrieverBase):
+    def __init__(self, nodes, tokenizer: Optional[Callable], similarity_top_k: int = DEFAULT_SIMILARITY_TOP_K,
+                 callback_manager=None, objects=None, object_map=None, verbose: bool = False,
+                 stopwords=("",), embed_type: int = 0, bm25_type: int = 0,
+                 engine: Optional[RetrievalEngine] = None, payload_on_device: bool = False) -> None:
+        self._nodes = list(nodes)
+        self._tokenizer = tokenizer
+        self._similarity_top_k = similarity_top_k
+        self.embed_type = embed_type
+        self.stopwords = stopwords
+        self._corpus = [tokenize_and_remove_stopwords(tokenizer, get_node_content(n, embed_type), stopwords)
+                        for n in self._nodes]
+        self.bm25_type = bm25_type
+        self.k1, self.b, self.epsilon = 1.5, 0.75, 0.25          # ref retrievers.py:103-105
+        self._corpus_state = _corpus_for(self._nodes, engine)
+        self.engine = self._corpus_state.engine
+        self.bm25: BM25Index = build_bm25_index(self._corpus, variant=1 if bm25_type == 1 else 0, k1=self.k1,
+                                                b=self.b, epsilon=self.epsilon,
+                                                compute_payload=not payload_on_device)
+        self.engine.set_bm25(self.bm25, payload_on_device=payload_on_device)
+        self.filter_dict = None
+
+    @classmethod
+    def from_defaults(cls, index=None, nodes=None, docstore=None, tokenizer=None,
+                      similarity_top_k: int = DEFAULT_SIMILARITY_TOP_K, verbose: bool = False,
+                      stopwords=("",), embed_type: int = 0, bm25_type: int = 0, **kwargs) -> "BM25Retriever":
+        if sum(bool(v) for v in (index, nodes, docstore)) != 1:
+            raise ValueError("Please pass exactly one of index, nodes, or docstore.")
+        if index is not None:
+            docstore = index.docstore
+        if docstore is not None:
+            nodes = list(docstore.docs.values())
+        assert nodes is not None, "Please pass exactly one of index, nodes, or docstore."
+        return cls(nodes=nodes, tokenizer=tokenizer, similarity_top_k=similarity_top_k, verbose=verbose,
+                   stopwords=stopwords, embed_type=embed_type, bm25_type=bm25_type, **kwargs)
+
+    # -- scoring ----------------------------------------------------------------------------------
+    def _query_ids(self, query: str, index: Optional[BM25Index] = None) -> np.ndarray:
+        toks = tokenize_and_remove_stopwords(self._tokenizer, query, self.stopwords)
+        if self.bm25_type == 1 and len(toks) == 0:
+            raise IndexError("list index out of range")     # bm25s sniffs tokens[0] (ref behaviour)
+        return (index or self.bm25).tokens_to_ids(toks)
+
+    def get_scores(self, query: str, docs: Optional[Sequence[str]] = None) -> np.ndarray:
+        """Score vector over all nodes (float64; float32 values widened for bm25_type 1).  With `docs` a
+        throw-away index over those strings is built first (ref retrievers.py:131-147)."""
+        if docs is None:
+            return self._cast(self.engine.bm25_scores(self._query_ids(query)))
+        corpus = [tokenize_and_remove_stopwords(self._tokenizer, d, self.stopwords) for d in docs]
+        idx = build_bm25_index(corpus, variant=1 if self.bm25_type == 1 else 0, k1=self.k1, b=self.b, epsilon=self.epsilon)
+        tmp = RetrievalEngine(self.engine.device)
+        try:
+            tmp.set_bm25(idx)
+            return self._cast(tmp.bm25_scores(self._query_ids(query, idx)))
+        finally:
+            tmp.close()
+
+    def _cast(self, s: np.ndarray) -> np.ndarray:
+        return s.astype(np.float32) if self.bm25_type == 1 else s
+
+    def filter(self, scores: np.ndarray) -> List[NodeWithScore]:
+        """Host helper over a caller-supplied score vector (ref retrievers.py:191-210): descending walk
+        (ties by node index), stop at score <= 0, metadata equality filter, first k."""
+        scores = np.asarray(scores)
+        order = np.lexsort((np.arange(scores.shape[0]), -scores.astype(np.float64)))
+        out: List[NodeWithScore] = []
+        for ix in order:
+            if scores[ix] <= 0:
+                break
+            if self.filter_dict is not None and any(self._nodes[ix].metadata[k] != v for k, v in self.filter_dict.items()):
+                continue
+            out.append(NodeWithScore(node=self._nodes[ix], score=float(scores[ix])))
+            if len(out) == self._similarity_top_k:
+                break
+        return out
+
+    def _retrieve(self, query_bundle: QueryBundle) -> List[NodeWithScore]:
+        if query_bundle.custom_embedding_strs or query_bundle.embedding:
+            logger.warning("BM25Retriever does not support embeddings, skipping...")
+        return self.retrieve_batch([query_bundle.query_str])[0]
+
+    def retrieve_batch(self, queries: Sequence[str]) -> List[List[NodeWithScore]]:
+        """get_scores + filter for a whole batch, fused on the GPU (no score vector leaves the chip)."""
+        qi, qt = queries_to_csr([self._query_ids(q) for q in queries])
+        cls = self._corpus_state.filter_class(self.filter_dict)
+        filt = None if cls < 0 else np.full(len(queries), cls, np.int16)
+        ids, sc, ln = self.engine.bm25_topk(qi, qt, self._similarity_top_k, filter_dir=filt)
+        return [[NodeWithScore(node=self._nodes[i], score=float(s)) for i, s in zip(ids[b, :ln[b]], sc[b, :ln[b]])]
+                for b in range(len(queries))]
+
+
+_FUSION_ENGINE: Optional[RetrievalEngine] = None
+
+
+def _fusion_engine() -> RetrievalEngine:
+    global _FUSION_ENGINE
+    if _FUSION_ENGINE is None:
+        _FUSION_ENGINE = RetrievalEngine()
+    return _FUSION_ENGINE
+
+
+def _lists_to_device_form(lists):
+    """Flatten lists of NodeWithScore into local item ids + content ids for the fusion kernels."""
+    items, cid, key = [], [], {}
+    per_list = []
+    for lst in lists:
+        ids = []
+        for it in lst:
+            ids.append(len(items))
+            cid.append(key.setdefault(it.get_content(), len(key)))
+            items.append(it)
+        per_list.append(ids)
+    return items, np.asarray(cid, np.int32), per_list
+
+
+class HybridRetriever(_RetrieverBase):
+    def __init__(self, dense_retriever: QdrantRetriever, sparse_retriever: BM25Retriever, retrieval_type: int = 1,
+                 topk: int = 256):
+        self.dense_retriever = dense_retriever
+        self.sparse_retriever = sparse_retriever
+        self.retrieval_type = retrieval_type     # 1: dense only  2: sparse only  3: hybrid (RRF)
+        self.filters = None
+        self.filter_dict = None
+        self.topk = topk
+
+    # -- classmethods over already-retrieved lists (ref retrievers.py:239-274) ----------------------------
+    @classmethod
+    def _fuse(cls, lists, rrf: bool, K: int, topk: int):
+        lists = [list(x) for x in lists]
+        if len(lists) == 1:
+            lists.append([])
+        if len(lists) != 2:
+            # fold left: fusing more than two lists is not used by the reference pipeline
+            raise ValueError("exactly two rank lists are supported")
+        items, cid, per_list = _lists_to_device_form(lists)
+        if not items:
+            return []
+        eng = _fusion_engine()
+        eng.set_doc_meta(len(items), cid, None)
+        da, db = max(len(per_list[0]), 1), max(len(per_list[1]), 1)
+        ia = np.full((1, da), -1, np.int32)
+        ib = np.full((1, db), -1, np.int32)
+        ia[0, :len(per_list[0])] = per_list[0]
+        ib[0, :len(per_list[1])] = per_list[1]
+        la = np.asarray([len(per_list[0])], np.int32)
+        lb = np.asarray([len(per_list[1])], np.int32)
+        if rrf:
+            ids, sc, ln = eng.rrf(ia, la, ib, lb, K=K, topk=topk)
+        else:
+            sa = np.zeros((1, da), np.float64)
+            sb = np.zeros((1, db), np.float64)
+            sa[0, :la[0]] = [items[i].score for i in per_list[0]]
+            sb[0, :lb[0]] = [items[i].score for i in per_list[1]]
+            ids, sc, ln = eng.fusion(ia, sa, la, ib, sb, lb, topk=topk)
+        out = []
+        for i, s in zip(ids[0, :ln[0]], sc[0, :ln[0]]):
+            node = items[i]
+            if rrf:
+                node.score = float(s)        # the reference overwrites the node's score with the RRF score
+            out.append(node)
+        return out
+
+    @classmethod
+    def fusion(cls, list_of_list_ranks_system, topk: int = 256):
+        return cls._fuse(list_of_list_ranks_system, rrf=False, K=0, topk=topk)
+
+    @classmethod
+    def reciprocal_rank_fusion(cls, list_of_list_ranks_system, K: int = 60, topk: int = 256):
+        return cls._fuse(list_of_list_ranks_system, rrf=True, K=K, topk=topk)
+
+    # -- routes ---------------------------------------------------------------------------------------------
+    def _fused_possible(self) -> bool:
+        vs = getattr(self.dense_retriever, "_vector_store", None)
+        return (isinstance(vs, HipVectorStore) and vs.engine is self.sparse_retriever.engine
+                and len(vs.nodes) == len(self.sparse_retriever._nodes))
+
+    def _retrieve(self, query_bundle: QueryBundle) -> List[NodeWithScore]:
+        return self.retrieve_batch([query_bundle.query_str])[0]
+
+    def retrieve_batch(self, queries: Sequence[str]) -> List[List[NodeWithScore]]:
+        sp, de = self.sparse_retriever, self.dense_retriever
+        if self.retrieval_type != 1:
+            sp.filter_dict = self.filter_dict
+            if self.retrieval_type == 2:
+                return sp.retrieve_batch(queries)
+        if self.retrieval_type != 2:
+            de.filters = self.filters
+            if self.retrieval_type == 1:
+                return de.retrieve_batch(queries)
+        if not self._fused_possible():
+            sparse, dense = sp.retrieve_batch(queries), de.retrieve_batch(queries)
+            return [self.reciprocal_rank_fusion([s, d], topk=self.topk) for s, d in zip(sparse, dense)]
+        # both routes share one engine: BM25 -> dense -> RRF([sparse, dense]) in a single device pipeline
+        fd = self.filter_dict if self.filter_dict is not None else _filter_to_dict(self.filters)
+        cls = sp._corpus_state.filter_class(fd)
+        filt = None if cls < 0 else np.full(len(queries), cls, np.int16)
+        qi, qt = queries_to_csr([sp._query_ids(q) for q in queries])
+        embs = np.asarray([de._embed_model.get_query_embedding(q) for q in queries], dtype=np.float32)
+        ids, sc, ln = sp.engine.hybrid_topk(embs, qi, qt, k_dense=de._similarity_top_k,
+                                            k_sparse=sp._similarity_top_k, K=60, topk=self.topk,
+                                            filter_dir=filt, normalize_q=True)
+        nodes = sp._nodes
+        return [[NodeWithScore(node=nodes[i], score=float(s)) for i, s in zip(ids[b, :ln[b]], sc[b, :ln[b]])]
+                for b in range(len(queries))]

@@ -1,0 +1,187 @@
+/*
+ * easyrag_hip.h -- C ABI of libeasyrag_hip.so: the MI355X (gfx950) coarse-ranking hot path of
+ * BUAADreamer/EasyRAG (reference @ 2024-12-20), i.e. what src/easyrag/custom/retrievers.py
+ * computes through rank_bm25 / bm25s / qdrant on the CPU.
+ *
+ * Every entry point is `extern "C"`, takes plain pointers and sizes (no torch / C++ types),
+ * returns an int status (0 = ok, < 0 = error, see ERH_ERR_*), never throws and never aborts.
+ * The library is HIP-only: without a gfx950 device erh_create() fails with ERH_ERR_NO_DEVICE;
+ * there is no CPU fallback behind this ABI.
+ *
+ * Ownership: the caller owns every input and output buffer; the handle owns its device copies
+ * (chunk matrix, postings, metadata, work space).  Output slots beyond out_len[b] are padded
+ * with id = -1, score = 0.  A handle is thread-compatible (one handle per host thread).
+ * All device work of a call is enqueued on `stream` (a hipStream_t passed as void*, NULL = the
+ * default stream).  With host output buffers the call returns after the results have landed;
+ * with device output buffers (out_is_device = 1) it returns after enqueueing and erh_sync()
+ * (or any stream synchronisation) completes it.
+ *
+ * Tie rule everywhere: score descending, then document index ascending ("canonical" order; the
+ * reference's numpy argsort()[::-1] order among equal scores is implementation-defined).
+ *
+ * Reference interface each entry point replaces (paths relative to /root/reference):
+ *   erh_set_dense        Qdrant collection of chunk embeddings, Distance.COSINE
+ *                        (src/easyrag/pipeline/ingestion.py:155-191)
+ *   erh_set_bm25_csr     BM25Retriever.__init__ index build (src/easyrag/custom/retrievers.py:94-118)
+ *   erh_set_bm25_tf      same, with the per-posting IDF*TF/(TF + k1*lenNorm) evaluated on the GPU
+ *   erh_set_doc_meta     node text identity (get_content(), retrievers.py:245,263) and the `dir`
+ *                        metadata used by filter_dict / qdrant filters (retrievers.py:198-202,
+ *                        ingestion.py:207-216, pipeline.py:301-312)
+ *   erh_dense_topk       QdrantRetriever._aretrieve / _retrieve (retrievers.py:37-69)
+ *   erh_bm25_scores      BM25Retriever.get_scores (retrievers.py:128-151)
+ *   erh_bm25_topk        BM25Retriever._retrieve = get_scores + filter (retrievers.py:191-220)
+ *   erh_rrf              HybridRetriever.reciprocal_rank_fusion (retrievers.py:256-274)
+ *   erh_fusion           HybridRetriever.fusion (retrievers.py:239-253)
+ *   erh_hybrid_topk      HybridRetriever._aretrieve, retrieval_type == 3 (retrievers.py:276-291)
+ */
+#ifndef EASYRAG_HIP_H
+#define EASYRAG_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct erh_handle erh_handle;
+
+/* status codes */
+#define ERH_OK               0
+#define ERH_ERR_INVALID     (-1)  /* bad argument */
+#define ERH_ERR_NO_DEVICE   (-2)  /* no usable HIP device / wrong architecture */
+#define ERH_ERR_HIP         (-3)  /* a HIP runtime call failed (see erh_last_error) */
+#define ERH_ERR_STATE       (-4)  /* required data not set (e.g. dense search before erh_set_dense) */
+#define ERH_ERR_UNSUPPORTED (-5)  /* shape outside the supported range */
+#define ERH_ERR_OVERFLOW    (-6)  /* candidate work space overflowed; result not produced */
+#define ERH_ERR_NOMEM       (-7)  /* device allocation failed */
+
+/* element types */
+#define ERH_F16 0
+#define ERH_F32 1
+
+/* BM25 variants; numbering = `bm25_type` of the reference config (src/configs/easyrag.yaml:21) */
+#define ERH_BM25_OKAPI 0   /* rank_bm25.BM25Okapi: float64 accumulation */
+#define ERH_BM25_BM25S 1   /* bm25s lucene:        float32 accumulation */
+
+/* dense result modes */
+#define ERH_DENSE_EXACT 0  /* candidates from the fp32 MFMA scan, re-scored and ranked in pinned fp64 */
+#define ERH_DENSE_FAST  1  /* ranked by the fp32 MFMA score itself */
+
+int         erh_version(void);
+const char *erh_status_str(int status);
+
+int         erh_create(int device, erh_handle **out);
+int         erh_destroy(erh_handle *h);
+const char *erh_last_error(erh_handle *h);
+int         erh_sync(erh_handle *h, void *stream);
+
+/* ---- corpus state ------------------------------------------------------------------- */
+
+/* Chunk-embedding matrix, row-major [n x d], d % 64 == 0.  dtype ERH_F16 rows are taken as they
+ * are; ERH_F32 rows are converted to fp16 on the device.  normalize != 0 L2-normalises each row
+ * (in fp32) before the fp16 rounding, which is what Qdrant does at insert for Distance.COSINE.
+ * The handle keeps its own device copy. */
+int erh_set_dense(erh_handle *h, const void *x, int64_t n, int d, int dtype, int is_device_ptr, int normalize);
+
+/* Inverted postings with precomputed ("eager") per-posting scores, CSR by term:
+ *   indptr  int64[V+1]; doc_ids int32[nnz] strictly ascending inside each term;
+ *   payload float32[nnz] (ERH_BM25_BM25S) or float64[nnz] (ERH_BM25_OKAPI).
+ * score(q, doc) = sum over the query's term ids, in query order, repeats included, of the
+ * payload of (term, doc); accumulated in the payload's type.  All pointers are host pointers. */
+int erh_set_bm25_csr(erh_handle *h, int variant, int64_t V, int64_t N, int64_t nnz,
+                     const int64_t *indptr, const int32_t *doc_ids, const void *payload);
+
+/* Same postings, payload evaluated on the GPU from term frequencies:
+ *   BM25S : float32  idf[t] * ( tf / ( f32(k1*((1-b) + b*dl/avgdl)) + tf ) )
+ *   OKAPI : float64  idf[t] * ( tf*(k1+1) / ( tf + k1*((1-b) + b*dl/avgdl) ) )
+ * idf is float32[V] (BM25S) or float64[V] (OKAPI), doc_len int32[N].  Bit-identical to the
+ * host evaluation (operation order as rank_bm25 / bm25s, no contraction). */
+int erh_set_bm25_tf(erh_handle *h, int variant, int64_t V, int64_t N, int64_t nnz,
+                    const int64_t *indptr, const int32_t *doc_ids, const int32_t *tf,
+                    const int32_t *doc_len, const void *idf, double avgdl, double k1, double b);
+
+/* Copy the payload the handle holds back to the host (float32 or float64 [nnz]); parity/debug. */
+int erh_get_bm25_payload(erh_handle *h, void *out_payload);
+
+/* Per-document metadata (host pointers, either may be NULL):
+ *   content_id int32[N]: documents with equal text share an id (RRF / fusion key); NULL = identity.
+ *   dir_id     int16[N]: class id for the equality filter; NULL = no filtering possible. */
+int erh_set_doc_meta(erh_handle *h, int64_t N, const int32_t *content_id, const int16_t *dir_id);
+
+/* ---- queries ------------------------------------------------------------------------- */
+
+/* Dense top-k for B queries.  q is [B x d] (ERH_F16 or ERH_F32, host or device); normalize_q != 0
+ * L2-normalises each query.  filter_dir: host int16[B], -1 = unfiltered, or NULL.
+ * out_ids int32[B*k], out_scores float64[B*k], out_len int32[B] (all host or all device). */
+int erh_dense_topk(erh_handle *h, const void *q, int q_dtype, int q_is_device, int normalize_q,
+                   int B, int k, const int16_t *filter_dir, int mode,
+                   int32_t *out_ids, double *out_scores, int32_t *out_len, int out_is_device, void *stream);
+
+/* BM25 top-k.  Queries as CSR of term ids (host): q_indptr int32[B+1], q_tok int32[q_indptr[B]].
+ * Documents with score <= 0 are never returned (retrievers.py:195-196), so out_len[b] <= k. */
+int erh_bm25_topk(erh_handle *h, const int32_t *q_indptr, const int32_t *q_tok, int B, int k,
+                  const int16_t *filter_dir,
+                  int32_t *out_ids, double *out_scores, int32_t *out_len, int out_is_device, void *stream);
+
+/* Dense score vector of one query (host int32[n_tok]) over all N documents: float64[N] on the host
+ * (float32 sums widened exactly for ERH_BM25_BM25S).  Mirrors BM25Retriever.get_scores. */
+int erh_bm25_scores(erh_handle *h, const int32_t *q_tok, int n_tok, double *out_scores);
+
+/* Reciprocal-rank fusion of two rank lists per query (list a first: the reference passes
+ * [sparse, dense]).  ids_x int32[B*depth_x] (entries >= len_x[b] ignored).  Key = content_id;
+ * score = sum over occurrences of 1/(rank + K), rank 1-based inside each list, float64, added in
+ * list order; ties keep first-seen order; returned id = the LAST document seen for that content. */
+int erh_rrf(erh_handle *h, const int32_t *ids_a, const int32_t *len_a, int depth_a,
+            const int32_t *ids_b, const int32_t *len_b, int depth_b, int B, int K, int topk,
+            int32_t *out_ids, double *out_scores, int32_t *out_len, int io_is_device, void *stream);
+
+/* Simple-merge fusion: de-duplicate by content keeping the FIRST occurrence, stable sort by the
+ * raw route score (float64) descending, first topk. */
+int erh_fusion(erh_handle *h, const int32_t *ids_a, const double *scores_a, const int32_t *len_a, int depth_a,
+               const int32_t *ids_b, const double *scores_b, const int32_t *len_b, int depth_b, int B, int topk,
+               int32_t *out_ids, double *out_scores, int32_t *out_len, int io_is_device, void *stream);
+
+/* Dual route fused on the device: BM25 top-k_sparse and dense top-k_dense (ERH_DENSE_EXACT),
+ * then RRF([sparse, dense], K) -> topk, without a host round trip between the stages. */
+int erh_hybrid_topk(erh_handle *h, const void *q, int q_dtype, int q_is_device, int normalize_q,
+                    const int32_t *q_indptr, const int32_t *q_tok, int B,
+                    int k_dense, int k_sparse, int K, int topk, const int16_t *filter_dir,
+                    int32_t *out_ids, double *out_scores, int32_t *out_len, int out_is_device, void *stream);
+
+/* ---- measurement / diagnostics --------------------------------------------------------- */
+
+/* Kernel timing with HIP events on the launch stream.  Kernel classes: */
+#define ERH_K_DENSE_SCAN   0   /* MFMA scan of the chunk matrix (all stages of a call) */
+#define ERH_K_DENSE_SELECT 1   /* threshold / candidate selection + fp64 re-score */
+#define ERH_K_BM25_SCAN    2   /* posting scatter-add + running top-k */
+#define ERH_K_BM25_MERGE   3
+#define ERH_K_FUSE         4   /* RRF / fusion */
+#define ERH_K_COUNT        5
+int erh_set_profiling(erh_handle *h, int enable);
+/* Sum of event-measured milliseconds and number of launches since the last reset. */
+int erh_get_kernel_time(erh_handle *h, int kernel_class, double *total_ms, int64_t *launches);
+/* Algorithmic work booked for the same launches: bytes = what the kernel must read at least (chunk rows
+ * x d x 2 + query block for the dense scan; 8 or 12 bytes per posting touched for BM25), flops = 2*rows*B*d. */
+int erh_get_kernel_work(erh_handle *h, int kernel_class, double *bytes, double *flops);
+int erh_reset_kernel_time(erh_handle *h);
+
+/* Tuning knobs (defaults in DESIGN.md): name/value pairs, e.g. "dense_n0", "dense_n1". */
+int erh_set_option(erh_handle *h, const char *name, int64_t value);
+
+/* After a dense / hybrid call with DEVICE outputs: synchronise `stream`, read the call's flag words and
+ * return ERH_ERR_OVERFLOW if a candidate list overflowed (host-output calls do this themselves). */
+int erh_dense_check(erh_handle *h, void *stream);
+
+/* Diagnostics of the last dense EXACT call: max |fp64 - fp32| over re-scored candidates, the
+ * margin used, and the number of queries whose exactness certificate failed. */
+int erh_dense_diag(erh_handle *h, double *max_abs_err, double *margin, int32_t *uncertified);
+
+/* Debug: plain (non-MFMA) fp32 scores of B fp16 queries against rows [row0, row0+rows) of the stored
+ * matrix, out float32[B*rows] on the host; and the MFMA scores of the same block. */
+int erh_debug_dense_scores(erh_handle *h, const void *q_f16_host, int B, int64_t row0, int rows,
+                           int use_mfma, float *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EASYRAG_HIP_H */
