@@ -1,0 +1,229 @@
+#!/usr/bin/env python
+"""bench.py -- queries/sec of the dual-route coarse ranker (dense + BM25 + RRF top-10) at 1M x 1024 chunks.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched under
+torch.distributed.run, one rank per GPU (RCCL).  A "step" is one pass of the hot path over one batch of
+synthetic queries: BM25 top-192 over ~50M CSR postings + dense cosine top-288 over the fp16 chunk matrix +
+RRF(K=60) -> top-10 (BASELINE.json configs[3]; the depths are the reference's yaml defaults f_topk_2 / f_topk_1).
+Per-GPU work is fixed (1024 queries per rank, corpus replicated) and the fused top-k blocks are all-gathered
+(configs[4] at N = 8): weak scaling.  Inputs are resident in HBM before the timed region; rank 0 prints ONE
+JSON line with the whole-job aggregate, the roofline of the dominant kernel (dense MFMA scan, timed with HIP
+events on the launch stream inside the library) and the CPU baseline (oracle port, rank 0, N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F16_PEAK_TF = 2500.0    # dense fp16/bf16 MFMA peak (no sparsity)
+RIDGE = MFMA_F16_PEAK_TF * 1e12 / (HBM_PEAK_GBS * 1e9)   # FLOP per byte
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="hybrid", choices=["hybrid", "dense", "bm25"])
+    ap.add_argument("--chunks", type=int, default=1_000_000)
+    ap.add_argument("--dim", type=int, default=1024)
+    ap.add_argument("--vocab", type=int, default=262_144)
+    ap.add_argument("--batch", type=int, default=0, help="queries per GPU per step (default 1024; dense-only 256)")
+    ap.add_argument("--variant", default="bm25s", choices=["bm25s", "okapi"])
+    ap.add_argument("--cpu-queries", type=int, default=12, help="queries in the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--option", action="append", default=[], help="library option name=value (e.g. dense_n1=131072)")
+    return ap.parse_args()
+
+
+def cpu_baseline(x_dev, q16_dev, idx, payload, queries, k_dense, k_sparse, topk, n_sample, workload):
+    """Oracle (reference restatement) timed on this box's host cores on a bounded sample of the same batch."""
+    import torch
+    from oracle import BM25SLucene, bm25_filter, qdrant_cosine_search, reciprocal_rank_fusion
+    from oracle.retrievers import Item
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    n_sample = min(n_sample, len(queries))
+    x32 = None
+    if workload in ("hybrid", "dense"):
+        x32 = x_dev.cpu().numpy().astype(np.float32)            # what a Qdrant local collection would hold (fp32)
+        q32 = q16_dev[:n_sample].float().cpu().numpy()
+    ora = None
+    if workload in ("hybrid", "bm25"):
+        ora = BM25SLucene()
+        ora.data, ora.indices, ora.indptr, ora.num_docs = payload, idx.doc_ids, idx.indptr, idx.n_docs
+    t0 = time.perf_counter()
+    for b in range(n_sample):
+        sp = de = None
+        if ora is not None:
+            if idx.variant == 1:
+                scores = ora.get_scores_from_ids(queries[b])
+            else:                                               # Okapi payloads: same scatter-add in float64
+                scores = np.zeros(idx.n_docs)
+                for t in queries[b]:
+                    s, e = idx.indptr[t], idx.indptr[t + 1]
+                    np.add.at(scores, idx.doc_ids[s:e], payload[s:e])
+            sp = bm25_filter(scores, k_sparse, tie="literal")
+        if x32 is not None:
+            did, dsc = qdrant_cosine_search(x32, q32[b], k_dense, prenormalized=True)
+            de = list(zip(did.tolist(), dsc.tolist()))
+        if workload == "hybrid":
+            reciprocal_rank_fusion([[Item(i, i, s) for i, s in sp], [Item(i, i, s) for i, s in de]], K=60, topk=topk)
+    dt = time.perf_counter() - t0
+    what = {"hybrid": "BM25(add.at over CSR, argsort, walk) + dense(np.dot fp32 1Mx1024, argsort, walk) + RRF",
+            "dense": "dense(np.dot fp32, argsort, walk)", "bm25": "BM25(add.at over CSR, argsort, walk)"}[workload]
+    return {"value": n_sample / dt, "unit": "queries/s", "cores": int(threads), "kind": "port",
+            "sample": f"{n_sample} queries of the same batch, one at a time as the reference does; {what}; "
+                      f"{dt:.1f} s of CPU work"}
+
+
+def main():
+    args = parse_args()
+    import torch
+    from easyrag_amd import dist as erd
+    from easyrag_amd import synth
+    from easyrag_amd._lib import ERH_K_BM25_MERGE, ERH_K_BM25_SCAN, ERH_K_DENSE_SCAN, ERH_K_DENSE_SELECT, ERH_K_FUSE
+    from easyrag_amd.engine import RetrievalEngine, queries_to_csr
+    from easyrag_amd.index import BM25S, OKAPI, build_bm25_index_from_postings
+
+    rank, world = erd.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1")
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    n, d, vocab = args.chunks, args.dim, args.vocab
+    B = args.batch or (256 if args.workload == "dense" else 1024)
+    k_dense, k_sparse, topk = (100, 0, 100) if args.workload == "dense" else (288, 192, 10)
+    if args.workload == "bm25":
+        k_dense, k_sparse, topk = 0, 100, 100
+    variant = BM25S if args.variant == "bm25s" else OKAPI
+
+    # ---- synthetic corpus, replicated on every rank (same seeds); queries differ per rank -------------------
+    eng = RetrievalEngine(local)
+    for opt in args.option:
+        name, val = opt.split("=")
+        eng.set_option(name, int(val))
+    x = q16 = idx = None
+    queries = []
+    if args.workload in ("hybrid", "dense"):
+        x = synth.dense_corpus_torch(n, d, seed=2, device=dev)
+        q16 = synth.dense_queries_torch(x, B, seed=1000 + rank)
+        eng.set_dense(x)
+    if args.workload in ("hybrid", "bm25"):
+        indptr, doc, tf, lens, flat = synth.token_csr_torch(n, vocab, seed=3, device=dev)
+        idx = build_bm25_index_from_postings(indptr, doc, tf, lens, variant, compute_payload=False)
+        eng.set_bm25(idx, payload_on_device=True)            # IDF*TF/(TF + k1*lenNorm) evaluated by the GPU
+        queries = synth.token_queries(flat, lens, vocab, B, seed=2000 + rank)
+        del flat
+    eng.set_doc_meta(n, None, None)
+    qi, qt = queries_to_csr(queries) if queries else (None, None)
+    torch.cuda.synchronize()
+
+    def step():
+        if args.workload == "hybrid":
+            out = eng.hybrid_topk(q16, qi, qt, k_dense=k_dense, k_sparse=k_sparse, K=60, topk=topk, device_out=True)
+        elif args.workload == "dense":
+            out = eng.dense_topk(q16, k_dense, device_out=True)
+        else:
+            out = eng.bm25_topk(qi, qt, k_sparse, device_out=True)
+        if world > 1:
+            out = erd.allgather_topk(out[0], out[1], out[2], B * world)
+        return out
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if args.workload != "bm25":
+        eng.dense_check()                                     # raises on candidate overflow
+    eng.set_profiling(True)
+    eng.reset_kernel_time()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    eng.set_profiling(False)
+    if args.workload != "bm25":
+        eng.dense_check()
+
+    if rank == 0:
+        kt = {name: eng.kernel_time(cls) for name, cls in
+              (("dense_scan", ERH_K_DENSE_SCAN), ("dense_select", ERH_K_DENSE_SELECT), ("bm25_scan", ERH_K_BM25_SCAN),
+               ("bm25_merge", ERH_K_BM25_MERGE), ("fuse", ERH_K_FUSE))}
+        per_step = {k_: (v["ms"] / args.steps) for k_, v in kt.items()}
+        dom = "bm25_scan" if args.workload == "bm25" else "dense_scan"
+        kd = kt[dom]
+        roof = None
+        if kd["launches"]:
+            sec = kd["ms"] * 1e-3
+            ai = kd["flops"] / kd["bytes"] if kd["bytes"] else 0.0
+            if dom == "dense_scan" and ai > RIDGE:
+                ach = kd["flops"] / sec / 1e12
+                roof = {"bound": "mfma", "achieved": ach, "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s",
+                        "frac": ach / MFMA_F16_PEAK_TF, "traffic": None}
+            else:
+                ach = kd["bytes"] / sec / 1e9
+                roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": ach / HBM_PEAK_GBS, "traffic": None}
+            roof.update({"kernel": dom, "launches": int(kd["launches"]),
+                         "avg_launch_ms": kd["ms"] / kd["launches"],
+                         "algorithmic_bytes_per_launch": kd["bytes"] / kd["launches"],
+                         "flops_per_launch": kd["flops"] / kd["launches"],
+                         "arithmetic_intensity": ai,
+                         "hbm_equiv_gbs": kd["bytes"] / sec / 1e9 if kd["bytes"] else None})
+        cpu = None
+        if world == 1 and args.cpu_queries > 0:
+            payload = eng.get_bm25_payload() if idx is not None else None
+            cpu = cpu_baseline(x, q16, idx, payload, queries, k_dense, k_sparse, topk, args.cpu_queries, args.workload)
+        total_q = B * world * args.steps
+        workload_name = {
+            "hybrid": f"configs[3]: 1M chunks, dual-route dense(top-{k_dense})+BM25(top-{k_sparse}) with RRF top-{topk}",
+            "dense": f"configs[1]: 1M chunks x 1024-d fp16, dense cosine top-{k_dense} only",
+            "bm25": f"configs[2]: 1M chunks, BM25 only top-{k_sparse}"}[args.workload]
+        rec = {
+            "metric": "queries/sec (dense+BM25+RRF top-10) at 1Mx1024 chunks" if args.workload == "hybrid"
+                      else f"queries/sec ({args.workload} only) at 1Mx1024 chunks",
+            "value": total_q / dt, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16" if args.workload != "bm25" else ("f32" if variant == BM25S else "f64"),
+            "data": "synthetic",
+            "config": {"workload": workload_name, "chunks": n, "dim": d, "vocab": vocab,
+                       "postings": int(idx.nnz) if idx is not None else 0,
+                       "queries_per_gpu": B, "global_batch": B * world,
+                       "bm25_variant": args.variant if idx is not None else None,
+                       "parallelism": f"query-sharded x{world}, corpus replicated, all-gather of fused top-k"},
+            "roofline": roof,
+            "cpu_baseline": cpu,
+            "kernel_ms_per_step": per_step,
+        }
+        print(json.dumps(rec), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

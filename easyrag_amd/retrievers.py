@@ -66,6 +66,17 @@ def tokenize_and_remove_stopwords(tokenizer, text, stopwords):
     return [w for w in tokenizer.cut(text) if w not in stopwords and w != " "]
 
 
+def _unit_f16(v) -> np.ndarray:
+    """L2-normalise rows in float64, round once to float16: the query / chunk representation the kernels score.
+    (Qdrant normalises both sides for Distance.COSINE; doing it here pins the fp16 rounding on the host.)"""
+    v64 = np.asarray(v, dtype=np.float32).astype(np.float64)
+    if v64.ndim == 1:
+        v64 = v64[None, :]
+    n = np.sqrt(np.sum(v64 * v64, axis=-1, keepdims=True))
+    n = np.where(n != 0.0, n, 1e-12)
+    return (v64 / n).astype(np.float16)
+
+
 def _as_bundle(q) -> QueryBundle:
     return q if isinstance(q, QueryBundle) else QueryBundle(query_str=str(q))
 
@@ -158,7 +169,10 @@ class HipVectorStore:
         self.corpus = _corpus_for(nodes, engine)
         self.engine = self.corpus.engine
         is_f16 = str(getattr(embeddings, "dtype", "")).endswith("float16")
-        self.engine.set_dense(embeddings, normalize=normalize and not is_f16)
+        if normalize and not is_f16 and isinstance(embeddings, np.ndarray):
+            self.engine.set_dense(_unit_f16(embeddings))             # host: fp16 rounding of the unit rows is pinned
+        else:
+            self.engine.set_dense(embeddings, normalize=normalize and not is_f16)   # device tensors: normalise on the GPU
 
     @property
     def nodes(self):
@@ -166,12 +180,10 @@ class HipVectorStore:
 
     def query_batch(self, query_embeddings, similarity_top_k: int, filters=None, mode: int = _lib.ERH_DENSE_EXACT):
         fd = _filter_to_dict(filters)
-        q = np.asarray(query_embeddings, dtype=np.float32)
-        if q.ndim == 1:
-            q = q[None, :]
+        q = _unit_f16(query_embeddings)
         cls = self.corpus.filter_class(fd)
         filt = None if cls < 0 else np.full(q.shape[0], cls, np.int16)
-        return self.engine.dense_topk(q, similarity_top_k, filter_dir=filt, mode=mode, normalize_q=True)
+        return self.engine.dense_topk(q, similarity_top_k, filter_dir=filt, mode=mode)
 
     def query(self, query_embedding, similarity_top_k: int, filters=None):
         ids, sc, ln = self.query_batch(query_embedding, similarity_top_k, filters)
@@ -409,10 +421,10 @@ class HybridRetriever(_RetrieverBase):
         cls = sp._corpus_state.filter_class(fd)
         filt = None if cls < 0 else np.full(len(queries), cls, np.int16)
         qi, qt = queries_to_csr([sp._query_ids(q) for q in queries])
-        embs = np.asarray([de._embed_model.get_query_embedding(q) for q in queries], dtype=np.float32)
+        embs = _unit_f16(np.asarray([de._embed_model.get_query_embedding(q) for q in queries], dtype=np.float32))
         ids, sc, ln = sp.engine.hybrid_topk(embs, qi, qt, k_dense=de._similarity_top_k,
                                             k_sparse=sp._similarity_top_k, K=60, topk=self.topk,
-                                            filter_dir=filt, normalize_q=True)
+                                            filter_dir=filt)
         nodes = sp._nodes
         return [[NodeWithScore(node=nodes[i], score=float(s)) for i, s in zip(ids[b, :ln[b]], sc[b, :ln[b]])]
                 for b in range(len(queries))]

@@ -45,13 +45,18 @@ def to_f16_unit(v: np.ndarray) -> np.ndarray:
 
 
 def qdrant_cosine_search(vectors: np.ndarray, query: np.ndarray, limit: int,
-                         mask: Optional[np.ndarray] = None) -> Tuple[np.ndarray, np.ndarray]:
+                         mask: Optional[np.ndarray] = None, prenormalized: bool = False
+                         ) -> Tuple[np.ndarray, np.ndarray]:
     """qdrant-client local-mode COSINE search restated.  `vectors` is whatever was upserted
     (any float dtype; stored as float32), `query` the embedding list.  Returns (ids, scores)
-    in the literal ``np.argsort(scores)[::-1]`` order (ties implementation-defined)."""
+    in the literal ``np.argsort(scores)[::-1]`` order (ties implementation-defined).
+    prenormalized=True = the insert-time normalisation already happened (the per-query work is
+    then only the query normalisation, the GEMV, the argsort and the walk -- what a timed
+    baseline should count)."""
     vec = np.asarray(vectors, dtype=np.float32)
-    norm = np.linalg.norm(vec, axis=-1)[:, np.newaxis]
-    vec = vec / np.where(norm != 0.0, norm, EPS).astype(np.float32)
+    if not prenormalized:
+        norm = np.linalg.norm(vec, axis=-1)[:, np.newaxis]
+        vec = vec / np.where(norm != 0.0, norm, EPS).astype(np.float32)
     q = np.asarray(query, dtype=np.float32)
     qn = np.linalg.norm(q)
     q = q / np.float32(qn if qn != 0.0 else EPS)

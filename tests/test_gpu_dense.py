@@ -1,0 +1,169 @@
+"""GPU parity, dense route: HIP path (through the C ABI) vs the oracle on the same seeded inputs.
+
+Bars (BASELINE.json north_star): fp32 MFMA cosine within 1e-3 of the reference-style fp32 scores; ranking
+ids and fp64 scores bit-identical to oracle.dense_exact_topk (pinned summation order, canonical ties).
+"""
+import numpy as np
+import pytest
+
+from easyrag_amd import _lib, synth
+from oracle import dense_exact_scores, dense_exact_topk, qdrant_cosine_search, to_f16_unit
+
+pytestmark = pytest.mark.gpu
+
+
+def test_mfma_scores_match_plain_gpu_and_numpy(engine):
+    # asymmetric operands: a swapped C/D layout or a wrong swizzle cannot pass
+    rng = np.random.default_rng(11)
+    n, d, b = 1000, 128, 70
+    x = to_f16_unit(rng.standard_normal((n, d)) * np.linspace(0.2, 3.0, d))
+    q = to_f16_unit(rng.standard_normal((b, d)) + 0.5)
+    engine.set_dense(x)
+    ref = x.astype(np.float32) @ q.astype(np.float32).T          # [n, b]
+    for row0, rows in ((0, 1000), (37, 300), (999, 1)):
+        naive = engine.debug_dense_scores(q, row0, rows, use_mfma=False)
+        mfma = engine.debug_dense_scores(q, row0, rows, use_mfma=True)
+        want = ref[row0:row0 + rows].T
+        assert np.max(np.abs(naive - want)) < 1e-4
+        assert np.max(np.abs(mfma - want)) < 1e-4
+        assert np.max(np.abs(mfma - naive)) < 1e-4
+
+
+CASES = [
+    # n, d, B, k, n0, n1
+    (300, 64, 3, 10, 32768, 262144),        # everything inside the seed prefix, N < k*...
+    (5000, 256, 17, 100, 1024, 3072),       # seed -> append -> refine -> append
+    (5000, 768, 40, 288, 512, 0),           # no refine stage
+    (20000, 1024, 300, 10, 2048, 8192),     # B > one query tile
+    (257, 64, 1, 288, 32768, 0),            # k > N
+]
+
+
+@pytest.mark.parametrize("n,d,b,k,n0,n1", CASES)
+def test_dense_topk_exact_matches_oracle(engine, n, d, b, k, n0, n1):
+    x = synth.dense_corpus(n, d, seed=n + d)
+    q32 = synth.dense_queries(x, b, seed=b + k)
+    q16 = to_f16_unit(q32)
+    engine.set_dense(x)
+    engine.set_option("dense_n0", n0)
+    engine.set_option("dense_n1", n1)
+    try:
+        ids, sc, ln = engine.dense_topk(q16, k, mode=_lib.ERH_DENSE_EXACT)
+        fids, fsc, fln = engine.dense_topk(q16, k, mode=_lib.ERH_DENSE_FAST)
+    finally:
+        engine.set_option("dense_n0", 32768)
+        engine.set_option("dense_n1", 262144)
+    diag = engine.dense_diag()
+    assert diag["uncertified"] == 0 and diag["max_abs_err"] <= diag["margin"]
+    kk = min(k, n)
+    assert np.all(ln == kk) and np.all(fln == kk)
+    check = sorted(set(list(range(min(b, 6))) + list(range(0, b, max(1, b // 10))) + [b - 1, min(b - 1, 256)]))
+    for i in check:                                   # the oracle is O(n*d) fp64 per query: sample large batches
+        oid, osc = dense_exact_topk(x, q16[i], k)
+        assert ln[i] == kk and fln[i] == kk
+        assert np.array_equal(ids[i, :kk], oid), f"query {i}: ids differ"
+        assert np.array_equal(sc[i, :kk].view(np.uint64), osc.view(np.uint64)), f"query {i}: fp64 scores differ"
+        assert np.all(ids[i, kk:] == -1)
+        # fp32 MFMA ranking: scores within 1e-3 (in practice ~1e-6) of the exact ones
+        exact_of_fast = dense_exact_scores(x, q16[i], rows=fids[i, :kk])
+        assert np.max(np.abs(fsc[i, :kk] - exact_of_fast)) < 1e-3
+        assert np.all(np.diff(fsc[i, :kk]) <= 0)
+    # against the qdrant-local style fp32 search (reference semantics): cosine within 1e-3, same id set
+    for i in range(min(b, 4)):
+        qi, qs = qdrant_cosine_search(x.astype(np.float32), q32[i], k)
+        assert np.max(np.abs(np.sort(qs)[::-1] - sc[i, :kk])) < 1e-3
+        assert len(set(qi) & set(ids[i, :kk])) >= kk - 2            # only near-ties at the cut may differ
+
+
+def test_dense_duplicates_and_filter(engine):
+    rng = np.random.default_rng(3)
+    base = to_f16_unit(rng.standard_normal((50, 128)))
+    x = np.repeat(base, 8, axis=0)                        # every chunk 8 times: exact ties everywhere
+    n = x.shape[0]
+    q16 = base[[5, 17, 33]]
+    dir_id = (np.arange(n) % 3).astype(np.int16)
+    engine.set_dense(x)
+    engine.set_doc_meta(n, None, dir_id)
+    ids, sc, ln = engine.dense_topk(q16, 12)
+    for i in range(3):
+        oid, osc = dense_exact_topk(x, q16[i], 12)
+        assert np.array_equal(ids[i], oid) and np.array_equal(sc[i], osc)
+    filt = np.array([0, 2, -1], np.int16)
+    ids, sc, ln = engine.dense_topk(q16, 12, filter_dir=filt)
+    for i in range(3):
+        mask = None if filt[i] < 0 else (dir_id == filt[i])
+        oid, osc = dense_exact_topk(x, q16[i], 12, mask)
+        assert np.array_equal(ids[i, :ln[i]], oid) and np.array_equal(sc[i, :ln[i]], osc)
+
+
+def test_dense_fp32_inputs_normalised_on_device(engine):
+    rng = np.random.default_rng(8)
+    x32 = (rng.standard_normal((3000, 192)) * 3).astype(np.float32)
+    q32 = (rng.standard_normal((9, 192)) * 0.1).astype(np.float32)
+    engine.set_dense(x32, normalize=True)
+    ids, sc, ln = engine.dense_topk(q32, 20, normalize_q=True)
+    for i in range(9):
+        qi, qs = qdrant_cosine_search(x32, q32[i], 20)             # reference semantics on the fp32 originals
+        assert np.max(np.abs(qs - sc[i])) < 1e-3                   # fp16 storage of unit rows: ~1e-4
+        assert len(set(qi) & set(ids[i])) >= 18
+
+
+def test_dense_errors(engine):
+    x = synth.dense_corpus(100, 64, seed=1)
+    engine.set_dense(x)
+    with pytest.raises(_lib.ErhError):
+        engine.dense_topk(x[:2], 0)
+    with pytest.raises(_lib.ErhError):
+        engine.dense_topk(x[:2], 5000)
+    with pytest.raises(_lib.ErhError):
+        engine.set_dense(np.zeros((10, 100), np.float16))          # d % 64 != 0
+    from easyrag_amd.engine import RetrievalEngine
+    fresh = RetrievalEngine(0)
+    try:
+        with pytest.raises(_lib.ErhError):
+            fresh.dense_topk(x[:2], 5)                              # before set_dense
+        fresh.set_dense(x)
+        with pytest.raises(_lib.ErhError):
+            fresh.dense_topk(x[:2], 5, filter_dir=np.array([1, 1], np.int16))   # filter without dir metadata
+        ids, sc, ln = fresh.dense_topk(x[:2], 5, filter_dir=np.array([-1, -1], np.int16))
+        assert np.all(ln == 5) and ids[0, 0] == 0 and ids[1, 0] == 1
+    finally:
+        fresh.close()
+
+
+def test_dense_full_size_properties(engine):
+    """Config 2 shape (1M x 1024 fp16, B = 256, k = 100): size-independent properties + sampled exactness."""
+    import torch
+    dev = torch.device("cuda", 0)
+    n, d, b, k = 1_000_000, 1024, 256, 100
+    x = synth.dense_corpus_torch(n, d, seed=2, device=dev)
+    q = synth.dense_queries_torch(x, b, seed=5)
+    planted = torch.randint(0, n, (b,), generator=torch.Generator().manual_seed(9))
+    q[:16] = x[planted[:16].to(dev)]                                # exact copies: top-1 must be the row itself
+    engine.set_dense(x)
+    ids, sc, ln = engine.dense_topk(q, k)
+    diag = engine.dense_diag()
+    assert diag["uncertified"] == 0 and diag["max_abs_err"] <= diag["margin"]
+    assert np.all(ln == k) and np.all(ids >= 0) and np.all(ids < n)
+    assert np.all(np.diff(sc, axis=1) <= 0)                        # sorted
+    for i in range(b):
+        assert len(set(ids[i])) == k                               # no duplicates
+    for i in range(16):
+        assert ids[i, 0] == int(planted[i]) or sc[i, 0] == sc[i, 1]
+        assert abs(sc[i, 0] - 1.0) < 2e-3
+    # returned fp64 scores are the pinned-order scores of exactly those rows
+    xs = x[torch.from_numpy(ids[:4].reshape(-1).astype(np.int64)).to(dev)].cpu().numpy().reshape(4, k, d)
+    qh = q[:4].cpu().numpy()
+    for i in range(4):
+        assert np.array_equal(dense_exact_scores(xs[i], qh[i]), sc[i])
+    # no chunk outside the result beats the k-th score: exact check on a 200k-row slab for 4 queries
+    slab = x[300_000:500_000].cpu().numpy()
+    for i in range(4):
+        s = slab.astype(np.float32) @ qh[i].astype(np.float32)
+        top = np.argsort(-s)[:5] + 300_000
+        for t in top:
+            st = dense_exact_scores(slab[t - 300_000][None], qh[i])[0]
+            assert (t in ids[i]) or st < sc[i, k - 1] or (st == sc[i, k - 1] and t > ids[i, k - 1])
+    # idempotence
+    ids2, sc2, _ = engine.dense_topk(q, k)
+    assert np.array_equal(ids, ids2) and np.array_equal(sc, sc2)

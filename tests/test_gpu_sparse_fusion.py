@@ -1,0 +1,218 @@
+"""GPU parity, sparse route + fusion + the fused dual route: HIP path (C ABI) vs the oracle.
+Bar: ids and scores bit-identical (float64 for Okapi, float32 for bm25s) under canonical ties."""
+import numpy as np
+import pytest
+
+from easyrag_amd import synth
+from easyrag_amd.engine import queries_to_csr
+from easyrag_amd.index import BM25S, OKAPI, build_bm25_index, build_bm25_index_from_ids
+from oracle import (BM25Okapi, BM25SLucene, bm25_filter, dense_exact_topk, fusion, reciprocal_rank_fusion,
+                    to_f16_unit)
+from oracle.retrievers import Item
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_for(variant, docs):
+    if variant == OKAPI:
+        return BM25Okapi(docs, k1=1.5, b=0.75, epsilon=0.25)
+    return BM25SLucene(k1=1.5, b=0.75).index(docs)
+
+
+def _oracle_scores(ora, variant, q):
+    if variant == BM25S and len(q) == 0:
+        return np.zeros(ora.num_docs, np.float32)
+    return ora.get_scores(q)
+
+
+@pytest.mark.parametrize("variant", [OKAPI, BM25S])
+@pytest.mark.parametrize("n_docs,vocab,seed", [(60, 10, 0), (3000, 500, 1), (40000, 2000, 2)])
+def test_bm25_scores_and_topk_match_oracle(engine, variant, n_docs, vocab, seed):
+    flat, lens = synth.token_corpus(n_docs, vocab, seed=seed, mean_len=20)
+    docs = [list(map(int, d)) for d in synth.split_docs(flat, lens)]
+    ora = _oracle_for(variant, docs)
+    idx = build_bm25_index(docs, variant)
+    engine.set_bm25(idx)
+    rng = np.random.default_rng(seed + 100)
+    queries = [list(map(int, q)) for q in synth.token_queries(flat, lens, vocab, 24, seed=seed + 7)]
+    queries[3] = []                                                   # empty query
+    queries[4] = [vocab + 5, vocab + 6]                                # all out of vocabulary
+    queries[5] = queries[6] + queries[6]                               # repeats count twice
+    oscores = [_oracle_scores(ora, variant, q) for q in queries]
+    # get_scores parity (dense vector)
+    for b in list(range(6)) + [21, 22, 23]:
+        got = engine.bm25_scores(idx.tokens_to_ids(queries[b]))
+        assert np.array_equal(got, oscores[b].astype(np.float64)), "score vector differs"
+    # fused scan + top-k parity
+    qi, qt = queries_to_csr([idx.tokens_to_ids(q) for q in queries])
+    for k in (1, 10, 192):
+        ids, sc, ln = engine.bm25_topk(qi, qt, k)
+        for b, q in enumerate(queries):
+            want = bm25_filter(oscores[b], k)
+            assert ln[b] == len(want)
+            assert list(ids[b, :ln[b]]) == [w[0] for w in want], f"k={k} query {b}: ids differ"
+            assert list(sc[b, :ln[b]]) == [w[1] for w in want], f"k={k} query {b}: scores differ"
+            assert np.all(ids[b, ln[b]:] == -1)
+
+
+@pytest.mark.parametrize("variant", [OKAPI, BM25S])
+def test_bm25_ties_and_filter(engine, variant):
+    # 16 distinct documents repeated 40 times each: exact score ties across the whole corpus, ordered by index
+    rng = np.random.default_rng(4)
+    base = [list(map(int, rng.integers(0, 12, size=rng.integers(3, 9)))) for _ in range(16)]
+    docs = [base[i % 16] for i in range(640)]
+    ora = _oracle_for(variant, docs)
+    idx = build_bm25_index(docs, variant)
+    engine.set_bm25(idx)
+    dir_id = (np.arange(640) // 100).astype(np.int16)
+    engine.set_doc_meta(640, None, dir_id)
+    queries = [[0, 1, 2], [5], [3, 3, 7, 11], [2, 9]]
+    qi, qt = queries_to_csr([idx.tokens_to_ids(q) for q in queries])
+    filt = np.array([-1, 2, 6, 0], np.int16)
+    for k in (7, 100):
+        ids, sc, ln = engine.bm25_topk(qi, qt, k, filter_dir=filt)
+        for b, q in enumerate(queries):
+            mask = None if filt[b] < 0 else dir_id == filt[b]
+            want = bm25_filter(_oracle_scores(ora, variant, q), k, mask)
+            assert list(ids[b, :ln[b]]) == [w[0] for w in want] and list(sc[b, :ln[b]]) == [w[1] for w in want]
+
+
+@pytest.mark.parametrize("variant", [OKAPI, BM25S])
+def test_bm25_payload_evaluated_on_gpu_is_bit_identical(engine, variant):
+    flat, lens = synth.token_corpus(5000, 800, seed=21, mean_len=30)
+    idx = build_bm25_index_from_ids(flat=flat, doc_lens=lens, n_vocab=800, variant=variant)
+    engine.set_bm25(idx, payload_on_device=True)
+    got = engine.get_bm25_payload()
+    assert got.dtype == idx.payload.dtype and np.array_equal(got, idx.payload)
+
+
+def test_bm25_single_query_uses_segments_and_merge(engine):
+    # B = 1 splits the document range over several workgroups and merges the partial lists
+    flat, lens = synth.token_corpus(150000, 3000, seed=5, mean_len=16)
+    idx = build_bm25_index_from_ids(flat=flat, doc_lens=lens, n_vocab=3000, variant=BM25S)
+    engine.set_bm25(idx)
+    q = synth.token_queries(flat, lens, 3000, 1, seed=1)[0]
+    qi, qt = queries_to_csr([q])
+    ids, sc, ln = engine.bm25_topk(qi, qt, 50)
+    scores = engine.bm25_scores(q)
+    want = bm25_filter(scores, 50)
+    assert list(ids[0, :ln[0]]) == [w[0] for w in want] and list(sc[0, :ln[0]]) == [w[1] for w in want]
+    # and the score vector itself against a numpy scatter-add in token order
+    acc = np.zeros(idx.n_docs, np.float32)
+    for t in q:
+        s, e = idx.indptr[t], idx.indptr[t + 1]
+        np.add.at(acc, idx.doc_ids[s:e], idx.payload[s:e])
+    assert np.array_equal(scores, acc.astype(np.float64))
+
+
+def _random_lists(rng, n_items, la, lb, dup_rate):
+    ids_a = rng.choice(n_items, size=la, replace=False)
+    ids_b = rng.choice(n_items, size=lb, replace=False)
+    cid = np.arange(n_items)
+    dup = rng.random(n_items) < dup_rate
+    cid[dup] = rng.integers(0, n_items, size=int(dup.sum()))
+    cid = np.minimum(cid, np.arange(n_items))             # content id = some earlier-or-equal index
+    return ids_a, ids_b, cid.astype(np.int32)
+
+
+def test_rrf_and_fusion_match_oracle(engine):
+    rng = np.random.default_rng(12)
+    n_items, B = 5000, 40
+    depth_a, depth_b = 192, 288
+    _, _, cid = _random_lists(rng, n_items, 1, 1, 0.05)
+    engine.set_doc_meta(n_items, cid, None)
+    ids_a = np.full((B, depth_a), -1, np.int32)
+    ids_b = np.full((B, depth_b), -1, np.int32)
+    sc_a = np.zeros((B, depth_a))
+    sc_b = np.zeros((B, depth_b))
+    la = rng.integers(0, depth_a + 1, size=B).astype(np.int32)
+    lb = rng.integers(0, depth_b + 1, size=B).astype(np.int32)
+    la[0], lb[0] = 0, 0
+    la[1], lb[1] = 0, 7
+    la[2], lb[2] = depth_a, depth_b
+    for b in range(B):
+        ids_a[b, :la[b]] = rng.choice(n_items, size=la[b], replace=False)
+        # overlap the two routes heavily, as real retrieval does
+        pool = np.concatenate([ids_a[b, :la[b]], rng.choice(n_items, size=depth_b, replace=False)])
+        ids_b[b, :lb[b]] = rng.permutation(np.unique(pool))[:lb[b]]
+        sc_a[b, :la[b]] = np.sort(rng.integers(1, 30, size=la[b]))[::-1]          # integer scores -> many ties
+        sc_b[b, :lb[b]] = np.sort(rng.random(lb[b]))[::-1]
+    for topk in (10, 256):
+        rid, rsc, rln = engine.rrf(ids_a, la, ids_b, lb, K=60, topk=topk)
+        fid, fsc, fln = engine.fusion(ids_a, sc_a, la, ids_b, sc_b, lb, topk=topk)
+        for b in range(B):
+            A = [Item(int(i), int(cid[i]), float(s)) for i, s in zip(ids_a[b, :la[b]], sc_a[b, :la[b]])]
+            Bl = [Item(int(i), int(cid[i]), float(s)) for i, s in zip(ids_b[b, :lb[b]], sc_b[b, :lb[b]])]
+            want = reciprocal_rank_fusion([A, Bl], K=60, topk=topk)
+            assert rln[b] == len(want)
+            assert list(rid[b, :rln[b]]) == [w.idx for w in want]
+            assert list(rsc[b, :rln[b]]) == [w.score for w in want]
+            wantf = fusion([A, Bl], topk=topk)
+            assert fln[b] == len(wantf)
+            assert list(fid[b, :fln[b]]) == [w.idx for w in wantf]
+            assert list(fsc[b, :fln[b]]) == [w.score for w in wantf]
+
+
+@pytest.mark.parametrize("variant", [OKAPI, BM25S])
+def test_hybrid_dual_route_matches_oracle_composition(engine, variant):
+    """Config 1 shape scaled to the GPU test budget: dense(288) + BM25(192) + RRF(60) -> top-10."""
+    n, d, vocab, B = 10000, 768, 4096, 24
+    x = synth.dense_corpus(n, d, seed=1)
+    q16 = to_f16_unit(synth.dense_queries(x, B, seed=2))
+    flat, lens = synth.token_corpus(n, vocab, seed=3)
+    docs = [list(map(int, t)) for t in synth.split_docs(flat, lens)]
+    idx = build_bm25_index(docs, variant)
+    ora = _oracle_for(variant, docs)
+    queries = [list(map(int, q)) for q in synth.token_queries(flat, lens, vocab, B, seed=4)]
+    # 1 % duplicated contents (SURVEY.md 8(d) config 4 variant)
+    rng = np.random.default_rng(6)
+    cid = np.arange(n, dtype=np.int32)
+    dup = rng.choice(n, size=n // 100, replace=False)
+    cid[dup] = np.minimum(cid[dup], rng.integers(0, n, size=dup.shape[0]))
+    engine.set_dense(x)
+    engine.set_bm25(idx)
+    engine.set_doc_meta(n, cid, None)
+    qi, qt = queries_to_csr([idx.tokens_to_ids(q) for q in queries])
+    o_sparse = [bm25_filter(_oracle_scores(ora, variant, queries[b]), 192) for b in range(B)]
+    o_dense = [dense_exact_topk(x, q16[b], 288) for b in range(B)]
+    for topk in (10, 256):
+        ids, sc, ln = engine.hybrid_topk(q16, qi, qt, k_dense=288, k_sparse=192, K=60, topk=topk)
+        for b in range(B):
+            sp = o_sparse[b]
+            did, dsc = o_dense[b]
+            A = [Item(i, int(cid[i]), s) for i, s in sp]
+            Bl = [Item(int(i), int(cid[i]), float(s)) for i, s in zip(did, dsc)]
+            want = reciprocal_rank_fusion([A, Bl], K=60, topk=topk)
+            assert ln[b] == len(want)
+            assert list(ids[b, :ln[b]]) == [w.idx for w in want], f"query {b}: fused ids differ"
+            assert list(sc[b, :ln[b]]) == [w.score for w in want]
+
+
+def test_bm25_full_size_properties(engine):
+    """Config 3 shape: 1M documents, ~50M postings, B = 256, bm25s payloads.  Exact comparison against a numpy
+    scatter-add for a sample of queries plus size-independent properties for all of them."""
+    import torch
+    dev = torch.device("cuda", 0)
+    n, vocab, B, k = 1_000_000, 262_144, 256, 100
+    indptr, doc, tf, lens, flat = synth.token_csr_torch(n, vocab, seed=3, device=dev)
+    from easyrag_amd.index import build_bm25_index_from_postings
+    idx = build_bm25_index_from_postings(indptr, doc, tf, lens, BM25S)
+    assert 30_000_000 < idx.nnz < 70_000_000
+    engine.set_bm25(idx)
+    queries = synth.token_queries(flat, lens, vocab, B, seed=9)
+    qi, qt = queries_to_csr(queries)
+    ids, sc, ln = engine.bm25_topk(qi, qt, k)
+    assert np.all(ln <= k) and np.all(ln > 0)
+    for b in range(B):
+        m = ln[b]
+        assert np.all(sc[b, :m] > 0) and np.all(np.diff(sc[b, :m]) <= 0)
+        assert len(set(ids[b, :m])) == m
+        tie = np.diff(sc[b, :m]) == 0
+        assert np.all(np.diff(ids[b, :m])[tie] > 0)                  # equal scores ordered by index
+    for b in (0, 1, 77, 255):
+        acc = np.zeros(n, np.float32)
+        for t in queries[b]:
+            s, e = idx.indptr[t], idx.indptr[t + 1]
+            np.add.at(acc, idx.doc_ids[s:e], idx.payload[s:e])
+        want = bm25_filter(acc, k)
+        assert list(ids[b, :ln[b]]) == [w[0] for w in want] and list(sc[b, :ln[b]]) == [w[1] for w in want]
