@@ -24,6 +24,6 @@ if [[ "$what" == "all" || "$what" == "bench" ]]; then
   tail -c 2000 gpurun_out/bench_bm25.json; tail -5 gpurun_out/bench_bm25.err
 fi
 if [[ "$what" == "all" || "$what" == "prof" ]]; then
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_hybrid -o hybrid -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --cpu-queries 0 > $GRAFT_REPO_ROOT/gpurun_out/prof_hybrid.log 2>&1); echo "rocprof exit $?"
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_hybrid -o hybrid -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --cpu-queries 0 > $GRAFT_REPO_ROOT/gpurun_out/prof_hybrid.log 2>&1); echo "rocprof exit $?"
   find gpurun_out/prof_hybrid -name "*stats*" | head; for f in $(find gpurun_out/prof_hybrid -name "*kernel_stats.csv"); do head -20 $f; done
 fi
