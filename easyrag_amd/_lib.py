@@ -56,6 +56,7 @@ SIGNATURES = {
     "erh_reset_kernel_time": (_i32, [_vp]),
     "erh_set_option": (_i32, [_vp, C.c_char_p, _i64]),
     "erh_dense_check": (_i32, [_vp, _vp]),
+    "erh_debug_counters": (_i32, [_vp, _vp]),
     "erh_dense_diag": (_i32, [_vp, C.POINTER(_dbl), C.POINTER(_dbl), C.POINTER(_i32)]),
     "erh_debug_dense_scores": (_i32, [_vp, _vp, _i32, _i64, _i32, _i32, _vp]),
 }

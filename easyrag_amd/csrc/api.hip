@@ -62,8 +62,14 @@ struct erh_handle {
     DevBuf hy_sids, hy_ssc, hy_slen, hy_dids, hy_dsc, hy_dlen;
     DevBuf fa_ids, fa_sc, fa_len, fb_ids, fb_sc, fb_len;
     DevBuf scores_tmp, scores_wide;
+    DevBuf dbg;                              // 16 x u64 section counters (measurement only)
+    int opt_debug_counters = 0;
     // options
-    int64_t opt_n0 = 32768, opt_n1 = 262144;
+    int64_t opt_n0 = 32768, opt_n1 = 131072;
+    int opt_dense_ablate = 0, opt_bm25_ablate = 0;
+    int opt_dense_cfg = 0;                 // dense scan tile configuration (dense_scan.hip)
+    int opt_dense_persist = 1;             // persistent append scan (falls back to the plain launch when it does not apply)
+    int n_cus = 0;   // measurement only (results invalid when non-zero)
     // profiling
     bool prof = false;
     std::vector<EvPair> pending;
@@ -131,6 +137,21 @@ void drain_events(erh_handle *h) {
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
+// Append-stage scan: persistent kernel when enabled and applicable, else one workgroup per tile.
+hipError_t scan_append(erh_handle *h, const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1, const _Float16 *Q16,
+                       int Bpad, int B, const float *tau, const int16_t *filt, const int16_t *dir, ErhCand *cand,
+                       uint32_t *cnt, int cap, uint32_t *flags, hipStream_t st) {
+    if (h->opt_dense_persist && (h->opt_dense_ablate == 0 || h->opt_dense_ablate >= 6)) {
+        hipError_t e = erh::launch_dense_scan_persist(h->opt_dense_cfg, X, N, d, c0, c1, Q16, Bpad, B, tau, filt, dir, cand,
+                                                      cnt, cap, flags, h->n_cus, h->opt_dense_ablate, st);
+        if (e != hipErrorInvalidValue) return e;
+        (void)hipGetLastError();
+    }
+    return erh::launch_dense_scan_append(h->opt_dense_cfg, X, N, d, c0, c1, Q16, Bpad, B, tau, filt, dir, cand, cnt, cap,
+                                         flags, h->opt_dense_ablate,
+                                         h->opt_debug_counters ? h->dbg.as<unsigned long long>() : nullptr, st);
+}
+
 // ---- dense pipeline on device buffers ------------------------------------------------------------
 int dense_topk_dev(erh_handle *h, const void *q_dev, int q_dtype, int normalize_q, int B, int k,
                    const int16_t *filter_dev, int mode, int32_t *d_ids, double *d_sc, int32_t *d_len, hipStream_t st) {
@@ -166,7 +187,7 @@ int dense_topk_dev(erh_handle *h, const void *q_dev, int q_dtype, int normalize_
     // stage A: score the seed prefix densely, k-th best -> pruning threshold
     scan_work(n0, &wb, &wf);
     { ProfScope ps(h, st, ERH_K_DENSE_SCAN, wb, wf);
-      HIPCHK(h, erh::launch_dense_scan_store(Q16, Bpad, X, N, d, 0, (int)n0, h->S0.as<float>(), ld, st)); }
+      HIPCHK(h, erh::launch_dense_scan_store(h->opt_dense_cfg, Q16, Bpad, X, N, d, 0, (int)n0, h->S0.as<float>(), ld, st)); }
     { ProfScope ps(h, st, ERH_K_DENSE_SELECT, 0, 0);
       HIPCHK(h, erh::launch_seed_select(h->S0.as<float>(), ld, (int)n0, 0, B, k, h->qnorm.as<float>(), h->xnorm_max, d,
                                         filter_dev, dir, h->tau.as<float>(), h->cand.as<ErhCand>(),
@@ -177,16 +198,16 @@ int dense_topk_dev(erh_handle *h, const void *q_dev, int q_dtype, int normalize_
         const int64_t b_end = n1 ? n1 : N;
         scan_work(b_end - n0, &wb, &wf);
         { ProfScope ps(h, st, ERH_K_DENSE_SCAN, wb, wf);
-          HIPCHK(h, erh::launch_dense_scan_append(X, N, d, n0, b_end, Q16, Bpad, B, h->tau.as<float>(), filter_dev, dir,
-                                                  h->cand.as<ErhCand>(), h->cand_cnt.as<uint32_t>(), cap, flags, st)); }
+          HIPCHK(h, scan_append(h, X, N, d, n0, b_end, Q16, Bpad, B, h->tau.as<float>(), filter_dev, dir,
+                                 h->cand.as<ErhCand>(), h->cand_cnt.as<uint32_t>(), cap, flags, st)); }
         if (n1) {
             { ProfScope ps(h, st, ERH_K_DENSE_SELECT, 0, 0);
               HIPCHK(h, erh::launch_cand_refine(B, k, h->qnorm.as<float>(), h->xnorm_max, d, h->tau.as<float>(),
                                                 h->cand.as<ErhCand>(), h->cand_cnt.as<uint32_t>(), cap, st)); }
             scan_work(N - n1, &wb, &wf);
             { ProfScope ps(h, st, ERH_K_DENSE_SCAN, wb, wf);
-              HIPCHK(h, erh::launch_dense_scan_append(X, N, d, n1, N, Q16, Bpad, B, h->tau.as<float>(), filter_dev, dir,
-                                                      h->cand.as<ErhCand>(), h->cand_cnt.as<uint32_t>(), cap, flags, st)); }
+              HIPCHK(h, scan_append(h, X, N, d, n1, N, Q16, Bpad, B, h->tau.as<float>(), filter_dev, dir,
+                                     h->cand.as<ErhCand>(), h->cand_cnt.as<uint32_t>(), cap, flags, st)); }
         }
     }
     { ProfScope ps(h, st, ERH_K_DENSE_SELECT, 0, 0);
@@ -221,7 +242,8 @@ int bm25_topk_dev(erh_handle *h, const int32_t *qptr_dev, const int32_t *qtok_de
         ProfScope ps(h, st, ERH_K_BM25_SCAN, postings_bytes, 0);
         HIPCHK(h, erh::launch_bm25_scan(h->variant, h->indptr.as<int64_t>(), h->doc_ids.as<int32_t>(), h->payload.p,
                                         h->tile_off.as<int32_t>(), h->n_tiles, h->Nb, qptr_dev, qtok_dev, B, k, 1,
-                                        filter_dev, dir, d_sc, d_ids, d_len, st));
+                                        filter_dev, dir, d_sc, d_ids, d_len, h->opt_bm25_ablate,
+                                        h->opt_debug_counters ? h->dbg.as<unsigned long long>() : nullptr, st));
         return ERH_OK;
     }
     HIPCHK(h, h->part_sc.ensure((size_t)B * segs * k * 8));
@@ -231,7 +253,8 @@ int bm25_topk_dev(erh_handle *h, const int32_t *qptr_dev, const int32_t *qtok_de
       HIPCHK(h, erh::launch_bm25_scan(h->variant, h->indptr.as<int64_t>(), h->doc_ids.as<int32_t>(), h->payload.p,
                                       h->tile_off.as<int32_t>(), h->n_tiles, h->Nb, qptr_dev, qtok_dev, B, k, segs,
                                       filter_dev, dir, h->part_sc.as<double>(), h->part_ids.as<int32_t>(),
-                                      h->part_len.as<int32_t>(), st)); }
+                                      h->part_len.as<int32_t>(), h->opt_bm25_ablate,
+                                      h->opt_debug_counters ? h->dbg.as<unsigned long long>() : nullptr, st)); }
     { ProfScope ps(h, st, ERH_K_BM25_MERGE, 0, 0);
       HIPCHK(h, erh::launch_bm25_merge(B, k, segs, h->part_sc.as<double>(), h->part_ids.as<int32_t>(),
                                        h->part_len.as<int32_t>(), d_ids, d_sc, d_len, st)); }
@@ -292,7 +315,9 @@ int erh_create(int device, erh_handle **out) {
     erh_handle *h = new (std::nothrow) erh_handle();
     if (!h) return ERH_ERR_NOMEM;
     h->device = device;
-    if (erh::dense_scan_init() != hipSuccess || erh::select_init() != hipSuccess || erh::bm25_init() != hipSuccess) {
+    h->n_cus = prop.multiProcessorCount;
+    if (erh::dense_scan_init() != hipSuccess || erh::select_init() != hipSuccess || erh::bm25_init() != hipSuccess ||
+        erh::fuse_init() != hipSuccess) {
         delete h;
         return ERH_ERR_HIP;
     }
@@ -311,7 +336,7 @@ int erh_destroy(erh_handle *h) {
                       &h->o_ids, &h->o_sc, &h->o_len, &h->qptr, &h->qtok, &h->part_sc, &h->part_ids, &h->part_len,
                       &h->hy_sids, &h->hy_ssc, &h->hy_slen, &h->hy_dids, &h->hy_dsc, &h->hy_dlen,
                       &h->fa_ids, &h->fa_sc, &h->fa_len, &h->fb_ids, &h->fb_sc, &h->fb_len,
-                      &h->scores_tmp, &h->scores_wide};
+                      &h->scores_tmp, &h->scores_wide, &h->dbg};
     for (DevBuf *b : bufs) b->release();
     delete h;
     return ERH_OK;
@@ -330,6 +355,19 @@ int erh_set_option(erh_handle *h, const char *name, int64_t value) {
     if (!h || !name) return ERH_ERR_INVALID;
     if (!strcmp(name, "dense_n0")) { if (value < 1) return h->fail(ERH_ERR_INVALID, "dense_n0 < 1"); h->opt_n0 = value; return ERH_OK; }
     if (!strcmp(name, "dense_n1")) { if (value < 0) return h->fail(ERH_ERR_INVALID, "dense_n1 < 0"); h->opt_n1 = value; return ERH_OK; }
+    if (!strcmp(name, "dense_cfg")) { if (value < 0 || value > 2) return h->fail(ERH_ERR_INVALID, "dense_cfg"); h->opt_dense_cfg = (int)value; return ERH_OK; }
+    if (!strcmp(name, "dense_persist")) { h->opt_dense_persist = value != 0; return ERH_OK; }
+    if (!strcmp(name, "dense_ablate")) { h->opt_dense_ablate = (int)value; return ERH_OK; }
+    if (!strcmp(name, "bm25_ablate")) { h->opt_bm25_ablate = (int)value; return ERH_OK; }
+    if (!strcmp(name, "debug_counters")) {
+        h->opt_debug_counters = value != 0;
+        if (value) {
+            HIPCHK(h, hipSetDevice(h->device));
+            HIPCHK(h, h->dbg.ensure(16 * 8));
+            HIPCHK(h, hipMemset(h->dbg.p, 0, 16 * 8));
+        }
+        return ERH_OK;
+    }
     return h->fail(ERH_ERR_INVALID, "unknown option");
 }
 
@@ -368,6 +406,16 @@ int erh_dense_check(erh_handle *h, void *stream) {
     if (!h->flags.p) return ERH_OK;
     HIPCHK(h, hipSetDevice(h->device));
     return dense_check_flags(h, (hipStream_t)stream);
+}
+
+int erh_debug_counters(erh_handle *h, uint64_t *out16) {
+    if (!h || !out16) return ERH_ERR_INVALID;
+    if (!h->dbg.p) { memset(out16, 0, 16 * 8); return ERH_OK; }
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipDeviceSynchronize());
+    HIPCHK(h, hipMemcpy(out16, h->dbg.p, 16 * 8, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemset(h->dbg.p, 0, 16 * 8));
+    return ERH_OK;
 }
 
 int erh_dense_diag(erh_handle *h, double *max_abs_err, double *margin, int32_t *uncertified) {
@@ -775,7 +823,7 @@ int erh_debug_dense_scores(erh_handle *h, const void *q_f16_host, int B, int64_t
     if (use_mfma) {
         const int ld = round_up(rows, 256);
         HIPCHK(h, h->S0.ensure((size_t)Bpad * ld * 4));
-        HIPCHK(h, erh::launch_dense_scan_store(h->Q16.as<_Float16>(), Bpad, h->X.as<_Float16>(), h->N, d, row0, rows,
+        HIPCHK(h, erh::launch_dense_scan_store(h->opt_dense_cfg, h->Q16.as<_Float16>(), Bpad, h->X.as<_Float16>(), h->N, d, row0, rows,
                                                h->S0.as<float>(), ld, st));
         HIPCHK(h, hipMemcpy2DAsync(out, (size_t)rows * 4, h->S0.p, (size_t)ld * 4, (size_t)rows * 4, B, hipMemcpyDeviceToHost, st));
     } else {

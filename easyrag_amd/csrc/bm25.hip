@@ -25,7 +25,7 @@ namespace {
 
 constexpr int kBmThreads = 1024;
 constexpr int kBmCap = 2048;       // LDS candidate slots (k <= 1024 so that k + one sweep chunk always fits)
-constexpr int kBmTokChunk = 256;   // query tokens whose tile ranges are staged at once
+constexpr int kBmTokChunk = 192;   // query tokens whose tile ranges are staged at once
 
 // ---- index-time kernels ---------------------------------------------------------------------------
 __global__ void bm25_tile_off_kernel(const int64_t *__restrict__ indptr, const int32_t *__restrict__ doc_ids,
@@ -81,25 +81,75 @@ __global__ void bm25_payload_kernel(int64_t V, int64_t nnz, const int64_t *__res
 }
 
 // ---- query-time scan -------------------------------------------------------------------------------
+constexpr int kBmPre = 2;          // postings per thread per (token, tile) held in prefetch registers
+
 template <typename ST>
 struct BmLds {
     static constexpr int TILE = (sizeof(ST) == 4) ? erh::kBm25TileF32 : erh::kBm25TileF64;
-    // layout (bytes): [0,64) header | acc TILE*ST | cand_s CAP*ST | cand_i CAP*4 | lo CHUNK*8 | hi CHUNK*8
+    // layout (bytes): [0,64) header | acc TILE*ST | cand_s CAP*ST | cand_i CAP*4 | lo CHUNK*8 | hi CHUNK*8 | tmax 1024*4
     static constexpr size_t OFF_ACC = 64;
     static constexpr size_t OFF_CS = OFF_ACC + (size_t)TILE * sizeof(ST);
     static constexpr size_t OFF_CI = OFF_CS + (size_t)kBmCap * sizeof(ST);
     static constexpr size_t OFF_LO = OFF_CI + (size_t)kBmCap * 4;
     static constexpr size_t OFF_HI = OFF_LO + (size_t)kBmTokChunk * 8;
-    static constexpr size_t BYTES = OFF_HI + (size_t)kBmTokChunk * 8;
+    static constexpr size_t OFF_TM = OFF_HI + (size_t)kBmTokChunk * 8;
+    static constexpr size_t BYTES = OFF_TM + (size_t)kBmThreads * 4;
+    static_assert(BYTES <= 160 * 1024, "BM25 scan LDS layout exceeds one CU");
 };
 
 struct BmHdr {
     int ncand;      // live entries in the candidate list
     int total;      // scratch for block-wide counts
-    int tau_idx;    // running k-th best: index part (INT_MAX when fewer than k so far)
+    int tau_idx;    // running k-th best: index part
     int pad;
     double tau_s;   // running k-th best: score part (0 => "score > 0" is the only condition)
 };
+
+template <typename ST>
+struct BmPre {
+    int32_t d[kBmPre];
+    ST v[kBmPre];
+};
+
+template <typename ST>
+__device__ __forceinline__ void bm_prefetch(BmPre<ST> &P, const int32_t *__restrict__ doc_ids,
+                                            const ST *__restrict__ payload, int64_t lo, int64_t hi, int tid) {
+#pragma unroll
+    for (int u = 0; u < kBmPre; ++u) {
+        const int64_t p = lo + tid + (int64_t)u * kBmThreads;
+        const bool ok = p < hi;
+        P.d[u] = ok ? doc_ids[p] : -1;
+        P.v[u] = ok ? payload[p] : (ST)0;
+    }
+}
+
+// Apply one token to the tile: this thread's prefetched postings, then (lists longer than kBmPre*1024
+// inside this tile) the rest straight from memory.  Each document occurs at most once per term, so the
+// read-add-write needs no atomics; the caller's barrier orders token j before token j+1.
+template <typename ST>
+__device__ __forceinline__ void bm_apply(const BmPre<ST> &P, ST *acc, int64_t base_doc,
+                                         const int32_t *__restrict__ doc_ids, const ST *__restrict__ payload,
+                                         int64_t lo, int64_t hi, int tid) {
+#pragma unroll
+    for (int u = 0; u < kBmPre; ++u) {
+        if (P.d[u] >= 0) {
+            const int slot = (int)((int64_t)P.d[u] - base_doc);
+            acc[slot] = acc[slot] + P.v[u];
+        }
+    }
+#pragma unroll 4
+    for (int64_t p = lo + tid + (int64_t)kBmPre * kBmThreads; p < hi; p += kBmThreads) {
+        const int slot = (int)((int64_t)doc_ids[p] - base_doc);
+        acc[slot] = acc[slot] + payload[p];
+    }
+}
+
+// Thresholds are compared in the accumulation type: every threshold value originates from a score (or a
+// float lower bound) of that type, so the conversion from the header's double is exact.
+template <typename ST>
+__device__ __forceinline__ bool bm_pass(ST s, int64_t doc, ST tau_s, int tau_idx) {
+    return (s > tau_s) || (s == tau_s && doc < (int64_t)tau_idx);
+}
 
 // Sort the candidate list (score desc, idx asc), cut to k, refresh the running threshold.  Uniform call.
 template <typename ST>
@@ -110,10 +160,60 @@ __device__ __forceinline__ void bm_shrink(BmHdr *hdr, ST *cs, int32_t *ci, int k
     erh_bitonic_rec_desc<ST>(cs, ci, kBmCap);
     if (threadIdx.x == 0 && n >= k) {
         hdr->ncand = k;
-        hdr->tau_s = (double)cs[k - 1];
-        hdr->tau_idx = ci[k - 1];
+        const double ts = (double)cs[k - 1];
+        if (ts > hdr->tau_s || (ts == hdr->tau_s && ci[k - 1] < hdr->tau_idx)) { hdr->tau_s = ts; hdr->tau_idx = ci[k - 1]; }
     }
     __syncthreads();
+}
+
+// Sweep pass over the tile accumulators (16-byte LDS accesses): entries that fail the threshold are cleared,
+// survivors stay in place and are counted.  Returns this thread's survivor count.  The common case after the
+// first tiles is "touched but nowhere near the threshold": one max + one compare + one zero store per vector.
+template <typename ST>
+__device__ __forceinline__ int bm_sweep_count(ST *acc, int tile_docs, int64_t base_doc, int64_t N, int fd,
+                                              const int16_t *__restrict__ dir_id, ST tau_s, int tau_idx, int tid) {
+    constexpr int VEC = 16 / (int)sizeof(ST);
+    typedef ST VT __attribute__((ext_vector_type(VEC)));
+    typedef uint32_t UT __attribute__((ext_vector_type(4)));
+    int mine = 0;
+    for (int i = tid * VEC; i < tile_docs; i += kBmThreads * VEC) {
+        VT v = *reinterpret_cast<VT *>(acc + i);
+        const UT bits = *reinterpret_cast<const UT *>(&v);
+        if ((bits[0] | bits[1] | bits[2] | bits[3]) == 0u) continue;       // untouched
+        ST m = v[0];
+#pragma unroll
+        for (int e = 1; e < VEC; ++e) m = v[e] > m ? v[e] : m;
+        if (m < tau_s) {                                                    // nothing here can reach the top k
+            VT z;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) z[e] = (ST)0;
+            *reinterpret_cast<VT *>(acc + i) = z;
+            continue;
+        }
+        bool changed = false;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const ST sv = v[e];
+            if (sv != (ST)0) {
+                const int64_t doc = base_doc + i + e;
+                bool pass = bm_pass<ST>(sv, doc, tau_s, tau_idx);
+                if (pass && (doc >= N || (fd >= 0 && (int)dir_id[doc] != fd))) pass = false;
+                if (pass) ++mine; else { v[e] = (ST)0; changed = true; }
+            }
+        }
+        if (changed) *reinterpret_cast<VT *>(acc + i) = v;
+    }
+    return mine;
+}
+
+__device__ __forceinline__ int bm_block_total(BmHdr *hdr, int mine) {
+    for (int o = 32; o >= 1; o >>= 1) mine += __shfl_xor(mine, o);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&hdr->total, mine);
+    __syncthreads();
+    const int total = hdr->total;
+    __syncthreads();
+    if (threadIdx.x == 0) hdr->total = 0;
+    return total;
 }
 
 // grid = (segs, B), block = 1024.  Segment `seg` of query q walks tiles [n_tiles*seg/segs, n_tiles*(seg+1)/segs).
@@ -123,8 +223,13 @@ __global__ __launch_bounds__(kBmThreads) void bm25_scan_kernel(
     const int32_t *__restrict__ tile_off, int n_tiles, int64_t N,
     const int32_t *__restrict__ q_indptr, const int32_t *__restrict__ q_tok, int k, int segs,
     const int16_t *__restrict__ filter_dir, const int16_t *__restrict__ dir_id,
-    double *__restrict__ part_scores, int32_t *__restrict__ part_ids, int32_t *__restrict__ part_len) {
+    double *__restrict__ part_scores, int32_t *__restrict__ part_ids, int32_t *__restrict__ part_len,
+    int ablate /* measurement only: 1 no add, 2 no sweep, 4 no token barrier, 8 no posting loads */,
+    unsigned long long *__restrict__ dbg /* measurement only: per-section shader-clock sums of thread 0, or null */) {
     using L = BmLds<ST>;
+    long long t_sec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long t_mark = dbg ? clock64() : 0;
+#define ERH_SEC(I) do { if (dbg) { const long long n_ = clock64(); t_sec[I] += n_ - t_mark; t_mark = n_; } } while (0)
     constexpr int TILE = L::TILE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     BmHdr *hdr = reinterpret_cast<BmHdr *>(smem);
@@ -133,6 +238,7 @@ __global__ __launch_bounds__(kBmThreads) void bm25_scan_kernel(
     int32_t *ci = reinterpret_cast<int32_t *>(smem + L::OFF_CI);
     int64_t *s_lo = reinterpret_cast<int64_t *>(smem + L::OFF_LO);
     int64_t *s_hi = reinterpret_cast<int64_t *>(smem + L::OFF_HI);
+    uint32_t *tmax = reinterpret_cast<uint32_t *>(smem + L::OFF_TM);
 
     const int seg = blockIdx.x, q = blockIdx.y, tid = threadIdx.x;
     const int qs = q_indptr[q], nq = q_indptr[q + 1] - qs;
@@ -148,7 +254,8 @@ __global__ __launch_bounds__(kBmThreads) void bm25_scan_kernel(
     if (nq > 0) {
         for (int tile = t_begin; tile < t_end; ++tile) {
             const int64_t base_doc = (int64_t)tile * TILE;
-            // ---- scatter-add, one query token after the other --------------------------------
+            ERH_SEC(7);
+            // ---- scatter-add, one query token after the other, postings prefetched two tokens ahead ----------
             for (int c0 = 0; c0 < nq; c0 += kBmTokChunk) {
                 const int nqc = (nq - c0 < kBmTokChunk) ? (nq - c0) : kBmTokChunk;
                 for (int j = tid; j < nqc; j += kBmThreads) {
@@ -159,69 +266,109 @@ __global__ __launch_bounds__(kBmThreads) void bm25_scan_kernel(
                     s_hi[j] = ip + to[1];
                 }
                 __syncthreads();
-                for (int j = 0; j < nqc; ++j) {
-                    const int64_t lo = s_lo[j], hi = s_hi[j];      // block-uniform
-                    if (lo < hi) {
-                        for (int64_t p = lo + tid; p < hi; p += kBmThreads) {
-                            const int slot = (int)((int64_t)doc_ids[p] - base_doc);
-                            acc[slot] = acc[slot] + payload[p];
-                        }
-                        __syncthreads();                          // token j complete before token j+1
-                    }
+                ERH_SEC(0);
+                BmPre<ST> P0, P1, P2;
+#pragma unroll
+                for (int u = 0; u < kBmPre; ++u) { P0.d[u] = P1.d[u] = P2.d[u] = -1; P0.v[u] = P1.v[u] = P2.v[u] = (ST)0; }
+                if (!(ablate & 8)) {
+                    bm_prefetch<ST>(P0, doc_ids, payload, s_lo[0], s_hi[0], tid);
+                    if (nqc > 1) bm_prefetch<ST>(P1, doc_ids, payload, s_lo[1], s_hi[1], tid);
                 }
-                __syncthreads();                                  // s_lo/s_hi free for the next chunk
+#define ERH_BM_STEP(CUR, NXT, J)                                                                         \
+    do {                                                                                                 \
+        const int j_ = (J);                                                                              \
+        if (j_ + 2 < nqc && !(ablate & 8))                                                               \
+            bm_prefetch<ST>(NXT, doc_ids, payload, s_lo[j_ + 2], s_hi[j_ + 2], tid);                     \
+        const int64_t lo_ = s_lo[j_], hi_ = s_hi[j_]; /* block-uniform */                                \
+        if (lo_ < hi_) {                                                                                 \
+            if (!(ablate & 1)) bm_apply<ST>(CUR, acc, base_doc, doc_ids, payload, lo_, hi_, tid);        \
+            if (!(ablate & 4)) __syncthreads(); /* token j complete before token j+1 */                  \
+        }                                                                                                \
+    } while (0)
+                for (int j0 = 0; j0 < nqc; j0 += 3) {
+                    ERH_BM_STEP(P0, P2, j0);
+                    if (j0 + 1 >= nqc) break;
+                    ERH_BM_STEP(P1, P0, j0 + 1);
+                    if (j0 + 2 >= nqc) break;
+                    ERH_BM_STEP(P2, P1, j0 + 2);
+                }
+#undef ERH_BM_STEP
+                __syncthreads();                                      // s_lo/s_hi free for the next chunk
+                ERH_SEC(1);
             }
-            // ---- sweep: keep what beats the running k-th best, clear the rest -------------------
-            double tau_s = hdr->tau_s;
+            if (ablate & 2) continue;
+            // ---- sweep: keep what beats the running k-th best, clear the rest ---------------------------------
+            ST tau_s = (ST)hdr->tau_s;
             int tau_idx = hdr->tau_idx;
-            int mine = 0;
-            for (int i = tid; i < TILE; i += kBmThreads) {
-                const ST s = acc[i];
-                if (s != (ST)0) {
-                    const int64_t doc = base_doc + i;
-                    bool pass = ((double)s > tau_s) || ((double)s == tau_s && doc < (int64_t)tau_idx);
-                    if (pass && (doc >= N || (fd >= 0 && (int)dir_id[doc] != fd))) pass = false;
-                    if (pass) ++mine; else acc[i] = (ST)0;
+            int total = bm_block_total(hdr, bm_sweep_count<ST>(acc, TILE, base_doc, N, fd, dir_id, tau_s, tau_idx, tid));
+            ERH_SEC(2);
+            if (total == 0) continue;                                 // uniform
+            int have = hdr->ncand;
+            if (have + total > kBmCap && k <= kBmThreads) {
+                // Too many survivors for the list (warm-up tiles).  The k-th largest of the 1024 per-thread maxima
+                // is a lower bound of this tile's k-th best score, hence of the final k-th best: raise the
+                // threshold to "score >= p" (ties stay eligible) and sweep again.
+                constexpr int VEC = 16 / (int)sizeof(ST);
+                typedef ST VT __attribute__((ext_vector_type(VEC)));
+                ST mx = (ST)0;
+                for (int i = tid * VEC; i < TILE; i += kBmThreads * VEC) {
+                    const VT v = *reinterpret_cast<const VT *>(acc + i);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) mx = v[e] > mx ? v[e] : mx;
+                }
+                float mxf;
+                if (sizeof(ST) == 8) mxf = __double2float_rd((double)mx); else mxf = (float)mx;
+                tmax[tid] = __float_as_uint(mxf);                     // non-negative floats order like their bits
+                erh_bitonic_desc<uint32_t>(tmax, kBmThreads);
+                const ST p = (ST)__uint_as_float(tmax[k - 1]);
+                if (p > tau_s) {
+                    tau_s = p;
+                    tau_idx = 0x7fffffff;
+                    __syncthreads();
+                    if (tid == 0 && ((double)p > hdr->tau_s)) { hdr->tau_s = (double)p; hdr->tau_idx = 0x7fffffff; }
+                    total = bm_block_total(hdr, bm_sweep_count<ST>(acc, TILE, base_doc, N, fd, dir_id, tau_s, tau_idx, tid));
+                    have = hdr->ncand;
                 }
             }
-            for (int o = 32; o >= 1; o >>= 1) mine += __shfl_xor(mine, o);
-            if ((tid & 63) == 0 && mine) atomicAdd(&hdr->total, mine);
-            __syncthreads();
-            const int total = hdr->total;
-            const int have = hdr->ncand;
-            __syncthreads();
-            if (tid == 0) hdr->total = 0;
-            if (total == 0) continue;                             // uniform
+            ERH_SEC(3);
             if (have + total <= kBmCap) {
-                for (int i = tid; i < TILE; i += kBmThreads) {
-                    const ST s = acc[i];
-                    if (s != (ST)0) {
-                        const int pos = atomicAdd(&hdr->ncand, 1);
-                        cs[pos] = s;
-                        ci[pos] = (int32_t)(base_doc + i);
-                        acc[i] = (ST)0;
+                constexpr int VEC = 16 / (int)sizeof(ST);
+                typedef ST VT __attribute__((ext_vector_type(VEC)));
+                typedef uint32_t UT __attribute__((ext_vector_type(4)));
+                for (int i = tid * VEC; i < TILE; i += kBmThreads * VEC) {
+                    VT v = *reinterpret_cast<VT *>(acc + i);
+                    const UT bits = *reinterpret_cast<const UT *>(&v);
+                    if ((bits[0] | bits[1] | bits[2] | bits[3]) == 0u) continue;
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        if (v[e] != (ST)0) {
+                            const int pos = atomicAdd(&hdr->ncand, 1);
+                            cs[pos] = v[e];
+                            ci[pos] = (int32_t)(base_doc + i + e);
+                            v[e] = (ST)0;
+                        }
                     }
+                    *reinterpret_cast<VT *>(acc + i) = v;
                 }
                 __syncthreads();
             } else {
-                // warm-up / adversarial path: go chunk by chunk, shrinking whenever the list may overflow
+                // adversarial path: go chunk by chunk, shrinking whenever the list may overflow
                 for (int cb = 0; cb < TILE; cb += kBmThreads) {
                     __syncthreads();
                     const int have_now = hdr->ncand;              // read between two barriers: uniform
                     __syncthreads();
                     if (have_now + kBmThreads > kBmCap) {
                         bm_shrink<ST>(hdr, cs, ci, k);
-                        tau_s = hdr->tau_s;
+                        tau_s = (ST)hdr->tau_s;
                         tau_idx = hdr->tau_idx;
                     }
                     const int i = cb + tid;
-                    const ST s = acc[i];
-                    if (s != (ST)0) {
+                    const ST sv = acc[i];
+                    if (sv != (ST)0) {
                         const int64_t doc = base_doc + i;
-                        const bool pass = ((double)s > tau_s) || ((double)s == tau_s && doc < (int64_t)tau_idx);
-                        if (pass) {
+                        if (bm_pass<ST>(sv, doc, tau_s, tau_idx)) {
                             const int pos = atomicAdd(&hdr->ncand, 1);
-                            cs[pos] = s;
+                            cs[pos] = sv;
                             ci[pos] = (int32_t)doc;
                         }
                         acc[i] = (ST)0;
@@ -229,6 +376,10 @@ __global__ __launch_bounds__(kBmThreads) void bm25_scan_kernel(
                 }
                 __syncthreads();
             }
+            ERH_SEC(4);
+            // keep the list short and the threshold exact once it holds more than k entries
+            if (hdr->ncand > k + kBmThreads / 2) bm_shrink<ST>(hdr, cs, ci, k);   // uniform (read after a barrier)
+            ERH_SEC(5);
         }
     }
     // ---- emit this segment's list, sorted --------------------------------------------------------
@@ -239,6 +390,12 @@ __global__ __launch_bounds__(kBmThreads) void bm25_scan_kernel(
         else { part_scores[out_base + i] = 0.0; part_ids[out_base + i] = -1; }
     }
     if (tid == 0) part_len[(int64_t)q * segs + seg] = n;
+    ERH_SEC(6);
+    if (dbg && tid == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) atomicAdd(&dbg[i], (unsigned long long)t_sec[i]);
+    }
+#undef ERH_SEC
 }
 
 // Merge `segs` sorted partial lists of one query: grid = B, block = 1024, LDS = P*(8+4) (+64), P = pow2 >= segs*k.
@@ -334,17 +491,18 @@ hipError_t launch_bm25_scan(int variant, const int64_t *indptr, const int32_t *d
                             const int32_t *tile_off, int n_tiles, int64_t N,
                             const int32_t *q_indptr, const int32_t *q_tok, int B, int k, int segs,
                             const int16_t *filter_dir, const int16_t *dir_id,
-                            double *part_scores, int32_t *part_ids, int32_t *part_len, hipStream_t st) {
+                            double *part_scores, int32_t *part_ids, int32_t *part_len, int ablate,
+                            unsigned long long *dbg, hipStream_t st) {
     if (B <= 0) return hipSuccess;
     dim3 grid(segs, B), block(kBmThreads);
     if (variant == 0)
         hipLaunchKernelGGL(bm25_scan_kernel<double>, grid, block, BmLds<double>::BYTES, st, indptr, doc_ids,
                            (const double *)payload, tile_off, n_tiles, N, q_indptr, q_tok, k, segs, filter_dir, dir_id,
-                           part_scores, part_ids, part_len);
+                           part_scores, part_ids, part_len, ablate, dbg);
     else
         hipLaunchKernelGGL(bm25_scan_kernel<float>, grid, block, BmLds<float>::BYTES, st, indptr, doc_ids,
                            (const float *)payload, tile_off, n_tiles, N, q_indptr, q_tok, k, segs, filter_dir, dir_id,
-                           part_scores, part_ids, part_len);
+                           part_scores, part_ids, part_len, ablate, dbg);
     return hipGetLastError();
 }
 

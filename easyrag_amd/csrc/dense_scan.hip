@@ -3,66 +3,86 @@
 // (/root/reference/src/easyrag/custom/retrievers.py:37-52; collection ingestion.py:178-183).
 //
 // Shape: S = Rows_A . Rows_B^T over K = d, both operands fp16 row-major with d contiguous, fp32
-// accumulation in v_mfma_f32_32x32x16_f16.  A workgroup of 8 waves owns a BM x BN score tile:
-//   - both operand tiles are staged HBM/L2 -> LDS with global_load_lds_dwordx4 (16 B per lane, no
-//     VGPR round trip), BK = 64 halves = one 128-byte line per row per K-step, double buffered;
-//   - the LDS image is lane-linear (the DMA requires it), so the 16-byte slot index inside each
-//     128-byte row is XOR-swizzled on the *source* address with ((row>>1)&7) and un-swizzled on
-//     the ds_read_b128 side: the 16 lanes of a b128 lane group then hit 16 distinct slots of the
-//     256-byte bank row (conflict-free), and the 8 lanes of a row still fetch one whole line;
-//   - the fragment k-mapping (lane>>5 picks the 8-half slot inside a 16-wide k-substep) is the same
-//     for both operands, which is all a dot product needs.
+// accumulation in v_mfma_f32_32x32x16_f16.  A workgroup owns a BM x BN score tile:
+//   - both operand tiles are staged HBM/L2 -> LDS with global_load_lds_dwordx4 (16 B per lane, no VGPR
+//     round trip), BK halves per K-step, in per-operand rings (A_STAGES / B_STAGES deep) so that several
+//     K-steps of loads stay in flight across the (raw) barrier; completion is tracked with a counted
+//     s_waitcnt vmcnt(N), never a drain, except in the last steps of a tile;
+//   - the LDS image is lane-linear (the DMA requires it), so the 16-byte slot index inside each row is
+//     XOR-swizzled on the *source* address and un-swizzled on the ds_read_b128 side: the 16 lanes of a
+//     b128 lane group hit 16 distinct slots of the 256-byte bank row (conflict-free) while the lanes of a
+//     row still fetch one contiguous run of a cache line;
+//   - the fragment k-mapping (lane>>5 picks the 8-half slot inside a 16-wide k-substep) is the same for
+//     both operands, which is all a dot product needs.
 // The score matrix is never written.  Epilogues:
 //   STORE  (A = queries, B = chunks): lane = chunk column -> coalesced rows of S0[q][chunk] for the
 //          threshold-seeding prefix of the corpus;
 //   APPEND (A = chunks, B = queries): lane = query column; a score survives if >= tau[q] (the
 //          pruning threshold from the previous stage, already lowered by the fp32 error margin),
 //          passes the optional dir filter, and is appended to the query's candidate list.
+// Two tile configurations are built (option "dense_cfg"):
+//   0: 256 x 256, BK 64, 8 waves, A ring 3 / B ring 2, 160 KiB LDS  -> one workgroup per CU
+//   1: 128 x 256, BK 32, 4 waves, A ring 4 / B ring 3,  80 KiB LDS  -> two independent workgroups per CU,
+//      whose barrier / issue bubbles overlap each other's MFMA phases
 #include "common.h"
 #include "kernels.h"
 
 namespace {
 
-template <int BM_, int BN_, int WGM_, int WGN_>
+template <int BM_, int BN_, int WGM_, int WGN_, int BK_, int AST_, int BST_>
 struct ScanCfg {
-    static constexpr int BM = BM_, BN = BN_, WGM = WGM_, WGN = WGN_;
+    static constexpr int BM = BM_, BN = BN_, WGM = WGM_, WGN = WGN_, BK = BK_;
     static constexpr int NW = WGM * WGN;
     static constexpr int NT = NW * 64;
     static constexpr int WM = BM / WGM, WN = BN / WGN;
     static constexpr int MT = WM / 32, NTL = WN / 32;
-    static constexpr int BK = 64;                       // halves per K-step = 128 bytes per row
-    static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
-    static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
-    static constexpr int LDS_BYTES = 2 * STAGE_BYTES;
+    static constexpr int RB = BK * 2;                   // bytes per row per K-step (64 or 128)
+    static constexpr int PR = RB / 16;                  // 16-byte pieces per row (4 or 8)
+    static constexpr int KS = BK / 16;                  // k-substeps (one MFMA K) per K-step
+    static constexpr int A_BYTES = BM * RB, B_BYTES = BN * RB;
+    static constexpr int A_STAGES = AST_, B_STAGES = BST_;
+    static constexpr int DA = AST_ - 1, DB = BST_ - 1;  // prefetch distances in K-steps
+    static constexpr int B_BASE = A_STAGES * A_BYTES;
+    static constexpr int LDS_BYTES = A_STAGES * A_BYTES + B_STAGES * B_BYTES;
+    static constexpr int A_ITERS = (BM * PR) / NT, B_ITERS = (BN * PR) / NT;   // LDS-DMA instructions per wave per stage
+    // loads that may still be in flight at the top of a K-step: everything issued after B(kt)
+    static constexpr int WAIT_N = A_ITERS * DB + B_ITERS * (DB - 1);
+    static_assert(BK == 32 || BK == 64, "BK");
     static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile must be a multiple of the 32x32 MFMA tile");
-    static_assert((BM * 8) % NT == 0 && (BN * 8) % NT == 0, "staging must divide evenly");
+    static_assert((BM * PR) % NT == 0 && (BN * PR) % NT == 0, "staging must divide evenly");
+    static_assert(DA >= DB && DB >= 1, "ring depths");
+    static_assert(MT * 16 <= 64, "survivor mask is 64 bits");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
 
-// Per-lane source pointers of one operand tile (ROWS rows x 128 bytes per K-step), computed once per tile:
-// piece = 16-byte unit, 8 per row; instruction `it` of wave `w` moves pieces [(it*NW + w)*64, +64).
-template <int ROWS, int NW>
+template <int PR>
+__device__ __forceinline__ int row_swizzle(int r) { return PR == 8 ? ((r >> 1) & 7) : ((r >> 2) & 3); }
+
+// Per-lane source pointers of one operand tile (ROWS rows x RB bytes per K-step), computed once per tile:
+// piece = 16-byte unit, PR per row; instruction `it` of wave `w` moves pieces [(it*NW + w)*64, +64).
+template <int ROWS, int NW, int PR>
 struct TileSrc {
-    static constexpr int ITERS = (ROWS * 8) / (NW * 64);
+    static constexpr int ITERS = (ROWS * PR) / (NW * 64);
     const _Float16 *src[ITERS];
     __device__ __forceinline__ void init(const _Float16 *__restrict__ base, int64_t row0, int64_t rows_total,
                                          int d, int wave, int lane) {
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
             const int piece = (it * NW + wave) * 64 + lane;
-            const int r = piece >> 3;                   // row inside the tile
-            const int p = piece & 7;                    // physical 16-byte slot inside the 128-byte row
+            const int r = piece / PR;                   // row inside the tile
+            const int p = piece % PR;                   // physical 16-byte slot inside the row
             int64_t grow = row0 + r;
             if (grow > rows_total - 1) grow = rows_total - 1;   // clamp: rows past the end are masked later
-            const int ls = p ^ ((r >> 1) & 7);          // logical slot stored at physical slot p
+            const int ls = p ^ row_swizzle<PR>(r);      // logical slot stored at physical slot p
             src[it] = base + grow * (int64_t)d + ls * 8;
         }
     }
-    // Issue the LDS-DMA loads for K-step kt into lds_tile (lane-linear image).
-    __device__ __forceinline__ void issue(int kt, char *lds_tile, int wave) const {
+    // Issue the LDS-DMA loads for K-step kt (bk halves each) into lds_tile (lane-linear image).
+    __device__ __forceinline__ void issue(int kt, int bk, char *lds_tile, int wave) const {
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
             const int piece0 = (it * NW + wave) * 64;   // wave-uniform
-            __builtin_amdgcn_global_load_lds((const void *)(src[it] + (int64_t)kt * 64),
+            __builtin_amdgcn_global_load_lds((const void *)(src[it] + (int64_t)kt * bk),
                                              ERH_LDS_PTR(lds_tile + piece0 * 16), 16, 0, 0);
         }
     }
@@ -70,12 +90,16 @@ struct TileSrc {
 
 // The K-loop: on return acc[mt][nt] holds the 32x32 fp32 tiles of this wave
 // (rows = A rows wave_m*WM + mt*32 + .., cols = B rows wave_n*WN + nt*32 + ..).
-template <class C>
+// ABL (measurement builds only, option "dense_ablate"; results are garbage for ABL 2..4):
+//   0 full kernel   1 no epilogue   2 no MFMA (LDS reads kept alive)   3 no LDS fragment reads   4 no LDS-DMA
+template <class C, int ABL>
 __device__ __forceinline__ void gemm_tile(const _Float16 *__restrict__ A, int64_t a_row0, int64_t a_rows,
                                           const _Float16 *__restrict__ B, int64_t b_row0, int64_t b_rows,
                                           int d, char *lds, f32x16 (&acc)[C::MT][C::NTL],
-                                          int wave, int lane, int wave_m, int wave_n) {
+                                          int wave, int lane, int wave_m, int wave_n, long long *tsec = nullptr) {
     const int nk = d / C::BK;
+    long long t_mark = (ABL == 5) ? clock64() : 0;
+#define ERH_SEC(I) do { if (ABL == 5) { const long long n_ = clock64(); tsec[I] += n_ - t_mark; t_mark = n_; } } while (0)
 #pragma unroll
     for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
@@ -85,47 +109,86 @@ __device__ __forceinline__ void gemm_tile(const _Float16 *__restrict__ A, int64_
 
     // per-lane fragment addressing: row = .. + (lane & 31); logical slot for k-substep j = 2j + (lane >> 5)
     const int l31 = lane & 31, h = lane >> 5;
-    const int sw = (l31 >> 1) & 7;                      // == ((row >> 1) & 7): tile/wave/mt offsets are multiples of 16
-    int soff[4];
+    const int sw = row_swizzle<C::PR>(l31);             // tile / wave / mt offsets are multiples of 32
+    int soff[C::KS];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) soff[j] = (((2 * j + h) ^ sw) << 4);
-    const int a_lane_off = (wave_m * C::WM + l31) * 128;
-    const int b_lane_off = C::A_BYTES + (wave_n * C::WN + l31) * 128;
+    for (int j = 0; j < C::KS; ++j) soff[j] = (((2 * j + h) ^ sw) << 4);
+    const int a_lane_off = (wave_m * C::WM + l31) * C::RB;
+    const int b_lane_off = C::B_BASE + (wave_n * C::WN + l31) * C::RB;
 
-    TileSrc<C::BM, C::NW> ta;
-    TileSrc<C::BN, C::NW> tb;
+    TileSrc<C::BM, C::NW, C::PR> ta;
+    TileSrc<C::BN, C::NW, C::PR> tb;
     ta.init(A, a_row0, a_rows, d, wave, lane);
     tb.init(B, b_row0, b_rows, d, wave, lane);
-    ta.issue(0, lds, wave);
-    tb.issue(0, lds + C::A_BYTES, wave);
-
-    for (int kt = 0; kt < nk; ++kt) {
-        // stage kt has landed for this wave's DMAs; the barrier extends that to all waves and also
-        // guarantees every wave is done reading the other buffer (its MFMAs consumed the ds_reads).
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        char *cur = lds + (kt & 1) * C::STAGE_BYTES;
-        if (kt + 1 < nk) {
-            char *nxt = lds + ((kt + 1) & 1) * C::STAGE_BYTES;
-            ta.issue(kt + 1, nxt, wave);
-            tb.issue(kt + 1, nxt + C::A_BYTES, wave);
-        }
+    // Software pipeline.  At K-step s (after its barrier) every wave issues B(s + DB) and then A(s + DA); the
+    // prologue replays the "virtual" steps -DA .. -1.  vmcnt retires in order, so at the top of step kt everything
+    // issued after B(kt) -- A(kt-DB+DA .. kt-1+DA) and B(kt+1 .. kt-1+DB), WAIT_N instructions -- may stay in
+    // flight while A(kt) and B(kt) are guaranteed landed.  The barrier (a) extends "landed" to every wave's pieces
+    // and (b) proves all waves finished reading the slots overwritten by the loads issued right after it (their
+    // MFMAs consumed those ds_reads).  Raw s_barrier: __syncthreads() would drain vmcnt to 0.
+    if (ABL != 4) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int s = -C::DA; s < 0; ++s) {
+            if (s + C::DB >= 0 && s + C::DB < nk)
+                tb.issue(s + C::DB, C::BK, lds + C::B_BASE + ((s + C::DB) % C::B_STAGES) * C::B_BYTES, wave);
+            if (s + C::DA < nk) ta.issue(s + C::DA, C::BK, lds + ((s + C::DA) % C::A_STAGES) * C::A_BYTES, wave);
+        }
+    }
+    half8 fz;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) fz[u] = (_Float16)(0.001f * (float)(lane + u));
+
+    ERH_SEC(4);
+    int a_slot = 0, b_slot = 0;                         // kt % A_STAGES, kt % B_STAGES
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + C::DA <= nk)                           // steady state: every load counted in WAIT_N exists
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(C::WAIT_N) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        ERH_SEC(0);
+        const char *cur_a = lds + a_slot * C::A_BYTES;
+        const char *cur_b = lds + b_slot * C::B_BYTES;
+        if (ABL != 4) {
+            if (kt + C::DB < nk) {
+                int sb = b_slot + C::DB;                // (kt + DB) % B_STAGES
+                if (sb >= C::B_STAGES) sb -= C::B_STAGES;
+                tb.issue(kt + C::DB, C::BK, lds + C::B_BASE + sb * C::B_BYTES, wave);
+            }
+            if (kt + C::DA < nk) {
+                int sa = a_slot + C::DA;                // (kt + DA) % A_STAGES
+                if (sa >= C::A_STAGES) sa -= C::A_STAGES;
+                ta.issue(kt + C::DA, C::BK, lds + sa * C::A_BYTES, wave);
+            }
+        }
+        ERH_SEC(1);
+#pragma unroll
+        for (int j = 0; j < C::KS; ++j) {
             half8 af[C::MT], bf[C::NTL];
 #pragma unroll
             for (int mt = 0; mt < C::MT; ++mt)
-                af[mt] = *reinterpret_cast<const half8 *>(cur + a_lane_off + mt * 32 * 128 + soff[j]);
+                af[mt] = (ABL == 3) ? fz : *reinterpret_cast<const half8 *>(cur_a + a_lane_off + mt * 32 * C::RB + soff[j]);
 #pragma unroll
             for (int nt = 0; nt < C::NTL; ++nt)
-                bf[nt] = *reinterpret_cast<const half8 *>(cur + b_lane_off + nt * 32 * 128 + soff[j]);
+                bf[nt] = (ABL == 3) ? fz : *reinterpret_cast<const half8 *>(cur_b + b_lane_off + nt * 32 * C::RB + soff[j]);
+            if (ABL == 2) {
 #pragma unroll
-            for (int mt = 0; mt < C::MT; ++mt)
+                for (int mt = 0; mt < C::MT; ++mt) asm volatile("" ::"v"(af[mt]));
 #pragma unroll
-                for (int nt = 0; nt < C::NTL; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mt], bf[nt], acc[mt][nt], 0, 0, 0);
+                for (int nt = 0; nt < C::NTL; ++nt) asm volatile("" ::"v"(bf[nt]));
+            } else {
+#pragma unroll
+                for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < C::NTL; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mt], bf[nt], acc[mt][nt], 0, 0, 0);
+            }
         }
+        if (ABL == 5) asm volatile("s_nop 0" ::: "memory");   // MFMA issue only; the pipe drains in the next wait
+        ERH_SEC(2);
+        a_slot = (a_slot + 1 == C::A_STAGES) ? 0 : a_slot + 1;
+        b_slot = (b_slot + 1 == C::B_STAGES) ? 0 : b_slot + 1;
     }
+#undef ERH_SEC
 }
 
 // 32x32 MFMA C/D layout (dtype independent on gfx950): lane holds column (lane & 31) and rows
@@ -148,7 +211,7 @@ __global__ __launch_bounds__(C::NT) void dense_scan_store_kernel(
     const int64_t c_row0 = c0 + (int64_t)ct * C::BN;
 
     f32x16 acc[C::MT][C::NTL];
-    gemm_tile<C>(Q, q_row0, Bpad, X, c_row0, N, d, lds, acc, wave, lane, wave_m, wave_n);
+    gemm_tile<C, 0>(Q, q_row0, Bpad, X, c_row0, N, d, lds, acc, wave, lane, wave_m, wave_n);
 
 #pragma unroll
     for (int nt = 0; nt < C::NTL; ++nt) {
@@ -169,16 +232,19 @@ __global__ __launch_bounds__(C::NT) void dense_scan_store_kernel(
 
 // ---------------------------------------------------------------------------------------------
 // APPEND epilogue: chunks [c0, c1) against Bpad queries; survivors (>= tau[q]) go to cand[q][..].
-template <class C>
+template <class C, int ABL>
 __global__ __launch_bounds__(C::NT) void dense_scan_append_kernel(
     const _Float16 *__restrict__ X, int64_t N, int d, int64_t c0, int64_t c1,
     const _Float16 *__restrict__ Q, int Bpad, int B,
     const float *__restrict__ tau, const int16_t *__restrict__ filter_dir, const int16_t *__restrict__ dir_id,
-    ErhCand *__restrict__ cand, uint32_t *__restrict__ cand_cnt, int cap, uint32_t *__restrict__ overflow) {
+    ErhCand *__restrict__ cand, uint32_t *__restrict__ cand_cnt, int cap, uint32_t *__restrict__ overflow,
+    unsigned long long *__restrict__ dbg /* ABL == 5 only: section clock sums of lane 0 of wave 0 */) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wave_m = wave / C::WGN, wave_n = wave % C::WGN;
+    long long tsec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const long long t_begin = (ABL == 5) ? clock64() : 0;
 
     // XCD-aware mapping: block b runs on XCD b % 8.  The n_qt query tiles that share one chunk tile get
     // consecutive slots of the same XCD so the re-read of the chunk tile is served by that XCD's L2.
@@ -193,41 +259,332 @@ __global__ __launch_bounds__(C::NT) void dense_scan_append_kernel(
     const int64_t q_row0 = (int64_t)qt * C::BN;
 
     f32x16 acc[C::MT][C::NTL];
-    gemm_tile<C>(X, c_row0, N, Q, q_row0, Bpad, d, lds, acc, wave, lane, wave_m, wave_n);
+    gemm_tile<C, ABL>(X, c_row0, N, Q, q_row0, Bpad, d, lds, acc, wave, lane, wave_m, wave_n, tsec);
+    const long long t_loop_end = (ABL == 5) ? clock64() : 0;
+    if (ABL >= 1 && ABL <= 4) {
+        // measurement builds: keep the accumulators alive with a never-true store, skip the epilogue
+        float keep = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < C::NTL; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) keep += acc[mt][nt][r];
+        if (keep == 1.2345e-30f) *overflow = 7u;
+        return;
+    }
 
+    // Epilogue.  Lane = query column; its MT*16 accumulators are chunk rows.  The threshold admits well under 1 %
+    // of the scores, so everything is organised around "no lane of the wave survives":
+    //   - per 32x32 tile one max over the lane's 16 scores and ONE wave-uniform test; only tiles with a hit look
+    //     at individual registers, again with a wave-uniform test per register;
+    //   - a survivor goes to the lane's own staging slots in LDS ([slot][lane], plain non-returning ds_writes, the
+    //     slot counter lives in a register): no atomic and no wait inside the scan.  The staging area is the
+    //     B-ring slot the last K-step did not read, so no barrier is needed;
+    //   - the flush issues all staged records' global atomics back to back (one L2 round trip for the lot), then
+    //     writes the records.  A lane with more than kSlots survivors appends the surplus directly.
+    constexpr int kStageBytes = C::B_BYTES / C::NW;                  // per-wave share of one B slot
+    constexpr int kSlots = kStageBytes / (64 * 12);                  // records per lane
+    static_assert(C::B_STAGES >= 2 && kSlots >= 2, "staging area");
+    const int nk_ = d / C::BK;
+    char *stage = lds + C::B_BASE + (nk_ % C::B_STAGES) * C::B_BYTES + wave * kStageBytes;   // slot of step nk: unread
+    float *w_s = reinterpret_cast<float *>(stage);
+    int32_t *w_doc = reinterpret_cast<int32_t *>(stage + kSlots * 64 * 4);
+    int32_t *w_q = reinterpret_cast<int32_t *>(stage + kSlots * 64 * 8);
     const int64_t lim = (c1 < N) ? c1 : N;
+    const int64_t row_base = c_row0 + wave_m * C::WM + 4 * (lane >> 5);
+    int n_mine = 0;                                                  // this lane's staged records
 #pragma unroll
     for (int nt = 0; nt < C::NTL; ++nt) {
         const int q = (int)q_row0 + wave_n * C::WN + nt * 32 + (lane & 31);
         const float t = (q < B) ? tau[q] : INFINITY;
-        float m = -INFINITY;
+        const int fd = (filter_dir && q < B) ? (int)filter_dir[q] : -1;
 #pragma unroll
-        for (int mt = 0; mt < C::MT; ++mt)
+        for (int mt = 0; mt < C::MT; ++mt) {
+            float m = acc[mt][nt][0];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[mt][nt][r]);
-        if (m >= t) {
-            const int fd = filter_dir ? (int)filter_dir[q] : -1;
+            for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[mt][nt][r]);
+            if (__builtin_amdgcn_ballot_w64(m >= t) == 0) continue;   // wave-uniform: nothing in this tile
 #pragma unroll
-            for (int mt = 0; mt < C::MT; ++mt) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float s = acc[mt][nt][r];
-                    if (s >= t) {
-                        const int64_t chunk = c_row0 + wave_m * C::WM + mt * 32 + mfma_row(r, lane);
+            for (int r = 0; r < 16; ++r) {
+                const float sc = acc[mt][nt][r];
+                const bool hit = sc >= t;
+                if (__builtin_amdgcn_ballot_w64(hit)) {              // wave-uniform
+                    if (hit) {
+                        const int64_t chunk = row_base + mt * 32 + (r & 3) + 8 * (r >> 2);
                         if (chunk < lim && (fd < 0 || (int)dir_id[chunk] == fd)) {
-                            const uint32_t pos = atomicAdd(&cand_cnt[q], 1u);
-                            if (pos < (uint32_t)cap) {
-                                ErhCand c;
-                                c.s = s;
-                                c.idx = (int32_t)chunk;
-                                cand[(int64_t)q * cap + pos] = c;
-                            } else {
-                                atomicOr(overflow, 1u);
+                            if (n_mine < kSlots) {
+                                const int at = n_mine * 64 + lane;
+                                w_s[at] = sc;
+                                w_doc[at] = (int32_t)chunk;
+                                w_q[at] = q;
+                                ++n_mine;
+                            } else {                                 // staging full: straight to the list
+                                const uint32_t pos = atomicAdd(&cand_cnt[q], 1u);
+                                if (pos < (uint32_t)cap) {
+                                    ErhCand c;
+                                    c.s = sc;
+                                    c.idx = (int32_t)chunk;
+                                    cand[(int64_t)q * cap + pos] = c;
+                                } else {
+                                    atomicOr(overflow, 1u);
+                                }
                             }
                         }
                     }
                 }
             }
+        }
+    }
+    if (__builtin_amdgcn_ballot_w64(n_mine > 0)) {
+        uint32_t pos[kSlots];
+        int qj[kSlots];
+#pragma unroll
+        for (int j = 0; j < kSlots; ++j) {                           // all atomics in flight before any is consumed
+            qj[j] = (j < n_mine) ? w_q[j * 64 + lane] : 0;
+            pos[j] = (j < n_mine) ? atomicAdd(&cand_cnt[qj[j]], 1u) : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < kSlots; ++j) {
+            if (j < n_mine) {
+                if (pos[j] < (uint32_t)cap) {
+                    ErhCand c;
+                    c.s = w_s[j * 64 + lane];
+                    c.idx = w_doc[j * 64 + lane];
+                    cand[(int64_t)qj[j] * cap + pos[j]] = c;
+                } else {
+                    atomicOr(overflow, 1u);
+                }
+            }
+        }
+    }
+    if (ABL == 5 && dbg && threadIdx.x == 0) {
+        const long long t_end = clock64();
+        tsec[3] = t_end - t_loop_end;
+        tsec[5] = t_end - t_begin;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) atomicAdd(&dbg[8 + i], (unsigned long long)tsec[i]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Persistent APPEND scan.  One workgroup per CU walks a strided list of chunk tiles against ONE fixed query
+// tile, and the LDS-DMA pipeline runs continuously over the flattened (tile, K-step) sequence: while the
+// epilogue of tile i inspects the accumulators, the first two K-steps of tile i+1 are already in flight, so HBM
+// never idles between tiles and the pipeline is filled once per workgroup instead of once per tile.
+//   - thresholds tau[q] of the (fixed) query columns are loaded once;
+//   - survivors are staged in registers (a lane rarely has more than a couple per tile), their slot-reserving
+//     global atomics are issued together, and the records are written afterwards;
+//   - ring slots are numbered by the global step g = i*nk + kt (A: g % A_STAGES, B: g % B_STAGES), which keeps
+//     the write-after-read argument of gemm_tile valid across tile boundaries.
+// Block b -> XCD b % 8 (observed dispatch); the n_qt workgroups that share a chunk-tile stream sit on one XCD.
+// PABL (measurement only): 0 full, 6 no global atomics (records land at slot 0), 7 no epilogue at all,
+// 8 thresholds forced to +inf (scan runs, nothing survives)
+template <class C, int PABL>
+__global__ __launch_bounds__(C::NT) void dense_scan_persist_kernel(
+    const _Float16 *__restrict__ X, int64_t N, int d, int64_t c0, int64_t c1,
+    const _Float16 *__restrict__ Q, int Bpad, int B,
+    const float *__restrict__ tau, const int16_t *__restrict__ filter_dir, const int16_t *__restrict__ dir_id,
+    ErhCand *__restrict__ cand, uint32_t *__restrict__ cand_cnt, int cap, uint32_t *__restrict__ overflow) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr int kSlots = 6;                                          // staged survivors per lane (across tiles)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave_m = wave / C::WGN, wave_n = wave % C::WGN;
+    const int nk = d / C::BK;
+
+    const int n_qt = Bpad / C::BN;
+    const int64_t n_ct = (c1 - c0 + C::BM - 1) / C::BM;
+    const int xcd = blockIdx.x & 7;
+    const int jx = blockIdx.x >> 3;
+    const int qt = jx % n_qt;
+    const int stream = (jx / n_qt) * 8 + xcd;
+    const int n_streams = (gridDim.x / (8 * n_qt)) * 8;
+    if (stream >= n_ct) return;                                        // whole workgroup: no barrier was executed yet
+    const int n_tiles = (int)((n_ct - stream + n_streams - 1) / n_streams);
+    const int64_t q_row0 = (int64_t)qt * C::BN;
+    const int64_t lim = (c1 < N) ? c1 : N;
+
+    // fixed per workgroup: query-side source pointers, thresholds, filters
+    TileSrc<C::BN, C::NW, C::PR> tb;
+    tb.init(Q, q_row0, Bpad, d, wave, lane);
+    float t_q[C::NTL];
+    int fd_q[C::NTL], q_col[C::NTL];
+#pragma unroll
+    for (int nt = 0; nt < C::NTL; ++nt) {
+        const int q = (int)q_row0 + wave_n * C::WN + nt * 32 + (lane & 31);
+        q_col[nt] = q;
+        t_q[nt] = (q < B && PABL != 8) ? tau[q] : INFINITY;
+        fd_q[nt] = (filter_dir && q < B) ? (int)filter_dir[q] : -1;
+    }
+    const int l31 = lane & 31, h = lane >> 5;
+    const int sw = row_swizzle<C::PR>(l31);
+    int soff[C::KS];
+#pragma unroll
+    for (int j = 0; j < C::KS; ++j) soff[j] = (((2 * j + h) ^ sw) << 4);
+    const int a_lane_off = (wave_m * C::WM + l31) * C::RB;
+    const int b_lane_off = C::B_BASE + (wave_n * C::WN + l31) * C::RB;
+
+    // chunk-side source pointers: re-pointed at the next tile as soon as the current tile's last load is issued
+    TileSrc<C::BM, C::NW, C::PR> ta_cur;
+    ta_cur.init(X, c0 + (int64_t)stream * C::BM, N, d, wave, lane);
+
+    const int total = n_tiles * nk;                                   // length of the flattened (tile, K-step) sequence
+
+    // prologue: virtual steps -DA .. -1 of the flattened sequence (all inside tile 0: nk > DA is checked on the host)
+#pragma unroll
+    for (int s_ = -C::DA; s_ < 0; ++s_) {
+        if (s_ + C::DB >= 0 && s_ + C::DB < total)
+            tb.issue((s_ + C::DB) % nk, C::BK, lds + C::B_BASE + ((s_ + C::DB) % C::B_STAGES) * C::B_BYTES, wave);
+        if (s_ + C::DA < total)
+            ta_cur.issue((s_ + C::DA) % nk, C::BK, lds + ((s_ + C::DA) % C::A_STAGES) * C::A_BYTES, wave);
+    }
+
+    // survivors staged in registers ACROSS tiles: a global write (atomic or store) forces the next tile's first
+    // wait to drain the queue, so records are flushed only when some lane's buffer is nearly full
+    float rs[kSlots];
+    uint32_t rd[kSlots];                                               // chunk index | (query-tile index nt << 31)
+    int n_mine = 0;
+    static_assert(C::NTL <= 2, "one bit encodes the query tile");
+
+    int a_slot = 0, b_slot = 0, g = 0;
+    bool wrote = false;                                                // wave-uniform: vm writes issued since the last drain
+    for (int i = 0; i < n_tiles; ++i) {
+        const int64_t c_row0 = c0 + ((int64_t)stream + (int64_t)i * n_streams) * C::BM;
+        f32x16 acc[C::MT][C::NTL];
+#pragma unroll
+        for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < C::NTL; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+        for (int kt = 0; kt < nk; ++kt, ++g) {
+            // Counted wait: everything issued after B(g) may stay in flight.  Exceptions: the first step after an
+            // epilogue that wrote to memory (loads and stores/atomics retire out of order with respect to each other,
+            // so with both kinds outstanding only vmcnt(0) is meaningful) and the tail of the whole sequence.
+            if ((kt == 0 && wrote) || g + C::DA > total) {
+                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                wrote = false;
+            }
+            else
+                asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(C::WAIT_N) : "memory");
+            const char *cur_a = lds + a_slot * C::A_BYTES;
+            const char *cur_b = lds + b_slot * C::B_BYTES;
+            if (g + C::DB < total) {
+                int sb = b_slot + C::DB;
+                if (sb >= C::B_STAGES) sb -= C::B_STAGES;
+                int kb = kt + C::DB;
+                if (kb >= nk) kb -= nk;                               // wraps into the next tile: same query rows
+                tb.issue(kb, C::BK, lds + C::B_BASE + sb * C::B_BYTES, wave);
+            }
+            if (g + C::DA < total) {
+                int sa = a_slot + C::DA;
+                if (sa >= C::A_STAGES) sa -= C::A_STAGES;
+                int ka = kt + C::DA;
+                if (ka == nk)                                         // first load of the next tile (g + DA < total: it exists)
+                    ta_cur.init(X, c0 + ((int64_t)stream + (int64_t)(i + 1) * n_streams) * C::BM, N, d, wave, lane);
+                if (ka >= nk) ka -= nk;
+                ta_cur.issue(ka, C::BK, lds + sa * C::A_BYTES, wave);
+            }
+#pragma unroll
+            for (int j = 0; j < C::KS; ++j) {
+                half8 af[C::MT], bf[C::NTL];
+#pragma unroll
+                for (int mt = 0; mt < C::MT; ++mt)
+                    af[mt] = *reinterpret_cast<const half8 *>(cur_a + a_lane_off + mt * 32 * C::RB + soff[j]);
+#pragma unroll
+                for (int nt = 0; nt < C::NTL; ++nt)
+                    bf[nt] = *reinterpret_cast<const half8 *>(cur_b + b_lane_off + nt * 32 * C::RB + soff[j]);
+#pragma unroll
+                for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < C::NTL; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mt], bf[nt], acc[mt][nt], 0, 0, 0);
+            }
+            a_slot = (a_slot + 1 == C::A_STAGES) ? 0 : a_slot + 1;
+            b_slot = (b_slot + 1 == C::B_STAGES) ? 0 : b_slot + 1;
+        }
+
+        // ---- epilogue of tile i (the loads of tile i+1, steps 0 .. DA-1, are in flight) ------------------------
+        if (PABL == 7) {
+            float keep = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < C::NTL; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) keep += acc[mt][nt][r];
+            if (keep == 1.2345e-30f) *overflow = 7u;
+            continue;
+        }
+        const int64_t row_base = c_row0 + wave_m * C::WM + 4 * (lane >> 5);
+        bool direct = false;                                           // a lane had to append past its staging slots
+#pragma unroll
+        for (int nt = 0; nt < C::NTL; ++nt) {
+            const float t = t_q[nt];
+#pragma unroll
+            for (int mt = 0; mt < C::MT; ++mt) {
+                float m = acc[mt][nt][0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[mt][nt][r]);
+                if (__builtin_amdgcn_ballot_w64(m >= t) == 0) continue;   // wave-uniform: nothing in this 32x32 tile
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float sc = acc[mt][nt][r];
+                    const bool hit = sc >= t;
+                    if (__builtin_amdgcn_ballot_w64(hit)) {              // wave-uniform
+                        if (hit) {
+                            const int64_t chunk = row_base + mt * 32 + (r & 3) + 8 * (r >> 2);
+                            if (chunk < lim && (fd_q[nt] < 0 || (int)dir_id[chunk] == fd_q[nt])) {
+                                if (n_mine < kSlots) {
+#pragma unroll
+                                    for (int j = 0; j < kSlots; ++j)
+                                        if (n_mine == j) { rs[j] = sc; rd[j] = (uint32_t)chunk | ((uint32_t)nt << 31); }
+                                    ++n_mine;
+                                } else {                                 // staging full in this lane: append now
+                                    direct = true;
+                                    const uint32_t pos = atomicAdd(&cand_cnt[q_col[nt]], 1u);
+                                    if (pos < (uint32_t)cap) {
+                                        ErhCand c;
+                                        c.s = sc;
+                                        c.idx = (int32_t)chunk;
+                                        cand[(int64_t)q_col[nt] * cap + pos] = c;
+                                    } else {
+                                        atomicOr(overflow, 1u);
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if (__builtin_amdgcn_ballot_w64(direct)) wrote = true;
+        const bool last_tile = (i + 1 == n_tiles);
+        if (__builtin_amdgcn_ballot_w64(n_mine >= kSlots - 1) || (last_tile && __builtin_amdgcn_ballot_w64(n_mine > 0))) {
+            wrote = true;
+            uint32_t pos[kSlots];
+#pragma unroll
+            for (int j = 0; j < kSlots; ++j) {                           // all atomics in flight before any is consumed
+                const int qj = (C::NTL > 1 && (rd[j] >> 31)) ? q_col[C::NTL - 1] : q_col[0];
+                pos[j] = (j < n_mine && PABL != 6) ? atomicAdd(&cand_cnt[qj], 1u) : 0u;
+            }
+#pragma unroll
+            for (int j = 0; j < kSlots; ++j) {
+                if (j < n_mine) {
+                    const int qj = (C::NTL > 1 && (rd[j] >> 31)) ? q_col[C::NTL - 1] : q_col[0];
+                    if (pos[j] < (uint32_t)cap) {
+                        ErhCand c;
+                        c.s = rs[j];
+                        c.idx = (int32_t)(rd[j] & 0x7fffffffu);
+                        cand[(int64_t)qj * cap + pos[j]] = c;
+                    } else {
+                        atomicOr(overflow, 1u);
+                    }
+                }
+            }
+            n_mine = 0;
         }
     }
 }
@@ -246,47 +603,145 @@ __global__ void dense_naive_kernel(const _Float16 *__restrict__ Q, int B, const 
     out[t] = s;
 }
 
-using CfgMain = ScanCfg<256, 256, 2, 4>;   // 256 chunks x 256 queries, wave tile 128 x 64
+using Cfg0 = ScanCfg<256, 256, 2, 4, 64, 3, 2>;   // one 8-wave workgroup per CU, 160 KiB LDS
+using Cfg1 = ScanCfg<128, 256, 1, 4, 32, 4, 3>;   // two 4-wave workgroups per CU, 80 KiB LDS each
+using Cfg2 = ScanCfg<256, 256, 2, 4, 32, 5, 5>;   // one workgroup per CU, BK 32, both operands 4 half-steps ahead
+static_assert(Cfg2::LDS_BYTES == 160 * 1024, "cfg2");
+static_assert(Cfg0::WAIT_N == 4 && Cfg0::LDS_BYTES == 160 * 1024, "cfg0");
+static_assert(Cfg1::LDS_BYTES == 80 * 1024, "cfg1");
+
+template <class C>
+hipError_t set_attrs() {
+    hipError_t e = hipFuncSetAttribute((const void *)dense_scan_store_kernel<C>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    if (e != hipSuccess) return e;
+#define ERH_SET_ABL(A)                                                                                     \
+    e = hipFuncSetAttribute((const void *)dense_scan_append_kernel<C, A>,                                  \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);                      \
+    if (e != hipSuccess) return e;
+    ERH_SET_ABL(0) ERH_SET_ABL(1) ERH_SET_ABL(2) ERH_SET_ABL(3) ERH_SET_ABL(4) ERH_SET_ABL(5)
+#undef ERH_SET_ABL
+#define ERH_SET_P(A)                                                                                       \
+    e = hipFuncSetAttribute((const void *)dense_scan_persist_kernel<C, A>,                                 \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);                      \
+    if (e != hipSuccess) return e;
+    ERH_SET_P(0) ERH_SET_P(6) ERH_SET_P(7) ERH_SET_P(8)
+#undef ERH_SET_P
+    return hipSuccess;
+}
+
+// Persistent launch: `ctas` = workgroups that are co-resident (CUs x workgroups per CU for this configuration).
+template <class C>
+hipError_t launch_persist(const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1, const _Float16 *Q, int Bpad,
+                          int B, const float *tau, const int16_t *filter_dir, const int16_t *dir_id, ErhCand *cand,
+                          uint32_t *cand_cnt, int cap, uint32_t *overflow, int ctas, int pabl, hipStream_t st) {
+    const int n_qt = Bpad / C::BN;
+    int grid_n = ctas / (8 * n_qt) * (8 * n_qt);
+    if (grid_n <= 0) return hipErrorInvalidValue;
+    dim3 grid((unsigned)grid_n), block(C::NT);
+#define ERH_LAUNCH_P(A)                                                                                    \
+    hipLaunchKernelGGL((dense_scan_persist_kernel<C, A>), grid, block, C::LDS_BYTES, st, X, N, d, c0, c1, Q, Bpad, B, \
+                       tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow)
+    switch (pabl) {
+        case 6: ERH_LAUNCH_P(6); break;
+        case 7: ERH_LAUNCH_P(7); break;
+        case 8: ERH_LAUNCH_P(8); break;
+        default: ERH_LAUNCH_P(0); break;
+    }
+#undef ERH_LAUNCH_P
+    return hipGetLastError();
+}
+
+template <class C>
+hipError_t launch_store(const _Float16 *Q, int Bpad, const _Float16 *X, int64_t N, int d, int64_t c0, int nc,
+                        float *S0, int ld_s0, hipStream_t st) {
+    const int n_ctiles = (nc + C::BN - 1) / C::BN;
+    const int n_qtiles = Bpad / C::BM;
+    dim3 grid(n_ctiles * n_qtiles), block(C::NT);
+    hipLaunchKernelGGL(dense_scan_store_kernel<C>, grid, block, C::LDS_BYTES, st, Q, Bpad, X, N, d, c0, nc, S0, ld_s0);
+    return hipGetLastError();
+}
+
+template <class C>
+hipError_t launch_append(const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1, const _Float16 *Q, int Bpad,
+                         int B, const float *tau, const int16_t *filter_dir, const int16_t *dir_id, ErhCand *cand,
+                         uint32_t *cand_cnt, int cap, uint32_t *overflow, int ablate, unsigned long long *dbg,
+                         hipStream_t st) {
+    const int n_qt = Bpad / C::BN;
+    const int64_t n_ct = (c1 - c0 + C::BM - 1) / C::BM;
+    const int64_t n_ct8 = (n_ct + 7) / 8 * 8;
+    dim3 grid((unsigned)(n_ct8 * n_qt)), block(C::NT);
+#define ERH_LAUNCH_ABL(A)                                                                                  \
+    hipLaunchKernelGGL((dense_scan_append_kernel<C, A>), grid, block, C::LDS_BYTES, st, X, N, d, c0, c1, Q, Bpad, B, \
+                       tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow, dbg)
+    switch (ablate) {
+        case 1: ERH_LAUNCH_ABL(1); break;
+        case 2: ERH_LAUNCH_ABL(2); break;
+        case 3: ERH_LAUNCH_ABL(3); break;
+        case 4: ERH_LAUNCH_ABL(4); break;
+        case 5: ERH_LAUNCH_ABL(5); break;
+        default: ERH_LAUNCH_ABL(0); break;
+    }
+#undef ERH_LAUNCH_ABL
+    return hipGetLastError();
+}
 
 }  // namespace
 
 // ---- launchers ----------------------------------------------------------------------------------
 namespace erh {
 
-int dense_scan_lds_bytes() { return CfgMain::LDS_BYTES; }
-int dense_scan_q_tile() { return CfgMain::BN; }
+int dense_scan_q_tile() { return 256; }   // both configurations tile the query block by 256 (or a divisor)
 
 hipError_t dense_scan_init() {
-    hipError_t e = hipFuncSetAttribute((const void *)dense_scan_store_kernel<CfgMain>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, CfgMain::LDS_BYTES);
+    hipError_t e = set_attrs<Cfg0>();
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute((const void *)dense_scan_append_kernel<CfgMain>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, CfgMain::LDS_BYTES);
+    e = set_attrs<Cfg1>();
+    if (e != hipSuccess) return e;
+    return set_attrs<Cfg2>();
 }
 
-hipError_t launch_dense_scan_store(const _Float16 *Q, int Bpad, const _Float16 *X, int64_t N, int d,
+hipError_t launch_dense_scan_store(int cfg, const _Float16 *Q, int Bpad, const _Float16 *X, int64_t N, int d,
                                    int64_t c0, int nc, float *S0, int ld_s0, hipStream_t st) {
     if (nc <= 0) return hipSuccess;
-    const int n_ctiles = (nc + CfgMain::BN - 1) / CfgMain::BN;
-    const int n_qtiles = Bpad / CfgMain::BM;
-    dim3 grid(n_ctiles * n_qtiles), block(CfgMain::NT);
-    hipLaunchKernelGGL(dense_scan_store_kernel<CfgMain>, grid, block, CfgMain::LDS_BYTES, st,
-                       Q, Bpad, X, N, d, c0, nc, S0, ld_s0);
-    return hipGetLastError();
+    if (cfg == 1) return launch_store<Cfg1>(Q, Bpad, X, N, d, c0, nc, S0, ld_s0, st);
+    if (cfg == 2) return launch_store<Cfg2>(Q, Bpad, X, N, d, c0, nc, S0, ld_s0, st);
+    return launch_store<Cfg0>(Q, Bpad, X, N, d, c0, nc, S0, ld_s0, st);
 }
 
-hipError_t launch_dense_scan_append(const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1,
+hipError_t launch_dense_scan_append(int cfg, const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1,
                                     const _Float16 *Q, int Bpad, int B, const float *tau,
                                     const int16_t *filter_dir, const int16_t *dir_id,
-                                    ErhCand *cand, uint32_t *cand_cnt, int cap, uint32_t *overflow, hipStream_t st) {
+                                    ErhCand *cand, uint32_t *cand_cnt, int cap, uint32_t *overflow, int ablate,
+                                    unsigned long long *dbg, hipStream_t st) {
     if (c1 <= c0) return hipSuccess;
-    const int n_qt = Bpad / CfgMain::BN;
-    const int64_t n_ct = (c1 - c0 + CfgMain::BM - 1) / CfgMain::BM;
-    const int64_t n_ct8 = (n_ct + 7) / 8 * 8;
-    dim3 grid((unsigned)(n_ct8 * n_qt)), block(CfgMain::NT);
-    hipLaunchKernelGGL(dense_scan_append_kernel<CfgMain>, grid, block, CfgMain::LDS_BYTES, st,
-                       X, N, d, c0, c1, Q, Bpad, B, tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow);
-    return hipGetLastError();
+    if (cfg == 1)
+        return launch_append<Cfg1>(X, N, d, c0, c1, Q, Bpad, B, tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow,
+                                   ablate, dbg, st);
+    if (cfg == 2)
+        return launch_append<Cfg2>(X, N, d, c0, c1, Q, Bpad, B, tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow,
+                                   ablate, dbg, st);
+    return launch_append<Cfg0>(X, N, d, c0, c1, Q, Bpad, B, tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow,
+                               ablate, dbg, st);
+}
+
+// Persistent variant of the append scan; returns hipErrorInvalidValue when the shape does not qualify
+// (query tiles do not divide the resident grid, or too few K-steps) so that the caller uses the plain launch.
+hipError_t launch_dense_scan_persist(int cfg, const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1,
+                                     const _Float16 *Q, int Bpad, int B, const float *tau,
+                                     const int16_t *filter_dir, const int16_t *dir_id,
+                                     ErhCand *cand, uint32_t *cand_cnt, int cap, uint32_t *overflow, int n_cus,
+                                     int pabl, hipStream_t st) {
+    if (c1 <= c0) return hipSuccess;
+    if (cfg == 1) return hipErrorInvalidValue;   // the two-workgroup configuration keeps the per-tile launch
+    if (cfg == 2) {
+        if (d / Cfg2::BK <= Cfg2::DA) return hipErrorInvalidValue;
+        return launch_persist<Cfg2>(X, N, d, c0, c1, Q, Bpad, B, tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow,
+                                    n_cus, pabl, st);
+    }
+    if (d / Cfg0::BK <= Cfg0::DA) return hipErrorInvalidValue;
+    return launch_persist<Cfg0>(X, N, d, c0, c1, Q, Bpad, B, tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow, n_cus,
+                                pabl, st);
 }
 
 hipError_t launch_dense_naive(const _Float16 *Q, int B, const _Float16 *X, int64_t row0, int rows, int d,

@@ -16,17 +16,20 @@
 
 namespace {
 
-constexpr int kFuseThreads = 256;
+constexpr int kFuseThreads = 512;
 
 struct FuseLds {
     int32_t content[erh::kFuseMaxItems];
     int32_t doc[erh::kFuseMaxItems];
     int32_t out_doc[erh::kFuseMaxItems];
     int32_t leader[erh::kFuseMaxItems];
+    double w[erh::kFuseMaxItems];        // RRF: 1/(rank + K) of the item; fusion: its raw route score
     double score[erh::kFuseMaxItems];
     int n_leaders;
 };
 
+// One item per thread; the inner scans are branch-free counting loops over LDS (broadcast reads, unrolled so
+// that several reads are in flight) instead of early-exit walks.
 template <bool RRF>
 __global__ __launch_bounds__(kFuseThreads) void fuse_kernel(
     const int32_t *__restrict__ ids_a, const double *__restrict__ sc_a, const int32_t *__restrict__ len_a, int depth_a,
@@ -45,32 +48,41 @@ __global__ __launch_bounds__(kFuseThreads) void fuse_kernel(
     const int n = la + lb;
     if (tid == 0) L.n_leaders = 0;
     for (int i = tid; i < n; i += kFuseThreads) {
-        const int32_t id = (i < la) ? ids_a[(int64_t)q * depth_a + i] : ids_b[(int64_t)q * depth_b + (i - la)];
+        const bool in_a = i < la;
+        const int32_t id = in_a ? ids_a[(int64_t)q * depth_a + i] : ids_b[(int64_t)q * depth_b + (i - la)];
         L.doc[i] = id;
         L.content[i] = content_id ? content_id[id] : id;
+        if (RRF) {
+            const int rank = in_a ? (i + 1) : (i - la + 1);
+            L.w[i] = 1.0 / (double)(rank + K);
+        } else {
+            L.w[i] = in_a ? sc_a[(int64_t)q * depth_a + i] : sc_b[(int64_t)q * depth_b + (i - la)];
+        }
     }
     __syncthreads();
     for (int i = tid; i < n; i += kFuseThreads) {
         const int32_t c = L.content[i];
-        bool lead = true;
-        for (int j = 0; j < i; ++j) lead = lead && (L.content[j] != c);
+        int earlier = 0;
+#pragma unroll 8
+        for (int j = 0; j < i; ++j) earlier += (L.content[j] == c) ? 1 : 0;
+        const bool lead = earlier == 0;
         L.leader[i] = lead ? 1 : 0;
         if (lead) {
             atomicAdd(&L.n_leaders, 1);
             if (RRF) {
+                // occurrences are added in item order; a non-occurrence adds +0.0, which never changes the bits
                 double s = 0.0;
                 int32_t last = L.doc[i];
+#pragma unroll 8
                 for (int j = i; j < n; ++j) {
-                    if (L.content[j] == c) {
-                        const int rank = (j < la) ? (j + 1) : (j - la + 1);
-                        s = s + 1.0 / (double)(rank + K);
-                        last = L.doc[j];
-                    }
+                    const bool m = L.content[j] == c;
+                    s = s + (m ? L.w[j] : 0.0);
+                    last = m ? L.doc[j] : last;
                 }
                 L.score[i] = s;
                 L.out_doc[i] = last;
             } else {
-                L.score[i] = (i < la) ? sc_a[(int64_t)q * depth_a + i] : sc_b[(int64_t)q * depth_b + (i - la)];
+                L.score[i] = L.w[i];
                 L.out_doc[i] = L.doc[i];
             }
         }
@@ -82,11 +94,11 @@ __global__ __launch_bounds__(kFuseThreads) void fuse_kernel(
         if (!L.leader[i]) continue;
         const double s = L.score[i];
         int rank = 0;
+#pragma unroll 8
         for (int j = 0; j < n; ++j) {
-            if (L.leader[j]) {
-                const double sj = L.score[j];
-                rank += (sj > s || (sj == s && j < i)) ? 1 : 0;
-            }
+            const double sj = L.score[j];
+            const bool better = (sj > s) || (sj == s && j < i);
+            rank += (L.leader[j] && better) ? 1 : 0;
         }
         if (rank < kk) {
             out_ids[(int64_t)q * topk + rank] = L.out_doc[i];
@@ -103,6 +115,14 @@ __global__ __launch_bounds__(kFuseThreads) void fuse_kernel(
 }  // namespace
 
 namespace erh {
+
+hipError_t fuse_init() {
+    hipError_t e = hipFuncSetAttribute((const void *)fuse_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)sizeof(FuseLds));
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute((const void *)fuse_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)sizeof(FuseLds));
+}
 
 hipError_t launch_rrf(const int32_t *ids_a, const int32_t *len_a, int depth_a,
                       const int32_t *ids_b, const int32_t *len_b, int depth_b,

@@ -7,15 +7,20 @@
 namespace erh {
 
 // ---- dense_scan.hip --------------------------------------------------------------------------
-int dense_scan_lds_bytes();
 int dense_scan_q_tile();   // queries are padded to a multiple of this
 hipError_t dense_scan_init();
-hipError_t launch_dense_scan_store(const _Float16 *Q, int Bpad, const _Float16 *X, int64_t N, int d,
+hipError_t launch_dense_scan_store(int cfg, const _Float16 *Q, int Bpad, const _Float16 *X, int64_t N, int d,
                                    int64_t c0, int nc, float *S0, int ld_s0, hipStream_t st);
-hipError_t launch_dense_scan_append(const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1,
+hipError_t launch_dense_scan_append(int cfg, const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1,
                                     const _Float16 *Q, int Bpad, int B, const float *tau,
                                     const int16_t *filter_dir, const int16_t *dir_id,
-                                    ErhCand *cand, uint32_t *cand_cnt, int cap, uint32_t *overflow, hipStream_t st);
+                                    ErhCand *cand, uint32_t *cand_cnt, int cap, uint32_t *overflow, int ablate,
+                                    unsigned long long *dbg, hipStream_t st);
+hipError_t launch_dense_scan_persist(int cfg, const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1,
+                                     const _Float16 *Q, int Bpad, int B, const float *tau,
+                                     const int16_t *filter_dir, const int16_t *dir_id,
+                                     ErhCand *cand, uint32_t *cand_cnt, int cap, uint32_t *overflow, int n_cus,
+                                     int pabl, hipStream_t st);
 hipError_t launch_dense_naive(const _Float16 *Q, int B, const _Float16 *X, int64_t row0, int rows, int d,
                               float *out, hipStream_t st);
 
@@ -62,7 +67,8 @@ hipError_t launch_bm25_scan(int variant, const int64_t *indptr, const int32_t *d
                             const int32_t *tile_off, int n_tiles, int64_t N,
                             const int32_t *q_indptr, const int32_t *q_tok, int B, int k, int segs,
                             const int16_t *filter_dir, const int16_t *dir_id,
-                            double *part_scores, int32_t *part_ids, int32_t *part_len, hipStream_t st);
+                            double *part_scores, int32_t *part_ids, int32_t *part_len, int ablate,
+                            unsigned long long *dbg, hipStream_t st);
 hipError_t launch_bm25_merge(int B, int k, int segs, const double *part_scores, const int32_t *part_ids,
                              const int32_t *part_len, int32_t *out_ids, double *out_scores, int32_t *out_len,
                              hipStream_t st);
@@ -73,6 +79,7 @@ hipError_t launch_widen_f32(const float *in, int64_t n, double *out, hipStream_t
 
 // ---- fuse.hip --------------------------------------------------------------------------------
 constexpr int kFuseMaxItems = 2048;   // depth_a + depth_b
+hipError_t fuse_init();
 hipError_t launch_rrf(const int32_t *ids_a, const int32_t *len_a, int depth_a,
                       const int32_t *ids_b, const int32_t *len_b, int depth_b,
                       const int32_t *content_id, int B, int K, int topk,

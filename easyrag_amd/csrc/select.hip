@@ -92,7 +92,13 @@ __global__ __launch_bounds__(256) void row_norm_max_kernel(const _Float16 *__res
 }
 
 // ---- seed stage: k-th best of the stored prefix scores ------------------------------------------
-// grid = B, block = 1024, dynamic LDS = np2 * 4 bytes.
+// grid = B, block = 1024, dynamic LDS = 64 + np2*4 + 1024*4 + kSeedBuf*4 bytes.
+// Exact k-th largest without sorting the row: every thread keeps the maximum of its (strided) 32 keys; the
+// k-th largest of those 1024 maxima (one small bitonic sort) is a lower bound p of the true k-th value, and
+// only ~k*(1+k/2048) keys are >= p.  Those are compacted and sorted.  Inputs that defeat the pivot
+// (more than kSeedBuf keys >= p, or fewer than k threads holding a valid key) take the full-sort path.
+constexpr int kSeedBuf = 4096;
+
 __global__ __launch_bounds__(kSelThreads) void seed_select_kernel(
     const float *__restrict__ S0, int ld_s0, int n0, int np2, int64_t c0, int k,
     const float *__restrict__ qnorm, float xnorm_max, int d,
@@ -103,13 +109,17 @@ __global__ __launch_bounds__(kSelThreads) void seed_select_kernel(
     // all LDS lives in the dynamic region (a static __shared__ in front would misalign it): 64-byte header first
     int &s_nvalid = *reinterpret_cast<int *>(smem);
     int &s_cnt = *reinterpret_cast<int *>(smem + 4);
+    int &s_cnt2 = *reinterpret_cast<int *>(smem + 8);
     uint32_t *keys = reinterpret_cast<uint32_t *>(smem + 64);
+    uint32_t *tmax = keys + np2;
+    uint32_t *buf = tmax + kSelThreads;
     const int q = blockIdx.x, tid = threadIdx.x;
     const float *row = S0 + (int64_t)q * ld_s0;
     const int fd = filter_dir ? (int)filter_dir[q] : -1;
-    if (tid == 0) { s_nvalid = 0; s_cnt = 0; }
+    if (tid == 0) { s_nvalid = 0; s_cnt = 0; s_cnt2 = 0; }
     __syncthreads();
     int myvalid = 0;
+    uint32_t mx = 0;
     for (int i = tid; i < np2; i += kSelThreads) {
         uint32_t key = 0;
         if (i < n0) {
@@ -119,13 +129,41 @@ __global__ __launch_bounds__(kSelThreads) void seed_select_kernel(
             if (ok) { key = erh_f2ord(s); ++myvalid; }
         }
         keys[i] = key;
+        mx = key > mx ? key : mx;
     }
+    tmax[tid] = mx;
     for (int o = 32; o >= 1; o >>= 1) myvalid += __shfl_xor(myvalid, o);
     if ((tid & 63) == 0 && myvalid) atomicAdd(&s_nvalid, myvalid);
-    erh_bitonic_desc<uint32_t>(keys, np2);   // begins and ends with a barrier
+    erh_bitonic_desc<uint32_t>(tmax, kSelThreads);   // begins and ends with a barrier
     const int nv = s_nvalid;
     float prune = -INFINITY;
-    if (nv >= k) prune = erh_ord2f(keys[k - 1]) - margin_of(qnorm[q], xnorm_max, d);
+    if (nv >= k) {                                   // uniform
+        const uint32_t p = (k <= kSelThreads) ? tmax[k - 1] : 0u;
+        bool full_sort = (p == 0u);
+        if (!full_sort) {
+            for (int i = tid; i < n0; i += kSelThreads) {
+                const uint32_t key = keys[i];
+                if (key >= p) {
+                    const int pos = atomicAdd(&s_cnt2, 1);
+                    if (pos < kSeedBuf) buf[pos] = key;
+                }
+            }
+            __syncthreads();
+            const int c2 = s_cnt2;
+            if (c2 > kSeedBuf) {
+                full_sort = true;
+            } else {
+                const int ns = erh_next_pow2(c2 < 2 ? 2 : c2);
+                for (int i = c2 + tid; i < ns; i += kSelThreads) buf[i] = 0u;
+                erh_bitonic_desc<uint32_t>(buf, ns);
+                prune = erh_ord2f(buf[k - 1]) - margin_of(qnorm[q], xnorm_max, d);
+            }
+        }
+        if (full_sort) {
+            erh_bitonic_desc<uint32_t>(keys, np2);
+            prune = erh_ord2f(keys[k - 1]) - margin_of(qnorm[q], xnorm_max, d);
+        }
+    }
     if (tid == 0) tau[q] = prune;
     // every stored prefix score >= prune becomes a candidate
     for (int i = tid; i < n0; i += kSelThreads) {
@@ -256,19 +294,33 @@ __global__ __launch_bounds__(kSelThreads) void dense_finalize_kernel(
     // depends only on this order -- which oracle/dense.py: dense_exact_scores reproduces.
     const int lane = tid & 63, wave = tid >> 6;
     const _Float16 *qrow = Q16 + (int64_t)q * d;
-    for (int e = wave; e < m; e += kSelThreads / 64) {
-        const _Float16 *xrow = X + (int64_t)r_idx[e] * d;
-        double acc = 0.0;
+    // two candidates per wave iteration: twice the row loads in flight per wave
+    for (int e0 = wave * 2; e0 < m; e0 += (kSelThreads / 64) * 2) {
+        const bool two = (e0 + 1 < m);
+        const _Float16 *xr0 = X + (int64_t)r_idx[e0] * d;
+        const _Float16 *xr1 = X + (int64_t)r_idx[two ? e0 + 1 : e0] * d;
+        double acc0 = 0.0, acc1 = 0.0;
         for (int off = 8 * lane; off < d; off += 512) {
-            const half8 xv = *reinterpret_cast<const half8 *>(xrow + off);
             const half8 qv = *reinterpret_cast<const half8 *>(qrow + off);
+            const half8 xv0 = *reinterpret_cast<const half8 *>(xr0 + off);
+            const half8 xv1 = *reinterpret_cast<const half8 *>(xr1 + off);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc = acc + (double)xv[u] * (double)qv[u];
+            for (int u = 0; u < 8; ++u) {
+                acc0 = acc0 + (double)xv0[u] * (double)qv[u];
+                acc1 = acc1 + (double)xv1[u] * (double)qv[u];
+            }
         }
-        for (int o = 32; o >= 1; o >>= 1) acc = acc + __shfl_xor(acc, o);
+        for (int o = 32; o >= 1; o >>= 1) {
+            acc0 = acc0 + __shfl_xor(acc0, o);
+            acc1 = acc1 + __shfl_xor(acc1, o);
+        }
         if (lane == 0) {
-            r_s64[e] = acc;
-            const float err = fabsf((float)(acc - (double)r_s32[e]));
+            r_s64[e0] = acc0;
+            float err = fabsf((float)(acc0 - (double)r_s32[e0]));
+            if (two) {
+                r_s64[e0 + 1] = acc1;
+                err = fmaxf(err, fabsf((float)(acc1 - (double)r_s32[e0 + 1])));
+            }
             atomicMax(&s_maxerr, __float_as_uint(err));
         }
     }
@@ -278,6 +330,7 @@ __global__ __launch_bounds__(kSelThreads) void dense_finalize_kernel(
         const double s = r_s64[tid];
         const int32_t ix = r_idx[tid];
         int rank = 0;
+#pragma unroll 8
         for (int f = 0; f < m; ++f) {
             const double sf = r_s64[f];
             const int32_t jf = r_idx[f];
@@ -300,7 +353,8 @@ static int pow2_ge(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
 hipError_t select_init() {
     hipError_t e;
-    e = hipFuncSetAttribute((const void *)seed_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kDenseN0Max * 4 + 64);
+    e = hipFuncSetAttribute((const void *)seed_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            kDenseN0Max * 4 + 64 + kSelThreads * 4 + kSeedBuf * 4);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void *)cand_refine_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kDenseCapMax * 8 + 64);
     if (e != hipSuccess) return e;
@@ -340,7 +394,7 @@ hipError_t launch_seed_select(const float *S0, int ld_s0, int n0, int64_t c0, in
                               float *tau, ErhCand *cand, uint32_t *cand_cnt, int cap, uint32_t *overflow,
                               hipStream_t st) {
     const int np2 = pow2_ge(n0 < 2 ? 2 : n0);
-    hipLaunchKernelGGL(seed_select_kernel, dim3(B), dim3(kSelThreads), (size_t)np2 * 4 + 64, st,
+    hipLaunchKernelGGL(seed_select_kernel, dim3(B), dim3(kSelThreads), (size_t)np2 * 4 + 64 + kSelThreads * 4 + kSeedBuf * 4, st,
                        S0, ld_s0, n0, np2, c0, k, qnorm, xnorm_max, d, filter_dir, dir_id, tau, cand, cand_cnt, cap,
                        overflow);
     return hipGetLastError();

@@ -274,6 +274,11 @@ class RetrievalEngine:
     def set_option(self, name: str, value: int):
         self._check(self._lib.erh_set_option(self._h, name.encode(), int(value)))
 
+    def debug_counters(self):
+        out = np.zeros(16, np.uint64)
+        self._check(self._lib.erh_debug_counters(self._h, _ptr(out)))
+        return out
+
     def dense_diag(self):
         e, m, u = C.c_double(), C.c_double(), C.c_int()
         self._check(self._lib.erh_dense_diag(self._h, C.byref(e), C.byref(m), C.byref(u)))

@@ -172,6 +172,10 @@ int erh_set_option(erh_handle *h, const char *name, int64_t value);
  * return ERH_ERR_OVERFLOW if a candidate list overflowed (host-output calls do this themselves). */
 int erh_dense_check(erh_handle *h, void *stream);
 
+/* Measurement only: with option "debug_counters" = 1 the scan kernels add per-section shader-clock sums
+ * (thread 0 of every workgroup) into 16 counters; this reads and clears them. */
+int erh_debug_counters(erh_handle *h, uint64_t *out16);
+
 /* Diagnostics of the last dense EXACT call: max |fp64 - fp32| over re-scored candidates, the
  * margin used, and the number of queries whose exactness certificate failed. */
 int erh_dense_diag(erh_handle *h, double *max_abs_err, double *margin, int32_t *uncertified);

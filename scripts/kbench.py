@@ -1,0 +1,110 @@
+#!/usr/bin/env python
+"""Kernel micro-bench on the 1M-chunk shapes: sweeps library options (ablations, stage sizes) in ONE process
+and prints per-class kernel milliseconds from the library's HIP-event timers.  Measurement tool only."""
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from easyrag_amd import synth  # noqa: E402
+from easyrag_amd._lib import ERH_K_BM25_SCAN, ERH_K_DENSE_SCAN, ERH_K_DENSE_SELECT, ERH_K_FUSE  # noqa: E402
+from easyrag_amd.engine import RetrievalEngine, queries_to_csr  # noqa: E402
+from easyrag_amd.index import BM25S, OKAPI, build_bm25_index_from_postings  # noqa: E402
+
+
+def timed(eng, fn, reps=5):
+    fn()
+    torch.cuda.synchronize()
+    eng.set_profiling(True)
+    eng.reset_kernel_time()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    eng.set_profiling(False)
+    out = {}
+    for name, cls in (("dense_scan", ERH_K_DENSE_SCAN), ("dense_select", ERH_K_DENSE_SELECT),
+                      ("bm25_scan", ERH_K_BM25_SCAN), ("fuse", ERH_K_FUSE)):
+        kt = eng.kernel_time(cls)
+        if kt["launches"]:
+            out[name] = round(kt["ms"] / reps, 4)
+    return out
+
+
+def main():
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    dev = torch.device("cuda", 0)
+    n, d, vocab = 1_000_000, 1024, 262_144
+    eng = RetrievalEngine(0)
+    res = {}
+    if what in ("all", "dense"):
+        x = synth.dense_corpus_torch(n, d, seed=2, device=dev)
+        eng.set_dense(x)
+        for B, k in ((256, 100), (1024, 288)):
+            q = synth.dense_queries_torch(x, B, seed=7)
+            for cfg, persist in ((0, 0), (0, 1), (2, 1)):
+                eng.set_option("dense_cfg", cfg)
+                eng.set_option("dense_persist", persist)
+                res[f"dense B={B} k={k} cfg={cfg} persist={persist}"] = timed(eng, lambda: eng.dense_topk(q, k, device_out=True))
+            eng.set_option("dense_cfg", 0)
+            eng.set_option("dense_persist", 1)
+            for abl in (0, 6, 7, 8, 0, 6, 7, 8):
+                eng.set_option("dense_ablate", abl)
+                res[f"dense B={B} k={k} persist pabl={abl} (run {'b' if f'dense B={B} k={k} persist pabl={abl} (run a)' in res else 'a'})"] = timed(eng, lambda: eng.dense_topk(q, k, device_out=True))
+            eng.set_option("dense_ablate", 0)
+            eng.set_option("dense_persist", 0)
+            for cfg in ():
+                eng.set_option("dense_cfg", cfg)
+                for abl in (0, 1):
+                    eng.set_option("dense_ablate", abl)
+                    res[f"dense B={B} k={k} cfg={cfg} ablate={abl}"] = timed(eng, lambda: eng.dense_topk(q, k, device_out=True))
+                eng.set_option("dense_ablate", 0)
+            eng.set_option("dense_cfg", 0)
+            eng.set_option("debug_counters", 1)
+            eng.set_option("dense_ablate", 5)
+            eng.dense_topk(q, k, device_out=True)
+            c = eng.debug_counters().astype(np.float64)[8:14]
+            eng.set_option("dense_ablate", 0)
+            eng.set_option("debug_counters", 0)
+            names = ["wait+barrier", "dma_issue", "lds_read+mfma_issue", "epilogue", "prologue", "total"]
+            res[f"dense B={B} cfg=0 sections (% of wave-0 clocks)"] = {n_: round(100 * v / c[5], 1) for n_, v in zip(names, c)}
+            for n0, n1 in ((32768, 131072), (32768, 229376)):
+                eng.set_option("dense_n0", n0)
+                eng.set_option("dense_n1", n1)
+                res[f"dense B={B} k={k} n0={n0} n1={n1}"] = timed(eng, lambda: eng.dense_topk(q, k, device_out=True))
+            eng.set_option("dense_n0", 32768)
+            eng.set_option("dense_n1", 131072)
+            eng.set_option("dense_persist", 1)
+        del x
+    if what in ("all", "bm25"):
+        indptr, doc, tf, lens, flat = synth.token_csr_torch(n, vocab, seed=3, device=dev)
+        for variant, name in ((BM25S, "bm25s"), (OKAPI, "okapi")):
+            idx = build_bm25_index_from_postings(indptr, doc, tf, lens, variant, compute_payload=False)
+            eng.set_bm25(idx, payload_on_device=True)
+            queries = synth.token_queries(flat, lens, vocab, 1024, seed=9)
+            qi, qt = queries_to_csr(queries)
+            for k in (100, 192):
+                for abl in ((0, 1, 2, 3, 8, 15) if (variant == BM25S and k == 192) else (0,)):
+                    eng.set_option("bm25_ablate", abl)
+                    res[f"{name} B=1024 k={k} ablate={abl}"] = timed(eng, lambda: eng.bm25_topk(qi, qt, k, device_out=True), 3)
+                eng.set_option("bm25_ablate", 0)
+            eng.set_option("debug_counters", 1)
+            eng.bm25_topk(qi, qt, 192, device_out=True)
+            c = eng.debug_counters().astype(np.float64)
+            eng.set_option("debug_counters", 0)
+            names = ["ranges", "token_loop", "sweep_count", "tighten", "append", "shrink", "final", "tile_misc"]
+            tot = c[:8].sum()
+            res[f"{name} sections (% of thread-0 cycles, k=192)"] = {n_: round(100 * v / tot, 1) for n_, v in zip(names, c[:8])}
+            res[f"{name} cycles per query (thread 0)"] = {"total": round(tot / 1024)}
+            qi, qt = queries_to_csr(queries[:256])
+            res[f"{name} B=256 k=100"] = timed(eng, lambda: eng.bm25_topk(qi, qt, 100, device_out=True), 3)
+    for k_, v in res.items():
+        print(f"{k_:44s} {json.dumps(v)}")
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,36 @@
+#!/usr/bin/env python
+"""Condense a rocprofv3 *_kernel_stats.csv to this library's kernels (drops torch's data-generation kernels)."""
+import csv
+import re
+import sys
+
+OURS = ("dense_scan", "dense_naive", "bm25_", "seed_select", "cand_refine", "dense_finalize", "fuse_kernel",
+        "prep_queries", "convert_rows", "row_norm", "widen_f32")
+
+
+def short(name: str) -> str:
+    m = re.search(r"(" + "|".join(OURS) + r")[A-Za-z0-9_]*(<[^>(]*>)?", name)
+    if not m:
+        return name[:60]
+    s = m.group(0)
+    if name.startswith("_ZN"):
+        cfg = re.search(r"ScanCfgILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)", name)
+        s = re.sub(r"(kernel).*", r"\1", s)
+        if cfg:
+            s += "<%s,%s,%s,%s>" % cfg.groups()
+    return s
+
+
+def main(src, dst):
+    rows = [r for r in csv.DictReader(open(src)) if any(k in r["Name"] for k in OURS)]
+    with open(dst, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Kernel", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs", "StdDev"])
+        for r in rows:
+            w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["MinNs"], r["MaxNs"],
+                        r["StdDev"]])
+    print(open(dst).read())
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])

@@ -12,7 +12,18 @@ from oracle import dense_exact_scores, dense_exact_topk, qdrant_cosine_search, t
 pytestmark = pytest.mark.gpu
 
 
-def test_mfma_scores_match_plain_gpu_and_numpy(engine):
+@pytest.fixture(params=[(0, 1), (0, 0), (1, 0), (2, 1)],
+                ids=["cfg0-256x256x64-persistent", "cfg0-per-tile", "cfg1-128x256x32-per-tile", "cfg2-256x256x32-persistent"])
+def scan_cfg(request, engine):
+    """Every dense-scan tile configuration / launch style must satisfy every parity test."""
+    engine.set_option("dense_cfg", request.param[0])
+    engine.set_option("dense_persist", request.param[1])
+    yield request.param
+    engine.set_option("dense_cfg", 0)
+    engine.set_option("dense_persist", 1)
+
+
+def test_mfma_scores_match_plain_gpu_and_numpy(engine, scan_cfg):
     # asymmetric operands: a swapped C/D layout or a wrong swizzle cannot pass
     rng = np.random.default_rng(11)
     n, d, b = 1000, 128, 70
@@ -40,7 +51,7 @@ CASES = [
 
 
 @pytest.mark.parametrize("n,d,b,k,n0,n1", CASES)
-def test_dense_topk_exact_matches_oracle(engine, n, d, b, k, n0, n1):
+def test_dense_topk_exact_matches_oracle(engine, scan_cfg, n, d, b, k, n0, n1):
     x = synth.dense_corpus(n, d, seed=n + d)
     q32 = synth.dense_queries(x, b, seed=b + k)
     q16 = to_f16_unit(q32)
@@ -52,7 +63,7 @@ def test_dense_topk_exact_matches_oracle(engine, n, d, b, k, n0, n1):
         fids, fsc, fln = engine.dense_topk(q16, k, mode=_lib.ERH_DENSE_FAST)
     finally:
         engine.set_option("dense_n0", 32768)
-        engine.set_option("dense_n1", 262144)
+        engine.set_option("dense_n1", 131072)
     diag = engine.dense_diag()
     assert diag["uncertified"] == 0 and diag["max_abs_err"] <= diag["margin"]
     kk = min(k, n)
@@ -75,7 +86,7 @@ def test_dense_topk_exact_matches_oracle(engine, n, d, b, k, n0, n1):
         assert len(set(qi) & set(ids[i, :kk])) >= kk - 2            # only near-ties at the cut may differ
 
 
-def test_dense_duplicates_and_filter(engine):
+def test_dense_duplicates_and_filter(engine, scan_cfg):
     rng = np.random.default_rng(3)
     base = to_f16_unit(rng.standard_normal((50, 128)))
     x = np.repeat(base, 8, axis=0)                        # every chunk 8 times: exact ties everywhere
@@ -131,7 +142,7 @@ def test_dense_errors(engine):
         fresh.close()
 
 
-def test_dense_full_size_properties(engine):
+def test_dense_full_size_properties(engine, scan_cfg):
     """Config 2 shape (1M x 1024 fp16, B = 256, k = 100): size-independent properties + sampled exactness."""
     import torch
     dev = torch.device("cuda", 0)
