@@ -86,14 +86,13 @@ constexpr int kBmPre = 2;          // postings per thread per (token, tile) held
 template <typename ST>
 struct BmLds {
     static constexpr int TILE = (sizeof(ST) == 4) ? erh::kBm25TileF32 : erh::kBm25TileF64;
-    // layout (bytes): [0,64) header | acc TILE*ST | cand_s CAP*ST | cand_i CAP*4 | lo CHUNK*8 | hi CHUNK*8 | tmax 1024*4
+    // layout (bytes): [0,64) header | acc TILE*ST | cand_s CAP*ST | cand_i CAP*4 | lo CHUNK*8 | hi CHUNK*8
     static constexpr size_t OFF_ACC = 64;
     static constexpr size_t OFF_CS = OFF_ACC + (size_t)TILE * sizeof(ST);
     static constexpr size_t OFF_CI = OFF_CS + (size_t)kBmCap * sizeof(ST);
     static constexpr size_t OFF_LO = OFF_CI + (size_t)kBmCap * 4;
     static constexpr size_t OFF_HI = OFF_LO + (size_t)kBmTokChunk * 8;
-    static constexpr size_t OFF_TM = OFF_HI + (size_t)kBmTokChunk * 8;
-    static constexpr size_t BYTES = OFF_TM + (size_t)kBmThreads * 4;
+    static constexpr size_t BYTES = OFF_HI + (size_t)kBmTokChunk * 8;
     static_assert(BYTES <= 160 * 1024, "BM25 scan LDS layout exceeds one CU");
 };
 
@@ -152,30 +151,36 @@ __device__ __forceinline__ bool bm_pass(ST s, int64_t doc, ST tau_s, int tau_idx
 }
 
 // Sort the candidate list (score desc, idx asc), cut to k, refresh the running threshold.  Uniform call.
+// hdr->ncand may exceed kBmCap by the failed reservations of a full list; only the first kBmCap slots are real.
 template <typename ST>
 __device__ __forceinline__ void bm_shrink(BmHdr *hdr, ST *cs, int32_t *ci, int k) {
     __syncthreads();
-    const int n = hdr->ncand;
-    for (int i = n + (int)threadIdx.x; i < kBmCap; i += kBmThreads) { cs[i] = (ST)-1; ci[i] = 0x7fffffff; }
-    erh_bitonic_rec_desc<ST>(cs, ci, kBmCap);
-    if (threadIdx.x == 0 && n >= k) {
-        hdr->ncand = k;
-        const double ts = (double)cs[k - 1];
-        if (ts > hdr->tau_s || (ts == hdr->tau_s && ci[k - 1] < hdr->tau_idx)) { hdr->tau_s = ts; hdr->tau_idx = ci[k - 1]; }
+    const int n = hdr->ncand < kBmCap ? hdr->ncand : kBmCap;
+    const int np2 = erh_next_pow2(n < 2 ? 2 : n);                      // sort only what is there
+    for (int i = n + (int)threadIdx.x; i < np2; i += kBmThreads) { cs[i] = (ST)-1; ci[i] = 0x7fffffff; }
+    erh_bitonic_rec_desc<ST>(cs, ci, np2);
+    if (threadIdx.x == 0) {
+        hdr->ncand = n < k ? n : k;
+        if (n >= k) {
+            const double ts = (double)cs[k - 1];
+            if (ts > hdr->tau_s || (ts == hdr->tau_s && ci[k - 1] < hdr->tau_idx)) { hdr->tau_s = ts; hdr->tau_idx = ci[k - 1]; }
+        }
     }
     __syncthreads();
 }
 
-// Sweep pass over the tile accumulators (16-byte LDS accesses): entries that fail the threshold are cleared,
-// survivors stay in place and are counted.  Returns this thread's survivor count.  The common case after the
-// first tiles is "touched but nowhere near the threshold": one max + one compare + one zero store per vector.
+// Sweep pass over the tile accumulators (16-byte LDS accesses).  Entries that cannot reach the top k are cleared;
+// survivors are moved to the candidate list straight away.  When the list is full the survivor stays in its
+// accumulator and hdr->total is raised: the caller shrinks the list (which tightens the threshold) and sweeps the
+// leftovers again.  The common case after the first tiles is "touched but nowhere near the threshold": one max,
+// one compare and one zero store per 16-byte vector.
 template <typename ST>
-__device__ __forceinline__ int bm_sweep_count(ST *acc, int tile_docs, int64_t base_doc, int64_t N, int fd,
-                                              const int16_t *__restrict__ dir_id, ST tau_s, int tau_idx, int tid) {
+__device__ __forceinline__ void bm_sweep(BmHdr *hdr, ST *acc, ST *cs, int32_t *ci, int tile_docs, int64_t base_doc,
+                                         int64_t N, int fd, const int16_t *__restrict__ dir_id, ST tau_s, int tau_idx,
+                                         int tid) {
     constexpr int VEC = 16 / (int)sizeof(ST);
     typedef ST VT __attribute__((ext_vector_type(VEC)));
     typedef uint32_t UT __attribute__((ext_vector_type(4)));
-    int mine = 0;
     for (int i = tid * VEC; i < tile_docs; i += kBmThreads * VEC) {
         VT v = *reinterpret_cast<VT *>(acc + i);
         const UT bits = *reinterpret_cast<const UT *>(&v);
@@ -183,37 +188,36 @@ __device__ __forceinline__ int bm_sweep_count(ST *acc, int tile_docs, int64_t ba
         ST m = v[0];
 #pragma unroll
         for (int e = 1; e < VEC; ++e) m = v[e] > m ? v[e] : m;
-        if (m < tau_s) {                                                    // nothing here can reach the top k
+        if (!(m < tau_s)) {                                                 // something here may reach the top k
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const ST sv = v[e];
+                if (sv != (ST)0) {
+                    const int64_t doc = base_doc + i + e;
+                    bool pass = bm_pass<ST>(sv, doc, tau_s, tau_idx);
+                    if (pass && (doc >= N || (fd >= 0 && (int)dir_id[doc] != fd))) pass = false;
+                    if (pass) {
+                        const int pos = atomicAdd(&hdr->ncand, 1);
+                        if (pos < kBmCap) {
+                            cs[pos] = sv;
+                            ci[pos] = (int32_t)doc;
+                            v[e] = (ST)0;
+                        } else {
+                            hdr->total = 1;                                 // list full: keep it for the next sweep
+                        }
+                    } else {
+                        v[e] = (ST)0;
+                    }
+                }
+            }
+            *reinterpret_cast<VT *>(acc + i) = v;
+        } else {
             VT z;
 #pragma unroll
             for (int e = 0; e < VEC; ++e) z[e] = (ST)0;
             *reinterpret_cast<VT *>(acc + i) = z;
-            continue;
         }
-        bool changed = false;
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            const ST sv = v[e];
-            if (sv != (ST)0) {
-                const int64_t doc = base_doc + i + e;
-                bool pass = bm_pass<ST>(sv, doc, tau_s, tau_idx);
-                if (pass && (doc >= N || (fd >= 0 && (int)dir_id[doc] != fd))) pass = false;
-                if (pass) ++mine; else { v[e] = (ST)0; changed = true; }
-            }
-        }
-        if (changed) *reinterpret_cast<VT *>(acc + i) = v;
     }
-    return mine;
-}
-
-__device__ __forceinline__ int bm_block_total(BmHdr *hdr, int mine) {
-    for (int o = 32; o >= 1; o >>= 1) mine += __shfl_xor(mine, o);
-    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&hdr->total, mine);
-    __syncthreads();
-    const int total = hdr->total;
-    __syncthreads();
-    if (threadIdx.x == 0) hdr->total = 0;
-    return total;
 }
 
 // grid = (segs, B), block = 1024.  Segment `seg` of query q walks tiles [n_tiles*seg/segs, n_tiles*(seg+1)/segs).
@@ -238,7 +242,6 @@ __global__ __launch_bounds__(kBmThreads) void bm25_scan_kernel(
     int32_t *ci = reinterpret_cast<int32_t *>(smem + L::OFF_CI);
     int64_t *s_lo = reinterpret_cast<int64_t *>(smem + L::OFF_LO);
     int64_t *s_hi = reinterpret_cast<int64_t *>(smem + L::OFF_HI);
-    uint32_t *tmax = reinterpret_cast<uint32_t *>(smem + L::OFF_TM);
 
     const int seg = blockIdx.x, q = blockIdx.y, tid = threadIdx.x;
     const int qs = q_indptr[q], nq = q_indptr[q + 1] - qs;
@@ -297,87 +300,20 @@ __global__ __launch_bounds__(kBmThreads) void bm25_scan_kernel(
                 ERH_SEC(1);
             }
             if (ablate & 2) continue;
-            // ---- sweep: keep what beats the running k-th best, clear the rest ---------------------------------
-            ST tau_s = (ST)hdr->tau_s;
-            int tau_idx = hdr->tau_idx;
-            int total = bm_block_total(hdr, bm_sweep_count<ST>(acc, TILE, base_doc, N, fd, dir_id, tau_s, tau_idx, tid));
+            // ---- sweep: move what beats the running k-th best into the list, clear the rest -----------------------
+            for (;;) {
+                const ST tau_s = (ST)hdr->tau_s;
+                const int tau_idx = hdr->tau_idx;
+                bm_sweep<ST>(hdr, acc, cs, ci, TILE, base_doc, N, fd, dir_id, tau_s, tau_idx, tid);
+                __syncthreads();
+                const int full = hdr->total;                          // uniform: read between two barriers
+                __syncthreads();
+                if (!full) break;
+                if (tid == 0) hdr->total = 0;
+                bm_shrink<ST>(hdr, cs, ci, k);                        // list was full: cut to k, threshold becomes exact
+            }
             ERH_SEC(2);
-            if (total == 0) continue;                                 // uniform
-            int have = hdr->ncand;
-            if (have + total > kBmCap && k <= kBmThreads) {
-                // Too many survivors for the list (warm-up tiles).  The k-th largest of the 1024 per-thread maxima
-                // is a lower bound of this tile's k-th best score, hence of the final k-th best: raise the
-                // threshold to "score >= p" (ties stay eligible) and sweep again.
-                constexpr int VEC = 16 / (int)sizeof(ST);
-                typedef ST VT __attribute__((ext_vector_type(VEC)));
-                ST mx = (ST)0;
-                for (int i = tid * VEC; i < TILE; i += kBmThreads * VEC) {
-                    const VT v = *reinterpret_cast<const VT *>(acc + i);
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) mx = v[e] > mx ? v[e] : mx;
-                }
-                float mxf;
-                if (sizeof(ST) == 8) mxf = __double2float_rd((double)mx); else mxf = (float)mx;
-                tmax[tid] = __float_as_uint(mxf);                     // non-negative floats order like their bits
-                erh_bitonic_desc<uint32_t>(tmax, kBmThreads);
-                const ST p = (ST)__uint_as_float(tmax[k - 1]);
-                if (p > tau_s) {
-                    tau_s = p;
-                    tau_idx = 0x7fffffff;
-                    __syncthreads();
-                    if (tid == 0 && ((double)p > hdr->tau_s)) { hdr->tau_s = (double)p; hdr->tau_idx = 0x7fffffff; }
-                    total = bm_block_total(hdr, bm_sweep_count<ST>(acc, TILE, base_doc, N, fd, dir_id, tau_s, tau_idx, tid));
-                    have = hdr->ncand;
-                }
-            }
-            ERH_SEC(3);
-            if (have + total <= kBmCap) {
-                constexpr int VEC = 16 / (int)sizeof(ST);
-                typedef ST VT __attribute__((ext_vector_type(VEC)));
-                typedef uint32_t UT __attribute__((ext_vector_type(4)));
-                for (int i = tid * VEC; i < TILE; i += kBmThreads * VEC) {
-                    VT v = *reinterpret_cast<VT *>(acc + i);
-                    const UT bits = *reinterpret_cast<const UT *>(&v);
-                    if ((bits[0] | bits[1] | bits[2] | bits[3]) == 0u) continue;
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) {
-                        if (v[e] != (ST)0) {
-                            const int pos = atomicAdd(&hdr->ncand, 1);
-                            cs[pos] = v[e];
-                            ci[pos] = (int32_t)(base_doc + i + e);
-                            v[e] = (ST)0;
-                        }
-                    }
-                    *reinterpret_cast<VT *>(acc + i) = v;
-                }
-                __syncthreads();
-            } else {
-                // adversarial path: go chunk by chunk, shrinking whenever the list may overflow
-                for (int cb = 0; cb < TILE; cb += kBmThreads) {
-                    __syncthreads();
-                    const int have_now = hdr->ncand;              // read between two barriers: uniform
-                    __syncthreads();
-                    if (have_now + kBmThreads > kBmCap) {
-                        bm_shrink<ST>(hdr, cs, ci, k);
-                        tau_s = (ST)hdr->tau_s;
-                        tau_idx = hdr->tau_idx;
-                    }
-                    const int i = cb + tid;
-                    const ST sv = acc[i];
-                    if (sv != (ST)0) {
-                        const int64_t doc = base_doc + i;
-                        if (bm_pass<ST>(sv, doc, tau_s, tau_idx)) {
-                            const int pos = atomicAdd(&hdr->ncand, 1);
-                            cs[pos] = sv;
-                            ci[pos] = (int32_t)doc;
-                        }
-                        acc[i] = (ST)0;
-                    }
-                }
-                __syncthreads();
-            }
-            ERH_SEC(4);
-            // keep the list short and the threshold exact once it holds more than k entries
+            // keep the list short and the threshold exact once it holds clearly more than k entries
             if (hdr->ncand > k + kBmThreads / 2) bm_shrink<ST>(hdr, cs, ci, k);   // uniform (read after a barrier)
             ERH_SEC(5);
         }

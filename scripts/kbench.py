@@ -95,7 +95,7 @@ def main():
             eng.bm25_topk(qi, qt, 192, device_out=True)
             c = eng.debug_counters().astype(np.float64)
             eng.set_option("debug_counters", 0)
-            names = ["ranges", "token_loop", "sweep_count", "tighten", "append", "shrink", "final", "tile_misc"]
+            names = ["ranges", "token_loop", "sweep", "-", "-", "shrink", "final", "tile_misc"]
             tot = c[:8].sum()
             res[f"{name} sections (% of thread-0 cycles, k=192)"] = {n_: round(100 * v / tot, 1) for n_, v in zip(names, c[:8])}
             res[f"{name} cycles per query (thread 0)"] = {"total": round(tot / 1024)}
