@@ -47,6 +47,10 @@ struct ScanCfg {
     static constexpr int A_ITERS = (BM * PR) / NT, B_ITERS = (BN * PR) / NT;   // LDS-DMA instructions per wave per stage
     // loads that may still be in flight at the top of a K-step: everything issued after B(kt)
     static constexpr int WAIT_N = A_ITERS * DB + B_ITERS * (DB - 1);
+    // read-ahead variant (needs DA == DB >= 2): stage kt+1 must have landed too, so only the loads issued after
+    // A(kt+1) -- the later (DB - 2) steps -- may stay in flight
+    static constexpr bool CAN_RA = (AST_ == BST_) && (BST_ >= 3);
+    static constexpr int WAIT_RA = (DB - 2) * (A_ITERS + B_ITERS);
     static_assert(BK == 32 || BK == 64, "BK");
     static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile must be a multiple of the 32x32 MFMA tile");
     static_assert((BM * PR) % NT == 0 && (BN * PR) % NT == 0, "staging must divide evenly");
@@ -75,6 +79,16 @@ struct TileSrc {
             if (grow > rows_total - 1) grow = rows_total - 1;   // clamp: rows past the end are masked later
             const int ls = p ^ row_swizzle<PR>(r);      // logical slot stored at physical slot p
             src[it] = base + grow * (int64_t)d + ls * 8;
+        }
+    }
+    // Issue instructions [it0, it1) of the K-step's DMA set (used to spread the issue cost between MFMA groups).
+    __device__ __forceinline__ void issue_part(int kt, int bk, char *lds_tile, int wave, int it0, int it1) const {
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            if (it < it0 || it >= it1) continue;
+            const int piece0 = (it * NW + wave) * 64;   // wave-uniform
+            __builtin_amdgcn_global_load_lds((const void *)(src[it] + (int64_t)kt * bk),
+                                             ERH_LDS_PTR(lds_tile + piece0 * 16), 16, 0, 0);
         }
     }
     // Issue the LDS-DMA loads for K-step kt (bk halves each) into lds_tile (lane-linear image).
@@ -380,7 +394,7 @@ __global__ __launch_bounds__(C::NT) void dense_scan_append_kernel(
 // Block b -> XCD b % 8 (observed dispatch); the n_qt workgroups that share a chunk-tile stream sit on one XCD.
 // PABL (measurement only): 0 full, 6 no global atomics (records land at slot 0), 7 no epilogue at all,
 // 8 thresholds forced to +inf (scan runs, nothing survives)
-template <class C, int PABL>
+template <class C, int PABL, bool RA>
 __global__ __launch_bounds__(C::NT) void dense_scan_persist_kernel(
     const _Float16 *__restrict__ X, int64_t N, int d, int64_t c0, int64_t c1,
     const _Float16 *__restrict__ Q, int Bpad, int B,
@@ -449,6 +463,7 @@ __global__ __launch_bounds__(C::NT) void dense_scan_persist_kernel(
 
     int a_slot = 0, b_slot = 0, g = 0;
     bool wrote = false;                                                // wave-uniform: vm writes issued since the last drain
+    half8 fa_next[C::MT], fb_next[C::NTL];                             // RA: first fragments of the next K-step
     for (int i = 0; i < n_tiles; ++i) {
         const int64_t c_row0 = c0 + ((int64_t)stream + (int64_t)i * n_streams) * C::BM;
         f32x16 acc[C::MT][C::NTL];
@@ -468,39 +483,68 @@ __global__ __launch_bounds__(C::NT) void dense_scan_persist_kernel(
                 wrote = false;
             }
             else
-                asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(C::WAIT_N) : "memory");
+                asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(RA ? C::WAIT_RA : C::WAIT_N) : "memory");
             const char *cur_a = lds + a_slot * C::A_BYTES;
             const char *cur_b = lds + b_slot * C::B_BYTES;
-            if (g + C::DB < total) {
-                int sb = b_slot + C::DB;
-                if (sb >= C::B_STAGES) sb -= C::B_STAGES;
-                int kb = kt + C::DB;
-                if (kb >= nk) kb -= nk;                               // wraps into the next tile: same query rows
-                tb.issue(kb, C::BK, lds + C::B_BASE + sb * C::B_BYTES, wave);
-            }
-            if (g + C::DA < total) {
-                int sa = a_slot + C::DA;
-                if (sa >= C::A_STAGES) sa -= C::A_STAGES;
-                int ka = kt + C::DA;
-                if (ka == nk)                                         // first load of the next tile (g + DA < total: it exists)
-                    ta_cur.init(X, c0 + ((int64_t)stream + (int64_t)(i + 1) * n_streams) * C::BM, N, d, wave, lane);
-                if (ka >= nk) ka -= nk;
-                ta_cur.issue(ka, C::BK, lds + sa * C::A_BYTES, wave);
+            // targets of this step's prefetches (B first, then A: the order the wait count assumes)
+            const bool do_b = g + C::DB < total, do_a = g + C::DA < total;
+            int sb = b_slot + C::DB;
+            if (sb >= C::B_STAGES) sb -= C::B_STAGES;
+            int kb = kt + C::DB;
+            if (kb >= nk) kb -= nk;                                   // wraps into the next tile: same query rows
+            int sa = a_slot + C::DA;
+            if (sa >= C::A_STAGES) sa -= C::A_STAGES;
+            int ka = kt + C::DA;
+            if (do_a && ka == nk)                                     // first load of the next tile (it exists: g + DA < total)
+                ta_cur.init(X, c0 + ((int64_t)stream + (int64_t)(i + 1) * n_streams) * C::BM, N, d, wave, lane);
+            if (ka >= nk) ka -= nk;
+            char *dst_b = lds + C::B_BASE + sb * C::B_BYTES;
+            char *dst_a = lds + sa * C::A_BYTES;
+            constexpr bool kSpread = (PABL != 10);                    // DMA issue spread behind the MFMA groups (10 = all at once)
+            if (!kSpread) {
+                if (do_b) tb.issue(kb, C::BK, dst_b, wave);
+                if (do_a) ta_cur.issue(ka, C::BK, dst_a, wave);
             }
 #pragma unroll
             for (int j = 0; j < C::KS; ++j) {
                 half8 af[C::MT], bf[C::NTL];
+                if (RA && j == 0 && kt > 0) {                         // read before the barrier, at the end of step kt-1
 #pragma unroll
-                for (int mt = 0; mt < C::MT; ++mt)
-                    af[mt] = *reinterpret_cast<const half8 *>(cur_a + a_lane_off + mt * 32 * C::RB + soff[j]);
+                    for (int mt = 0; mt < C::MT; ++mt) af[mt] = fa_next[mt];
 #pragma unroll
-                for (int nt = 0; nt < C::NTL; ++nt)
-                    bf[nt] = *reinterpret_cast<const half8 *>(cur_b + b_lane_off + nt * 32 * C::RB + soff[j]);
+                    for (int nt = 0; nt < C::NTL; ++nt) bf[nt] = fb_next[nt];
+                } else {
+#pragma unroll
+                    for (int mt = 0; mt < C::MT; ++mt)
+                        af[mt] = *reinterpret_cast<const half8 *>(cur_a + a_lane_off + mt * 32 * C::RB + soff[j]);
+#pragma unroll
+                    for (int nt = 0; nt < C::NTL; ++nt)
+                        bf[nt] = *reinterpret_cast<const half8 *>(cur_b + b_lane_off + nt * 32 * C::RB + soff[j]);
+                }
+                if (RA && j == C::KS - 1 && kt + 1 < nk) {
+                    // Read-ahead: stage g+1 has been complete since this step's barrier (the wait above covers it), so
+                    // its first fragments are fetched now and the MFMAs of step kt+1 can start right after its barrier.
+                    const char *nx_a = lds + ((a_slot + 1 == C::A_STAGES) ? 0 : a_slot + 1) * C::A_BYTES;
+                    const char *nx_b = lds + ((b_slot + 1 == C::B_STAGES) ? 0 : b_slot + 1) * C::B_BYTES;
+#pragma unroll
+                    for (int mt = 0; mt < C::MT; ++mt)
+                        fa_next[mt] = *reinterpret_cast<const half8 *>(nx_a + a_lane_off + mt * 32 * C::RB + soff[0]);
+#pragma unroll
+                    for (int nt = 0; nt < C::NTL; ++nt)
+                        fb_next[nt] = *reinterpret_cast<const half8 *>(nx_b + b_lane_off + nt * 32 * C::RB + soff[0]);
+                }
 #pragma unroll
                 for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < C::NTL; ++nt)
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mt], bf[nt], acc[mt][nt], 0, 0, 0);
+                if (kSpread) {
+                    // all B instructions go out before any A instruction (first half of the sub-steps / second half)
+                    constexpr int HB = (C::KS + 1) / 2;
+                    constexpr int PB = (C::B_ITERS + HB - 1) / HB, PA = (C::A_ITERS + (C::KS - HB) - 1) / (C::KS - HB);
+                    if (j < HB) { if (do_b) tb.issue_part(kb, C::BK, dst_b, wave, j * PB, (j + 1) * PB); }
+                    else        { if (do_a) ta_cur.issue_part(ka, C::BK, dst_a, wave, (j - HB) * PA, (j - HB + 1) * PA); }
+                }
             }
             a_slot = (a_slot + 1 == C::A_STAGES) ? 0 : a_slot + 1;
             b_slot = (b_slot + 1 == C::B_STAGES) ? 0 : b_slot + 1;
@@ -568,7 +612,7 @@ __global__ __launch_bounds__(C::NT) void dense_scan_persist_kernel(
 #pragma unroll
             for (int j = 0; j < kSlots; ++j) {                           // all atomics in flight before any is consumed
                 const int qj = (C::NTL > 1 && (rd[j] >> 31)) ? q_col[C::NTL - 1] : q_col[0];
-                pos[j] = (j < n_mine && PABL != 6) ? atomicAdd(&cand_cnt[qj], 1u) : 0u;
+                pos[j] = (j < n_mine) ? atomicAdd(&cand_cnt[qj], 1u) : 0u;
             }
 #pragma unroll
             for (int j = 0; j < kSlots; ++j) {
@@ -622,10 +666,15 @@ hipError_t set_attrs() {
     ERH_SET_ABL(0) ERH_SET_ABL(1) ERH_SET_ABL(2) ERH_SET_ABL(3) ERH_SET_ABL(4) ERH_SET_ABL(5)
 #undef ERH_SET_ABL
 #define ERH_SET_P(A)                                                                                       \
-    e = hipFuncSetAttribute((const void *)dense_scan_persist_kernel<C, A>,                                 \
+    e = hipFuncSetAttribute((const void *)dense_scan_persist_kernel<C, A, false>,                          \
                             hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);                      \
-    if (e != hipSuccess) return e;
-    ERH_SET_P(0) ERH_SET_P(6) ERH_SET_P(7) ERH_SET_P(8)
+    if (e != hipSuccess) return e;                                                                         \
+    if (C::CAN_RA) {                                                                                       \
+        e = hipFuncSetAttribute((const void *)dense_scan_persist_kernel<C, A, C::CAN_RA>,                  \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);                  \
+        if (e != hipSuccess) return e;                                                                     \
+    }
+    ERH_SET_P(0) ERH_SET_P(7) ERH_SET_P(8) ERH_SET_P(10)
 #undef ERH_SET_P
     return hipSuccess;
 }
@@ -634,18 +683,24 @@ hipError_t set_attrs() {
 template <class C>
 hipError_t launch_persist(const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1, const _Float16 *Q, int Bpad,
                           int B, const float *tau, const int16_t *filter_dir, const int16_t *dir_id, ErhCand *cand,
-                          uint32_t *cand_cnt, int cap, uint32_t *overflow, int ctas, int pabl, hipStream_t st) {
+                          uint32_t *cand_cnt, int cap, uint32_t *overflow, int ctas, int pabl, bool ra, hipStream_t st) {
     const int n_qt = Bpad / C::BN;
     int grid_n = ctas / (8 * n_qt) * (8 * n_qt);
     if (grid_n <= 0) return hipErrorInvalidValue;
     dim3 grid((unsigned)grid_n), block(C::NT);
 #define ERH_LAUNCH_P(A)                                                                                    \
-    hipLaunchKernelGGL((dense_scan_persist_kernel<C, A>), grid, block, C::LDS_BYTES, st, X, N, d, c0, c1, Q, Bpad, B, \
-                       tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow)
+    do {                                                                                                   \
+        if (ra && C::CAN_RA)                                                                               \
+            hipLaunchKernelGGL((dense_scan_persist_kernel<C, A, C::CAN_RA>), grid, block, C::LDS_BYTES, st, X, N, d, c0, \
+                               c1, Q, Bpad, B, tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow);     \
+        else                                                                                               \
+            hipLaunchKernelGGL((dense_scan_persist_kernel<C, A, false>), grid, block, C::LDS_BYTES, st, X, N, d, c0, c1, \
+                               Q, Bpad, B, tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow);         \
+    } while (0)
     switch (pabl) {
-        case 6: ERH_LAUNCH_P(6); break;
         case 7: ERH_LAUNCH_P(7); break;
         case 8: ERH_LAUNCH_P(8); break;
+        case 10: ERH_LAUNCH_P(10); break;
         default: ERH_LAUNCH_P(0); break;
     }
 #undef ERH_LAUNCH_P
@@ -731,17 +786,17 @@ hipError_t launch_dense_scan_persist(int cfg, const _Float16 *X, int64_t N, int 
                                      const _Float16 *Q, int Bpad, int B, const float *tau,
                                      const int16_t *filter_dir, const int16_t *dir_id,
                                      ErhCand *cand, uint32_t *cand_cnt, int cap, uint32_t *overflow, int n_cus,
-                                     int pabl, hipStream_t st) {
+                                     int pabl, int readahead, hipStream_t st) {
     if (c1 <= c0) return hipSuccess;
     if (cfg == 1) return hipErrorInvalidValue;   // the two-workgroup configuration keeps the per-tile launch
     if (cfg == 2) {
         if (d / Cfg2::BK <= Cfg2::DA) return hipErrorInvalidValue;
         return launch_persist<Cfg2>(X, N, d, c0, c1, Q, Bpad, B, tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow,
-                                    n_cus, pabl, st);
+                                    n_cus, pabl, readahead != 0, st);
     }
     if (d / Cfg0::BK <= Cfg0::DA) return hipErrorInvalidValue;
     return launch_persist<Cfg0>(X, N, d, c0, c1, Q, Bpad, B, tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow, n_cus,
-                                pabl, st);
+                                pabl, false, st);
 }
 
 hipError_t launch_dense_naive(const _Float16 *Q, int B, const _Float16 *X, int64_t row0, int rows, int d,

@@ -20,7 +20,7 @@ hipError_t launch_dense_scan_persist(int cfg, const _Float16 *X, int64_t N, int 
                                      const _Float16 *Q, int Bpad, int B, const float *tau,
                                      const int16_t *filter_dir, const int16_t *dir_id,
                                      ErhCand *cand, uint32_t *cand_cnt, int cap, uint32_t *overflow, int n_cus,
-                                     int pabl, hipStream_t st);
+                                     int pabl, int readahead, hipStream_t st);
 hipError_t launch_dense_naive(const _Float16 *Q, int B, const _Float16 *X, int64_t row0, int rows, int d,
                               float *out, hipStream_t st);
 
@@ -69,6 +69,16 @@ hipError_t launch_bm25_scan(int variant, const int64_t *indptr, const int32_t *d
                             const int16_t *filter_dir, const int16_t *dir_id,
                             double *part_scores, int32_t *part_ids, int32_t *part_len, int ablate,
                             unsigned long long *dbg, hipStream_t st);
+// wave-autonomous scan (fine skip table: one entry per (term, wave tile))
+int bm25_wave_tile_docs(int variant);
+int bm25_wave_max_tokens();
+int bm25_wave_bytes(int variant, int k);
+int bm25_wave_waves_per_cu(int variant, int k);
+hipError_t launch_bm25_wave_scan(int variant, const int64_t *indptr, const int32_t *doc_ids, const void *payload,
+                                 const int32_t *fine_off, int n_fine, int64_t N,
+                                 const int32_t *q_indptr, const int32_t *q_tok, int B, int k, int segs,
+                                 const int16_t *filter_dir, const int16_t *dir_id,
+                                 double *part_scores, int32_t *part_ids, int32_t *part_len, hipStream_t st);
 hipError_t launch_bm25_merge(int B, int k, int segs, const double *part_scores, const int32_t *part_ids,
                              const int32_t *part_len, int32_t *out_ids, double *out_scores, int32_t *out_len,
                              hipStream_t st);

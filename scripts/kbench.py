@@ -45,16 +45,21 @@ def main():
         eng.set_dense(x)
         for B, k in ((256, 100), (1024, 288)):
             q = synth.dense_queries_torch(x, B, seed=7)
-            for cfg, persist in ((0, 0), (0, 1), (2, 1)):
+            for cfg, persist in ():
                 eng.set_option("dense_cfg", cfg)
                 eng.set_option("dense_persist", persist)
                 res[f"dense B={B} k={k} cfg={cfg} persist={persist}"] = timed(eng, lambda: eng.dense_topk(q, k, device_out=True))
             eng.set_option("dense_cfg", 0)
             eng.set_option("dense_persist", 1)
-            for abl in (0, 6, 7, 8, 0, 6, 7, 8):
-                eng.set_option("dense_ablate", abl)
-                res[f"dense B={B} k={k} persist pabl={abl} (run {'b' if f'dense B={B} k={k} persist pabl={abl} (run a)' in res else 'a'})"] = timed(eng, lambda: eng.dense_topk(q, k, device_out=True))
+            for rep in "ab":
+                for cfg, ra, abl in ((0, 0, 0), (0, 0, 10), (2, 0, 0), (2, 1, 0), (2, 1, 7), (0, 0, 7)):
+                    eng.set_option("dense_cfg", cfg)
+                    eng.set_option("dense_readahead", ra)
+                    eng.set_option("dense_ablate", abl)
+                    res[f"dense B={B} k={k} persist cfg={cfg} ra={ra} pabl={abl} (run {rep})"] = timed(eng, lambda: eng.dense_topk(q, k, device_out=True))
             eng.set_option("dense_ablate", 0)
+            eng.set_option("dense_cfg", 0)
+            eng.set_option("dense_readahead", 1)
             eng.set_option("dense_persist", 0)
             for cfg in ():
                 eng.set_option("dense_cfg", cfg)
@@ -83,6 +88,13 @@ def main():
         indptr, doc, tf, lens, flat = synth.token_csr_torch(n, vocab, seed=3, device=dev)
         for variant, name in ((BM25S, "bm25s"), (OKAPI, "okapi")):
             idx = build_bm25_index_from_postings(indptr, doc, tf, lens, variant, compute_payload=False)
+            eng.set_option("bm25_mode", 1)
+            eng.set_bm25(idx, payload_on_device=True)
+            queries = synth.token_queries(flat, lens, vocab, 1024, seed=9)
+            for Bq in (1024, 16):
+                qi, qt = queries_to_csr(queries[:Bq])
+                res[f"{name} WAVE B={Bq} k=192"] = timed(eng, lambda: eng.bm25_topk(qi, qt, 192, device_out=True), 3)
+            eng.set_option("bm25_mode", 0)
             eng.set_bm25(idx, payload_on_device=True)
             queries = synth.token_queries(flat, lens, vocab, 1024, seed=9)
             qi, qt = queries_to_csr(queries)
@@ -99,8 +111,9 @@ def main():
             tot = c[:8].sum()
             res[f"{name} sections (% of thread-0 cycles, k=192)"] = {n_: round(100 * v / tot, 1) for n_, v in zip(names, c[:8])}
             res[f"{name} cycles per query (thread 0)"] = {"total": round(tot / 1024)}
-            qi, qt = queries_to_csr(queries[:256])
-            res[f"{name} B=256 k=100"] = timed(eng, lambda: eng.bm25_topk(qi, qt, 100, device_out=True), 3)
+            for Bq in (256, 16):
+                qi, qt = queries_to_csr(queries[:Bq])
+                res[f"{name} B={Bq} k=192"] = timed(eng, lambda: eng.bm25_topk(qi, qt, 192, device_out=True), 3)
     for k_, v in res.items():
         print(f"{k_:44s} {json.dumps(v)}")
     eng.close()
