@@ -48,10 +48,7 @@ struct erh_handle {
     // bm25 state
     int variant = -1;
     int64_t V = 0, Nb = 0, nnz = 0;
-    DevBuf indptr, doc_ids, payload, tile_off, fine_off;
-    int n_fine = 0, fine_docs = 0;         // wave-autonomous scan: fine skip table (0 = not built)
-    int opt_bm25_mode = 0;                 // 0 = block scan (default, faster today); 1 = wave-autonomous scan (fine skip table)
-    int last_max_qlen = 0;                 // longest query (tokens) of the batch uploaded last
+    DevBuf indptr, doc_ids, payload, tile_off;
     std::vector<int64_t> host_indptr;     // host copy: query validation + algorithmic-byte accounting
     int n_tiles = 0, tile_docs = 0;
     // metadata
@@ -217,7 +214,7 @@ int dense_topk_dev(erh_handle *h, const void *q_dev, int q_dtype, int normalize_
     { ProfScope ps(h, st, ERH_K_DENSE_SELECT, 0, 0);
       HIPCHK(h, erh::launch_dense_finalize(B, k, mode, h->qnorm.as<float>(), h->xnorm_max, d, X, Q16,
                                            h->cand.as<ErhCand>(), h->cand_cnt.as<uint32_t>(), cap, d_ids, d_sc, d_len,
-                                           reinterpret_cast<float *>(flags + 1), flags + 2, st)); }
+                                           reinterpret_cast<float *>(flags + 1), flags + 2, flags, st)); }
     return ERH_OK;
 }
 
@@ -239,34 +236,6 @@ int bm25_topk_dev(erh_handle *h, const int32_t *qptr_dev, const int32_t *qtok_de
                   const int16_t *filter_dev, int32_t *d_ids, double *d_sc, int32_t *d_len, double postings_bytes,
                   hipStream_t st) {
     const int16_t *dir = h->has_dir ? h->dir_id.as<int16_t>() : nullptr;
-    if (h->opt_bm25_mode == 1 && h->n_fine > 0 && h->opt_bm25_ablate == 0 &&
-        h->last_max_qlen <= erh::bm25_wave_max_tokens() &&
-        erh::bm25_wave_bytes(h->variant, k) * 4 <= 160 * 1024) {
-        // wave-autonomous scan: one wave per (query, segment); enough segments to fill every CU's wave slots once
-        const int conc = h->n_cus * erh::bm25_wave_waves_per_cu(h->variant, k);
-        int wsegs = std::max(1, conc / B);
-        wsegs = std::min(wsegs, h->n_fine);
-        while (wsegs > 1 && (int64_t)wsegs * k > 8192) --wsegs;
-        if (wsegs == 1) {
-            ProfScope ps(h, st, ERH_K_BM25_SCAN, postings_bytes, 0);
-            HIPCHK(h, erh::launch_bm25_wave_scan(h->variant, h->indptr.as<int64_t>(), h->doc_ids.as<int32_t>(), h->payload.p,
-                                                 h->fine_off.as<int32_t>(), h->n_fine, h->Nb, qptr_dev, qtok_dev, B, k, 1,
-                                                 filter_dev, dir, d_sc, d_ids, d_len, st));
-            return ERH_OK;
-        }
-        HIPCHK(h, h->part_sc.ensure((size_t)B * wsegs * k * 8));
-        HIPCHK(h, h->part_ids.ensure((size_t)B * wsegs * k * 4));
-        HIPCHK(h, h->part_len.ensure((size_t)B * wsegs * 4));
-        { ProfScope ps(h, st, ERH_K_BM25_SCAN, postings_bytes, 0);
-          HIPCHK(h, erh::launch_bm25_wave_scan(h->variant, h->indptr.as<int64_t>(), h->doc_ids.as<int32_t>(), h->payload.p,
-                                               h->fine_off.as<int32_t>(), h->n_fine, h->Nb, qptr_dev, qtok_dev, B, k, wsegs,
-                                               filter_dev, dir, h->part_sc.as<double>(), h->part_ids.as<int32_t>(),
-                                               h->part_len.as<int32_t>(), st)); }
-        { ProfScope ps(h, st, ERH_K_BM25_MERGE, 0, 0);
-          HIPCHK(h, erh::launch_bm25_merge(B, k, wsegs, h->part_sc.as<double>(), h->part_ids.as<int32_t>(),
-                                           h->part_len.as<int32_t>(), d_ids, d_sc, d_len, st)); }
-        return ERH_OK;
-    }
     int segs = (512 + B - 1) / B;
     segs = std::max(1, std::min(segs, h->n_tiles));
     while (segs > 1 && (int64_t)segs * k > 8192) --segs;
@@ -300,9 +269,6 @@ int upload_bm25_queries(erh_handle *h, const int32_t *q_indptr, const int32_t *q
     for (int b = 0; b < B; ++b)
         if (q_indptr[b + 1] < q_indptr[b]) return h->fail(ERH_ERR_INVALID, "q_indptr must be non-decreasing");
     const int nt = q_indptr[B];
-    int max_len = 0;
-    for (int b = 0; b < B; ++b) max_len = std::max(max_len, q_indptr[b + 1] - q_indptr[b]);
-    h->last_max_qlen = max_len;
     const size_t per = (h->variant == ERH_BM25_OKAPI) ? 12 : 8;
     double total = 0;
     for (int i = 0; i < nt; ++i) {
@@ -371,7 +337,7 @@ int erh_destroy(erh_handle *h) {
                       &h->o_ids, &h->o_sc, &h->o_len, &h->qptr, &h->qtok, &h->part_sc, &h->part_ids, &h->part_len,
                       &h->hy_sids, &h->hy_ssc, &h->hy_slen, &h->hy_dids, &h->hy_dsc, &h->hy_dlen,
                       &h->fa_ids, &h->fa_sc, &h->fa_len, &h->fb_ids, &h->fb_sc, &h->fb_len,
-                      &h->scores_tmp, &h->scores_wide, &h->dbg, &h->fine_off};
+                      &h->scores_tmp, &h->scores_wide, &h->dbg};
     for (DevBuf *b : bufs) b->release();
     delete h;
     return ERH_OK;
@@ -394,7 +360,6 @@ int erh_set_option(erh_handle *h, const char *name, int64_t value) {
     if (!strcmp(name, "dense_readahead")) { h->opt_dense_readahead = value != 0; return ERH_OK; }
     if (!strcmp(name, "dense_persist")) { h->opt_dense_persist = value != 0; return ERH_OK; }
     if (!strcmp(name, "dense_ablate")) { h->opt_dense_ablate = (int)value; return ERH_OK; }
-    if (!strcmp(name, "bm25_mode")) { h->opt_bm25_mode = value != 0; return ERH_OK; }   // takes effect at the next erh_set_bm25_*
     if (!strcmp(name, "bm25_ablate")) { h->opt_bm25_ablate = (int)value; return ERH_OK; }
     if (!strcmp(name, "debug_counters")) {
         h->opt_debug_counters = value != 0;
@@ -528,19 +493,6 @@ static int bm25_common_upload(erh_handle *h, int variant, int64_t V, int64_t N, 
     HIPCHK(h, h->tile_off.ensure((size_t)V * (h->n_tiles + 1) * 4));
     HIPCHK(h, erh::launch_bm25_tile_off(h->indptr.as<int64_t>(), h->doc_ids.as<int32_t>(), V, h->tile_docs, h->n_tiles,
                                         h->tile_off.as<int32_t>(), st));
-    h->n_fine = 0;
-    if (h->opt_bm25_mode == 1) {
-        const int fd = erh::bm25_wave_tile_docs(variant);
-        const int64_t nf = (N + fd - 1) / fd;
-        const size_t bytes = (size_t)V * (size_t)(nf + 1) * 4;
-        if (bytes <= ((size_t)8 << 30)) {            // one int per (term, wave tile); beyond 8 GiB keep the block scan
-            HIPCHK(h, h->fine_off.ensure(bytes));
-            HIPCHK(h, erh::launch_bm25_tile_off(h->indptr.as<int64_t>(), h->doc_ids.as<int32_t>(), V, fd, (int)nf,
-                                                h->fine_off.as<int32_t>(), st));
-            h->n_fine = (int)nf;
-            h->fine_docs = fd;
-        }
-    }
     h->host_indptr.assign(indptr, indptr + V + 1);
     h->variant = variant;
     h->V = V;

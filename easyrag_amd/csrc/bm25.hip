@@ -334,254 +334,6 @@ __global__ __launch_bounds__(kBmThreads) void bm25_scan_kernel(
 #undef ERH_SEC
 }
 
-// ---- wave-autonomous scan ---------------------------------------------------------------------------------
-// One WAVE = one (query, segment) task: it walks small document tiles (8 KiB of accumulators: 2048 fp32 / 1024
-// fp64 sums) with its own candidate list, all in its private slice of LDS.  Nothing is shared between waves, so
-// there is no block barrier anywhere: LDS operations of one wave execute in program order, which is exactly the
-// "token j before token j+1" rule bit parity needs.  Latency is hidden by the ~12 independent waves per CU instead
-// of by a prefetch pipeline.  Per tile:
-//   - the [lo, hi) posting range of every query token comes from the fine skip table with wave-uniform (scalar)
-//     loads; the postings of a chunk of 8 tokens are all requested before the first is applied;
-//   - survivors of the sweep are appended with ballot + prefix-popcount positions (no atomics);
-//   - the list is cut to k by an in-wave bitonic sort when fewer than one sweep step of free slots remain.
-constexpr int kWvWaves = 4;                 // waves per workgroup (independent; grouped only for launch granularity)
-constexpr int kWvBytesAcc = 8192;           // accumulator bytes per wave
-
-template <typename ST>
-__device__ __forceinline__ void wv_sort_desc(ST *cs, int32_t *ci, int P, int lane) {
-    for (int kk = 2; kk <= P; kk <<= 1) {
-        for (int j = kk >> 1; j > 0; j >>= 1) {
-            for (int t = lane; t < (P >> 1); t += 64) {
-                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                const int p = i | j;
-                const bool desc = ((i & kk) == 0);
-                const ST sx = cs[i], sy = cs[p];
-                const int32_t ix = ci[i], iy = ci[p];
-                const bool x_first = (sx > sy) || (sx == sy && ix < iy);
-                const bool y_first = (sy > sx) || (sx == sy && iy < ix);
-                if (desc ? y_first : x_first) { cs[i] = sy; cs[p] = sx; ci[i] = iy; ci[p] = ix; }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // keep the steps ordered (same-wave LDS is in order)
-        }
-    }
-}
-
-constexpr int kWvMaxTok = 16;               // query tokens handled by the wave scan (longer queries use the block scan)
-
-template <typename ST>
-struct WvState {
-    int n;          // live candidates
-    ST tau_s;       // running k-th best (score, index); (0, -1) = "score > 0" only
-    int tau_idx;
-};
-
-// Cut the wave's candidate list to k (in-wave bitonic sort) and make the threshold exact.  Deliberately NOT inlined:
-// it is rare, and inlining it at every call site bloats the scan loop past the instruction cache.
-template <typename ST>
-__device__ __noinline__ WvState<ST> wv_shrink(ST *cs, int32_t *ci, WvState<ST> st, int k, int lane) {
-    const int P = erh_next_pow2(st.n < 2 ? 2 : st.n);
-    for (int i = st.n + lane; i < P; i += 64) { cs[i] = (ST)-1; ci[i] = 0x7fffffff; }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    wv_sort_desc<ST>(cs, ci, P, lane);
-    if (st.n >= k) {
-        const ST ts = cs[k - 1];
-        const int ti = ci[k - 1];
-        if (ts > st.tau_s || (ts == st.tau_s && ti < st.tau_idx)) { st.tau_s = ts; st.tau_idx = ti; }
-        st.n = k;
-    }
-    return st;
-}
-
-// Postings of one tile, one register pair per query token (first 64 postings of the token inside the tile).
-template <typename ST>
-struct WvPost {
-    int32_t d[kWvMaxTok];
-    ST v[kWvMaxTok];
-};
-
-template <typename ST>
-__global__ __launch_bounds__(kWvWaves * 64) void bm25_wave_scan_kernel(
-    const int64_t *__restrict__ indptr, const int32_t *__restrict__ doc_ids, const ST *__restrict__ payload,
-    const int32_t *__restrict__ fine_off, int n_fine, int64_t N,
-    const int32_t *__restrict__ q_indptr, const int32_t *__restrict__ q_tok, int B, int k, int segs, int capw,
-    const int16_t *__restrict__ filter_dir, const int16_t *__restrict__ dir_id,
-    double *__restrict__ part_scores, int32_t *__restrict__ part_ids, int32_t *__restrict__ part_len) {
-    constexpr int TILE = kWvBytesAcc / (int)sizeof(ST);
-    constexpr int VEC = 16 / (int)sizeof(ST);
-    typedef ST VT __attribute__((ext_vector_type(VEC)));
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int task = blockIdx.x * kWvWaves + wave;
-    if (task >= B * segs) return;                                       // whole wave; no block-level sync exists
-    const int q = task / segs, seg = task - q * segs;
-    const int wave_bytes = kWvBytesAcc + capw * ((int)sizeof(ST) + 4);
-    char *mine = smem + wave * wave_bytes;
-    ST *acc = reinterpret_cast<ST *>(mine);
-    ST *cs = reinterpret_cast<ST *>(mine + kWvBytesAcc);
-    int32_t *ci = reinterpret_cast<int32_t *>(mine + kWvBytesAcc + capw * (int)sizeof(ST));
-
-    const int qs = q_indptr[q];
-    int nq = q_indptr[q + 1] - qs;
-    if (nq > kWvMaxTok) nq = kWvMaxTok;                                 // the host routes longer queries to the block scan
-    const int fd = filter_dir ? (int)filter_dir[q] : -1;
-    const int t_begin = (int)((int64_t)n_fine * seg / segs);
-    const int t_end = (int)((int64_t)n_fine * (seg + 1) / segs);
-    const int64_t out_base = ((int64_t)q * segs + seg) * k;
-
-    for (int i = lane * VEC; i < TILE; i += 64 * VEC) {
-        VT z;
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) z[e] = (ST)0;
-        *reinterpret_cast<VT *>(acc + i) = z;
-    }
-    WvState<ST> st;                                                     // wave-uniform
-    st.n = 0;
-    st.tau_s = (ST)0;
-    st.tau_idx = -1;
-
-    // lane j owns query token j: its posting base and its row of the skip table (loaded once per task)
-    int64_t my_ip = 0;
-    const int32_t *my_row = fine_off;
-    if (lane < nq) {
-        const int64_t tok = q_tok[qs + lane];
-        my_ip = indptr[tok];
-        my_row = fine_off + tok * (n_fine + 1);
-    }
-    // ranges of a tile: every lane < nq reads its token's two table entries (one vector load pair for the query)
-    auto load_ranges = [&](int tile, int64_t &r_lo, int32_t &r_cnt) {
-        r_lo = 0;
-        r_cnt = 0;
-        if (lane < nq && tile < t_end) {
-            const int32_t a0 = my_row[tile], a1 = my_row[tile + 1];
-            r_lo = my_ip + a0;
-            r_cnt = a1 - a0;
-        }
-    };
-    // postings of a tile: for token u the wave reads postings lo_u + lane (lane < cnt_u); issued for all tokens at once
-    auto load_posts = [&](WvPost<ST> &P, int64_t r_lo, int32_t r_cnt) {
-#pragma unroll
-        for (int u = 0; u < kWvMaxTok; ++u) {
-            P.d[u] = -1;
-            P.v[u] = (ST)0;
-            if (u < nq) {                                               // wave-uniform
-                const int64_t lo_u = ((int64_t)__builtin_amdgcn_readlane((int)(r_lo >> 32), u) << 32) |
-                                     (uint32_t)__builtin_amdgcn_readlane((int)r_lo, u);
-                const int cnt_u = __builtin_amdgcn_readlane(r_cnt, u);
-                if (lane < cnt_u) { P.d[u] = doc_ids[lo_u + lane]; P.v[u] = payload[lo_u + lane]; }
-            }
-        }
-    };
-    if (nq > 0 && t_begin < t_end) {
-        // software pipeline over tiles: ranges two tiles ahead, postings one tile ahead
-        int64_t rlo_a, rlo_b;
-        int32_t rcnt_a, rcnt_b;
-        WvPost<ST> Pa, Pb;
-        load_ranges(t_begin, rlo_a, rcnt_a);
-        load_ranges(t_begin + 1, rlo_b, rcnt_b);
-        load_posts(Pa, rlo_a, rcnt_a);
-        for (int tile = t_begin; tile < t_end; ++tile) {
-            // (a = current tile, b = next tile); issue next tile's postings and the ranges after that
-            int64_t rlo_c;
-            int32_t rcnt_c;
-            load_ranges(tile + 2, rlo_c, rcnt_c);
-            load_posts(Pb, rlo_b, rcnt_b);
-            const int64_t base_doc = (int64_t)tile * TILE;
-            // ---- scatter-add, token order = program order --------------------------------------------------------
-#pragma unroll
-            for (int u = 0; u < kWvMaxTok; ++u) {
-                if (u < nq) {
-                    if (Pa.d[u] >= 0) {
-                        const int slot = (int)((int64_t)Pa.d[u] - base_doc);
-                        acc[slot] = acc[slot] + Pa.v[u];
-                    }
-                    const int cnt_u = __builtin_amdgcn_readlane(rcnt_a, u);
-                    if (cnt_u > 64) {                                   // longer than one wave load (wave-uniform, rare)
-                        const int64_t lo_u = ((int64_t)__builtin_amdgcn_readlane((int)(rlo_a >> 32), u) << 32) |
-                                             (uint32_t)__builtin_amdgcn_readlane((int)rlo_a, u);
-                        for (int o = 64 + lane; o < cnt_u; o += 64) {
-                            const int slot = (int)((int64_t)doc_ids[lo_u + o] - base_doc);
-                            acc[slot] = acc[slot] + payload[lo_u + o];
-                        }
-                    }
-                }
-            }
-            // ---- collect: walk the same postings again; the first visitor of a document reads its finished sum,
-            //      clears the accumulator and emits it if it beats the running k-th best (later visitors read 0).
-            //      Cost follows the postings touched, not the tile size; untouched accumulators are never read.
-            //      Capacity is checked once per group of 4 tokens (at most 256 emissions).
-#pragma unroll
-            for (int u = 0; u < kWvMaxTok; ++u) {
-                if (u < nq) {
-                    if ((u & 3) == 0 && st.n + 256 > capw) st = wv_shrink<ST>(cs, ci, st, k, lane);
-                    const bool live = Pa.d[u] >= 0;
-                    ST sv = (ST)0;
-                    const int64_t doc = (int64_t)Pa.d[u];
-                    if (live) {
-                        const int slot = (int)(doc - base_doc);
-                        sv = acc[slot];
-                        acc[slot] = (ST)0;
-                    }
-                    bool pass = live && sv != (ST)0 && bm_pass<ST>(sv, doc, st.tau_s, st.tau_idx);
-                    if (pass && (doc >= N || (fd >= 0 && (int)dir_id[doc] != fd))) pass = false;
-                    const unsigned long long mask = __builtin_amdgcn_ballot_w64(pass);
-                    if (mask) {                                         // wave-uniform, rare once the threshold is tight
-                        if (pass) {
-                            const int pos = st.n + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
-                                                                                  __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                            cs[pos] = sv;
-                            ci[pos] = (int32_t)doc;
-                        }
-                        st.n += __popcll(mask);
-                    }
-                    const int cnt_u = __builtin_amdgcn_readlane(rcnt_a, u);
-                    if (cnt_u > 64) {                                   // wave-uniform, rare
-                        const int64_t lo_u = ((int64_t)__builtin_amdgcn_readlane((int)(rlo_a >> 32), u) << 32) |
-                                             (uint32_t)__builtin_amdgcn_readlane((int)rlo_a, u);
-                        for (int o0 = 64; o0 < cnt_u; o0 += 64) {
-                            if (st.n + 64 > capw) st = wv_shrink<ST>(cs, ci, st, k, lane);
-                            const bool lv = o0 + lane < cnt_u;
-                            ST s2 = (ST)0;
-                            int64_t d2 = -1;
-                            if (lv) {
-                                d2 = doc_ids[lo_u + o0 + lane];
-                                const int slot = (int)(d2 - base_doc);
-                                s2 = acc[slot];
-                                acc[slot] = (ST)0;
-                            }
-                            bool p2 = lv && s2 != (ST)0 && bm_pass<ST>(s2, d2, st.tau_s, st.tau_idx);
-                            if (p2 && (d2 >= N || (fd >= 0 && (int)dir_id[d2] != fd))) p2 = false;
-                            const unsigned long long m2 = __builtin_amdgcn_ballot_w64(p2);
-                            if (m2) {
-                                if (p2) {
-                                    const int pos = st.n + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m2 >> 32),
-                                                                                          __builtin_amdgcn_mbcnt_lo((unsigned)m2, 0u));
-                                    cs[pos] = s2;
-                                    ci[pos] = (int32_t)d2;
-                                }
-                                st.n += __popcll(m2);
-                            }
-                        }
-                    }
-                }
-            }
-            // rotate the pipeline registers
-            Pa = Pb;
-            rlo_a = rlo_b; rcnt_a = rcnt_b;
-            rlo_b = rlo_c; rcnt_b = rcnt_c;
-        }
-    }
-    // ---- emit this task's list, sorted -------------------------------------------------------------------------------
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    st = wv_shrink<ST>(cs, ci, st, k, lane);
-    const int n_out = st.n < k ? st.n : k;
-    for (int i = lane; i < k; i += 64) {
-        if (i < n_out) { part_scores[out_base + i] = (double)cs[i]; part_ids[out_base + i] = ci[i]; }
-        else { part_scores[out_base + i] = 0.0; part_ids[out_base + i] = -1; }
-    }
-    if (lane == 0) part_len[(int64_t)q * segs + seg] = n_out;
-}
-
 // Merge `segs` sorted partial lists of one query: grid = B, block = 1024, LDS = P*(8+4) (+64), P = pow2 >= segs*k.
 __global__ __launch_bounds__(kBmThreads) void bm25_merge_kernel(
     int k, int segs, int P, const double *__restrict__ part_scores, const int32_t *__restrict__ part_ids,
@@ -687,47 +439,6 @@ hipError_t launch_bm25_scan(int variant, const int64_t *indptr, const int32_t *d
         hipLaunchKernelGGL(bm25_scan_kernel<float>, grid, block, BmLds<float>::BYTES, st, indptr, doc_ids,
                            (const float *)payload, tile_off, n_tiles, N, q_indptr, q_tok, k, segs, filter_dir, dir_id,
                            part_scores, part_ids, part_len, ablate, dbg);
-    return hipGetLastError();
-}
-
-int bm25_wave_max_tokens() { return kWvMaxTok; }
-int bm25_wave_tile_docs(int variant) { return kWvBytesAcc / (variant == 0 ? 8 : 4); }
-
-// LDS bytes of one wave for top-k = k; capw = slots of the per-wave candidate list (power of two >= k + 256)
-static int wave_capw(int k) { return pow2_ge(k + 256); }
-int bm25_wave_bytes(int variant, int k) { return kWvBytesAcc + wave_capw(k) * ((variant == 0 ? 8 : 4) + 4); }
-int bm25_wave_waves_per_cu(int variant, int k) {
-    const int wg = kWvWaves * bm25_wave_bytes(variant, k);
-    int wgs = (160 * 1024) / wg;
-    if (wgs > 8) wgs = 8;
-    return wgs * kWvWaves;
-}
-
-hipError_t launch_bm25_wave_scan(int variant, const int64_t *indptr, const int32_t *doc_ids, const void *payload,
-                                 const int32_t *fine_off, int n_fine, int64_t N,
-                                 const int32_t *q_indptr, const int32_t *q_tok, int B, int k, int segs,
-                                 const int16_t *filter_dir, const int16_t *dir_id,
-                                 double *part_scores, int32_t *part_ids, int32_t *part_len, hipStream_t st) {
-    if (B <= 0) return hipSuccess;
-    const int capw = wave_capw(k);
-    const size_t lds = (size_t)kWvWaves * bm25_wave_bytes(variant, k);
-    if (lds > 160 * 1024) return hipErrorInvalidValue;
-    const int tasks = B * segs;
-    dim3 grid((tasks + kWvWaves - 1) / kWvWaves), block(kWvWaves * 64);
-    hipError_t e;
-    if (variant == 0) {
-        e = hipFuncSetAttribute((const void *)bm25_wave_scan_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(bm25_wave_scan_kernel<double>, grid, block, lds, st, indptr, doc_ids, (const double *)payload,
-                           fine_off, n_fine, N, q_indptr, q_tok, B, k, segs, capw, filter_dir, dir_id, part_scores, part_ids,
-                           part_len);
-    } else {
-        e = hipFuncSetAttribute((const void *)bm25_wave_scan_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(bm25_wave_scan_kernel<float>, grid, block, lds, st, indptr, doc_ids, (const float *)payload,
-                           fine_off, n_fine, N, q_indptr, q_tok, B, k, segs, capw, filter_dir, dir_id, part_scores, part_ids,
-                           part_len);
-    }
     return hipGetLastError();
 }
 

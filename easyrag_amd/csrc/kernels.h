@@ -51,7 +51,7 @@ hipError_t launch_dense_finalize(int B, int k, int mode, const float *qnorm, flo
                                  const _Float16 *X, const _Float16 *Q16,
                                  const ErhCand *cand, const uint32_t *cand_cnt, int cap,
                                  int32_t *out_ids, double *out_scores, int32_t *out_len,
-                                 float *diag_maxerr, uint32_t *diag_uncert, hipStream_t st);
+                                 float *diag_maxerr, uint32_t *diag_uncert, uint32_t *overflow, hipStream_t st);
 
 // ---- bm25.hip --------------------------------------------------------------------------------
 constexpr int kBm25TileF32 = 32768;   // documents per LDS accumulator tile (fp32 sums)
@@ -69,16 +69,6 @@ hipError_t launch_bm25_scan(int variant, const int64_t *indptr, const int32_t *d
                             const int16_t *filter_dir, const int16_t *dir_id,
                             double *part_scores, int32_t *part_ids, int32_t *part_len, int ablate,
                             unsigned long long *dbg, hipStream_t st);
-// wave-autonomous scan (fine skip table: one entry per (term, wave tile))
-int bm25_wave_tile_docs(int variant);
-int bm25_wave_max_tokens();
-int bm25_wave_bytes(int variant, int k);
-int bm25_wave_waves_per_cu(int variant, int k);
-hipError_t launch_bm25_wave_scan(int variant, const int64_t *indptr, const int32_t *doc_ids, const void *payload,
-                                 const int32_t *fine_off, int n_fine, int64_t N,
-                                 const int32_t *q_indptr, const int32_t *q_tok, int B, int k, int segs,
-                                 const int16_t *filter_dir, const int16_t *dir_id,
-                                 double *part_scores, int32_t *part_ids, int32_t *part_len, hipStream_t st);
 hipError_t launch_bm25_merge(int B, int k, int segs, const double *part_scores, const int32_t *part_ids,
                              const int32_t *part_len, int32_t *out_ids, double *out_scores, int32_t *out_len,
                              hipStream_t st);

@@ -230,54 +230,78 @@ __global__ __launch_bounds__(kSelThreads) void cand_refine_kernel(
     if (tid == 0) { cand_cnt[q] = (uint32_t)m; tau[q] = t_new; }
 }
 
-// ---- final: sort, pinned fp64 re-score of the margin set, rank, emit --------------------------------
-// grid = B, block = 1024, dynamic LDS = cp2 * 8 + kDenseRescoreMax * 16 bytes.
+// ---- final: select, pinned fp64 re-score of the margin set, rank, emit ------------------------------------------
+// grid = B, block = 1024, static LDS ~ 40 KiB (two workgroups per CU).
+// The candidate list (a few thousand entries, a few hundred of which matter) is never fully sorted: every thread
+// takes the maximum of its strided share, the k-th largest of those 1024 maxima is a lower bound p of the k-th best
+// score, and only entries >= p - margin (about k of them) are gathered into LDS and sorted.
+constexpr int kFinBuf = 2048;
+
 __global__ __launch_bounds__(kSelThreads) void dense_finalize_kernel(
-    int k, int mode, int cp2, const float *__restrict__ qnorm, float xnorm_max, int d,
+    int k, int mode, const float *__restrict__ qnorm, float xnorm_max, int d,
     const _Float16 *__restrict__ X, const _Float16 *__restrict__ Q16,
     const ErhCand *__restrict__ cand, const uint32_t *__restrict__ cand_cnt, int cap,
     int32_t *__restrict__ out_ids, double *__restrict__ out_scores, int32_t *__restrict__ out_len,
-    float *__restrict__ diag_maxerr, uint32_t *__restrict__ diag_uncert) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    int &s_m = *reinterpret_cast<int *>(smem);
-    unsigned int &s_maxerr = *reinterpret_cast<unsigned int *>(smem + 4);
-    uint64_t *keys = reinterpret_cast<uint64_t *>(smem + 64);
-    double *r_s64 = reinterpret_cast<double *>(smem + 64 + (size_t)cp2 * 8);
-    int32_t *r_idx = reinterpret_cast<int32_t *>(r_s64 + erh::kDenseRescoreMax);
-    float *r_s32 = reinterpret_cast<float *>(r_idx + erh::kDenseRescoreMax);
+    float *__restrict__ diag_maxerr, uint32_t *__restrict__ diag_uncert, uint32_t *__restrict__ overflow) {
+    __shared__ __attribute__((aligned(16))) uint64_t buf[kFinBuf];
+    __shared__ uint32_t tmax[kSelThreads];
+    __shared__ double r_s64[erh::kDenseRescoreMax];
+    __shared__ int32_t r_idx[erh::kDenseRescoreMax];
+    __shared__ float r_s32[erh::kDenseRescoreMax];
+    __shared__ int s_cnt, s_m;
+    __shared__ unsigned int s_maxerr;
     const int q = blockIdx.x, tid = threadIdx.x;
     int c = (int)cand_cnt[q];
     if (c > cap) c = cap;
     const ErhCand *mine = cand + (int64_t)q * cap;
-    const int ns = erh_next_pow2(c < 2 ? 2 : c);           // sort only what is there (ns <= cp2)
-    for (int i = tid; i < ns; i += kSelThreads) {
-        uint64_t key = 0;
-        if (i < c) { const ErhCand e = mine[i]; key = erh_key32(e.s, e.idx); }
-        keys[i] = key;
-    }
-    if (tid == 0) { s_m = 0; s_maxerr = 0; }
-    erh_bitonic_desc<uint64_t>(keys, ns);
     const int kk = k < c ? k : c;
     int32_t *o_ids = out_ids + (int64_t)q * k;
     double *o_sc = out_scores + (int64_t)q * k;
-    if (tid == 0) out_len[q] = kk;
+    if (tid == 0) { out_len[q] = kk; s_cnt = 0; s_m = 0; s_maxerr = 0; }
     for (int i = kk + tid; i < k; i += kSelThreads) { o_ids[i] = -1; o_sc[i] = 0.0; }
-    if (kk == 0) return;
+    if (kk == 0) return;                                                // uniform
+
+    const float delta = 0.5f * margin_of(qnorm[q], xnorm_max, d);
+    // pivot: k-th largest of the per-thread maxima (all of them candidates, so it bounds the k-th best from below)
+    uint32_t mx = 0;
+    for (int i = tid; i < c; i += kSelThreads) {
+        const uint32_t o = erh_f2ord(mine[i].s);
+        mx = o > mx ? o : mx;
+    }
+    tmax[tid] = mx;
+    erh_bitonic_desc<uint32_t>(tmax, kSelThreads);
+    float gather_thr = -INFINITY;
+    if (kk <= kSelThreads && tmax[kk - 1] != 0u) gather_thr = erh_ord2f(tmax[kk - 1]) - ((mode == 1) ? 0.f : 2.0f * delta);
+    for (int i = tid; i < c; i += kSelThreads) {
+        const ErhCand e = mine[i];
+        if (e.s >= gather_thr) {
+            const int pos = atomicAdd(&s_cnt, 1);
+            if (pos < kFinBuf) buf[pos] = erh_key32(e.s, e.idx);
+        }
+    }
+    __syncthreads();
+    int g = s_cnt;
+    if (g > kFinBuf) {                                                  // uniform; pathological tie clusters only
+        if (tid == 0) { atomicOr(overflow, 1u); atomicAdd(diag_uncert, 1u); }
+        g = kFinBuf;
+    }
+    const int ns = erh_next_pow2(g < 2 ? 2 : g);
+    for (int i = g + tid; i < ns; i += kSelThreads) buf[i] = 0ull;
+    erh_bitonic_desc<uint64_t>(buf, ns);
 
     if (mode == 1 /* ERH_DENSE_FAST */) {
         for (int i = tid; i < kk; i += kSelThreads) {
-            o_ids[i] = erh_key32_idx(keys[i]);
-            o_sc[i] = (double)erh_key32_score(keys[i]);
+            o_ids[i] = erh_key32_idx(buf[i]);
+            o_sc[i] = (double)erh_key32_score(buf[i]);
         }
         return;
     }
 
     // EXACT: everything whose fp32 score is within the margin of the kk-th best can still be in the top kk
-    const float delta = 0.5f * margin_of(qnorm[q], xnorm_max, d);
-    const float thr = erh_key32_score(keys[kk - 1]) - 2.0f * delta;
-    for (int i = tid; i < c; i += kSelThreads) {
-        const bool in_i = erh_key32_score(keys[i]) >= thr;
-        const bool in_n = (i + 1 < c) ? (erh_key32_score(keys[i + 1]) >= thr) : false;
+    const float thr = erh_key32_score(buf[kk - 1]) - 2.0f * delta;
+    for (int i = tid; i < g; i += kSelThreads) {
+        const bool in_i = erh_key32_score(buf[i]) >= thr;
+        const bool in_n = (i + 1 < g) ? (erh_key32_score(buf[i + 1]) >= thr) : false;
         if (in_i && !in_n) s_m = i + 1;
     }
     __syncthreads();
@@ -285,41 +309,68 @@ __global__ __launch_bounds__(kSelThreads) void dense_finalize_kernel(
     bool uncertified = false;
     if (m > erh::kDenseRescoreMax) { m = erh::kDenseRescoreMax; uncertified = true; }
     for (int i = tid; i < m; i += kSelThreads) {
-        r_idx[i] = erh_key32_idx(keys[i]);
-        r_s32[i] = erh_key32_score(keys[i]);
+        r_idx[i] = erh_key32_idx(buf[i]);
+        r_s32[i] = erh_key32_score(buf[i]);
     }
     __syncthreads();
-    // one wave per candidate: lane j accumulates elements 512*t + 8*j + e (e = 0..7) sequentially in fp64,
-    // then an xor butterfly 32,16,..,1.  Products of two fp16 values are exact in fp64, so the result
-    // depends only on this order -- which oracle/dense.py: dense_exact_scores reproduces.
+    // one wave per candidate group: lane j accumulates elements 512*t + 8*j + e (e = 0..7) sequentially in fp64,
+    // then an xor butterfly 32,16,..,1.  Products of two fp16 values are exact in fp64, so the result depends only
+    // on this order -- which oracle/dense.py: dense_exact_scores reproduces.  The query's fragments stay in
+    // registers (rounds of 512 elements, up to 4 = d <= 2048; longer rows reload them) and four rows are in flight.
     const int lane = tid & 63, wave = tid >> 6;
     const _Float16 *qrow = Q16 + (int64_t)q * d;
-    // two candidates per wave iteration: twice the row loads in flight per wave
-    for (int e0 = wave * 2; e0 < m; e0 += (kSelThreads / 64) * 2) {
-        const bool two = (e0 + 1 < m);
-        const _Float16 *xr0 = X + (int64_t)r_idx[e0] * d;
-        const _Float16 *xr1 = X + (int64_t)r_idx[two ? e0 + 1 : e0] * d;
-        double acc0 = 0.0, acc1 = 0.0;
-        for (int off = 8 * lane; off < d; off += 512) {
-            const half8 qv = *reinterpret_cast<const half8 *>(qrow + off);
-            const half8 xv0 = *reinterpret_cast<const half8 *>(xr0 + off);
-            const half8 xv1 = *reinterpret_cast<const half8 *>(xr1 + off);
+    constexpr int QR = 4;
+    half8 qreg[QR];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                acc0 = acc0 + (double)xv0[u] * (double)qv[u];
-                acc1 = acc1 + (double)xv1[u] * (double)qv[u];
+    for (int t = 0; t < QR; ++t) {
+        const int off = 512 * t + 8 * lane;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) qreg[t][u] = (_Float16)0.f;
+        if (off < d) qreg[t] = *reinterpret_cast<const half8 *>(qrow + off);
+    }
+    constexpr int RW = 2;                                               // rows per wave iteration (register budget: 128 VGPRs at 1024 threads)
+    for (int e0 = wave * RW; e0 < m; e0 += (kSelThreads / 64) * RW) {
+        const _Float16 *xr[RW];
+        double acc[RW];
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            const int e = (e0 + r < m) ? e0 + r : e0;
+            xr[r] = X + (int64_t)r_idx[e] * d;
+            acc[r] = 0.0;
+        }
+#pragma unroll
+        for (int t = 0; t < QR; ++t) {
+            const int off = 512 * t + 8 * lane;
+            if (off < d) {
+                half8 xv[RW];
+#pragma unroll
+                for (int r = 0; r < RW; ++r) xv[r] = *reinterpret_cast<const half8 *>(xr[r] + off);
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+#pragma unroll
+                    for (int r = 0; r < RW; ++r) acc[r] = acc[r] + (double)xv[r][u] * (double)qreg[t][u];
             }
         }
-        for (int o = 32; o >= 1; o >>= 1) {
-            acc0 = acc0 + __shfl_xor(acc0, o);
-            acc1 = acc1 + __shfl_xor(acc1, o);
+        for (int off = 512 * QR + 8 * lane; off < d; off += 512) {      // d > 2048
+            const half8 qv = *reinterpret_cast<const half8 *>(qrow + off);
+#pragma unroll
+            for (int r = 0; r < RW; ++r) {
+                const half8 xv = *reinterpret_cast<const half8 *>(xr[r] + off);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc[r] = acc[r] + (double)xv[u] * (double)qv[u];
+            }
         }
+#pragma unroll
+        for (int r = 0; r < RW; ++r)
+            for (int o = 32; o >= 1; o >>= 1) acc[r] = acc[r] + __shfl_xor(acc[r], o);
         if (lane == 0) {
-            r_s64[e0] = acc0;
-            float err = fabsf((float)(acc0 - (double)r_s32[e0]));
-            if (two) {
-                r_s64[e0 + 1] = acc1;
-                err = fmaxf(err, fabsf((float)(acc1 - (double)r_s32[e0 + 1])));
+            float err = 0.f;
+#pragma unroll
+            for (int r = 0; r < RW; ++r) {
+                if (e0 + r < m) {
+                    r_s64[e0 + r] = acc[r];
+                    err = fmaxf(err, fabsf((float)(acc[r] - (double)r_s32[e0 + r])));
+                }
             }
             atomicMax(&s_maxerr, __float_as_uint(err));
         }
@@ -358,8 +409,7 @@ hipError_t select_init() {
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void *)cand_refine_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kDenseCapMax * 8 + 64);
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute((const void *)dense_finalize_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               kDenseCapMax * 8 + kDenseRescoreMax * 16 + 64);
+    return hipSuccess;
 }
 
 hipError_t launch_prep_queries(const void *q, int q_dtype, int normalize, int B, int Bpad, int d,
@@ -412,12 +462,10 @@ hipError_t launch_dense_finalize(int B, int k, int mode, const float *qnorm, flo
                                  const _Float16 *X, const _Float16 *Q16,
                                  const ErhCand *cand, const uint32_t *cand_cnt, int cap,
                                  int32_t *out_ids, double *out_scores, int32_t *out_len,
-                                 float *diag_maxerr, uint32_t *diag_uncert, hipStream_t st) {
-    const int cp2 = pow2_ge(cap);
-    hipLaunchKernelGGL(dense_finalize_kernel, dim3(B), dim3(kSelThreads),
-                       (size_t)cp2 * 8 + (size_t)kDenseRescoreMax * 16 + 64, st,
-                       k, mode, cp2, qnorm, xnorm_max, d, X, Q16, cand, cand_cnt, cap,
-                       out_ids, out_scores, out_len, diag_maxerr, diag_uncert);
+                                 float *diag_maxerr, uint32_t *diag_uncert, uint32_t *overflow, hipStream_t st) {
+    hipLaunchKernelGGL(dense_finalize_kernel, dim3(B), dim3(kSelThreads), 0, st,
+                       k, mode, qnorm, xnorm_max, d, X, Q16, cand, cand_cnt, cap,
+                       out_ids, out_scores, out_len, diag_maxerr, diag_uncert, overflow);
     return hipGetLastError();
 }
 

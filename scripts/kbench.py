@@ -88,13 +88,6 @@ def main():
         indptr, doc, tf, lens, flat = synth.token_csr_torch(n, vocab, seed=3, device=dev)
         for variant, name in ((BM25S, "bm25s"), (OKAPI, "okapi")):
             idx = build_bm25_index_from_postings(indptr, doc, tf, lens, variant, compute_payload=False)
-            eng.set_option("bm25_mode", 1)
-            eng.set_bm25(idx, payload_on_device=True)
-            queries = synth.token_queries(flat, lens, vocab, 1024, seed=9)
-            for Bq in (1024, 16):
-                qi, qt = queries_to_csr(queries[:Bq])
-                res[f"{name} WAVE B={Bq} k=192"] = timed(eng, lambda: eng.bm25_topk(qi, qt, 192, device_out=True), 3)
-            eng.set_option("bm25_mode", 0)
             eng.set_bm25(idx, payload_on_device=True)
             queries = synth.token_queries(flat, lens, vocab, 1024, seed=9)
             qi, qt = queries_to_csr(queries)

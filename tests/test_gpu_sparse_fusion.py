@@ -13,14 +13,6 @@ from oracle.retrievers import Item
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[0, 1], ids=["block-scan", "wave-scan"], autouse=True)
-def bm25_mode(request, engine):
-    """Both BM25 scan kernels (wave-autonomous, block-wide) must satisfy every parity test."""
-    engine.set_option("bm25_mode", request.param)      # takes effect at the next set_bm25
-    yield request.param
-    engine.set_option("bm25_mode", 0)
-
-
 def _oracle_for(variant, docs):
     if variant == OKAPI:
         return BM25Okapi(docs, k1=1.5, b=0.75, epsilon=0.25)
