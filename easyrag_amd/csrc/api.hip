@@ -69,6 +69,7 @@ struct erh_handle {
     int opt_dense_ablate = 0, opt_bm25_ablate = 0;
     int opt_dense_cfg = 0;                 // dense scan tile configuration (dense_scan.hip)
     int opt_dense_readahead = 1;           // cfg 2 only: fragments of the next K-step are read before its barrier
+    int opt_dense_pp = 1;                  // ping-pong persistent append scan (falls back to the kernels below when it does not apply)
     int opt_dense_persist = 1;             // persistent append scan (falls back to the plain launch when it does not apply)
     int n_cus = 0;   // measurement only (results invalid when non-zero)
     // profiling
@@ -142,6 +143,12 @@ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 hipError_t scan_append(erh_handle *h, const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1, const _Float16 *Q16,
                        int Bpad, int B, const float *tau, const int16_t *filt, const int16_t *dir, ErhCand *cand,
                        uint32_t *cnt, int cap, uint32_t *flags, hipStream_t st) {
+    if (h->opt_dense_pp && (h->opt_dense_ablate == 0 || (h->opt_dense_ablate >= 7 && h->opt_dense_ablate <= 15 && h->opt_dense_ablate != 10))) {
+        hipError_t e = erh::launch_dense_scan_pp(X, N, d, c0, c1, Q16, Bpad, B, tau, filt, dir, cand, cnt, cap, flags,
+                                                 h->n_cus, h->opt_dense_ablate, st);
+        if (e != hipErrorInvalidValue) return e;
+        (void)hipGetLastError();
+    }
     if (h->opt_dense_persist && (h->opt_dense_ablate == 0 || h->opt_dense_ablate >= 6)) {
         hipError_t e = erh::launch_dense_scan_persist(h->opt_dense_cfg, X, N, d, c0, c1, Q16, Bpad, B, tau, filt, dir, cand,
                                                       cnt, cap, flags, h->n_cus, h->opt_dense_ablate, h->opt_dense_readahead, st);
@@ -356,8 +363,9 @@ int erh_set_option(erh_handle *h, const char *name, int64_t value) {
     if (!h || !name) return ERH_ERR_INVALID;
     if (!strcmp(name, "dense_n0")) { if (value < 1) return h->fail(ERH_ERR_INVALID, "dense_n0 < 1"); h->opt_n0 = value; return ERH_OK; }
     if (!strcmp(name, "dense_n1")) { if (value < 0) return h->fail(ERH_ERR_INVALID, "dense_n1 < 0"); h->opt_n1 = value; return ERH_OK; }
-    if (!strcmp(name, "dense_cfg")) { if (value < 0 || value > 2) return h->fail(ERH_ERR_INVALID, "dense_cfg"); h->opt_dense_cfg = (int)value; return ERH_OK; }
+    if (!strcmp(name, "dense_cfg")) { if (value < 0 || value > 3) return h->fail(ERH_ERR_INVALID, "dense_cfg"); h->opt_dense_cfg = (int)value; return ERH_OK; }
     if (!strcmp(name, "dense_readahead")) { h->opt_dense_readahead = value != 0; return ERH_OK; }
+    if (!strcmp(name, "dense_pp")) { h->opt_dense_pp = value != 0; return ERH_OK; }
     if (!strcmp(name, "dense_persist")) { h->opt_dense_persist = value != 0; return ERH_OK; }
     if (!strcmp(name, "dense_ablate")) { h->opt_dense_ablate = (int)value; return ERH_OK; }
     if (!strcmp(name, "bm25_ablate")) { h->opt_bm25_ablate = (int)value; return ERH_OK; }

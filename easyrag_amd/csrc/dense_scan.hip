@@ -46,7 +46,7 @@ struct ScanCfg {
     static constexpr int LDS_BYTES = A_STAGES * A_BYTES + B_STAGES * B_BYTES;
     static constexpr int A_ITERS = (BM * PR) / NT, B_ITERS = (BN * PR) / NT;   // LDS-DMA instructions per wave per stage
     // loads that may still be in flight at the top of a K-step: everything issued after B(kt)
-    static constexpr int WAIT_N = A_ITERS * DB + B_ITERS * (DB - 1);
+    static constexpr int WAIT_N = (AST_ > BST_) ? A_ITERS * DB + B_ITERS * (DB - 1) : (DB - 1) * (A_ITERS + B_ITERS);
     // read-ahead variant (needs DA == DB >= 2): stage kt+1 must have landed too, so only the loads issued after
     // A(kt+1) -- the later (DB - 2) steps -- may stay in flight
     static constexpr bool CAN_RA = (AST_ == BST_) && (BST_ >= 3);
@@ -647,9 +647,327 @@ __global__ void dense_naive_kernel(const _Float16 *__restrict__ Q, int B, const 
     out[t] = s;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Ping-pong persistent append scan (option "dense_pp", default on).  Same tiles, streams and results as the
+// persistent kernel above; what changes is who does what when.  The 8 waves form two groups (waves 0-3 / 4-7:
+// one wave of each group per SIMD, group = chunk-row half of the tile).  A K-step is BK = 32 halves ("stage").
+// Per stage g there is ONE raw barrier; between barrier g and barrier g+1
+//     group 0:  M(g)  then the 16 MFMAs of stage g+1          group 1:  the 16 MFMAs of stage g  then M(g)
+// so each SIMD's matrix pipe has one wave feeding it from registers while its partner wave does
+// the LDS/DMA work (MI355X_MICROARCH "two waves per SIMD").  Memory phase M(h): four LDS-DMA instructions per wave --
+// the A stage pair (h+4, h+5) when h is even, the B pair (h+3, h+4) when h is odd, the two 64-byte halves of each
+// 128-byte line back to back -- then ds_read_b128 the 12 fragments of stage h+1.
+// Rings: A 5 stages, B 4 stages (16 KiB each).  Every read of stage g precedes barrier g (it happens in M(g-1)),
+// so M(g) may overwrite the slots of stages g-1 and g.  Before barrier g each wave waits until everything it
+// issued up to B(g+1) has landed: with M(g-1) the youngest issue, the 8 instructions of M(g-2) M(g-1) may stay in
+// flight for even g, the 4 of M(g-1) for odd g -- and the barrier publishes stage g+1 to the reads of M(g).
+// Epilogue (one extra phase per tile, both groups together): scores >= tau[q] become records
+// {score, query-in-wave-tile | row-in-tile << 6 | tile << 14} (two 4-byte arrays) in the wave's LDS record area (ballot + mbcnt, no
+// per-hit branches, no global traffic).  Records go to the global candidate lists only when a buffer is half
+// full (decided for the whole workgroup one tile ahead so that all waves drain together), at the last tile,
+// or -- pass repeated with a shifted window -- when one tile alone overflows the buffer.  The flush ends with
+// vmcnt(0): stores and loads retire out of order with respect to each other, so no store may be outstanding
+// when the counted waits resume.
+namespace pp {
+constexpr int BM = 256, BN = 256, BK = 32, NW = 8, NT = 512, RB = 64, PR = 4;
+constexpr int AST = 5, BST = 4;
+constexpr int A_BYTES = BM * RB, B_BYTES = BN * RB;
+constexpr int B_BASE = AST * A_BYTES;
+constexpr int REC_BASE = B_BASE + BST * B_BYTES;
+constexpr int REC_BYTES = 2048;                       // per wave: 256 score words, then 256 packed-location words
+constexpr int CAPW = 254;                             // records per wave; the last 16 bytes of wave 0's area hold the flush flags
+constexpr int FLAG_OFF = REC_BASE + CAPW * 4;           // wave 0: score words 254, 255
+constexpr int LDS_BYTES = REC_BASE + NW * REC_BYTES;
+constexpr int TILE_BITS = 18;
+static_assert(LDS_BYTES == 160 * 1024, "pp LDS");
+}  // namespace pp
+
+#define ERH_PP_BARRIER()                                   \
+    do {                                                   \
+        asm volatile("s_barrier" ::: "memory");            \
+        __builtin_amdgcn_sched_barrier(0);                 \
+    } while (0)
+
+// PABL (measurement only): 0 full, 7 no epilogue, 8 thresholds forced to +inf, 9 s_setprio 1 around the MFMA phase;
+// without epilogue AND: 11 no MFMA, 12 no LDS-DMA, 13 no chunk-side DMA, 14 no fragment reads, 15 no query-side DMA
+template <int PABL>
+__global__ __launch_bounds__(pp::NT) void dense_scan_pp_kernel(
+    const _Float16 *__restrict__ X, int64_t N, int d, int64_t c0, int64_t c1,
+    const _Float16 *__restrict__ Q, int Bpad, int B,
+    const float *__restrict__ tau, const int16_t *__restrict__ filter_dir, const int16_t *__restrict__ dir_id,
+    ErhCand *__restrict__ cand, uint32_t *__restrict__ cand_cnt, int cap, uint32_t *__restrict__ overflow) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp = wave >> 2, wave_n = wave & 3;
+    const int nk = d / pp::BK;
+
+    const int n_qt = Bpad / pp::BN;
+    const int64_t n_ct = (c1 - c0 + pp::BM - 1) / pp::BM;
+    const int xcd = blockIdx.x & 7;
+    const int jx = blockIdx.x >> 3;
+    const int qt = jx % n_qt;
+    const int stream = (jx / n_qt) * 8 + xcd;
+    const int n_streams = (gridDim.x / (8 * n_qt)) * 8;
+    if (stream >= n_ct) return;                                        // whole workgroup, before any barrier
+    const int n_tiles = (int)((n_ct - stream + n_streams - 1) / n_streams);
+    const int total = n_tiles * nk;                                    // flattened (tile, stage) sequence
+    const int64_t q_row0 = (int64_t)qt * pp::BN;
+    const int64_t lim = (c1 < N) ? c1 : N;
+
+    const int l31 = lane & 31, hh = lane >> 5;
+    float t_q[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int q = (int)q_row0 + wave_n * 64 + nt * 32 + l31;
+        t_q[nt] = (q < B && PABL != 8) ? tau[q] : INFINITY;
+    }
+    asm volatile("" ::"v"(t_q[0]), "v"(t_q[1]));                      // loaded before the DMA stream starts (keeps vmcnt countable)
+
+    TileSrc<pp::BN, pp::NW, pp::PR> tb;
+    TileSrc<pp::BM, pp::NW, pp::PR> ta;
+    tb.init(Q, q_row0, Bpad, d, wave, lane);
+    ta.init(X, c0 + (int64_t)stream * pp::BM, N, d, wave, lane);
+    const int sw = row_swizzle<pp::PR>(l31);
+    const int soff0 = ((hh ^ sw) << 4), soff1 = (((2 + hh) ^ sw) << 4);
+    const int a_lane_off = (grp * 128 + l31) * pp::RB;
+    const int b_lane_off = pp::B_BASE + (wave_n * 64 + l31) * pp::RB;
+    char *const rec = lds + pp::REC_BASE + wave * pp::REC_BYTES;
+    volatile int *const flag = reinterpret_cast<volatile int *>(lds + pp::FLAG_OFF);
+    if (threadIdx.x == 0) { flag[0] = 0; flag[1] = 0; }
+
+    // issue state: next B stage pair (gb even, kb = gb % nk, sb = gb % BST), next A stage pair (ga, ka, sa, tile of ga);
+    // m_odd = parity of the next memory phase M(h): even h issues the A pair (h+4, h+5), odd h the B pair (h+3, h+4)
+    int gb = 0, kb = 0, sb = 0, ga = 0, ka = 0, sa = 0, ta_tile = 0, m_odd = 0;
+    // fragment-read state: next stage to read (gf) and its ring slots
+    int gf = 0, fa_slot = 0, fb_slot = 0;
+    half8 fa[4][2], fb[2][2];
+
+// Both 64-byte halves of the same 128-byte lines go out back to back (first halves -> slot s, second halves ->
+// slot s+1): the second request hits in L1 / merges, so L2 sees each line once (scripts/ubench/ldsdma.hip: 129 vs
+// 70 GB/s per CU when the halves are a stage apart).
+#define ERH_PP_ISSUE_B()                                                                              \
+    do {                                                                                              \
+        if (gb < total && PABL != 12 && PABL != 15) {                                                 \
+            char *d0_ = lds + pp::B_BASE + sb * pp::B_BYTES;                                          \
+            char *d1_ = lds + pp::B_BASE + ((sb + 1) & (pp::BST - 1)) * pp::B_BYTES;                  \
+            tb.issue_part(kb, pp::BK, d0_, wave, 0, 1);                                               \
+            tb.issue_part(kb + 1, pp::BK, d1_, wave, 0, 1);                                           \
+            tb.issue_part(kb, pp::BK, d0_, wave, 1, 2);                                               \
+            tb.issue_part(kb + 1, pp::BK, d1_, wave, 1, 2);                                           \
+        }                                                                                             \
+        gb += 2; kb = (kb + 2 == nk) ? 0 : kb + 2; sb = (sb + 2) & (pp::BST - 1);                     \
+    } while (0)
+#define ERH_PP_ISSUE_A()                                                                              \
+    do {                                                                                              \
+        if (ga < total && PABL != 12 && PABL != 13) {                                                 \
+            if (ka == 0 && ga > 0) {                                                                  \
+                ++ta_tile;                                                                            \
+                ta.init(X, c0 + ((int64_t)stream + (int64_t)ta_tile * n_streams) * pp::BM, N, d, wave, lane); \
+            }                                                                                         \
+            char *d0_ = lds + sa * pp::A_BYTES;                                                       \
+            char *d1_ = lds + ((sa + 1 == pp::AST) ? 0 : sa + 1) * pp::A_BYTES;                       \
+            ta.issue_part(ka, pp::BK, d0_, wave, 0, 1);                                               \
+            ta.issue_part(ka + 1, pp::BK, d1_, wave, 0, 1);                                           \
+            ta.issue_part(ka, pp::BK, d0_, wave, 1, 2);                                               \
+            ta.issue_part(ka + 1, pp::BK, d1_, wave, 1, 2);                                           \
+        }                                                                                             \
+        ga += 2; ka = (ka + 2 == nk) ? 0 : ka + 2; sa += 2; if (sa >= pp::AST) sa -= pp::AST;         \
+    } while (0)
+// memory phase M(h): the fragments of stage h+1, then the A pair (h+4, h+5) for even h / the B pair (h+3, h+4) for odd h
+#define ERH_PP_MEM()                                                                                  \
+    do {                                                                                              \
+        if (gf < total && (PABL != 14 || gf == 0)) {                                                  \
+            const char *pa_ = lds + fa_slot * pp::A_BYTES + a_lane_off;                               \
+            const char *pb_ = lds + fb_slot * pp::B_BYTES + b_lane_off;                               \
+            _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                        \
+                fa[mt][0] = *reinterpret_cast<const half8 *>(pa_ + mt * 32 * pp::RB + soff0);         \
+                fa[mt][1] = *reinterpret_cast<const half8 *>(pa_ + mt * 32 * pp::RB + soff1);         \
+            }                                                                                         \
+            _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                                        \
+                fb[nt][0] = *reinterpret_cast<const half8 *>(pb_ + nt * 32 * pp::RB + soff0);         \
+                fb[nt][1] = *reinterpret_cast<const half8 *>(pb_ + nt * 32 * pp::RB + soff1);         \
+            }                                                                                         \
+        }                                                                                             \
+        ++gf; fa_slot = (fa_slot + 1 == pp::AST) ? 0 : fa_slot + 1; fb_slot = (fb_slot + 1) & (pp::BST - 1); \
+        __builtin_amdgcn_sched_barrier(0);   /* reads first: the DMA issue below covers their latency */ \
+        if (m_odd) ERH_PP_ISSUE_B(); else ERH_PP_ISSUE_A();                                           \
+        m_odd ^= 1;                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+    } while (0)
+#define ERH_PP_COMPUTE()                                                                              \
+    do {                                                                                              \
+        if (PABL == 11) {                                                                             \
+            _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) asm volatile("" ::"v"(fa[mt][0]), "v"(fa[mt][1])); \
+            _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) asm volatile("" ::"v"(fb[nt][0]), "v"(fb[nt][1])); \
+            if (kt == 0) { _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f; }                \
+            break;                                                                                    \
+        }                                                                                             \
+        if (PABL == 9) asm volatile("s_setprio 1");                                                   \
+        if (kt == 0) {                                                                                \
+            const f32x16 z_ = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; \
+            _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                          \
+                _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                      \
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mt][0], fb[nt][0], z_, 0, 0, 0); \
+        } else {                                                                                      \
+            _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                          \
+                _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                      \
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mt][0], fb[nt][0], acc[mt][nt], 0, 0, 0); \
+        }                                                                                             \
+        _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                              \
+            _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                          \
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mt][1], fb[nt][1], acc[mt][nt], 0, 0, 0); \
+        if (PABL == 9) asm volatile("s_setprio 0");                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+    } while (0)
+// end of P_a(g): stage g+1 complete for this wave's pieces (see the header comment), then publish
+#define ERH_PP_WAIT()                                                                                 \
+    do {                                                                                              \
+        if (g + 4 >= total) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                          \
+        else if (g & 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                              \
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                         \
+    } while (0)
+
+    // prologue: the issue halves of M(-4) M(-3) M(-2) = A(0,1) B(0,1) A(2,3); stage 0 complete = the last 4 in flight
+    ERH_PP_ISSUE_A();
+    ERH_PP_ISSUE_B();
+    ERH_PP_ISSUE_A();
+    m_odd = 1;                                                         // next: M(-1)
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    ERH_PP_BARRIER();
+
+    f32x16 acc[4][2];
+    int fill = 0;                                                      // records buffered in this wave's area
+    int flush_now = 0;                                                 // workgroup-uniform, decided one tile ahead
+    int g = 0;
+
+// Epilogue of tile i for this wave (acc final).  See the header comment.
+#define ERH_PP_EPILOGUE()                                                                             \
+    do {                                                                                              \
+        if (PABL == 7 || PABL >= 11) {                                                                \
+            float keep_ = 0.f;                                                                        \
+            _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                          \
+                _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                      \
+                    _Pragma("unroll") for (int r = 0; r < 16; ++r) keep_ += acc[mt][nt][r];           \
+            if (keep_ == 1.2345e-30f) *overflow = 7u;                                                 \
+            break;                                                                                    \
+        }                                                                                             \
+        if (threadIdx.x == 0) flag[(i + 1) & 1] = 0;                                                  \
+        const bool last_ = (i + 1 == n_tiles);                                                        \
+        const int fill0_ = fill;                                                                      \
+        for (int shift_ = 0;; shift_ += pp::CAPW) {                                                   \
+            int cnt_ = fill0_;                                                                        \
+            float tt_[2] = {t_q[0], t_q[1]};                                                          \
+            asm volatile("" : "+v"(tt_[0]), "+v"(tt_[1]));   /* opaque per pass: nothing of the pass is hoisted out of the loop */ \
+            _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                                        \
+                const float t_ = tt_[nt];                                                             \
+                uint32_t pk_l_ = (uint32_t)(nt * 32 + l31) | ((uint32_t)(grp * 128 + 4 * hh) << 6) |     \
+                                 ((uint32_t)i << 14);                                                 \
+                asm volatile("" : "+v"(pk_l_));                                                       \
+                _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                    \
+                    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                  \
+                        const float sc_ = acc[mt][nt][r];                                             \
+                        const bool hit_ = sc_ >= t_;                                                  \
+                        const unsigned long long m_ = __builtin_amdgcn_ballot_w64(hit_);              \
+                        if (m_) {                                                                     \
+                            const int pos_ = cnt_ - shift_ +                                          \
+                                (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m_ >> 32),                  \
+                                                               __builtin_amdgcn_mbcnt_lo((uint32_t)m_, 0u)); \
+                            if (hit_ && (unsigned)pos_ < (unsigned)pp::CAPW) {                        \
+                                *reinterpret_cast<float *>(rec + pos_ * 4) = sc_;                     \
+                                *reinterpret_cast<uint32_t *>(rec + 1024 + pos_ * 4) =                \
+                                    pk_l_ + ((uint32_t)(mt * 32 + (r & 3) + 8 * (r >> 2)) << 6);      \
+                            }                                                                         \
+                            cnt_ += __builtin_popcountll(m_);                                         \
+                        }                                                                             \
+                        __builtin_amdgcn_sched_barrier(0);   /* keeps one ballot mask live at a time */ \
+                    }                                                                                 \
+                }                                                                                     \
+            }                                                                                         \
+            const int avail_ = cnt_ - shift_;                                                         \
+            const bool over_ = avail_ > pp::CAPW;                                                     \
+            const int nrec_ = over_ ? pp::CAPW : avail_;                                              \
+            if (over_ || flush_now || last_) {                                                        \
+                for (int base_ = 0; base_ < nrec_; base_ += 64) {                                     \
+                    const int j_ = base_ + lane;                                                      \
+                    if (j_ < nrec_) {                                                                 \
+                        uint2 rc_;                                                                    \
+                        rc_.x = *reinterpret_cast<const uint32_t *>(rec + j_ * 4);                    \
+                        rc_.y = *reinterpret_cast<const uint32_t *>(rec + 1024 + j_ * 4);             \
+                        const int q_ = (int)q_row0 + wave_n * 64 + (int)(rc_.y & 63u);                \
+                        const int64_t chunk_ = c0 + ((int64_t)stream + (int64_t)(rc_.y >> 14) * n_streams) * pp::BM + \
+                                               (int64_t)((rc_.y >> 6) & 255u);                        \
+                        bool ok_ = chunk_ < lim;                                                      \
+                        if (ok_ && filter_dir) {                                                      \
+                            const int fd_ = (int)filter_dir[q_];                                      \
+                            ok_ = fd_ < 0 || (int)dir_id[chunk_] == fd_;                              \
+                        }                                                                             \
+                        if (ok_) {                                                                    \
+                            const uint32_t p_ = atomicAdd(&cand_cnt[q_], 1u);                         \
+                            if (p_ < (uint32_t)cap) {                                                 \
+                                ErhCand c_;                                                           \
+                                c_.s = __uint_as_float(rc_.x);                                        \
+                                c_.idx = (int32_t)chunk_;                                             \
+                                cand[(int64_t)q_ * cap + p_] = c_;                                    \
+                            } else {                                                                  \
+                                atomicOr(overflow, 1u);                                               \
+                            }                                                                         \
+                        }                                                                             \
+                    }                                                                                 \
+                }                                                                                     \
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                      \
+                fill = 0;                                                                             \
+            } else {                                                                                  \
+                fill = nrec_;                                                                         \
+            }                                                                                         \
+            if (!over_) break;                                                                        \
+        }                                                                                             \
+        if (fill > pp::CAPW / 2 && lane == 0) flag[i & 1] = 1;                                        \
+    } while (0)
+
+    // One barrier per stage: between barrier g and barrier g+1 group 0 runs M(g) then C(g+1), group 1 runs C(g) then
+    // M(g) -- opposite order, so on every SIMD one wave is in its matrix segment while its partner does the memory
+    // segment.  (The barrier is only needed where a stage changes hands: before it every read of stage g is done
+    // and every piece of stage g+1 has landed.)
+    if (grp == 0) {
+        ERH_PP_MEM();                                                  // M(-1): B(2,3), fragments of stage 0
+        for (int i = 0; i < n_tiles; ++i) {
+            for (int kt = 0; kt < nk; ++kt, ++g) {
+                ERH_PP_COMPUTE();
+                ERH_PP_WAIT();
+                ERH_PP_BARRIER();                                      // barrier g
+                ERH_PP_MEM();                                          // M(g)
+            }
+            ERH_PP_EPILOGUE();
+            ERH_PP_BARRIER();
+            if (PABL != 7 && PABL < 11) flush_now = __builtin_amdgcn_readfirstlane(flag[i & 1]);
+        }
+    } else {
+        for (int i = 0; i < n_tiles; ++i) {
+            for (int kt = 0; kt < nk; ++kt, ++g) {
+                ERH_PP_MEM();                                          // M(g-1)
+                ERH_PP_WAIT();
+                ERH_PP_BARRIER();                                      // barrier g
+                ERH_PP_COMPUTE();
+            }
+            ERH_PP_EPILOGUE();
+            ERH_PP_BARRIER();
+            if (PABL != 7 && PABL < 11) flush_now = __builtin_amdgcn_readfirstlane(flag[i & 1]);
+        }
+    }
+#undef ERH_PP_ISSUE_A
+#undef ERH_PP_ISSUE_B
+#undef ERH_PP_MEM
+#undef ERH_PP_COMPUTE
+#undef ERH_PP_WAIT
+#undef ERH_PP_EPILOGUE
+}
+
 using Cfg0 = ScanCfg<256, 256, 2, 4, 64, 3, 2>;   // one 8-wave workgroup per CU, 160 KiB LDS
 using Cfg1 = ScanCfg<128, 256, 1, 4, 32, 4, 3>;   // two 4-wave workgroups per CU, 80 KiB LDS each
 using Cfg2 = ScanCfg<256, 256, 2, 4, 32, 5, 5>;   // one workgroup per CU, BK 32, both operands 4 half-steps ahead
+using Cfg3 = ScanCfg<256, 256, 2, 4, 64, 2, 2>;   // BK 64, both rings 2 deep (128 KiB): measures what the third A stage buys
 static_assert(Cfg2::LDS_BYTES == 160 * 1024, "cfg2");
 static_assert(Cfg0::WAIT_N == 4 && Cfg0::LDS_BYTES == 160 * 1024, "cfg0");
 static_assert(Cfg1::LDS_BYTES == 80 * 1024, "cfg1");
@@ -741,6 +1059,33 @@ hipError_t launch_append(const _Float16 *X, int64_t N, int d, int64_t c0, int64_
     return hipGetLastError();
 }
 
+hipError_t launch_pp(const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1, const _Float16 *Q, int Bpad, int B,
+                     const float *tau, const int16_t *filter_dir, const int16_t *dir_id, ErhCand *cand,
+                     uint32_t *cand_cnt, int cap, uint32_t *overflow, int ctas, int pabl, hipStream_t st) {
+    const int n_qt = Bpad / pp::BN;
+    const int grid_n = ctas / (8 * n_qt) * (8 * n_qt);
+    if (grid_n <= 0) return hipErrorInvalidValue;
+    const int64_t n_ct = (c1 - c0 + pp::BM - 1) / pp::BM;
+    if (n_ct / (grid_n / n_qt) + 1 >= (1ll << pp::TILE_BITS)) return hipErrorInvalidValue;   // tile index must fit the record
+    dim3 grid((unsigned)grid_n), block(pp::NT);
+#define ERH_LAUNCH_PP(A)                                                                                   \
+    hipLaunchKernelGGL((dense_scan_pp_kernel<A>), grid, block, pp::LDS_BYTES, st, X, N, d, c0, c1, Q, Bpad, B, tau, \
+                       filter_dir, dir_id, cand, cand_cnt, cap, overflow)
+    switch (pabl) {
+        case 7: ERH_LAUNCH_PP(7); break;
+        case 8: ERH_LAUNCH_PP(8); break;
+        case 9: ERH_LAUNCH_PP(9); break;
+        case 11: ERH_LAUNCH_PP(11); break;
+        case 12: ERH_LAUNCH_PP(12); break;
+        case 13: ERH_LAUNCH_PP(13); break;
+        case 14: ERH_LAUNCH_PP(14); break;
+        case 15: ERH_LAUNCH_PP(15); break;
+        default: ERH_LAUNCH_PP(0); break;
+    }
+#undef ERH_LAUNCH_PP
+    return hipGetLastError();
+}
+
 }  // namespace
 
 // ---- launchers ----------------------------------------------------------------------------------
@@ -753,7 +1098,29 @@ hipError_t dense_scan_init() {
     if (e != hipSuccess) return e;
     e = set_attrs<Cfg1>();
     if (e != hipSuccess) return e;
-    return set_attrs<Cfg2>();
+    e = set_attrs<Cfg2>();
+    if (e != hipSuccess) return e;
+    e = set_attrs<Cfg3>();
+    if (e != hipSuccess) return e;
+#define ERH_SET_PP(A)                                                                                      \
+    e = hipFuncSetAttribute((const void *)dense_scan_pp_kernel<A>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                            pp::LDS_BYTES);                                                                \
+    if (e != hipSuccess) return e;
+    ERH_SET_PP(0) ERH_SET_PP(7) ERH_SET_PP(8) ERH_SET_PP(9) ERH_SET_PP(11) ERH_SET_PP(12) ERH_SET_PP(13) ERH_SET_PP(14)
+    ERH_SET_PP(15)
+#undef ERH_SET_PP
+    return hipSuccess;
+}
+
+// Ping-pong persistent append scan; hipErrorInvalidValue when the shape does not qualify (fewer than 8 stages of
+// 32 halves, query tiles that do not divide the resident grid, tile index too wide for the record).
+hipError_t launch_dense_scan_pp(const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1, const _Float16 *Q,
+                                int Bpad, int B, const float *tau, const int16_t *filter_dir, const int16_t *dir_id,
+                                ErhCand *cand, uint32_t *cand_cnt, int cap, uint32_t *overflow, int n_cus, int pabl,
+                                hipStream_t st) {
+    if (c1 <= c0) return hipSuccess;
+    if (d % (2 * pp::BK) != 0 || d / pp::BK < 8) return hipErrorInvalidValue;   // stage pairs never straddle a tile
+    return launch_pp(X, N, d, c0, c1, Q, Bpad, B, tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow, n_cus, pabl, st);
 }
 
 hipError_t launch_dense_scan_store(int cfg, const _Float16 *Q, int Bpad, const _Float16 *X, int64_t N, int d,
@@ -761,6 +1128,7 @@ hipError_t launch_dense_scan_store(int cfg, const _Float16 *Q, int Bpad, const _
     if (nc <= 0) return hipSuccess;
     if (cfg == 1) return launch_store<Cfg1>(Q, Bpad, X, N, d, c0, nc, S0, ld_s0, st);
     if (cfg == 2) return launch_store<Cfg2>(Q, Bpad, X, N, d, c0, nc, S0, ld_s0, st);
+    if (cfg == 3) return launch_store<Cfg3>(Q, Bpad, X, N, d, c0, nc, S0, ld_s0, st);
     return launch_store<Cfg0>(Q, Bpad, X, N, d, c0, nc, S0, ld_s0, st);
 }
 
@@ -775,6 +1143,9 @@ hipError_t launch_dense_scan_append(int cfg, const _Float16 *X, int64_t N, int d
                                    ablate, dbg, st);
     if (cfg == 2)
         return launch_append<Cfg2>(X, N, d, c0, c1, Q, Bpad, B, tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow,
+                                   ablate, dbg, st);
+    if (cfg == 3)
+        return launch_append<Cfg3>(X, N, d, c0, c1, Q, Bpad, B, tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow,
                                    ablate, dbg, st);
     return launch_append<Cfg0>(X, N, d, c0, c1, Q, Bpad, B, tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow,
                                ablate, dbg, st);
@@ -793,6 +1164,11 @@ hipError_t launch_dense_scan_persist(int cfg, const _Float16 *X, int64_t N, int 
         if (d / Cfg2::BK <= Cfg2::DA) return hipErrorInvalidValue;
         return launch_persist<Cfg2>(X, N, d, c0, c1, Q, Bpad, B, tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow,
                                     n_cus, pabl, readahead != 0, st);
+    }
+    if (cfg == 3) {
+        if (d / Cfg3::BK <= Cfg3::DA) return hipErrorInvalidValue;
+        return launch_persist<Cfg3>(X, N, d, c0, c1, Q, Bpad, B, tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow,
+                                    n_cus, pabl, false, st);
     }
     if (d / Cfg0::BK <= Cfg0::DA) return hipErrorInvalidValue;
     return launch_persist<Cfg0>(X, N, d, c0, c1, Q, Bpad, B, tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow, n_cus,

@@ -16,6 +16,10 @@ hipError_t launch_dense_scan_append(int cfg, const _Float16 *X, int64_t N, int d
                                     const int16_t *filter_dir, const int16_t *dir_id,
                                     ErhCand *cand, uint32_t *cand_cnt, int cap, uint32_t *overflow, int ablate,
                                     unsigned long long *dbg, hipStream_t st);
+hipError_t launch_dense_scan_pp(const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1, const _Float16 *Q,
+                                int Bpad, int B, const float *tau, const int16_t *filter_dir, const int16_t *dir_id,
+                                ErhCand *cand, uint32_t *cand_cnt, int cap, uint32_t *overflow, int n_cus, int pabl,
+                                hipStream_t st);
 hipError_t launch_dense_scan_persist(int cfg, const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1,
                                      const _Float16 *Q, int Bpad, int B, const float *tau,
                                      const int16_t *filter_dir, const int16_t *dir_id,

@@ -12,15 +12,18 @@ from oracle import dense_exact_scores, dense_exact_topk, qdrant_cosine_search, t
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[(0, 1), (0, 0), (1, 0), (2, 1)],
-                ids=["cfg0-256x256x64-persistent", "cfg0-per-tile", "cfg1-128x256x32-per-tile", "cfg2-256x256x32-persistent"])
+@pytest.fixture(params=[(0, 1, 1), (0, 1, 0), (0, 0, 0), (1, 0, 0), (2, 1, 0)],
+                ids=["pingpong-256x256x32", "cfg0-256x256x64-persistent", "cfg0-per-tile", "cfg1-128x256x32-per-tile",
+                     "cfg2-256x256x32-persistent"])
 def scan_cfg(request, engine):
-    """Every dense-scan tile configuration / launch style must satisfy every parity test."""
+    """Every dense-scan kernel / tile configuration / launch style must satisfy every parity test."""
     engine.set_option("dense_cfg", request.param[0])
     engine.set_option("dense_persist", request.param[1])
+    engine.set_option("dense_pp", request.param[2])
     yield request.param
     engine.set_option("dense_cfg", 0)
     engine.set_option("dense_persist", 1)
+    engine.set_option("dense_pp", 1)
 
 
 def test_mfma_scores_match_plain_gpu_and_numpy(engine, scan_cfg):
