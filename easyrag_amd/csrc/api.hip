@@ -143,7 +143,7 @@ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 hipError_t scan_append(erh_handle *h, const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1, const _Float16 *Q16,
                        int Bpad, int B, const float *tau, const int16_t *filt, const int16_t *dir, ErhCand *cand,
                        uint32_t *cnt, int cap, uint32_t *flags, hipStream_t st) {
-    if (h->opt_dense_pp && (h->opt_dense_ablate == 0 || (h->opt_dense_ablate >= 7 && h->opt_dense_ablate <= 15 && h->opt_dense_ablate != 10))) {
+    if (h->opt_dense_pp && (h->opt_dense_ablate == 0 || (h->opt_dense_ablate >= 7 && h->opt_dense_ablate <= 16 && h->opt_dense_ablate != 10))) {
         hipError_t e = erh::launch_dense_scan_pp(X, N, d, c0, c1, Q16, Bpad, B, tau, filt, dir, cand, cnt, cap, flags,
                                                  h->n_cus, h->opt_dense_ablate, st);
         if (e != hipErrorInvalidValue) return e;

@@ -689,7 +689,7 @@ static_assert(LDS_BYTES == 160 * 1024, "pp LDS");
     } while (0)
 
 // PABL (measurement only): 0 full, 7 no epilogue, 8 thresholds forced to +inf, 9 s_setprio 1 around the MFMA phase;
-// without epilogue AND: 11 no MFMA, 12 no LDS-DMA, 13 no chunk-side DMA, 14 no fragment reads, 15 no query-side DMA
+// without epilogue AND: 11 no MFMA, 12 no LDS-DMA, 13 no chunk-side DMA, 14 no fragment reads, 15 no query-side DMA; 16 = full, s_setprio 1 around the memory phase
 template <int PABL>
 __global__ __launch_bounds__(pp::NT) void dense_scan_pp_kernel(
     const _Float16 *__restrict__ X, int64_t N, int d, int64_t c0, int64_t c1,
@@ -777,6 +777,7 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp_kernel(
 // memory phase M(h): the fragments of stage h+1, then the A pair (h+4, h+5) for even h / the B pair (h+3, h+4) for odd h
 #define ERH_PP_MEM()                                                                                  \
     do {                                                                                              \
+        if (PABL == 16) asm volatile("s_setprio 1");                                                  \
         if (gf < total && (PABL != 14 || gf == 0)) {                                                  \
             const char *pa_ = lds + fa_slot * pp::A_BYTES + a_lane_off;                               \
             const char *pb_ = lds + fb_slot * pp::B_BYTES + b_lane_off;                               \
@@ -793,6 +794,7 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp_kernel(
         __builtin_amdgcn_sched_barrier(0);   /* reads first: the DMA issue below covers their latency */ \
         if (m_odd) ERH_PP_ISSUE_B(); else ERH_PP_ISSUE_A();                                           \
         m_odd ^= 1;                                                                                   \
+        if (PABL == 16) asm volatile("s_setprio 0");                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                            \
     } while (0)
 #define ERH_PP_COMPUTE()                                                                              \
@@ -845,7 +847,7 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp_kernel(
 // Epilogue of tile i for this wave (acc final).  See the header comment.
 #define ERH_PP_EPILOGUE()                                                                             \
     do {                                                                                              \
-        if (PABL == 7 || PABL >= 11) {                                                                \
+        if (PABL == 7 || (PABL >= 11 && PABL <= 15)) {                                                \
             float keep_ = 0.f;                                                                        \
             _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                          \
                 _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                      \
@@ -941,7 +943,7 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp_kernel(
             }
             ERH_PP_EPILOGUE();
             ERH_PP_BARRIER();
-            if (PABL != 7 && PABL < 11) flush_now = __builtin_amdgcn_readfirstlane(flag[i & 1]);
+            if (PABL != 7 && !(PABL >= 11 && PABL <= 15)) flush_now = __builtin_amdgcn_readfirstlane(flag[i & 1]);
         }
     } else {
         for (int i = 0; i < n_tiles; ++i) {
@@ -953,7 +955,7 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp_kernel(
             }
             ERH_PP_EPILOGUE();
             ERH_PP_BARRIER();
-            if (PABL != 7 && PABL < 11) flush_now = __builtin_amdgcn_readfirstlane(flag[i & 1]);
+            if (PABL != 7 && !(PABL >= 11 && PABL <= 15)) flush_now = __builtin_amdgcn_readfirstlane(flag[i & 1]);
         }
     }
 #undef ERH_PP_ISSUE_A
@@ -1080,6 +1082,7 @@ hipError_t launch_pp(const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1
         case 13: ERH_LAUNCH_PP(13); break;
         case 14: ERH_LAUNCH_PP(14); break;
         case 15: ERH_LAUNCH_PP(15); break;
+        case 16: ERH_LAUNCH_PP(16); break;
         default: ERH_LAUNCH_PP(0); break;
     }
 #undef ERH_LAUNCH_PP
@@ -1107,7 +1110,7 @@ hipError_t dense_scan_init() {
                             pp::LDS_BYTES);                                                                \
     if (e != hipSuccess) return e;
     ERH_SET_PP(0) ERH_SET_PP(7) ERH_SET_PP(8) ERH_SET_PP(9) ERH_SET_PP(11) ERH_SET_PP(12) ERH_SET_PP(13) ERH_SET_PP(14)
-    ERH_SET_PP(15)
+    ERH_SET_PP(15) ERH_SET_PP(16)
 #undef ERH_SET_PP
     return hipSuccess;
 }

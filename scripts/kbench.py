@@ -46,14 +46,14 @@ def main():
         for B, k in ((256, 100), (1024, 288)):
             q = synth.dense_queries_torch(x, B, seed=7)
             eng.set_option("dense_pp", 0)
-            for cfg in (0, 3):
+            for cfg in ():
                 for abl in (0, 7):
                     eng.set_option("dense_cfg", cfg)
                     eng.set_option("dense_ablate", abl)
                     res[f"dense B={B} k={k} persist cfg={cfg} pabl={abl}"] = timed(eng, lambda: eng.dense_topk(q, k, device_out=True))
             eng.set_option("dense_cfg", 0)
-            for rep in "a":
-                for pp, abl in ((0, 0), (1, 0), (1, 7), (1, 11), (1, 12), (1, 13), (1, 15), (1, 14), (0, 7)):
+            for rep in "ab":
+                for pp, abl in ((1, 0), (1, 8), (1, 7)):
                     eng.set_option("dense_pp", pp)
                     eng.set_option("dense_ablate", abl)
                     res[f"dense B={B} k={k} pp={pp} pabl={abl} (run {rep})"] = timed(eng, lambda: eng.dense_topk(q, k, device_out=True))
