@@ -89,6 +89,25 @@ def cpu_baseline(x_dev, q16_dev, idx, payload, queries, k_dense, k_sparse, topk,
                       f"{dt:.1f} s of CPU work"}
 
 
+def pmc_traffic(args, kernel_class, algorithmic_bytes):
+    """HBM bytes per launch of the dominant kernel class from the committed PMC pass (scripts/gpu_traffic.sh ->
+    profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE in its own run, x2 gfx950 correction).  bench.py cannot
+    sample counters itself, so the figure is only attached when this run's shape is the profiled one (default
+    sizes, no option overrides); otherwise traffic stays null."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
+    default_shape = (args.chunks == 1_000_000 and args.dim == 1024 and args.vocab == 262_144 and args.batch == 0
+                     and not args.option and args.variant == "bm25s")
+    try:
+        rec = json.load(open(path))[args.workload]
+    except (OSError, KeyError, ValueError):
+        return {"traffic": None}
+    if not default_shape or rec.get("kernel_class") != kernel_class:
+        return {"traffic": None}
+    t = float(rec["hbm_bytes_per_launch"])
+    return {"traffic": t, "traffic_unit": "bytes/launch", "traffic_over_algorithmic": t / algorithmic_bytes,
+            "traffic_source": "profiles/pmc_traffic.json (" + rec["command"] + "; " + rec["correction"] + ")"}
+
+
 def main():
     args = parse_args()
     import torch
@@ -193,6 +212,8 @@ def main():
                          "flops_per_launch": kd["flops"] / kd["launches"],
                          "arithmetic_intensity": ai,
                          "hbm_equiv_gbs": kd["bytes"] / sec / 1e9 if kd["bytes"] else None})
+        if roof is not None:
+            roof.update(pmc_traffic(args, dom, roof["algorithmic_bytes_per_launch"]))
         cpu = None
         if world == 1 and args.cpu_queries > 0:
             payload = eng.get_bm25_payload() if idx is not None else None

@@ -40,6 +40,24 @@ def main():
     n, d, vocab = 1_000_000, 1024, 262_144
     eng = RetrievalEngine(0)
     res = {}
+    if what == "n0n1":                                       # seed / refine boundaries
+        x = synth.dense_corpus_torch(n, d, seed=2, device=dev)
+        eng.set_dense(x)
+        for B, k in ((256, 100), (1024, 288)):
+            q = synth.dense_queries_torch(x, B, seed=7)
+            for n0, n1 in ((32768, 131072), (16384, 131072), (16384, 65536), (8192, 65536), (32768, 262144), (16384, 98304)):
+                eng.set_option("dense_n0", n0)
+                eng.set_option("dense_n1", n1)
+                res[f"dense B={B} k={k} n0={n0} n1={n1}"] = timed(eng, lambda: eng.dense_topk(q, k, device_out=True))
+            eng.set_option("dense_n0", 32768)
+            eng.set_option("dense_n1", 131072)
+    if what == "fin":                                        # finalize: exact (fp64 re-score) vs fast (fp32 order only)
+        x = synth.dense_corpus_torch(n, d, seed=2, device=dev)
+        eng.set_dense(x)
+        for B, k in ((256, 100), (1024, 288)):
+            q = synth.dense_queries_torch(x, B, seed=7)
+            for mode in (0, 1, 0, 1):
+                res[f"dense B={B} k={k} mode={mode} ({len(res)})"] = timed(eng, lambda: eng.dense_topk(q, k, mode=mode, device_out=True))
     if what == "pp":                                         # ping-pong scan vs the persistent kernel, with ablations
         x = synth.dense_corpus_torch(n, d, seed=2, device=dev)
         eng.set_dense(x)
