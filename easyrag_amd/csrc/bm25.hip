@@ -82,17 +82,18 @@ __global__ void bm25_payload_kernel(int64_t V, int64_t nnz, const int64_t *__res
 
 // ---- query-time scan -------------------------------------------------------------------------------
 constexpr int kBmPre = 2;          // postings per thread per (token, tile) held in prefetch registers
+constexpr int kBmAhead = 4;        // tokens fetched ahead of the one being applied (5 rotating register sets)
 
 template <typename ST>
 struct BmLds {
     static constexpr int TILE = (sizeof(ST) == 4) ? erh::kBm25TileF32 : erh::kBm25TileF64;
-    // layout (bytes): [0,64) header | acc TILE*ST | cand_s CAP*ST | cand_i CAP*4 | lo CHUNK*8 | hi CHUNK*8
+    // layout (bytes): [0,64) header | acc TILE*ST | cand_s CAP*ST | cand_i CAP*4 | lo 2*CHUNK*8 | hi 2*CHUNK*8
     static constexpr size_t OFF_ACC = 64;
     static constexpr size_t OFF_CS = OFF_ACC + (size_t)TILE * sizeof(ST);
     static constexpr size_t OFF_CI = OFF_CS + (size_t)kBmCap * sizeof(ST);
     static constexpr size_t OFF_LO = OFF_CI + (size_t)kBmCap * 4;
-    static constexpr size_t OFF_HI = OFF_LO + (size_t)kBmTokChunk * 8;
-    static constexpr size_t BYTES = OFF_HI + (size_t)kBmTokChunk * 8;
+    static constexpr size_t OFF_HI = OFF_LO + (size_t)2 * kBmTokChunk * 8;   // lo / hi: two buffers (this tile, next tile)
+    static constexpr size_t BYTES = OFF_HI + (size_t)2 * kBmTokChunk * 8;
     static_assert(BYTES <= 160 * 1024, "BM25 scan LDS layout exceeds one CU");
 };
 
@@ -181,17 +182,42 @@ __device__ __forceinline__ void bm_sweep(BmHdr *hdr, ST *acc, ST *cs, int32_t *c
     constexpr int VEC = 16 / (int)sizeof(ST);
     typedef ST VT __attribute__((ext_vector_type(VEC)));
     typedef uint32_t UT __attribute__((ext_vector_type(4)));
-    for (int i = tid * VEC; i < tile_docs; i += kBmThreads * VEC) {
-        VT v = *reinterpret_cast<VT *>(acc + i);
-        const UT bits = *reinterpret_cast<const UT *>(&v);
-        if ((bits[0] | bits[1] | bits[2] | bits[3]) == 0u) continue;       // untouched
-        ST m = v[0];
+    constexpr int UNR = 2;                                                  // vectors per thread per iteration
+    // Common case per 16-byte vector: read, OR of the words (touched?), max, one compare, predicated zero store --
+    // no jump.  Only a wave that holds a possible survivor (ballot) enters the per-element path.
+    for (int i0 = tid * VEC; i0 < tile_docs; i0 += kBmThreads * VEC * UNR) {
+        VT v[UNR];
+        bool cand[UNR];
+        bool any = false;
 #pragma unroll
-        for (int e = 1; e < VEC; ++e) m = v[e] > m ? v[e] : m;
-        if (!(m < tau_s)) {                                                 // something here may reach the top k
+        for (int u = 0; u < UNR; ++u) {
+            const int i = i0 + u * kBmThreads * VEC;
+            cand[u] = false;
+            if (i < tile_docs) {
+                v[u] = *reinterpret_cast<VT *>(acc + i);
+                const UT bits = *reinterpret_cast<const UT *>(&v[u]);
+                const bool touched = (bits[0] | bits[1] | bits[2] | bits[3]) != 0u;
+                ST m = v[u][0];
+#pragma unroll
+                for (int e = 1; e < VEC; ++e) m = v[u][e] > m ? v[u][e] : m;
+                cand[u] = touched && !(m < tau_s);                          // something here may reach the top k
+                if (touched && !cand[u]) {
+                    VT z;
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) z[e] = (ST)0;
+                    *reinterpret_cast<VT *>(acc + i) = z;
+                }
+                any |= cand[u];
+            }
+        }
+        if (__builtin_amdgcn_ballot_w64(any) == 0) continue;                // wave-uniform
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            if (!cand[u]) continue;
+            const int i = i0 + u * kBmThreads * VEC;
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
-                const ST sv = v[e];
+                const ST sv = v[u][e];
                 if (sv != (ST)0) {
                     const int64_t doc = base_doc + i + e;
                     bool pass = bm_pass<ST>(sv, doc, tau_s, tau_idx);
@@ -201,21 +227,16 @@ __device__ __forceinline__ void bm_sweep(BmHdr *hdr, ST *acc, ST *cs, int32_t *c
                         if (pos < kBmCap) {
                             cs[pos] = sv;
                             ci[pos] = (int32_t)doc;
-                            v[e] = (ST)0;
+                            v[u][e] = (ST)0;
                         } else {
                             hdr->total = 1;                                 // list full: keep it for the next sweep
                         }
                     } else {
-                        v[e] = (ST)0;
+                        v[u][e] = (ST)0;
                     }
                 }
             }
-            *reinterpret_cast<VT *>(acc + i) = v;
-        } else {
-            VT z;
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) z[e] = (ST)0;
-            *reinterpret_cast<VT *>(acc + i) = z;
+            *reinterpret_cast<VT *>(acc + i) = v[u];
         }
     }
 }
@@ -255,48 +276,86 @@ __global__ __launch_bounds__(kBmThreads) void bm25_scan_kernel(
     __syncthreads();
 
     if (nq > 0) {
+        const bool single = nq <= kBmTokChunk;                        // one chunk of tokens: ranges and postings pipelined across tiles
+        BmPre<ST> P0, P1, P2, P3, P4;
         for (int tile = t_begin; tile < t_end; ++tile) {
             const int64_t base_doc = (int64_t)tile * TILE;
             ERH_SEC(7);
-            // ---- scatter-add, one query token after the other, postings prefetched two tokens ahead ----------
+            // ---- scatter-add, one query token after the other, postings prefetched kBmAhead tokens ahead ----------
+            // Five register sets rotate through the tokens of a tile.  When the whole query fits one chunk
+            // (the normal case) the ranges of the NEXT tile are staged while this one is processed and its first
+            // kBmAhead tokens are fetched before the sweep, so only the very first tile exposes the load latency.
             for (int c0 = 0; c0 < nq; c0 += kBmTokChunk) {
                 const int nqc = (nq - c0 < kBmTokChunk) ? (nq - c0) : kBmTokChunk;
-                for (int j = tid; j < nqc; j += kBmThreads) {
-                    const int64_t tok = q_tok[qs + c0 + j];
-                    const int64_t ip = indptr[tok];
-                    const int32_t *to = tile_off + tok * (n_tiles + 1) + tile;
-                    s_lo[j] = ip + to[0];
-                    s_hi[j] = ip + to[1];
+                const int rb = single ? (tile & 1) : 0;                   // range buffer of this tile
+                int64_t *lo_c = s_lo + rb * kBmTokChunk, *hi_c = s_hi + rb * kBmTokChunk;
+                const bool have_cur = single && tile > t_begin;           // staged (and prefetched) during the previous tile
+                if (!have_cur) {
+                    for (int j = tid; j < nqc; j += kBmThreads) {
+                        const int64_t tok = q_tok[qs + c0 + j];
+                        const int64_t ip = indptr[tok];
+                        const int32_t *to = tile_off + tok * (n_tiles + 1) + tile;
+                        lo_c[j] = ip + to[0];
+                        hi_c[j] = ip + to[1];
+                    }
+                }
+                const bool stage_next = single && tile + 1 < t_end;
+                if (stage_next) {
+                    int64_t *lo_n = s_lo + (rb ^ 1) * kBmTokChunk, *hi_n = s_hi + (rb ^ 1) * kBmTokChunk;
+                    for (int j = tid; j < nqc; j += kBmThreads) {
+                        const int64_t tok = q_tok[qs + j];
+                        const int64_t ip = indptr[tok];
+                        const int32_t *to = tile_off + tok * (n_tiles + 1) + tile + 1;
+                        lo_n[j] = ip + to[0];
+                        hi_n[j] = ip + to[1];
+                    }
                 }
                 __syncthreads();
                 ERH_SEC(0);
-                BmPre<ST> P0, P1, P2;
+                if (!have_cur) {
 #pragma unroll
-                for (int u = 0; u < kBmPre; ++u) { P0.d[u] = P1.d[u] = P2.d[u] = -1; P0.v[u] = P1.v[u] = P2.v[u] = (ST)0; }
-                if (!(ablate & 8)) {
-                    bm_prefetch<ST>(P0, doc_ids, payload, s_lo[0], s_hi[0], tid);
-                    if (nqc > 1) bm_prefetch<ST>(P1, doc_ids, payload, s_lo[1], s_hi[1], tid);
+                    for (int u = 0; u < kBmPre; ++u) {
+                        P0.d[u] = P1.d[u] = P2.d[u] = P3.d[u] = P4.d[u] = -1;
+                        P0.v[u] = P1.v[u] = P2.v[u] = P3.v[u] = P4.v[u] = (ST)0;
+                    }
+                    if (!(ablate & 8)) {
+                        bm_prefetch<ST>(P0, doc_ids, payload, lo_c[0], hi_c[0], tid);
+                        if (nqc > 1) bm_prefetch<ST>(P1, doc_ids, payload, lo_c[1], hi_c[1], tid);
+                        if (nqc > 2) bm_prefetch<ST>(P2, doc_ids, payload, lo_c[2], hi_c[2], tid);
+                        if (nqc > 3) bm_prefetch<ST>(P3, doc_ids, payload, lo_c[3], hi_c[3], tid);
+                    }
                 }
 #define ERH_BM_STEP(CUR, NXT, J)                                                                         \
     do {                                                                                                 \
         const int j_ = (J);                                                                              \
-        if (j_ + 2 < nqc && !(ablate & 8))                                                               \
-            bm_prefetch<ST>(NXT, doc_ids, payload, s_lo[j_ + 2], s_hi[j_ + 2], tid);                     \
-        const int64_t lo_ = s_lo[j_], hi_ = s_hi[j_]; /* block-uniform */                                \
+        if (j_ + kBmAhead < nqc && !(ablate & 8))                                                        \
+            bm_prefetch<ST>(NXT, doc_ids, payload, lo_c[j_ + kBmAhead], hi_c[j_ + kBmAhead], tid);       \
+        const int64_t lo_ = lo_c[j_], hi_ = hi_c[j_]; /* block-uniform */                                \
         if (lo_ < hi_) {                                                                                 \
             if (!(ablate & 1)) bm_apply<ST>(CUR, acc, base_doc, doc_ids, payload, lo_, hi_, tid);        \
             if (!(ablate & 4)) __syncthreads(); /* token j complete before token j+1 */                  \
         }                                                                                                \
     } while (0)
-                for (int j0 = 0; j0 < nqc; j0 += 3) {
-                    ERH_BM_STEP(P0, P2, j0);
+                for (int j0 = 0; j0 < nqc; j0 += 5) {
+                    ERH_BM_STEP(P0, P4, j0);
                     if (j0 + 1 >= nqc) break;
                     ERH_BM_STEP(P1, P0, j0 + 1);
                     if (j0 + 2 >= nqc) break;
                     ERH_BM_STEP(P2, P1, j0 + 2);
+                    if (j0 + 3 >= nqc) break;
+                    ERH_BM_STEP(P3, P2, j0 + 3);
+                    if (j0 + 4 >= nqc) break;
+                    ERH_BM_STEP(P4, P3, j0 + 4);
                 }
 #undef ERH_BM_STEP
-                __syncthreads();                                      // s_lo/s_hi free for the next chunk
+                __syncthreads();                                      // ranges of this chunk are free; next tile's are visible
+                if (stage_next && !(ablate & 8)) {                    // head of the next tile: lands during the sweep
+                    const int64_t *lo_n = s_lo + (rb ^ 1) * kBmTokChunk, *hi_n = s_hi + (rb ^ 1) * kBmTokChunk;
+                    bm_prefetch<ST>(P0, doc_ids, payload, lo_n[0], hi_n[0], tid);
+                    if (nqc > 1) bm_prefetch<ST>(P1, doc_ids, payload, lo_n[1], hi_n[1], tid);
+                    if (nqc > 2) bm_prefetch<ST>(P2, doc_ids, payload, lo_n[2], hi_n[2], tid);
+                    if (nqc > 3) bm_prefetch<ST>(P3, doc_ids, payload, lo_n[3], hi_n[3], tid);
+                }
                 ERH_SEC(1);
             }
             if (ablate & 2) continue;
@@ -305,14 +364,16 @@ __global__ __launch_bounds__(kBmThreads) void bm25_scan_kernel(
                 const ST tau_s = (ST)hdr->tau_s;
                 const int tau_idx = hdr->tau_idx;
                 bm_sweep<ST>(hdr, acc, cs, ci, TILE, base_doc, N, fd, dir_id, tau_s, tau_idx, tid);
+                ERH_SEC(3);
                 __syncthreads();
                 const int full = hdr->total;                          // uniform: read between two barriers
                 __syncthreads();
+                ERH_SEC(4);
                 if (!full) break;
                 if (tid == 0) hdr->total = 0;
                 bm_shrink<ST>(hdr, cs, ci, k);                        // list was full: cut to k, threshold becomes exact
+                ERH_SEC(2);
             }
-            ERH_SEC(2);
             // keep the list short and the threshold exact once it holds clearly more than k entries
             if (hdr->ncand > k + kBmThreads / 2) bm_shrink<ST>(hdr, cs, ci, k);   // uniform (read after a barrier)
             ERH_SEC(5);

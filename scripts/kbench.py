@@ -45,10 +45,10 @@ def main():
         eng.set_dense(x)
         for B, k in ((256, 100), (1024, 288)):
             q = synth.dense_queries_torch(x, B, seed=7)
-            for n0, n1 in ((32768, 131072), (16384, 131072), (16384, 65536), (8192, 65536), (32768, 262144), (16384, 98304)):
+            for n0, n1 in ((32768, 131072), (32768, 0), (32768, 262144), (32768, 393216), (16384, 262144), (32768, 131072), (32768, 0), (32768, 262144), (32768, 393216), (16384, 262144)):
                 eng.set_option("dense_n0", n0)
                 eng.set_option("dense_n1", n1)
-                res[f"dense B={B} k={k} n0={n0} n1={n1}"] = timed(eng, lambda: eng.dense_topk(q, k, device_out=True))
+                res[f"dense B={B} k={k} n0={n0} n1={n1} #{len(res)}"] = timed(eng, lambda: eng.dense_topk(q, k, device_out=True))
             eng.set_option("dense_n0", 32768)
             eng.set_option("dense_n1", 131072)
     if what == "fin":                                        # finalize: exact (fp64 re-score) vs fast (fp32 order only)
@@ -116,7 +116,7 @@ def main():
             for n0, n1 in ((32768, 131072), (32768, 229376)):
                 eng.set_option("dense_n0", n0)
                 eng.set_option("dense_n1", n1)
-                res[f"dense B={B} k={k} n0={n0} n1={n1}"] = timed(eng, lambda: eng.dense_topk(q, k, device_out=True))
+                res[f"dense B={B} k={k} n0={n0} n1={n1} #{len(res)}"] = timed(eng, lambda: eng.dense_topk(q, k, device_out=True))
             eng.set_option("dense_n0", 32768)
             eng.set_option("dense_n1", 131072)
             eng.set_option("dense_persist", 1)
@@ -129,7 +129,7 @@ def main():
             queries = synth.token_queries(flat, lens, vocab, 1024, seed=9)
             qi, qt = queries_to_csr(queries)
             for k in (100, 192):
-                for abl in ((0, 1, 2, 3, 8, 15) if (variant == BM25S and k == 192) else (0,)):
+                for abl in ((0,) if (variant == BM25S and k == 192) else (0,)):
                     eng.set_option("bm25_ablate", abl)
                     res[f"{name} B=1024 k={k} ablate={abl}"] = timed(eng, lambda: eng.bm25_topk(qi, qt, k, device_out=True), 3)
                 eng.set_option("bm25_ablate", 0)
@@ -137,7 +137,7 @@ def main():
             eng.bm25_topk(qi, qt, 192, device_out=True)
             c = eng.debug_counters().astype(np.float64)
             eng.set_option("debug_counters", 0)
-            names = ["ranges", "token_loop", "sweep", "-", "-", "shrink", "final", "tile_misc"]
+            names = ["ranges", "token_loop", "shrink_in_sweep", "sweep_own", "sweep_barriers", "shrink", "final", "tile_misc"]
             tot = c[:8].sum()
             res[f"{name} sections (% of thread-0 cycles, k=192)"] = {n_: round(100 * v / tot, 1) for n_, v in zip(names, c[:8])}
             res[f"{name} cycles per query (thread 0)"] = {"total": round(tot / 1024)}
