@@ -110,6 +110,34 @@ def test_dense_duplicates_and_filter(engine, scan_cfg):
         assert np.array_equal(ids[i, :ln[i]], oid) and np.array_equal(sc[i, :ln[i]], osc)
 
 
+def test_dense_tie_block_floods_the_survivor_buffers(engine, scan_cfg):
+    """600 chunks equal to the (identical) queries sit in three consecutive tiles behind the seed prefix: every
+    (chunk, query) pair of those tiles survives the threshold, i.e. thousands of hits per wave and tile -- far
+    more than a wave's staging area holds.  The result must still be the 100 lowest indices of the tie block."""
+    rng = np.random.default_rng(21)
+    n, d, b, k = 6000, 256, 70, 100
+    x = to_f16_unit(rng.standard_normal((n, d)))
+    hot = to_f16_unit(rng.standard_normal((1, d)))[0]
+    x[1500:2100] = hot
+    q16 = np.repeat(hot[None, :], b, axis=0)
+    engine.set_dense(x)
+    engine.set_option("dense_n0", 512)
+    engine.set_option("dense_n1", 1024)
+    try:
+        ids, sc, ln = engine.dense_topk(q16, k)
+    finally:
+        engine.set_option("dense_n0", 32768)
+        engine.set_option("dense_n1", 131072)
+    diag = engine.dense_diag()
+    assert diag["uncertified"] == 0
+    oid, osc = dense_exact_topk(x, hot, k)
+    assert np.array_equal(oid, np.arange(1500, 1600))
+    for i in (0, 1, 33, b - 1):
+        assert ln[i] == k
+        assert np.array_equal(ids[i], oid)
+        assert np.array_equal(sc[i].view(np.uint64), osc.view(np.uint64))
+
+
 def test_dense_fp32_inputs_normalised_on_device(engine):
     rng = np.random.default_rng(8)
     x32 = (rng.standard_normal((3000, 192)) * 3).astype(np.float32)
