@@ -34,20 +34,48 @@ __device__ __forceinline__ int32_t erh_key32_idx(uint64_t k) { return (int32_t)(
 
 // ---- block-wide bitonic sort, descending, n a power of two, data in LDS -----------------------
 // Every thread of the block must call it (contains __syncthreads()).
+// Compare-exchange steps with distance j <= 64 stay inside an aligned block of 128 elements, which one wave owns
+// (64 pairs, one per lane): those steps need no workgroup barrier -- a wave's LDS operations execute in order, so
+// only the compiler has to be kept from reordering them.  All phases k <= 128 therefore run back to back inside
+// the wave; the larger phases pay one barrier per step with j >= 128 plus one around their wave-local tail.
+// For n = 2048 that is about 20 barriers instead of 66.
+#define ERH_WAVE_LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+template <typename T>
+__device__ __forceinline__ void erh_bitonic_step(T *a, int t, int j, int k) {
+    const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));       // t-th compare-exchange pair of this (k, j) step
+    const int p = i | j;
+    const bool desc = ((i & k) == 0);
+    const T x = a[i], y = a[p];
+    const bool sw = desc ? (x < y) : (y < x);
+    if (sw) { a[i] = y; a[p] = x; }
+}
+
 template <typename T>
 __device__ __forceinline__ void erh_bitonic_desc(T *a, int n) {
     const int tid = threadIdx.x, nth = blockDim.x;
-    for (int k = 2; k <= n; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
+    const int half = n >> 1;
+    __syncthreads();
+    // phases k = 2 .. min(n, 128): entirely wave-local
+    for (int t0 = (tid & ~63); t0 < half; t0 += nth) {
+        const int t = t0 + (tid & 63);
+        for (int k = 2; k <= n && k <= 128; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                if (t < half) erh_bitonic_step<T>(a, t, j, k);
+                ERH_WAVE_LDS_FENCE();
+            }
+    }
+    for (int k = 256; k <= n; k <<= 1) {
+        for (int j = k >> 1; j >= 128; j >>= 1) {
             __syncthreads();
-            for (int t = tid; t < (n >> 1); t += nth) {
-                // t-th compare-exchange pair of this (k, j) step
-                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                const int p = i | j;
-                const bool desc = ((i & k) == 0);
-                const T x = a[i], y = a[p];
-                const bool sw = desc ? (x < y) : (y < x);
-                if (sw) { a[i] = y; a[p] = x; }
+            for (int t = tid; t < half; t += nth) erh_bitonic_step<T>(a, t, j, k);
+        }
+        __syncthreads();
+        for (int t0 = (tid & ~63); t0 < half; t0 += nth) {
+            const int t = t0 + (tid & 63);
+            for (int j = 64; j > 0; j >>= 1) {
+                if (t < half) erh_bitonic_step<T>(a, t, j, k);
+                ERH_WAVE_LDS_FENCE();
             }
         }
     }
@@ -59,22 +87,42 @@ __device__ __forceinline__ bool erh_rec_before(double s1, int32_t i1, double s2,
     return (s1 > s2) || (s1 == s2 && i1 < i2);
 }
 template <typename ST>
+__device__ __forceinline__ void erh_bitonic_rec_step(ST *s, int32_t *ix, int t, int j, int k) {
+    const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+    const int p = i | j;
+    const bool desc = ((i & k) == 0);
+    const ST sx = s[i], sy = s[p];
+    const int32_t ixx = ix[i], iyy = ix[p];
+    // "x before y" in the final descending order?
+    const bool x_first = (sx > sy) || (sx == sy && ixx < iyy);
+    const bool y_first = (sy > sx) || (sx == sy && iyy < ixx);
+    const bool sw = desc ? y_first : x_first;
+    if (sw) { s[i] = sy; s[p] = sx; ix[i] = iyy; ix[p] = ixx; }
+}
+template <typename ST>
 __device__ __forceinline__ void erh_bitonic_rec_desc(ST *s, int32_t *ix, int n) {
     const int tid = threadIdx.x, nth = blockDim.x;
-    for (int k = 2; k <= n; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
+    const int half = n >> 1;
+    __syncthreads();
+    for (int t0 = (tid & ~63); t0 < half; t0 += nth) {
+        const int t = t0 + (tid & 63);
+        for (int k = 2; k <= n && k <= 128; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                if (t < half) erh_bitonic_rec_step<ST>(s, ix, t, j, k);
+                ERH_WAVE_LDS_FENCE();
+            }
+    }
+    for (int k = 256; k <= n; k <<= 1) {
+        for (int j = k >> 1; j >= 128; j >>= 1) {
             __syncthreads();
-            for (int t = tid; t < (n >> 1); t += nth) {
-                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                const int p = i | j;
-                const bool desc = ((i & k) == 0);
-                const ST sx = s[i], sy = s[p];
-                const int32_t ixx = ix[i], iyy = ix[p];
-                // "x before y" in the final descending order?
-                const bool x_first = (sx > sy) || (sx == sy && ixx < iyy);
-                const bool y_first = (sy > sx) || (sx == sy && iyy < ixx);
-                const bool sw = desc ? y_first : x_first;
-                if (sw) { s[i] = sy; s[p] = sx; ix[i] = iyy; ix[p] = ixx; }
+            for (int t = tid; t < half; t += nth) erh_bitonic_rec_step<ST>(s, ix, t, j, k);
+        }
+        __syncthreads();
+        for (int t0 = (tid & ~63); t0 < half; t0 += nth) {
+            const int t = t0 + (tid & 63);
+            for (int j = 64; j > 0; j >>= 1) {
+                if (t < half) erh_bitonic_rec_step<ST>(s, ix, t, j, k);
+                ERH_WAVE_LDS_FENCE();
             }
         }
     }

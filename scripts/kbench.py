@@ -51,6 +51,20 @@ def main():
                 res[f"dense B={B} k={k} n0={n0} n1={n1} #{len(res)}"] = timed(eng, lambda: eng.dense_topk(q, k, device_out=True))
             eng.set_option("dense_n0", 32768)
             eng.set_option("dense_n1", 131072)
+    if what == "scale":                                      # time per chunk vs corpus size (is the scan memory-side bound?)
+        for nn in (65536 + 32768, 262144 + 32768, 1_000_000):
+            x = synth.dense_corpus_torch(nn, d, seed=2, device=dev)
+            eng.set_dense(x)
+            eng.set_option("dense_n1", 0)
+            for B, k in ((256, 100), (1024, 288)):
+                q = synth.dense_queries_torch(x, B, seed=7)
+                for abl in (0, 7):
+                    eng.set_option("dense_ablate", abl)
+                    r = timed(eng, lambda: eng.dense_topk(q, k, device_out=True))
+                    r["us_per_1k_chunks"] = round(1e3 * r["dense_scan"] / (nn / 1000), 4)
+                    res[f"dense N={nn} B={B} pabl={abl}"] = r
+            eng.set_option("dense_ablate", 0)
+            eng.set_option("dense_n1", 131072)
     if what == "fin":                                        # finalize: exact (fp64 re-score) vs fast (fp32 order only)
         x = synth.dense_corpus_torch(n, d, seed=2, device=dev)
         eng.set_dense(x)
@@ -71,7 +85,7 @@ def main():
                     res[f"dense B={B} k={k} persist cfg={cfg} pabl={abl}"] = timed(eng, lambda: eng.dense_topk(q, k, device_out=True))
             eng.set_option("dense_cfg", 0)
             for rep in "ab":
-                for pp, abl in ((1, 0), (1, 8), (1, 7)):
+                for pp, abl in ((1, 0), (1, 8), (1, 7), (1, 11), (1, 12)):
                     eng.set_option("dense_pp", pp)
                     eng.set_option("dense_ablate", abl)
                     res[f"dense B={B} k={k} pp={pp} pabl={abl} (run {rep})"] = timed(eng, lambda: eng.dense_topk(q, k, device_out=True))
