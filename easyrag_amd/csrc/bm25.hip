@@ -359,6 +359,25 @@ __global__ __launch_bounds__(kBmThreads) void bm25_scan_kernel(
                 ERH_SEC(1);
             }
             if (ablate & 2) continue;
+            // ---- first tile: seed the threshold.  The k-th largest of the 1024 per-thread maxima is a lower bound of
+            // the tile's k-th best score (k distinct documents reach it), so the first sweep admits about k entries
+            // instead of every touched document (which costs several fill-sort-resweep rounds).
+            if (tile == t_begin && k <= kBmThreads && fd < 0 && !(ablate & 16)) {   // (a dir filter would need the maxima of passing documents only)
+                constexpr int VEC = 16 / (int)sizeof(ST);
+                typedef ST VT __attribute__((ext_vector_type(VEC)));
+                ST mx = (ST)0;
+                for (int i = tid * VEC; i < TILE; i += kBmThreads * VEC) {
+                    const VT v = *reinterpret_cast<const VT *>(acc + i);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) mx = v[e] > mx ? v[e] : mx;
+                }
+                cs[tid] = mx;                                          // the candidate list is still empty
+                erh_bitonic_desc<ST>(cs, kBmThreads);                  // begins and ends with a barrier
+                const ST p = cs[k - 1];
+                __syncthreads();
+                if (tid == 0 && p > (ST)0) { hdr->tau_s = (double)p; hdr->tau_idx = 0x7fffffff; }   // ties at p pass whatever their index
+                __syncthreads();
+            }
             // ---- sweep: move what beats the running k-th best into the list, clear the rest -----------------------
             for (;;) {
                 const ST tau_s = (ST)hdr->tau_s;
