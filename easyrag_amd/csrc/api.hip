@@ -66,12 +66,13 @@ struct erh_handle {
     int opt_debug_counters = 0;
     // options
     int64_t opt_n0 = 32768, opt_n1 = 131072;
-    int opt_dense_ablate = 0, opt_bm25_ablate = 0;
+    int opt_n1_auto = 1;                   // snap n1 to a whole number of persistent-scan rounds (performance only)
+    int opt_dense_ablate = 0, opt_bm25_ablate = 0;   // measurement only (results invalid when non-zero)
     int opt_dense_cfg = 0;                 // dense scan tile configuration (dense_scan.hip)
     int opt_dense_readahead = 1;           // cfg 2 only: fragments of the next K-step are read before its barrier
     int opt_dense_pp = 1;                  // ping-pong persistent append scan (falls back to the kernels below when it does not apply)
     int opt_dense_persist = 1;             // persistent append scan (falls back to the plain launch when it does not apply)
-    int n_cus = 0;   // measurement only (results invalid when non-zero)
+    int n_cus = 0;                         // compute units of the device (persistent grids = one workgroup per CU)
     // profiling
     bool prof = false;
     std::vector<EvPair> pending;
@@ -203,6 +204,23 @@ int dense_topk_dev(erh_handle *h, const void *q_dev, int q_dtype, int normalize_
     if (N > n0) {
         int64_t n1 = h->opt_n1;
         if (n1 <= n0 || n1 >= N) n1 = 0;
+        if (n1 && h->opt_n1_auto && h->n_cus > 0) {
+            // Results do not depend on n1; the number of tile rounds of the persistent scans does.  Each stream
+            // (n_cus / query-tiles of them) walks ceil(tiles / streams) tiles, so move n1 (within -25 % .. +50 %)
+            // to the boundary where [n0, n1) is a whole number of rounds and the rest wastes least.
+            const int64_t streams = std::max<int64_t>(8, (h->n_cus / (8 * (Bpad / QT))) * 8);
+            const int64_t step = streams * QT;                          // chunks per round
+            int64_t best = n1, best_rounds = -1;
+            for (int64_t r1 = 1; n0 + r1 * step < N; ++r1) {
+                const int64_t c = n0 + r1 * step;
+                if (c < n1 - n1 / 4) continue;
+                if (c > n1 + n1 / 2) break;
+                const int64_t rest_tiles = (N - c + QT - 1) / QT;
+                const int64_t rounds = r1 + (rest_tiles + streams - 1) / streams;
+                if (best_rounds < 0 || rounds < best_rounds) { best_rounds = rounds; best = c; }
+            }
+            n1 = best;
+        }
         const int64_t b_end = n1 ? n1 : N;
         scan_work(b_end - n0, &wb, &wf);
         { ProfScope ps(h, st, ERH_K_DENSE_SCAN, wb, wf);
@@ -365,6 +383,7 @@ int erh_set_option(erh_handle *h, const char *name, int64_t value) {
     if (!strcmp(name, "dense_n1")) { if (value < 0) return h->fail(ERH_ERR_INVALID, "dense_n1 < 0"); h->opt_n1 = value; return ERH_OK; }
     if (!strcmp(name, "dense_cfg")) { if (value < 0 || value > 3) return h->fail(ERH_ERR_INVALID, "dense_cfg"); h->opt_dense_cfg = (int)value; return ERH_OK; }
     if (!strcmp(name, "dense_readahead")) { h->opt_dense_readahead = value != 0; return ERH_OK; }
+    if (!strcmp(name, "dense_n1_auto")) { h->opt_n1_auto = value != 0; return ERH_OK; }
     if (!strcmp(name, "dense_pp")) { h->opt_dense_pp = value != 0; return ERH_OK; }
     if (!strcmp(name, "dense_persist")) { h->opt_dense_persist = value != 0; return ERH_OK; }
     if (!strcmp(name, "dense_ablate")) { h->opt_dense_ablate = (int)value; return ERH_OK; }

@@ -51,6 +51,15 @@ def main():
                 res[f"dense B={B} k={k} n0={n0} n1={n1} #{len(res)}"] = timed(eng, lambda: eng.dense_topk(q, k, device_out=True))
             eng.set_option("dense_n0", 32768)
             eng.set_option("dense_n1", 131072)
+    if what == "n1auto":
+        x = synth.dense_corpus_torch(n, d, seed=2, device=dev)
+        eng.set_dense(x)
+        for B, k in ((256, 100), (1024, 288)):
+            q = synth.dense_queries_torch(x, B, seed=7)
+            for auto in (0, 1, 0, 1):
+                eng.set_option("dense_n1_auto", auto)
+                res[f"dense B={B} k={k} n1_auto={auto} #{len(res)}"] = timed(eng, lambda: eng.dense_topk(q, k, device_out=True))
+        eng.set_option("dense_n1_auto", 1)
     if what == "scale":                                      # time per chunk vs corpus size (is the scan memory-side bound?)
         for nn in (65536 + 32768, 262144 + 32768, 1_000_000):
             x = synth.dense_corpus_torch(nn, d, seed=2, device=dev)
