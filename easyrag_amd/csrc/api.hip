@@ -202,38 +202,47 @@ int dense_topk_dev(erh_handle *h, const void *q_dev, int q_dtype, int normalize_
                                         filter_dev, dir, h->tau.as<float>(), h->cand.as<ErhCand>(),
                                         h->cand_cnt.as<uint32_t>(), cap, flags, st)); }
     if (N > n0) {
-        int64_t n1 = h->opt_n1;
-        if (n1 <= n0 || n1 >= N) n1 = 0;
-        if (n1 && h->opt_n1_auto && h->n_cus > 0) {
-            // Results do not depend on n1; the number of tile rounds of the persistent scans does.  Each stream
-            // (n_cus / query-tiles of them) walks ceil(tiles / streams) tiles, so move n1 (within -25 % .. +50 %)
-            // to the boundary where [n0, n1) is a whole number of rounds and the rest wastes least.
-            const int64_t streams = std::max<int64_t>(8, (h->n_cus / (8 * (Bpad / QT))) * 8);
-            const int64_t step = streams * QT;                          // chunks per round
-            int64_t best = n1, best_rounds = -1;
-            for (int64_t r1 = 1; n0 + r1 * step < N; ++r1) {
-                const int64_t c = n0 + r1 * step;
-                if (c < n1 - n1 / 4) continue;
-                if (c > n1 + n1 / 2) break;
+        // Stage boundaries n0 < b1 < b2 < ... < N: the threshold is refined (and the candidate list cut back to what
+        // still matters) at every boundary, so a stage adds about k * (b_next - b) / b candidates however large N is.
+        // b1 = option dense_n1 (0: no refinement at all), then x4 while at least twice that much corpus remains.
+        // Results do not depend on the boundaries; the number of tile rounds of the persistent scans does: each
+        // stream (n_cus / query-tiles of them) walks ceil(tiles / streams) tiles, so with dense_n1_auto a boundary
+        // moves (within -25 % .. +50 %) to where the stage is a whole number of rounds and the rest wastes least.
+        const int64_t streams = std::max<int64_t>(8, (std::max(h->n_cus, 8) / (8 * (Bpad / QT))) * 8);
+        const int64_t step = streams * QT;                              // chunks per round
+        auto snap = [&](int64_t from, int64_t want) -> int64_t {
+            if (!h->opt_n1_auto) return want;
+            int64_t best = want, best_rounds = -1;
+            for (int64_t r1 = 1; from + r1 * step < N; ++r1) {
+                const int64_t c = from + r1 * step;
+                if (c < want - want / 4) continue;
+                if (c > want + want / 2) break;
                 const int64_t rest_tiles = (N - c + QT - 1) / QT;
                 const int64_t rounds = r1 + (rest_tiles + streams - 1) / streams;
                 if (best_rounds < 0 || rounds < best_rounds) { best_rounds = rounds; best = c; }
             }
-            n1 = best;
-        }
-        const int64_t b_end = n1 ? n1 : N;
-        scan_work(b_end - n0, &wb, &wf);
-        { ProfScope ps(h, st, ERH_K_DENSE_SCAN, wb, wf);
-          HIPCHK(h, scan_append(h, X, N, d, n0, b_end, Q16, Bpad, B, h->tau.as<float>(), filter_dev, dir,
-                                 h->cand.as<ErhCand>(), h->cand_cnt.as<uint32_t>(), cap, flags, st)); }
-        if (n1) {
-            { ProfScope ps(h, st, ERH_K_DENSE_SELECT, 0, 0);
-              HIPCHK(h, erh::launch_cand_refine(B, k, h->qnorm.as<float>(), h->xnorm_max, d, h->tau.as<float>(),
-                                                h->cand.as<ErhCand>(), h->cand_cnt.as<uint32_t>(), cap, st)); }
-            scan_work(N - n1, &wb, &wf);
+            return best;
+        };
+        int64_t cur = n0;
+        int64_t want = h->opt_n1;
+        if (want <= n0) want = 0;
+        while (cur < N) {
+            int64_t next = N;
+            if (want > cur && want < N) {
+                const int64_t b = snap(cur, want);
+                if (b > cur && b < N) next = b;
+            }
+            scan_work(next - cur, &wb, &wf);
             { ProfScope ps(h, st, ERH_K_DENSE_SCAN, wb, wf);
-              HIPCHK(h, scan_append(h, X, N, d, n1, N, Q16, Bpad, B, h->tau.as<float>(), filter_dev, dir,
+              HIPCHK(h, scan_append(h, X, N, d, cur, next, Q16, Bpad, B, h->tau.as<float>(), filter_dev, dir,
                                      h->cand.as<ErhCand>(), h->cand_cnt.as<uint32_t>(), cap, flags, st)); }
+            if (next < N) {
+                ProfScope ps(h, st, ERH_K_DENSE_SELECT, 0, 0);
+                HIPCHK(h, erh::launch_cand_refine(B, k, h->qnorm.as<float>(), h->xnorm_max, d, h->tau.as<float>(),
+                                                  h->cand.as<ErhCand>(), h->cand_cnt.as<uint32_t>(), cap, st));
+                want = (N >= 8 * next) ? 4 * next : 0;                  // another boundary only if plenty of corpus remains
+            }
+            cur = next;
         }
     }
     { ProfScope ps(h, st, ERH_K_DENSE_SELECT, 0, 0);
