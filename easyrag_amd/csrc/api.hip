@@ -45,6 +45,14 @@ struct erh_handle {
     int64_t N = 0;
     int d = 0;
     float xnorm_max = 0.f;
+    // Row placement: original row o is stored at position (o * pos_mul) mod N; pos_inv is the inverse multiplier
+    // (position -> original).  With the golden-ratio inverse every prefix of the stored order is an evenly spread
+    // sample of the caller's order, so the pruning thresholds seeded from a prefix are representative even when
+    // the corpus is sorted by topic.  (1, 1) = stored as given (option dense_shuffle = 0).
+    int64_t pos_mul = 1, pos_inv = 1;
+    int opt_dense_shuffle = 1;
+    DevBuf dir_pos;                         // dir id by stored position (built on demand)
+    bool dir_pos_valid = false;
     // bm25 state
     int variant = -1;
     int64_t V = 0, Nb = 0, nnz = 0;
@@ -140,6 +148,19 @@ void drain_events(erh_handle *h) {
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
+// Multiplier pair of the row placement (see erh_handle::pos_mul): inv ~ n / golden ratio, coprime with n; mul = inv^-1 mod n.
+void choose_placement(int64_t n, int64_t *mul, int64_t *inv) {
+    auto gcd = [](int64_t a, int64_t b) { while (b) { const int64_t t = a % b; a = b; b = t; } return a; };
+    int64_t g = (int64_t)((double)n * 0.6180339887498949);
+    if (g < 1) g = 1;
+    while (gcd(g, n) != 1) g = (g + 1 < n) ? g + 1 : 1;
+    // extended Euclid: x with g * x == 1 (mod n)
+    int64_t r0 = n, r1 = g, t0 = 0, t1 = 1;
+    while (r1) { const int64_t q = r0 / r1; int64_t t = r0 - q * r1; r0 = r1; r1 = t; t = t0 - q * t1; t0 = t1; t1 = t; }
+    *inv = g;
+    *mul = ((t0 % n) + n) % n;
+}
+
 // Append-stage scan: persistent kernel when enabled and applicable, else one workgroup per tile.
 hipError_t scan_append(erh_handle *h, const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1, const _Float16 *Q16,
                        int Bpad, int B, const float *tau, const int16_t *filt, const int16_t *dir, ErhCand *cand,
@@ -187,7 +208,19 @@ int dense_topk_dev(erh_handle *h, const void *q_dev, int q_dtype, int normalize_
                                          h->qnorm.as<float>(), st)); }
     const _Float16 *X = h->X.as<_Float16>();
     const _Float16 *Q16 = h->Q16.as<_Float16>();
-    const int16_t *dir = h->has_dir ? h->dir_id.as<int16_t>() : nullptr;
+    const int16_t *dir = nullptr;                 // dir id by stored position, only needed when a filter is present
+    if (filter_dev && h->has_dir) {
+        if (h->pos_mul == 1) {
+            dir = h->dir_id.as<int16_t>();
+        } else {
+            if (!h->dir_pos_valid) {
+                HIPCHK(h, h->dir_pos.ensure((size_t)N * 2));
+                HIPCHK(h, erh::launch_permute_dir(h->dir_id.as<int16_t>(), N, h->pos_inv, h->dir_pos.as<int16_t>(), st));
+                h->dir_pos_valid = true;
+            }
+            dir = h->dir_pos.as<int16_t>();
+        }
+    }
     auto scan_work = [&](int64_t rows, double *bytes, double *flops) {
         *bytes = (double)rows * d * 2.0 + (double)Bpad * d * 2.0;
         *flops = 2.0 * (double)rows * (double)Bpad * (double)d;
@@ -248,7 +281,7 @@ int dense_topk_dev(erh_handle *h, const void *q_dev, int q_dtype, int normalize_
     { ProfScope ps(h, st, ERH_K_DENSE_SELECT, 0, 0);
       HIPCHK(h, erh::launch_dense_finalize(B, k, mode, h->qnorm.as<float>(), h->xnorm_max, d, X, Q16,
                                            h->cand.as<ErhCand>(), h->cand_cnt.as<uint32_t>(), cap, d_ids, d_sc, d_len,
-                                           reinterpret_cast<float *>(flags + 1), flags + 2, flags, st)); }
+                                           reinterpret_cast<float *>(flags + 1), flags + 2, flags, N, h->pos_mul, h->pos_inv, st)); }
     return ERH_OK;
 }
 
@@ -371,7 +404,7 @@ int erh_destroy(erh_handle *h) {
                       &h->o_ids, &h->o_sc, &h->o_len, &h->qptr, &h->qtok, &h->part_sc, &h->part_ids, &h->part_len,
                       &h->hy_sids, &h->hy_ssc, &h->hy_slen, &h->hy_dids, &h->hy_dsc, &h->hy_dlen,
                       &h->fa_ids, &h->fa_sc, &h->fa_len, &h->fb_ids, &h->fb_sc, &h->fb_len,
-                      &h->scores_tmp, &h->scores_wide, &h->dbg};
+                      &h->scores_tmp, &h->scores_wide, &h->dbg, &h->dir_pos};
     for (DevBuf *b : bufs) b->release();
     delete h;
     return ERH_OK;
@@ -392,6 +425,7 @@ int erh_set_option(erh_handle *h, const char *name, int64_t value) {
     if (!strcmp(name, "dense_n1")) { if (value < 0) return h->fail(ERH_ERR_INVALID, "dense_n1 < 0"); h->opt_n1 = value; return ERH_OK; }
     if (!strcmp(name, "dense_cfg")) { if (value < 0 || value > 3) return h->fail(ERH_ERR_INVALID, "dense_cfg"); h->opt_dense_cfg = (int)value; return ERH_OK; }
     if (!strcmp(name, "dense_readahead")) { h->opt_dense_readahead = value != 0; return ERH_OK; }
+    if (!strcmp(name, "dense_shuffle")) { h->opt_dense_shuffle = value != 0; return ERH_OK; }   // takes effect at the next erh_set_dense
     if (!strcmp(name, "dense_n1_auto")) { h->opt_n1_auto = value != 0; return ERH_OK; }
     if (!strcmp(name, "dense_pp")) { h->opt_dense_pp = value != 0; return ERH_OK; }
     if (!strcmp(name, "dense_persist")) { h->opt_dense_persist = value != 0; return ERH_OK; }
@@ -478,20 +512,38 @@ int erh_set_dense(erh_handle *h, const void *x, int64_t n, int d, int dtype, int
     hipStream_t st = nullptr;
     HIPCHK(h, h->X.ensure((size_t)n * d * 2));
     const hipMemcpyKind kind = is_device_ptr ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-    if (dtype == ERH_F16) {
+    int64_t mul = 1, inv = 1;
+    if (h->opt_dense_shuffle && n > 2) choose_placement(n, &mul, &inv);
+    const size_t es = (dtype == ERH_F16) ? 2 : 4;
+    if (dtype == ERH_F16 && mul == 1) {
         HIPCHK(h, hipMemcpyAsync(h->X.p, x, (size_t)n * d * 2, kind, st));
+    } else if (dtype == ERH_F16 && is_device_ptr) {
+        HIPCHK(h, erh::launch_permute_rows((const _Float16 *)x, n, d, h->X.as<_Float16>(), 0, mul, n, st));
     } else {
-        // fp32 rows -> (optionally normalised) fp16 on the device, in slabs so that a 1M x 1024 fp32 host matrix
-        // never needs 4 GB of staging
-        const int64_t slab = std::max<int64_t>(1, (int64_t)(256u << 20) / ((int64_t)d * 4));
-        HIPCHK(h, h->qin.ensure((size_t)std::min<int64_t>(slab, n) * d * 4));
+        // host rows (or fp32 rows to convert) go through the device in slabs, so that a 1M x 1024 fp32 host matrix
+        // never needs 4 GB of staging; the slab kernels write every row at its stored position
+        const int64_t slab = std::max<int64_t>(1, (int64_t)(256u << 20) / ((int64_t)d * (int64_t)es));
+        const void *src = x;
         for (int64_t r0 = 0; r0 < n; r0 += slab) {
             const int64_t rows = std::min<int64_t>(slab, n - r0);
-            HIPCHK(h, hipMemcpyAsync(h->qin.p, (const float *)x + r0 * d, (size_t)rows * d * 4, kind, st));
-            HIPCHK(h, erh::launch_convert_rows(h->qin.as<float>(), rows, d, normalize, h->X.as<_Float16>() + r0 * d, st));
+            const char *from = (const char *)x + (size_t)r0 * d * es;
+            if (!is_device_ptr) {
+                HIPCHK(h, h->qin.ensure((size_t)std::min<int64_t>(slab, n) * d * es));
+                HIPCHK(h, hipMemcpyAsync(h->qin.p, from, (size_t)rows * d * es, kind, st));
+                src = h->qin.p;
+            } else {
+                src = from;
+            }
+            if (dtype == ERH_F16)
+                HIPCHK(h, erh::launch_permute_rows((const _Float16 *)src, rows, d, h->X.as<_Float16>(), r0, mul, n, st));
+            else
+                HIPCHK(h, erh::launch_convert_rows((const float *)src, rows, d, normalize, h->X.as<_Float16>(), r0, mul, n, st));
             HIPCHK(h, hipStreamSynchronize(st));
         }
     }
+    h->pos_mul = mul;
+    h->pos_inv = inv;
+    h->dir_pos_valid = false;
     HIPCHK(h, h->flags.ensure(64));
     HIPCHK(h, erh::launch_row_norm_max(h->X.as<_Float16>(), n, d, reinterpret_cast<float *>(h->flags.p), st));
     float xn = 0.f;
@@ -605,6 +657,7 @@ int erh_set_doc_meta(erh_handle *h, int64_t N, const int32_t *content_id, const 
     h->has_content = content_id != nullptr;
     h->has_dir = dir_id != nullptr;
     h->Nmeta = N;
+    h->dir_pos_valid = false;
     return ERH_OK;
 }
 
@@ -858,15 +911,19 @@ int erh_debug_dense_scores(erh_handle *h, const void *q_f16_host, int B, int64_t
     HIPCHK(h, h->Q16.ensure((size_t)Bpad * d * 2));
     HIPCHK(h, h->qnorm.ensure((size_t)Bpad * 4));
     HIPCHK(h, erh::launch_prep_queries(h->qin.p, ERH_F16, 0, B, Bpad, d, h->Q16.as<_Float16>(), h->qnorm.as<float>(), st));
+    // the requested ORIGINAL rows, gathered into a contiguous block
+    HIPCHK(h, h->scores_tmp.ensure((size_t)rows * d * 2));
+    HIPCHK(h, erh::launch_gather_rows(h->X.as<_Float16>(), row0, rows, d, h->pos_mul, h->N, h->scores_tmp.as<_Float16>(), st));
+    const _Float16 *Xg = h->scores_tmp.as<_Float16>();
     if (use_mfma) {
         const int ld = round_up(rows, 256);
         HIPCHK(h, h->S0.ensure((size_t)Bpad * ld * 4));
-        HIPCHK(h, erh::launch_dense_scan_store(h->opt_dense_cfg, h->Q16.as<_Float16>(), Bpad, h->X.as<_Float16>(), h->N, d, row0, rows,
+        HIPCHK(h, erh::launch_dense_scan_store(h->opt_dense_cfg, h->Q16.as<_Float16>(), Bpad, Xg, rows, d, 0, rows,
                                                h->S0.as<float>(), ld, st));
         HIPCHK(h, hipMemcpy2DAsync(out, (size_t)rows * 4, h->S0.p, (size_t)ld * 4, (size_t)rows * 4, B, hipMemcpyDeviceToHost, st));
     } else {
         HIPCHK(h, h->S0.ensure((size_t)B * rows * 4));
-        HIPCHK(h, erh::launch_dense_naive(h->Q16.as<_Float16>(), B, h->X.as<_Float16>(), row0, rows, d, h->S0.as<float>(), st));
+        HIPCHK(h, erh::launch_dense_naive(h->Q16.as<_Float16>(), B, Xg, 0, rows, d, h->S0.as<float>(), st));
         HIPCHK(h, hipMemcpyAsync(out, h->S0.p, (size_t)B * rows * 4, hipMemcpyDeviceToHost, st));
     }
     HIPCHK(h, hipStreamSynchronize(st));

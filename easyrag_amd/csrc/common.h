@@ -129,6 +129,12 @@ __device__ __forceinline__ void erh_bitonic_rec_desc(ST *s, int32_t *ix, int n) 
     __syncthreads();
 }
 
+// Row placement of the chunk matrix: original row o is stored at position (o * mul) mod n (mul coprime with n), so
+// that every prefix of the stored order is an evenly spread sample of the original order (api.hip: erh_set_dense).
+__device__ __forceinline__ int64_t erh_mulmod(int64_t a, int64_t mul, int64_t n) {
+    return (int64_t)(((uint64_t)a * (uint64_t)mul) % (uint64_t)n);        // a, mul < 2^31
+}
+
 __device__ __forceinline__ int erh_next_pow2(int v) {
     int p = 1;
     while (p < v) p <<= 1;

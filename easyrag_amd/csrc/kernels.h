@@ -37,7 +37,13 @@ hipError_t select_init();
 hipError_t launch_prep_queries(const void *q, int q_dtype, int normalize, int B, int Bpad, int d,
                                _Float16 *Q16, float *qnorm, hipStream_t st);
 // rows fp32 -> fp16 (optionally L2-normalised) for erh_set_dense
-hipError_t launch_convert_rows(const float *x, int64_t n, int d, int normalize, _Float16 *out, hipStream_t st);
+hipError_t launch_convert_rows(const float *x, int64_t n, int d, int normalize, _Float16 *out_base, int64_t r0,
+                               int64_t mul, int64_t N, hipStream_t st);
+hipError_t launch_permute_rows(const _Float16 *x, int64_t n, int d, _Float16 *out_base, int64_t r0, int64_t mul,
+                               int64_t N, hipStream_t st);
+hipError_t launch_gather_rows(const _Float16 *X, int64_t row0, int64_t n, int d, int64_t mul, int64_t N, _Float16 *out,
+                              hipStream_t st);
+hipError_t launch_permute_dir(const int16_t *dir_id, int64_t N, int64_t inv, int16_t *out, hipStream_t st);
 // max L2 norm over fp16 rows -> *out (float, device)
 hipError_t launch_row_norm_max(const _Float16 *x, int64_t n, int d, float *out, hipStream_t st);
 // Seed stage: k-th best of S0[q][0..n0) (filter applied) -> tau[q] = kth - margin(q); candidates >= tau
@@ -55,7 +61,8 @@ hipError_t launch_dense_finalize(int B, int k, int mode, const float *qnorm, flo
                                  const _Float16 *X, const _Float16 *Q16,
                                  const ErhCand *cand, const uint32_t *cand_cnt, int cap,
                                  int32_t *out_ids, double *out_scores, int32_t *out_len,
-                                 float *diag_maxerr, uint32_t *diag_uncert, uint32_t *overflow, hipStream_t st);
+                                 float *diag_maxerr, uint32_t *diag_uncert, uint32_t *overflow, int64_t N, int64_t pos_mul,
+                                 int64_t pos_inv, hipStream_t st);
 
 // ---- bm25.hip --------------------------------------------------------------------------------
 constexpr int kBm25TileF32 = 32768;   // documents per LDS accumulator tile (fp32 sums)

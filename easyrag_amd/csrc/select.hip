@@ -61,11 +61,14 @@ __global__ __launch_bounds__(256) void prep_queries_kernel(const TIN *__restrict
     if (threadIdx.x == 0) qnorm[row] = sqrtf(s2) * 1.0001f;
 }
 
+// fp32 rows [r0, r0 + n) of the caller's matrix -> fp16 rows at their stored positions ((r0 + row) * mul) mod N.
 __global__ __launch_bounds__(256) void convert_rows_kernel(const float *__restrict__ x, int64_t n, int d, int normalize,
-                                                          _Float16 *__restrict__ out) {
+                                                          _Float16 *__restrict__ out_base, int64_t r0, int64_t mul,
+                                                          int64_t N) {
     __shared__ float red[4];
     for (int64_t row = blockIdx.x; row < n; row += gridDim.x) {
         const float *in = x + row * d;
+        _Float16 *out = out_base + erh_mulmod(r0 + row, mul, N) * d;
         float inv = 1.f;
         if (normalize) {
             float ss = 0.f;
@@ -73,8 +76,38 @@ __global__ __launch_bounds__(256) void convert_rows_kernel(const float *__restri
             ss = block_sum_256(ss, red);
             inv = ss > 0.f ? 1.0f / sqrtf(ss) : 0.f;
         }
-        for (int i = threadIdx.x; i < d; i += 256) out[row * d + i] = (_Float16)(in[i] * inv);
+        for (int i = threadIdx.x; i < d; i += 256) out[i] = (_Float16)(in[i] * inv);
     }
+}
+
+// fp16 rows [r0, r0 + n) -> stored positions (same placement as convert_rows_kernel); 16 bytes per thread and step.
+__global__ __launch_bounds__(256) void permute_rows_kernel(const _Float16 *__restrict__ x, int64_t n, int d,
+                                                          _Float16 *__restrict__ out_base, int64_t r0, int64_t mul,
+                                                          int64_t N) {
+    const int vec = d / 8;
+    for (int64_t row = blockIdx.x; row < n; row += gridDim.x) {
+        const half8 *in = reinterpret_cast<const half8 *>(x + row * d);
+        half8 *out = reinterpret_cast<half8 *>(out_base + erh_mulmod(r0 + row, mul, N) * d);
+        for (int i = threadIdx.x; i < vec; i += 256) out[i] = in[i];
+    }
+}
+
+// Original rows [row0, row0 + n) gathered back into a contiguous block (debug scores path).
+__global__ __launch_bounds__(256) void gather_rows_kernel(const _Float16 *__restrict__ X, int64_t row0, int64_t n, int d,
+                                                         int64_t mul, int64_t N, _Float16 *__restrict__ out) {
+    const int vec = d / 8;
+    for (int64_t row = blockIdx.x; row < n; row += gridDim.x) {
+        const half8 *in = reinterpret_cast<const half8 *>(X + erh_mulmod(row0 + row, mul, N) * d);
+        half8 *o = reinterpret_cast<half8 *>(out + row * d);
+        for (int i = threadIdx.x; i < vec; i += 256) o[i] = in[i];
+    }
+}
+
+// dir id by stored position: out[s] = dir_id[(s * inv) mod N]
+__global__ __launch_bounds__(256) void permute_dir_kernel(const int16_t *__restrict__ dir_id, int64_t N, int64_t inv,
+                                                         int16_t *__restrict__ out) {
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s < N) out[s] = dir_id[erh_mulmod(s, inv, N)];
 }
 
 __global__ __launch_bounds__(256) void row_norm_max_kernel(const _Float16 *__restrict__ x, int64_t n, int d,
@@ -242,7 +275,8 @@ __global__ __launch_bounds__(kSelThreads) void dense_finalize_kernel(
     const _Float16 *__restrict__ X, const _Float16 *__restrict__ Q16,
     const ErhCand *__restrict__ cand, const uint32_t *__restrict__ cand_cnt, int cap,
     int32_t *__restrict__ out_ids, double *__restrict__ out_scores, int32_t *__restrict__ out_len,
-    float *__restrict__ diag_maxerr, uint32_t *__restrict__ diag_uncert, uint32_t *__restrict__ overflow) {
+    float *__restrict__ diag_maxerr, uint32_t *__restrict__ diag_uncert, uint32_t *__restrict__ overflow,
+    int64_t N, int64_t pos_mul, int64_t pos_inv /* candidates carry stored positions: orig = pos * pos_inv mod N */) {
     __shared__ __attribute__((aligned(16))) uint64_t buf[kFinBuf];
     __shared__ uint32_t tmax[kSelThreads];
     __shared__ double r_s64[erh::kDenseRescoreMax];
@@ -276,7 +310,7 @@ __global__ __launch_bounds__(kSelThreads) void dense_finalize_kernel(
         const ErhCand e = mine[i];
         if (e.s >= gather_thr) {
             const int pos = atomicAdd(&s_cnt, 1);
-            if (pos < kFinBuf) buf[pos] = erh_key32(e.s, e.idx);
+            if (pos < kFinBuf) buf[pos] = erh_key32(e.s, (int32_t)erh_mulmod(e.idx, pos_inv, N));   // ties rank by ORIGINAL index
         }
     }
     __syncthreads();
@@ -335,7 +369,7 @@ __global__ __launch_bounds__(kSelThreads) void dense_finalize_kernel(
 #pragma unroll
         for (int r = 0; r < RW; ++r) {
             const int e = (e0 + r < m) ? e0 + r : e0;
-            xr[r] = X + (int64_t)r_idx[e] * d;
+            xr[r] = X + erh_mulmod(r_idx[e], pos_mul, N) * d;
             acc[r] = 0.0;
         }
 #pragma unroll
@@ -423,10 +457,33 @@ hipError_t launch_prep_queries(const void *q, int q_dtype, int normalize, int B,
     return hipGetLastError();
 }
 
-hipError_t launch_convert_rows(const float *x, int64_t n, int d, int normalize, _Float16 *out, hipStream_t st) {
+hipError_t launch_convert_rows(const float *x, int64_t n, int d, int normalize, _Float16 *out_base, int64_t r0,
+                               int64_t mul, int64_t N, hipStream_t st) {
     if (n <= 0) return hipSuccess;
     const unsigned grid = (unsigned)(n < 65536 ? n : 65536);
-    hipLaunchKernelGGL(convert_rows_kernel, dim3(grid), dim3(256), 0, st, x, n, d, normalize, out);
+    hipLaunchKernelGGL(convert_rows_kernel, dim3(grid), dim3(256), 0, st, x, n, d, normalize, out_base, r0, mul, N);
+    return hipGetLastError();
+}
+
+hipError_t launch_permute_rows(const _Float16 *x, int64_t n, int d, _Float16 *out_base, int64_t r0, int64_t mul,
+                               int64_t N, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    const unsigned grid = (unsigned)(n < 65536 ? n : 65536);
+    hipLaunchKernelGGL(permute_rows_kernel, dim3(grid), dim3(256), 0, st, x, n, d, out_base, r0, mul, N);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather_rows(const _Float16 *X, int64_t row0, int64_t n, int d, int64_t mul, int64_t N, _Float16 *out,
+                              hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    const unsigned grid = (unsigned)(n < 65536 ? n : 65536);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid), dim3(256), 0, st, X, row0, n, d, mul, N, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_permute_dir(const int16_t *dir_id, int64_t N, int64_t inv, int16_t *out, hipStream_t st) {
+    if (N <= 0) return hipSuccess;
+    hipLaunchKernelGGL(permute_dir_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, dir_id, N, inv, out);
     return hipGetLastError();
 }
 
@@ -462,10 +519,11 @@ hipError_t launch_dense_finalize(int B, int k, int mode, const float *qnorm, flo
                                  const _Float16 *X, const _Float16 *Q16,
                                  const ErhCand *cand, const uint32_t *cand_cnt, int cap,
                                  int32_t *out_ids, double *out_scores, int32_t *out_len,
-                                 float *diag_maxerr, uint32_t *diag_uncert, uint32_t *overflow, hipStream_t st) {
+                                 float *diag_maxerr, uint32_t *diag_uncert, uint32_t *overflow, int64_t N,
+                                 int64_t pos_mul, int64_t pos_inv, hipStream_t st) {
     hipLaunchKernelGGL(dense_finalize_kernel, dim3(B), dim3(kSelThreads), 0, st,
                        k, mode, qnorm, xnorm_max, d, X, Q16, cand, cand_cnt, cap,
-                       out_ids, out_scores, out_len, diag_maxerr, diag_uncert, overflow);
+                       out_ids, out_scores, out_len, diag_maxerr, diag_uncert, overflow, N, pos_mul, pos_inv);
     return hipGetLastError();
 }
 

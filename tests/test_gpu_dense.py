@@ -139,6 +139,49 @@ def test_dense_tie_block_floods_the_survivor_buffers(engine, scan_cfg):
         assert np.array_equal(sc[i].view(np.uint64), osc.view(np.uint64))
 
 
+def test_dense_corpus_sorted_by_topic(engine):
+    """A corpus ordered by topic: the queries' topic fills the LAST 60 % of the rows, so a threshold seeded from the
+    first rows of the caller's order would admit tens of thousands of candidates per query (more than the candidate
+    lists hold).  Rows are stored in a golden-ratio placement, which makes every stored prefix an even sample of
+    the caller's order: the result is exact and no list overflows; with dense_shuffle=0 the same call reports the
+    overflow instead of returning a wrong answer."""
+    rng = np.random.default_rng(31)
+    n, d, b, k = 60000, 256, 12, 50
+    topic_a = rng.standard_normal(d)
+    topic_b = rng.standard_normal(d)
+    x32 = rng.standard_normal((n, d)) * 0.35
+    x32[: n * 2 // 5] += topic_a
+    x32[n * 2 // 5:] += topic_b
+    x = to_f16_unit(x32)
+    q16 = to_f16_unit(topic_b + 0.35 * rng.standard_normal((b, d)))
+    engine.set_option("dense_n0", 512)
+    engine.set_option("dense_n1", 2048)
+    try:
+        engine.set_dense(x)
+        ids, sc, ln = engine.dense_topk(q16, k)
+        diag = engine.dense_diag()
+        assert diag["uncertified"] == 0
+        for i in (0, 5, b - 1):
+            oid, osc = dense_exact_topk(x, q16[i], k)
+            assert np.array_equal(ids[i], oid)
+            assert np.array_equal(sc[i].view(np.uint64), osc.view(np.uint64))
+        # filter push-down goes through the by-position dir table
+        dir_id = (np.arange(n) % 5).astype(np.int16)
+        engine.set_doc_meta(n, None, dir_id)
+        filt = np.full(b, 3, np.int16)
+        ids, sc, ln = engine.dense_topk(q16, k, filter_dir=filt)
+        oid, osc = dense_exact_topk(x, q16[2], k, dir_id == 3)
+        assert np.array_equal(ids[2], oid) and np.array_equal(sc[2].view(np.uint64), osc.view(np.uint64))
+        engine.set_option("dense_shuffle", 0)
+        engine.set_dense(x)
+        with pytest.raises(_lib.ErhError):
+            engine.dense_topk(q16, k)
+    finally:
+        engine.set_option("dense_shuffle", 1)
+        engine.set_option("dense_n0", 32768)
+        engine.set_option("dense_n1", 131072)
+
+
 def test_dense_fp32_inputs_normalised_on_device(engine):
     rng = np.random.default_rng(8)
     x32 = (rng.standard_normal((3000, 192)) * 3).astype(np.float32)
