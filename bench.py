@@ -40,7 +40,7 @@ def parse_args():
     ap.add_argument("--vocab", type=int, default=262_144)
     ap.add_argument("--batch", type=int, default=0, help="queries per GPU per step (default 1024; dense-only 256)")
     ap.add_argument("--variant", default="bm25s", choices=["bm25s", "okapi"])
-    ap.add_argument("--cpu-queries", type=int, default=12, help="queries in the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-queries", type=int, default=96, help="queries in the bounded CPU-baseline sample, ~15 s of host work (0 = skip)")
     ap.add_argument("--option", action="append", default=[], help="library option name=value (e.g. dense_n1=131072)")
     return ap.parse_args()
 
