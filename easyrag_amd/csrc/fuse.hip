@@ -18,15 +18,21 @@ namespace {
 
 constexpr int kFuseThreads = 512;
 
+// LDS layout, sized at launch for cap = round_up(depth_a + depth_b, 64) items (480 in the reference config:
+// 16 KiB, four workgroups per CU instead of the two a kFuseMaxItems-sized block allows):
+//   [0,16) header | w f64[cap] | score f64[cap] | content i32[cap] | doc i32[cap] | out_doc i32[cap] | leader i32[cap]
 struct FuseLds {
-    int32_t content[erh::kFuseMaxItems];
-    int32_t doc[erh::kFuseMaxItems];
-    int32_t out_doc[erh::kFuseMaxItems];
-    int32_t leader[erh::kFuseMaxItems];
-    double w[erh::kFuseMaxItems];        // RRF: 1/(rank + K) of the item; fusion: its raw route score
-    double score[erh::kFuseMaxItems];
-    int n_leaders;
+    int *n_leaders_p;
+    double *w;                           // RRF: 1/(rank + K) of the item; fusion: its raw route score
+    double *score;
+    int32_t *content, *doc, *out_doc, *leader;
+    int &n_leaders;
+    __device__ FuseLds(char *smem, int cap)
+        : n_leaders_p(reinterpret_cast<int *>(smem)), w(reinterpret_cast<double *>(smem + 16)), score(w + cap),
+          content(reinterpret_cast<int32_t *>(score + cap)), doc(content + cap), out_doc(doc + cap),
+          leader(out_doc + cap), n_leaders(*n_leaders_p) {}
 };
+__host__ __device__ inline size_t fuse_lds_bytes(int cap) { return 16 + (size_t)cap * (8 + 8 + 4 * 4); }
 
 // One item per thread; the inner scans are branch-free counting loops over LDS (broadcast reads, unrolled so
 // that several reads are in flight) instead of early-exit walks.
@@ -37,7 +43,7 @@ __global__ __launch_bounds__(kFuseThreads) void fuse_kernel(
     const int32_t *__restrict__ content_id, int K, int topk,
     int32_t *__restrict__ out_ids, double *__restrict__ out_scores, int32_t *__restrict__ out_len) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    FuseLds &L = *reinterpret_cast<FuseLds *>(smem);
+    FuseLds L(smem, (depth_a + depth_b + 63) / 64 * 64);
     const int q = blockIdx.x, tid = threadIdx.x;
     int la = len_a ? len_a[q] : depth_a;
     int lb = len_b ? len_b[q] : depth_b;
@@ -118,10 +124,10 @@ namespace erh {
 
 hipError_t fuse_init() {
     hipError_t e = hipFuncSetAttribute((const void *)fuse_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)sizeof(FuseLds));
+                                       (int)fuse_lds_bytes(kFuseMaxItems));
     if (e != hipSuccess) return e;
     return hipFuncSetAttribute((const void *)fuse_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)sizeof(FuseLds));
+                               (int)fuse_lds_bytes(kFuseMaxItems));
 }
 
 hipError_t launch_rrf(const int32_t *ids_a, const int32_t *len_a, int depth_a,
@@ -129,7 +135,7 @@ hipError_t launch_rrf(const int32_t *ids_a, const int32_t *len_a, int depth_a,
                       const int32_t *content_id, int B, int K, int topk,
                       int32_t *out_ids, double *out_scores, int32_t *out_len, hipStream_t st) {
     if (B <= 0) return hipSuccess;
-    hipLaunchKernelGGL(fuse_kernel<true>, dim3(B), dim3(kFuseThreads), sizeof(FuseLds), st,
+    hipLaunchKernelGGL(fuse_kernel<true>, dim3(B), dim3(kFuseThreads), fuse_lds_bytes((depth_a + depth_b + 63) / 64 * 64), st,
                        ids_a, (const double *)nullptr, len_a, depth_a, ids_b, (const double *)nullptr, len_b, depth_b,
                        content_id, K, topk, out_ids, out_scores, out_len);
     return hipGetLastError();
@@ -140,7 +146,7 @@ hipError_t launch_fusion(const int32_t *ids_a, const double *sc_a, const int32_t
                          const int32_t *content_id, int B, int topk,
                          int32_t *out_ids, double *out_scores, int32_t *out_len, hipStream_t st) {
     if (B <= 0) return hipSuccess;
-    hipLaunchKernelGGL(fuse_kernel<false>, dim3(B), dim3(kFuseThreads), sizeof(FuseLds), st,
+    hipLaunchKernelGGL(fuse_kernel<false>, dim3(B), dim3(kFuseThreads), fuse_lds_bytes((depth_a + depth_b + 63) / 64 * 64), st,
                        ids_a, sc_a, len_a, depth_a, ids_b, sc_b, len_b, depth_b,
                        content_id, 0, topk, out_ids, out_scores, out_len);
     return hipGetLastError();
