@@ -64,7 +64,7 @@ struct erh_handle {
     DevBuf content_id, dir_id;
     bool has_content = false, has_dir = false;
     // work space
-    DevBuf qin, Q16, qnorm, tau, S0, cand, cand_cnt, flags, filt;
+    DevBuf qin, Q16, qnorm, tau, S0, cand, cand_cnt, flags, filt, seed_need;
     DevBuf o_ids, o_sc, o_len;              // staging for host outputs
     DevBuf qptr, qtok, part_sc, part_ids, part_len;
     DevBuf hy_sids, hy_ssc, hy_slen, hy_dids, hy_dsc, hy_dlen;
@@ -196,6 +196,7 @@ int dense_topk_dev(erh_handle *h, const void *q_dev, int q_dtype, int normalize_
     HIPCHK(h, h->cand.ensure((size_t)B * cap * sizeof(ErhCand)));
     HIPCHK(h, h->cand_cnt.ensure((size_t)B * 4));
     HIPCHK(h, h->flags.ensure(64));
+    HIPCHK(h, h->seed_need.ensure((size_t)B * 4));
     int64_t n0 = std::min<int64_t>(std::min<int64_t>(h->opt_n0, erh::kDenseN0Max), N);
     if (n0 < 1) n0 = 1;
     const int ld = round_up((int)n0, 256);
@@ -233,7 +234,7 @@ int dense_topk_dev(erh_handle *h, const void *q_dev, int q_dtype, int normalize_
     { ProfScope ps(h, st, ERH_K_DENSE_SELECT, 0, 0);
       HIPCHK(h, erh::launch_seed_select(h->S0.as<float>(), ld, (int)n0, 0, B, k, h->qnorm.as<float>(), h->xnorm_max, d,
                                         filter_dev, dir, h->tau.as<float>(), h->cand.as<ErhCand>(),
-                                        h->cand_cnt.as<uint32_t>(), cap, flags, st)); }
+                                        h->cand_cnt.as<uint32_t>(), cap, flags, h->seed_need.as<uint32_t>(), st)); }
     if (N > n0) {
         // Stage boundaries n0 < b1 < b2 < ... < N: the threshold is refined (and the candidate list cut back to what
         // still matters) at every boundary, so a stage adds about k * (b_next - b) / b candidates however large N is.
@@ -404,7 +405,7 @@ int erh_destroy(erh_handle *h) {
                       &h->o_ids, &h->o_sc, &h->o_len, &h->qptr, &h->qtok, &h->part_sc, &h->part_ids, &h->part_len,
                       &h->hy_sids, &h->hy_ssc, &h->hy_slen, &h->hy_dids, &h->hy_dsc, &h->hy_dlen,
                       &h->fa_ids, &h->fa_sc, &h->fa_len, &h->fb_ids, &h->fb_sc, &h->fb_len,
-                      &h->scores_tmp, &h->scores_wide, &h->dbg, &h->dir_pos};
+                      &h->scores_tmp, &h->scores_wide, &h->dbg, &h->dir_pos, &h->seed_need};
     for (DevBuf *b : bufs) b->release();
     delete h;
     return ERH_OK;

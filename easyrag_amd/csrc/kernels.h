@@ -51,7 +51,7 @@ hipError_t launch_row_norm_max(const _Float16 *x, int64_t n, int d, float *out, 
 hipError_t launch_seed_select(const float *S0, int ld_s0, int n0, int64_t c0, int B, int k,
                               const float *qnorm, float xnorm_max, int d,
                               const int16_t *filter_dir, const int16_t *dir_id,
-                              float *tau, ErhCand *cand, uint32_t *cand_cnt, int cap, uint32_t *overflow,
+                              float *tau, ErhCand *cand, uint32_t *cand_cnt, int cap, uint32_t *overflow, uint32_t *need_full,
                               hipStream_t st);
 // Refine: k-th best over the current candidates -> tighter tau; candidates below it are dropped.
 hipError_t launch_cand_refine(int B, int k, const float *qnorm, float xnorm_max, int d,

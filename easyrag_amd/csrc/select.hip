@@ -125,43 +125,74 @@ __global__ __launch_bounds__(256) void row_norm_max_kernel(const _Float16 *__res
 }
 
 // ---- seed stage: k-th best of the stored prefix scores ------------------------------------------
-// grid = B, block = 1024, dynamic LDS = 64 + np2*4 + 1024*4 + kSeedBuf*4 bytes.
-// Exact k-th largest without sorting the row: every thread keeps the maximum of its (strided) 32 keys; the
-// k-th largest of those 1024 maxima (one small bitonic sort) is a lower bound p of the true k-th value, and
-// only ~k*(1+k/2048) keys are >= p.  Those are compacted and sorted.  Inputs that defeat the pivot
-// (more than kSeedBuf keys >= p, or fewer than k threads holding a valid key) take the full-sort path.
+// grid = B, block = 1024.  Exact k-th largest without sorting the row: every thread keeps the maximum of its
+// (strided) keys; the k-th largest of those 1024 maxima (one small bitonic sort) is a lower bound p of the true
+// k-th value, and only ~k*(1+k/2048) keys are >= p.  Those are compacted and sorted.
+// Fast kernel (`seed_select_kernel`): the row is read three times from memory (it was written by the store kernel a
+// moment ago and sits in L2 / Infinity Cache) and only 20 KiB of LDS are used, so two workgroups share a CU.
+// Inputs that defeat the pivot (more than kSeedBuf keys >= p, or fewer than k threads holding a valid key) are
+// flagged in need_full[q] and redone by `seed_select_full_kernel`, which stages the whole row in LDS and sorts it
+// (it returns at once for every other query).
 constexpr int kSeedBuf = 4096;
+
+__device__ __forceinline__ uint32_t seed_key(const float *__restrict__ row, int i, int n0, int fd,
+                                             const int16_t *__restrict__ dir_id, int64_t c0) {
+    if (i >= n0) return 0u;
+    const float s = row[i];
+    bool ok = s > -INFINITY;                                          // chunks past N were stored as -inf
+    if (ok && fd >= 0) ok = ((int)dir_id[c0 + i] == fd);
+    return ok ? erh_f2ord(s) : 0u;
+}
+
+// every stored prefix score >= prune becomes a candidate; tau[q] = prune
+__device__ __forceinline__ void seed_emit(const float *__restrict__ row, int n0, int64_t c0, int fd,
+                                          const int16_t *__restrict__ dir_id, float prune, int q,
+                                          float *__restrict__ tau, ErhCand *__restrict__ cand,
+                                          uint32_t *__restrict__ cand_cnt, int cap, uint32_t *__restrict__ overflow,
+                                          int *s_cnt) {
+    const int tid = threadIdx.x;
+    if (tid == 0) tau[q] = prune;
+    for (int i = tid; i < n0; i += kSelThreads) {
+        const float s = row[i];
+        bool ok = (s > -INFINITY) && (s >= prune);
+        if (ok && fd >= 0) ok = ((int)dir_id[c0 + i] == fd);
+        if (ok) {
+            const int pos = atomicAdd(s_cnt, 1);
+            if (pos < cap) {
+                ErhCand c;
+                c.s = s;
+                c.idx = (int32_t)(c0 + i);
+                cand[(int64_t)q * cap + pos] = c;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const int c = *s_cnt;
+        cand_cnt[q] = (uint32_t)(c < cap ? c : cap);
+        if (c > cap) atomicOr(overflow, 1u);
+    }
+}
 
 __global__ __launch_bounds__(kSelThreads) void seed_select_kernel(
     const float *__restrict__ S0, int ld_s0, int n0, int np2, int64_t c0, int k,
     const float *__restrict__ qnorm, float xnorm_max, int d,
     const int16_t *__restrict__ filter_dir, const int16_t *__restrict__ dir_id,
     float *__restrict__ tau, ErhCand *__restrict__ cand, uint32_t *__restrict__ cand_cnt, int cap,
-    uint32_t *__restrict__ overflow) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    // all LDS lives in the dynamic region (a static __shared__ in front would misalign it): 64-byte header first
-    int &s_nvalid = *reinterpret_cast<int *>(smem);
-    int &s_cnt = *reinterpret_cast<int *>(smem + 4);
-    int &s_cnt2 = *reinterpret_cast<int *>(smem + 8);
-    uint32_t *keys = reinterpret_cast<uint32_t *>(smem + 64);
-    uint32_t *tmax = keys + np2;
-    uint32_t *buf = tmax + kSelThreads;
+    uint32_t *__restrict__ overflow, uint32_t *__restrict__ need_full) {
+    __shared__ int s_nvalid, s_cnt, s_cnt2;
+    __shared__ uint32_t tmax[kSelThreads];
+    __shared__ uint32_t buf[kSeedBuf];
     const int q = blockIdx.x, tid = threadIdx.x;
     const float *row = S0 + (int64_t)q * ld_s0;
     const int fd = filter_dir ? (int)filter_dir[q] : -1;
-    if (tid == 0) { s_nvalid = 0; s_cnt = 0; s_cnt2 = 0; }
+    if (tid == 0) { s_nvalid = 0; s_cnt = 0; s_cnt2 = 0; need_full[q] = 0u; }
     __syncthreads();
     int myvalid = 0;
     uint32_t mx = 0;
-    for (int i = tid; i < np2; i += kSelThreads) {
-        uint32_t key = 0;
-        if (i < n0) {
-            const float s = row[i];
-            bool ok = s > -INFINITY;                                  // chunks past N were stored as -inf
-            if (ok && fd >= 0) ok = ((int)dir_id[c0 + i] == fd);
-            if (ok) { key = erh_f2ord(s); ++myvalid; }
-        }
-        keys[i] = key;
+    for (int i = tid; i < n0; i += kSelThreads) {
+        const uint32_t key = seed_key(row, i, n0, fd, dir_id, c0);
+        myvalid += key ? 1 : 0;
         mx = key > mx ? key : mx;
     }
     tmax[tid] = mx;
@@ -175,7 +206,7 @@ __global__ __launch_bounds__(kSelThreads) void seed_select_kernel(
         bool full_sort = (p == 0u);
         if (!full_sort) {
             for (int i = tid; i < n0; i += kSelThreads) {
-                const uint32_t key = keys[i];
+                const uint32_t key = seed_key(row, i, n0, fd, dir_id, c0);
                 if (key >= p) {
                     const int pos = atomicAdd(&s_cnt2, 1);
                     if (pos < kSeedBuf) buf[pos] = key;
@@ -192,33 +223,34 @@ __global__ __launch_bounds__(kSelThreads) void seed_select_kernel(
                 prune = erh_ord2f(buf[k - 1]) - margin_of(qnorm[q], xnorm_max, d);
             }
         }
-        if (full_sort) {
-            erh_bitonic_desc<uint32_t>(keys, np2);
-            prune = erh_ord2f(keys[k - 1]) - margin_of(qnorm[q], xnorm_max, d);
+        if (full_sort) {                             // uniform: leave this query to seed_select_full_kernel
+            if (tid == 0) need_full[q] = 1u;
+            return;
         }
     }
-    if (tid == 0) tau[q] = prune;
-    // every stored prefix score >= prune becomes a candidate
-    for (int i = tid; i < n0; i += kSelThreads) {
-        const float s = row[i];
-        bool ok = (s > -INFINITY) && (s >= prune);
-        if (ok && fd >= 0) ok = ((int)dir_id[c0 + i] == fd);
-        if (ok) {
-            const int pos = atomicAdd(&s_cnt, 1);
-            if (pos < cap) {
-                ErhCand c;
-                c.s = s;
-                c.idx = (int32_t)(c0 + i);
-                cand[(int64_t)q * cap + pos] = c;
-            }
-        }
-    }
+    seed_emit(row, n0, c0, fd, dir_id, prune, q, tau, cand, cand_cnt, cap, overflow, &s_cnt);
+}
+
+// Full-sort fallback for the queries flagged by seed_select_kernel.  dynamic LDS = 64 + np2*4 bytes.
+__global__ __launch_bounds__(kSelThreads) void seed_select_full_kernel(
+    const float *__restrict__ S0, int ld_s0, int n0, int np2, int64_t c0, int k,
+    const float *__restrict__ qnorm, float xnorm_max, int d,
+    const int16_t *__restrict__ filter_dir, const int16_t *__restrict__ dir_id,
+    float *__restrict__ tau, ErhCand *__restrict__ cand, uint32_t *__restrict__ cand_cnt, int cap,
+    uint32_t *__restrict__ overflow, const uint32_t *__restrict__ need_full) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int q = blockIdx.x, tid = threadIdx.x;
+    if (!need_full[q]) return;                       // uniform
+    int &s_cnt = *reinterpret_cast<int *>(smem);
+    uint32_t *keys = reinterpret_cast<uint32_t *>(smem + 64);
+    const float *row = S0 + (int64_t)q * ld_s0;
+    const int fd = filter_dir ? (int)filter_dir[q] : -1;
+    if (tid == 0) s_cnt = 0;
+    for (int i = tid; i < np2; i += kSelThreads) keys[i] = seed_key(row, i, n0, fd, dir_id, c0);
+    erh_bitonic_desc<uint32_t>(keys, np2);
+    const float prune = erh_ord2f(keys[k - 1]) - margin_of(qnorm[q], xnorm_max, d);
     __syncthreads();
-    if (tid == 0) {
-        const int c = s_cnt;
-        cand_cnt[q] = (uint32_t)(c < cap ? c : cap);
-        if (c > cap) atomicOr(overflow, 1u);
-    }
+    seed_emit(row, n0, c0, fd, dir_id, prune, q, tau, cand, cand_cnt, cap, overflow, &s_cnt);
 }
 
 // ---- refine: tighten tau from the candidates gathered so far --------------------------------------
@@ -438,8 +470,8 @@ static int pow2_ge(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
 hipError_t select_init() {
     hipError_t e;
-    e = hipFuncSetAttribute((const void *)seed_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            kDenseN0Max * 4 + 64 + kSelThreads * 4 + kSeedBuf * 4);
+    e = hipFuncSetAttribute((const void *)seed_select_full_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            kDenseN0Max * 4 + 64);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void *)cand_refine_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kDenseCapMax * 8 + 64);
     if (e != hipSuccess) return e;
@@ -499,11 +531,14 @@ hipError_t launch_seed_select(const float *S0, int ld_s0, int n0, int64_t c0, in
                               const float *qnorm, float xnorm_max, int d,
                               const int16_t *filter_dir, const int16_t *dir_id,
                               float *tau, ErhCand *cand, uint32_t *cand_cnt, int cap, uint32_t *overflow,
-                              hipStream_t st) {
+                              uint32_t *need_full, hipStream_t st) {
     const int np2 = pow2_ge(n0 < 2 ? 2 : n0);
-    hipLaunchKernelGGL(seed_select_kernel, dim3(B), dim3(kSelThreads), (size_t)np2 * 4 + 64 + kSelThreads * 4 + kSeedBuf * 4, st,
+    hipLaunchKernelGGL(seed_select_kernel, dim3(B), dim3(kSelThreads), 0, st,
                        S0, ld_s0, n0, np2, c0, k, qnorm, xnorm_max, d, filter_dir, dir_id, tau, cand, cand_cnt, cap,
-                       overflow);
+                       overflow, need_full);
+    hipLaunchKernelGGL(seed_select_full_kernel, dim3(B), dim3(kSelThreads), (size_t)np2 * 4 + 64, st,
+                       S0, ld_s0, n0, np2, c0, k, qnorm, xnorm_max, d, filter_dir, dir_id, tau, cand, cand_cnt, cap,
+                       overflow, need_full);
     return hipGetLastError();
 }
 

@@ -139,6 +139,33 @@ def test_dense_tie_block_floods_the_survivor_buffers(engine, scan_cfg):
         assert np.array_equal(sc[i].view(np.uint64), osc.view(np.uint64))
 
 
+def test_dense_seed_full_sort_fallback(engine):
+    """A filter that leaves valid scores in only 32 of the 1024 per-thread strides of the seed row: the thread-maxima
+    pivot has fewer than k entries, so the query goes through the full-sort seed kernel."""
+    rng = np.random.default_rng(17)
+    n, d, b, k = 6000, 128, 5, 50
+    x = to_f16_unit(rng.standard_normal((n, d)))
+    q16 = to_f16_unit(rng.standard_normal((b, d)))
+    dir_id = np.where(np.arange(n) % 1024 < 32, 1, 0).astype(np.int16)
+    engine.set_option("dense_shuffle", 0)            # the stride pattern is about stored positions
+    engine.set_option("dense_n0", 4096)
+    engine.set_option("dense_n1", 0)
+    try:
+        engine.set_dense(x)
+        engine.set_doc_meta(n, None, dir_id)
+        filt = np.array([1, 1, -1, 0, 1], np.int16)
+        ids, sc, ln = engine.dense_topk(q16, k, filter_dir=filt)
+        for i in range(b):
+            mask = None if filt[i] < 0 else dir_id == filt[i]
+            oid, osc = dense_exact_topk(x, q16[i], k, mask)
+            assert ln[i] == len(oid)
+            assert np.array_equal(ids[i, :ln[i]], oid) and np.array_equal(sc[i, :ln[i]].view(np.uint64), osc.view(np.uint64))
+    finally:
+        engine.set_option("dense_shuffle", 1)
+        engine.set_option("dense_n0", 32768)
+        engine.set_option("dense_n1", 131072)
+
+
 def test_dense_corpus_sorted_by_topic(engine):
     """A corpus ordered by topic: the queries' topic fills the LAST 60 % of the rows, so a threshold seeded from the
     first rows of the caller's order would admit tens of thousands of candidates per query (more than the candidate
