@@ -302,7 +302,12 @@ __global__ __launch_bounds__(kSelThreads) void cand_refine_kernel(
 // score, and only entries >= p - margin (about k of them) are gathered into LDS and sorted.
 constexpr int kFinBuf = 2048;
 
-__global__ __launch_bounds__(kSelThreads) void dense_finalize_kernel(
+// 512 threads (a 256-VGPR budget): two workgroups per CU, and room to fetch the next pair of rows while the current
+// pair is accumulated -- the row gathers (2 KiB each, anywhere in HBM) are what this kernel waits for.
+constexpr int kFinThreads = 512;
+constexpr int kFinSlots = 1024;                      // pivot granularity: strided maxima of 1024 sub-sequences
+
+__global__ __launch_bounds__(kFinThreads) void dense_finalize_kernel(
     int k, int mode, const float *__restrict__ qnorm, float xnorm_max, int d,
     const _Float16 *__restrict__ X, const _Float16 *__restrict__ Q16,
     const ErhCand *__restrict__ cand, const uint32_t *__restrict__ cand_cnt, int cap,
@@ -310,7 +315,7 @@ __global__ __launch_bounds__(kSelThreads) void dense_finalize_kernel(
     float *__restrict__ diag_maxerr, uint32_t *__restrict__ diag_uncert, uint32_t *__restrict__ overflow,
     int64_t N, int64_t pos_mul, int64_t pos_inv /* candidates carry stored positions: orig = pos * pos_inv mod N */) {
     __shared__ __attribute__((aligned(16))) uint64_t buf[kFinBuf];
-    __shared__ uint32_t tmax[kSelThreads];
+    __shared__ uint32_t tmax[kFinSlots];
     __shared__ double r_s64[erh::kDenseRescoreMax];
     __shared__ int32_t r_idx[erh::kDenseRescoreMax];
     __shared__ float r_s32[erh::kDenseRescoreMax];
@@ -324,21 +329,24 @@ __global__ __launch_bounds__(kSelThreads) void dense_finalize_kernel(
     int32_t *o_ids = out_ids + (int64_t)q * k;
     double *o_sc = out_scores + (int64_t)q * k;
     if (tid == 0) { out_len[q] = kk; s_cnt = 0; s_m = 0; s_maxerr = 0; }
-    for (int i = kk + tid; i < k; i += kSelThreads) { o_ids[i] = -1; o_sc[i] = 0.0; }
+    for (int i = kk + tid; i < k; i += kFinThreads) { o_ids[i] = -1; o_sc[i] = 0.0; }
     if (kk == 0) return;                                                // uniform
 
     const float delta = 0.5f * margin_of(qnorm[q], xnorm_max, d);
-    // pivot: k-th largest of the per-thread maxima (all of them candidates, so it bounds the k-th best from below)
-    uint32_t mx = 0;
-    for (int i = tid; i < c; i += kSelThreads) {
-        const uint32_t o = erh_f2ord(mine[i].s);
-        mx = o > mx ? o : mx;
+    // pivot: k-th largest of the 1024 strided maxima (all of them candidates, so it bounds the k-th best from below)
+#pragma unroll
+    for (int h = 0; h < kFinSlots / kFinThreads; ++h) {
+        uint32_t mx = 0;
+        for (int i = tid + h * kFinThreads; i < c; i += kFinSlots) {
+            const uint32_t o = erh_f2ord(mine[i].s);
+            mx = o > mx ? o : mx;
+        }
+        tmax[tid + h * kFinThreads] = mx;
     }
-    tmax[tid] = mx;
-    erh_bitonic_desc<uint32_t>(tmax, kSelThreads);
+    erh_bitonic_desc<uint32_t>(tmax, kFinSlots);
     float gather_thr = -INFINITY;
-    if (kk <= kSelThreads && tmax[kk - 1] != 0u) gather_thr = erh_ord2f(tmax[kk - 1]) - ((mode == 1) ? 0.f : 2.0f * delta);
-    for (int i = tid; i < c; i += kSelThreads) {
+    if (kk <= kFinSlots && tmax[kk - 1] != 0u) gather_thr = erh_ord2f(tmax[kk - 1]) - ((mode == 1) ? 0.f : 2.0f * delta);
+    for (int i = tid; i < c; i += kFinThreads) {
         const ErhCand e = mine[i];
         if (e.s >= gather_thr) {
             const int pos = atomicAdd(&s_cnt, 1);
@@ -352,11 +360,11 @@ __global__ __launch_bounds__(kSelThreads) void dense_finalize_kernel(
         g = kFinBuf;
     }
     const int ns = erh_next_pow2(g < 2 ? 2 : g);
-    for (int i = g + tid; i < ns; i += kSelThreads) buf[i] = 0ull;
+    for (int i = g + tid; i < ns; i += kFinThreads) buf[i] = 0ull;
     erh_bitonic_desc<uint64_t>(buf, ns);
 
     if (mode == 1 /* ERH_DENSE_FAST */) {
-        for (int i = tid; i < kk; i += kSelThreads) {
+        for (int i = tid; i < kk; i += kFinThreads) {
             o_ids[i] = erh_key32_idx(buf[i]);
             o_sc[i] = (double)erh_key32_score(buf[i]);
         }
@@ -365,7 +373,7 @@ __global__ __launch_bounds__(kSelThreads) void dense_finalize_kernel(
 
     // EXACT: everything whose fp32 score is within the margin of the kk-th best can still be in the top kk
     const float thr = erh_key32_score(buf[kk - 1]) - 2.0f * delta;
-    for (int i = tid; i < g; i += kSelThreads) {
+    for (int i = tid; i < g; i += kFinThreads) {
         const bool in_i = erh_key32_score(buf[i]) >= thr;
         const bool in_n = (i + 1 < g) ? (erh_key32_score(buf[i + 1]) >= thr) : false;
         if (in_i && !in_n) s_m = i + 1;
@@ -374,18 +382,20 @@ __global__ __launch_bounds__(kSelThreads) void dense_finalize_kernel(
     int m = s_m;
     bool uncertified = false;
     if (m > erh::kDenseRescoreMax) { m = erh::kDenseRescoreMax; uncertified = true; }
-    for (int i = tid; i < m; i += kSelThreads) {
+    for (int i = tid; i < m; i += kFinThreads) {
         r_idx[i] = erh_key32_idx(buf[i]);
         r_s32[i] = erh_key32_score(buf[i]);
     }
     __syncthreads();
-    // one wave per candidate group: lane j accumulates elements 512*t + 8*j + e (e = 0..7) sequentially in fp64,
+    // one wave per pair of candidates: lane j accumulates elements 512*t + 8*j + e (e = 0..7) sequentially in fp64,
     // then an xor butterfly 32,16,..,1.  Products of two fp16 values are exact in fp64, so the result depends only
     // on this order -- which oracle/dense.py: dense_exact_scores reproduces.  The query's fragments stay in
-    // registers (rounds of 512 elements, up to 4 = d <= 2048; longer rows reload them) and four rows are in flight.
+    // registers (rounds of 512 elements, up to 4 = d <= 2048; longer rows reload them).
     const int lane = tid & 63, wave = tid >> 6;
     const _Float16 *qrow = Q16 + (int64_t)q * d;
     constexpr int QR = 4;
+    constexpr int RW = 2;                                               // rows per wave iteration
+    constexpr int kWaves = kFinThreads / 64;
     half8 qreg[QR];
 #pragma unroll
     for (int t = 0; t < QR; ++t) {
@@ -394,36 +404,57 @@ __global__ __launch_bounds__(kSelThreads) void dense_finalize_kernel(
         for (int u = 0; u < 8; ++u) qreg[t][u] = (_Float16)0.f;
         if (off < d) qreg[t] = *reinterpret_cast<const half8 *>(qrow + off);
     }
-    constexpr int RW = 2;                                               // rows per wave iteration (register budget: 128 VGPRs at 1024 threads)
-    for (int e0 = wave * RW; e0 < m; e0 += (kSelThreads / 64) * RW) {
-        const _Float16 *xr[RW];
+    half8 xa[RW][QR], xb[RW][QR];
+#pragma unroll
+    for (int r = 0; r < RW; ++r)
+#pragma unroll
+        for (int t = 0; t < QR; ++t)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { xa[r][t][u] = (_Float16)0.f; xb[r][t][u] = (_Float16)0.f; }
+#define ERH_FIN_LOAD(DST, E0)                                                                         \
+    do {                                                                                              \
+        _Pragma("unroll") for (int r = 0; r < RW; ++r) {                                              \
+            const int e_ = ((E0) + r < m) ? (E0) + r : (E0);                                          \
+            const _Float16 *xr_ = X + erh_mulmod(r_idx[e_], pos_mul, N) * d;                          \
+            _Pragma("unroll") for (int t = 0; t < QR; ++t) {                                          \
+                const int off_ = 512 * t + 8 * lane;                                                  \
+                if (off_ < d) DST[r][t] = *reinterpret_cast<const half8 *>(xr_ + off_);               \
+            }                                                                                         \
+        }                                                                                             \
+    } while (0)
+    int e0 = wave * RW;
+    if (e0 < m) ERH_FIN_LOAD(xa, e0);
+    for (; e0 < m; e0 += kWaves * RW) {
+        const int e1 = e0 + kWaves * RW;
+        if (e1 < m) ERH_FIN_LOAD(xb, e1);                               // next pair in flight during the sums below
         double acc[RW];
 #pragma unroll
-        for (int r = 0; r < RW; ++r) {
-            const int e = (e0 + r < m) ? e0 + r : e0;
-            xr[r] = X + erh_mulmod(r_idx[e], pos_mul, N) * d;
-            acc[r] = 0.0;
-        }
+        for (int r = 0; r < RW; ++r) acc[r] = 0.0;
 #pragma unroll
         for (int t = 0; t < QR; ++t) {
-            const int off = 512 * t + 8 * lane;
-            if (off < d) {
-                half8 xv[RW];
-#pragma unroll
-                for (int r = 0; r < RW; ++r) xv[r] = *reinterpret_cast<const half8 *>(xr[r] + off);
+            if (512 * t + 8 * lane < d) {
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
 #pragma unroll
-                    for (int r = 0; r < RW; ++r) acc[r] = acc[r] + (double)xv[r][u] * (double)qreg[t][u];
+                    for (int r = 0; r < RW; ++r) {
+                        // the product of two fp16 values has 22 significant bits: exact in fp32 (and far from its
+                        // subnormal range), so widening the PRODUCT gives the same double as multiplying widened factors
+                        const float p32 = (float)xa[r][t][u] * (float)qreg[t][u];
+                        acc[r] = acc[r] + (double)p32;
+                    }
             }
         }
-        for (int off = 512 * QR + 8 * lane; off < d; off += 512) {      // d > 2048
-            const half8 qv = *reinterpret_cast<const half8 *>(qrow + off);
+        if (d > 512 * QR) {                                             // d > 2048: the tail of the rows straight from memory
 #pragma unroll
             for (int r = 0; r < RW; ++r) {
-                const half8 xv = *reinterpret_cast<const half8 *>(xr[r] + off);
+                const int e = (e0 + r < m) ? e0 + r : e0;
+                const _Float16 *xr = X + erh_mulmod(r_idx[e], pos_mul, N) * d;
+                for (int off = 512 * QR + 8 * lane; off < d; off += 512) {
+                    const half8 qv = *reinterpret_cast<const half8 *>(qrow + off);
+                    const half8 xv = *reinterpret_cast<const half8 *>(xr + off);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) acc[r] = acc[r] + (double)xv[u] * (double)qv[u];
+                    for (int u = 0; u < 8; ++u) acc[r] = acc[r] + (double)((float)xv[u] * (float)qv[u]);
+                }
             }
         }
 #pragma unroll
@@ -440,21 +471,17 @@ __global__ __launch_bounds__(kSelThreads) void dense_finalize_kernel(
             }
             atomicMax(&s_maxerr, __float_as_uint(err));
         }
+#pragma unroll
+        for (int r = 0; r < RW; ++r)
+#pragma unroll
+            for (int t = 0; t < QR; ++t) xa[r][t] = xb[r][t];
     }
-    __syncthreads();
-    // rank by (fp64 desc, index asc) by counting; m <= 1024 = one element per thread
-    if (tid < m) {
-        const double s = r_s64[tid];
-        const int32_t ix = r_idx[tid];
-        int rank = 0;
-#pragma unroll 8
-        for (int f = 0; f < m; ++f) {
-            const double sf = r_s64[f];
-            const int32_t jf = r_idx[f];
-            rank += (sf > s || (sf == s && jf < ix)) ? 1 : 0;
-        }
-        if (rank < kk) { o_ids[rank] = ix; o_sc[rank] = s; }
-    }
+#undef ERH_FIN_LOAD
+    // order by (fp64 desc, index asc): one small record sort (m <= 1024), then the first kk entries are the answer
+    const int mp = erh_next_pow2(m < 2 ? 2 : m);
+    for (int t = m + tid; t < mp; t += kFinThreads) { r_s64[t] = -INFINITY; r_idx[t] = 0x7fffffff; }
+    erh_bitonic_rec_desc<double>(r_s64, r_idx, mp);                     // begins and ends with a barrier
+    for (int t = tid; t < kk; t += kFinThreads) { o_ids[t] = r_idx[t]; o_sc[t] = r_s64[t]; }
     if (tid == 0) {
         const float me = __uint_as_float(s_maxerr);
         atomicMax((unsigned int *)diag_maxerr, __float_as_uint(me));
@@ -556,7 +583,7 @@ hipError_t launch_dense_finalize(int B, int k, int mode, const float *qnorm, flo
                                  int32_t *out_ids, double *out_scores, int32_t *out_len,
                                  float *diag_maxerr, uint32_t *diag_uncert, uint32_t *overflow, int64_t N,
                                  int64_t pos_mul, int64_t pos_inv, hipStream_t st) {
-    hipLaunchKernelGGL(dense_finalize_kernel, dim3(B), dim3(kSelThreads), 0, st,
+    hipLaunchKernelGGL(dense_finalize_kernel, dim3(B), dim3(kFinThreads), 0, st,
                        k, mode, qnorm, xnorm_max, d, X, Q16, cand, cand_cnt, cap,
                        out_ids, out_scores, out_len, diag_maxerr, diag_uncert, overflow, N, pos_mul, pos_inv);
     return hipGetLastError();
