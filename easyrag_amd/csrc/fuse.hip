@@ -7,8 +7,12 @@
 //           its list; Python dict order = first-seen order, and the stable sort keeps it among equal
 //           scores; the node returned is the LAST one seen for the content (text_to_node[content] = item).
 //   fusion  first occurrence wins, ordered by its raw route score (stable).
-// Lists are tiny (<= 192 + 288 in the reference config), so one workgroup per query does the
-// quadratic leader / rank counting out of LDS; no host round trip between the routes and the fusion.
+// Lists are tiny (<= 192 + 288 in the reference config): one workgroup per query, two small LDS sorts
+// (common.h: wave-local bitonic steps), no host round trip between the routes and the fusion.
+//   1. sort items by (content, position): equal contents become adjacent, in item order;
+//   2. the first item of each run is the content's leader (first seen); its score is the sum of the run's
+//      weights in item order (RRF) or its own route score (fusion); the node is the run's last (RRF) / first item;
+//   3. sort the leaders by (score desc, first-seen position asc) = Python's stable sort over dict order; emit topk.
 #include "common.h"
 #include "kernels.h"
 
@@ -18,32 +22,24 @@ namespace {
 
 constexpr int kFuseThreads = 512;
 
-// LDS layout, sized at launch for cap = round_up(depth_a + depth_b, 64) items (480 in the reference config:
-// 16 KiB, four workgroups per CU instead of the two a kFuseMaxItems-sized block allows):
-//   [0,16) header | w f64[cap] | score f64[cap] | content i32[cap] | doc i32[cap] | out_doc i32[cap] | leader i32[cap]
-struct FuseLds {
-    int *n_leaders_p;
-    double *w;                           // RRF: 1/(rank + K) of the item; fusion: its raw route score
-    double *score;
-    int32_t *content, *doc, *out_doc, *leader;
-    int &n_leaders;
-    __device__ FuseLds(char *smem, int cap)
-        : n_leaders_p(reinterpret_cast<int *>(smem)), w(reinterpret_cast<double *>(smem + 16)), score(w + cap),
-          content(reinterpret_cast<int32_t *>(score + cap)), doc(content + cap), out_doc(doc + cap),
-          leader(out_doc + cap), n_leaders(*n_leaders_p) {}
-};
-__host__ __device__ inline size_t fuse_lds_bytes(int cap) { return 16 + (size_t)cap * (8 + 8 + 4 * 4); }
+// LDS layout for P = pow2 >= depth_a + depth_b slots:
+//   key u64[P] | w f64[P] | score f64[P] | doc i32[P] | lidx i32[P] | node i32[P]     (36 bytes per slot + 16 header)
+__host__ __device__ inline size_t fuse_lds_bytes(int P) { return 16 + (size_t)P * (8 + 8 + 8 + 4 + 4 + 4); }
 
-// One item per thread; the inner scans are branch-free counting loops over LDS (broadcast reads, unrolled so
-// that several reads are in flight) instead of early-exit walks.
 template <bool RRF>
 __global__ __launch_bounds__(kFuseThreads) void fuse_kernel(
     const int32_t *__restrict__ ids_a, const double *__restrict__ sc_a, const int32_t *__restrict__ len_a, int depth_a,
     const int32_t *__restrict__ ids_b, const double *__restrict__ sc_b, const int32_t *__restrict__ len_b, int depth_b,
-    const int32_t *__restrict__ content_id, int K, int topk,
+    const int32_t *__restrict__ content_id, int K, int topk, int P,
     int32_t *__restrict__ out_ids, double *__restrict__ out_scores, int32_t *__restrict__ out_len) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    FuseLds L(smem, (depth_a + depth_b + 63) / 64 * 64);
+    int &n_leaders = *reinterpret_cast<int *>(smem);
+    uint64_t *key = reinterpret_cast<uint64_t *>(smem + 16);
+    double *w = reinterpret_cast<double *>(key + P);       // by item: RRF 1/(rank + K); fusion: raw route score
+    double *score = w + P;                                 // by sorted slot
+    int32_t *doc = reinterpret_cast<int32_t *>(score + P); // by item
+    int32_t *lidx = doc + P;                               // by sorted slot: leader's item position (INT_MAX: none)
+    int32_t *node = lidx + P;                              // by item (leaders only): the node to return
     const int q = blockIdx.x, tid = threadIdx.x;
     int la = len_a ? len_a[q] : depth_a;
     int lb = len_b ? len_b[q] : depth_b;
@@ -52,68 +48,66 @@ __global__ __launch_bounds__(kFuseThreads) void fuse_kernel(
     if (la < 0) la = 0;
     if (lb < 0) lb = 0;
     const int n = la + lb;
-    if (tid == 0) L.n_leaders = 0;
-    for (int i = tid; i < n; i += kFuseThreads) {
-        const bool in_a = i < la;
-        const int32_t id = in_a ? ids_a[(int64_t)q * depth_a + i] : ids_b[(int64_t)q * depth_b + (i - la)];
-        L.doc[i] = id;
-        L.content[i] = content_id ? content_id[id] : id;
-        if (RRF) {
-            const int rank = in_a ? (i + 1) : (i - la + 1);
-            L.w[i] = 1.0 / (double)(rank + K);
-        } else {
-            L.w[i] = in_a ? sc_a[(int64_t)q * depth_a + i] : sc_b[(int64_t)q * depth_b + (i - la)];
-        }
-    }
-    __syncthreads();
-    for (int i = tid; i < n; i += kFuseThreads) {
-        const int32_t c = L.content[i];
-        int earlier = 0;
-#pragma unroll 8
-        for (int j = 0; j < i; ++j) earlier += (L.content[j] == c) ? 1 : 0;
-        const bool lead = earlier == 0;
-        L.leader[i] = lead ? 1 : 0;
-        if (lead) {
-            atomicAdd(&L.n_leaders, 1);
+    if (tid == 0) n_leaders = 0;
+    for (int i = tid; i < P; i += kFuseThreads) {
+        uint64_t kv = 0;                                   // empty slots sort to the end
+        if (i < n) {
+            const bool in_a = i < la;
+            const int32_t id = in_a ? ids_a[(int64_t)q * depth_a + i] : ids_b[(int64_t)q * depth_b + (i - la)];
+            doc[i] = id;
+            const uint32_t c = (uint32_t)(content_id ? content_id[id] : id);
+            kv = ~(((uint64_t)c << 32) | (uint32_t)i);     // descending sort of ~v = ascending (content, position)
             if (RRF) {
-                // occurrences are added in item order; a non-occurrence adds +0.0, which never changes the bits
-                double s = 0.0;
-                int32_t last = L.doc[i];
-#pragma unroll 8
-                for (int j = i; j < n; ++j) {
-                    const bool m = L.content[j] == c;
-                    s = s + (m ? L.w[j] : 0.0);
-                    last = m ? L.doc[j] : last;
-                }
-                L.score[i] = s;
-                L.out_doc[i] = last;
+                const int rank = in_a ? (i + 1) : (i - la + 1);
+                w[i] = 1.0 / (double)(rank + K);
             } else {
-                L.score[i] = L.w[i];
-                L.out_doc[i] = L.doc[i];
+                w[i] = in_a ? sc_a[(int64_t)q * depth_a + i] : sc_b[(int64_t)q * depth_b + (i - la)];
             }
         }
+        key[i] = kv;
     }
-    __syncthreads();
-    const int nl = L.n_leaders;
+    erh_bitonic_desc<uint64_t>(key, P);                    // begins and ends with a barrier
+    for (int p = tid; p < P; p += kFuseThreads) {
+        double s = -INFINITY;
+        int32_t li = 0x7fffffff;
+        if (p < n) {
+            const uint64_t v = ~key[p];
+            const uint32_t c = (uint32_t)(v >> 32);
+            const bool start = (p == 0) || ((uint32_t)((~key[p - 1]) >> 32) != c);
+            if (start) {
+                const int i0 = (int)(uint32_t)v;
+                int32_t last = doc[i0];
+                if (RRF) {
+                    s = 0.0;                               // occurrences are added in item order
+                    for (int pp = p; pp < n; ++pp) {
+                        const uint64_t vv = ~key[pp];
+                        if ((uint32_t)(vv >> 32) != c) break;
+                        const int it = (int)(uint32_t)vv;
+                        s = s + w[it];
+                        last = doc[it];                    // text_to_node[content] = the LAST node seen
+                    }
+                } else {
+                    s = w[i0];                             // first occurrence wins
+                }
+                li = i0;
+                node[i0] = last;
+                atomicAdd(&n_leaders, 1);
+            }
+        }
+        score[p] = s;
+        lidx[p] = li;
+    }
+    erh_bitonic_rec_desc<double>(score, lidx, P);          // (score desc, first-seen position asc)
+    const int nl = n_leaders;
     const int kk = topk < nl ? topk : nl;
-    for (int i = tid; i < n; i += kFuseThreads) {
-        if (!L.leader[i]) continue;
-        const double s = L.score[i];
-        int rank = 0;
-#pragma unroll 8
-        for (int j = 0; j < n; ++j) {
-            const double sj = L.score[j];
-            const bool better = (sj > s) || (sj == s && j < i);
-            rank += (L.leader[j] && better) ? 1 : 0;
+    for (int r = tid; r < topk; r += kFuseThreads) {
+        if (r < kk) {
+            out_ids[(int64_t)q * topk + r] = node[lidx[r]];
+            out_scores[(int64_t)q * topk + r] = score[r];
+        } else {
+            out_ids[(int64_t)q * topk + r] = -1;
+            out_scores[(int64_t)q * topk + r] = 0.0;
         }
-        if (rank < kk) {
-            out_ids[(int64_t)q * topk + rank] = L.out_doc[i];
-            out_scores[(int64_t)q * topk + rank] = s;
-        }
-    }
-    for (int i = kk + tid; i < topk; i += kFuseThreads) {
-        out_ids[(int64_t)q * topk + i] = -1;
-        out_scores[(int64_t)q * topk + i] = 0.0;
     }
     if (tid == 0) out_len[q] = kk;
 }
@@ -135,9 +129,11 @@ hipError_t launch_rrf(const int32_t *ids_a, const int32_t *len_a, int depth_a,
                       const int32_t *content_id, int B, int K, int topk,
                       int32_t *out_ids, double *out_scores, int32_t *out_len, hipStream_t st) {
     if (B <= 0) return hipSuccess;
-    hipLaunchKernelGGL(fuse_kernel<true>, dim3(B), dim3(kFuseThreads), fuse_lds_bytes((depth_a + depth_b + 63) / 64 * 64), st,
+    int P = 2;
+    while (P < depth_a + depth_b) P <<= 1;
+    hipLaunchKernelGGL(fuse_kernel<true>, dim3(B), dim3(kFuseThreads), fuse_lds_bytes(P), st,
                        ids_a, (const double *)nullptr, len_a, depth_a, ids_b, (const double *)nullptr, len_b, depth_b,
-                       content_id, K, topk, out_ids, out_scores, out_len);
+                       content_id, K, topk, P, out_ids, out_scores, out_len);
     return hipGetLastError();
 }
 
@@ -146,9 +142,11 @@ hipError_t launch_fusion(const int32_t *ids_a, const double *sc_a, const int32_t
                          const int32_t *content_id, int B, int topk,
                          int32_t *out_ids, double *out_scores, int32_t *out_len, hipStream_t st) {
     if (B <= 0) return hipSuccess;
-    hipLaunchKernelGGL(fuse_kernel<false>, dim3(B), dim3(kFuseThreads), fuse_lds_bytes((depth_a + depth_b + 63) / 64 * 64), st,
+    int P = 2;
+    while (P < depth_a + depth_b) P <<= 1;
+    hipLaunchKernelGGL(fuse_kernel<false>, dim3(B), dim3(kFuseThreads), fuse_lds_bytes(P), st,
                        ids_a, sc_a, len_a, depth_a, ids_b, sc_b, len_b, depth_b,
-                       content_id, 0, topk, out_ids, out_scores, out_len);
+                       content_id, 0, topk, P, out_ids, out_scores, out_len);
     return hipGetLastError();
 }
 
