@@ -165,7 +165,7 @@ void choose_placement(int64_t n, int64_t *mul, int64_t *inv) {
 hipError_t scan_append(erh_handle *h, const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1, const _Float16 *Q16,
                        int Bpad, int B, const float *tau, const int16_t *filt, const int16_t *dir, ErhCand *cand,
                        uint32_t *cnt, int cap, uint32_t *flags, hipStream_t st) {
-    if (h->opt_dense_pp && (h->opt_dense_ablate == 0 || (h->opt_dense_ablate >= 7 && h->opt_dense_ablate <= 16 && h->opt_dense_ablate != 10))) {
+    if (h->opt_dense_pp && (h->opt_dense_ablate == 0 || (h->opt_dense_ablate >= 7 && h->opt_dense_ablate <= 15 && h->opt_dense_ablate != 10 && h->opt_dense_ablate != 9))) {
         hipError_t e = erh::launch_dense_scan_pp(X, N, d, c0, c1, Q16, Bpad, B, tau, filt, dir, cand, cnt, cap, flags,
                                                  h->n_cus, h->opt_dense_ablate, st);
         if (e != hipErrorInvalidValue) return e;
@@ -424,7 +424,7 @@ int erh_set_option(erh_handle *h, const char *name, int64_t value) {
     if (!h || !name) return ERH_ERR_INVALID;
     if (!strcmp(name, "dense_n0")) { if (value < 1) return h->fail(ERH_ERR_INVALID, "dense_n0 < 1"); h->opt_n0 = value; return ERH_OK; }
     if (!strcmp(name, "dense_n1")) { if (value < 0) return h->fail(ERH_ERR_INVALID, "dense_n1 < 0"); h->opt_n1 = value; return ERH_OK; }
-    if (!strcmp(name, "dense_cfg")) { if (value < 0 || value > 3) return h->fail(ERH_ERR_INVALID, "dense_cfg"); h->opt_dense_cfg = (int)value; return ERH_OK; }
+    if (!strcmp(name, "dense_cfg")) { if (value < 0 || value > 2) return h->fail(ERH_ERR_INVALID, "dense_cfg"); h->opt_dense_cfg = (int)value; return ERH_OK; }
     if (!strcmp(name, "dense_readahead")) { h->opt_dense_readahead = value != 0; return ERH_OK; }
     if (!strcmp(name, "dense_shuffle")) { h->opt_dense_shuffle = value != 0; return ERH_OK; }   // takes effect at the next erh_set_dense
     if (!strcmp(name, "dense_n1_auto")) { h->opt_n1_auto = value != 0; return ERH_OK; }

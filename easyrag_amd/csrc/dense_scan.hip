@@ -50,6 +50,7 @@ struct ScanCfg {
     // read-ahead variant (needs DA == DB >= 2): stage kt+1 must have landed too, so only the loads issued after
     // A(kt+1) -- the later (DB - 2) steps -- may stay in flight
     static constexpr bool CAN_RA = (AST_ == BST_) && (BST_ >= 3);
+    static constexpr bool MEASURE = (BK_ == 64) && (AST_ == 3);   // ablation variants are built for the default lock-step config only
     static constexpr int WAIT_RA = (DB - 2) * (A_ITERS + B_ITERS);
     static_assert(BK == 32 || BK == 64, "BK");
     static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile must be a multiple of the 32x32 MFMA tile");
@@ -688,8 +689,8 @@ static_assert(LDS_BYTES == 160 * 1024, "pp LDS");
         __builtin_amdgcn_sched_barrier(0);                 \
     } while (0)
 
-// PABL (measurement only): 0 full, 7 no epilogue, 8 thresholds forced to +inf, 9 s_setprio 1 around the MFMA phase;
-// without epilogue AND: 11 no MFMA, 12 no LDS-DMA, 13 no chunk-side DMA, 14 no fragment reads, 15 no query-side DMA; 16 = full, s_setprio 1 around the memory phase
+// PABL (measurement only): 0 full, 7 no epilogue, 8 thresholds forced to +inf;
+// without epilogue AND: 11 no MFMA, 12 no LDS-DMA, 13 no chunk-side DMA, 14 no fragment reads, 15 no query-side DMA
 template <int PABL>
 __global__ __launch_bounds__(pp::NT) void dense_scan_pp_kernel(
     const _Float16 *__restrict__ X, int64_t N, int d, int64_t c0, int64_t c1,
@@ -777,7 +778,6 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp_kernel(
 // memory phase M(h): the fragments of stage h+1, then the A pair (h+4, h+5) for even h / the B pair (h+3, h+4) for odd h
 #define ERH_PP_MEM()                                                                                  \
     do {                                                                                              \
-        if (PABL == 16) asm volatile("s_setprio 1");                                                  \
         if (gf < total && (PABL != 14 || gf == 0)) {                                                  \
             const char *pa_ = lds + fa_slot * pp::A_BYTES + a_lane_off;                               \
             const char *pb_ = lds + fb_slot * pp::B_BYTES + b_lane_off;                               \
@@ -794,7 +794,6 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp_kernel(
         __builtin_amdgcn_sched_barrier(0);   /* reads first: the DMA issue below covers their latency */ \
         if (m_odd) ERH_PP_ISSUE_B(); else ERH_PP_ISSUE_A();                                           \
         m_odd ^= 1;                                                                                   \
-        if (PABL == 16) asm volatile("s_setprio 0");                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                            \
     } while (0)
 #define ERH_PP_COMPUTE()                                                                              \
@@ -806,7 +805,6 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp_kernel(
                 _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f; }                \
             break;                                                                                    \
         }                                                                                             \
-        if (PABL == 9) asm volatile("s_setprio 1");                                                   \
         if (kt == 0) {                                                                                \
             const f32x16 z_ = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; \
             _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                          \
@@ -820,7 +818,6 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp_kernel(
         _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                              \
             _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                          \
                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mt][1], fb[nt][1], acc[mt][nt], 0, 0, 0); \
-        if (PABL == 9) asm volatile("s_setprio 0");                                                   \
         __builtin_amdgcn_sched_barrier(0);                                                            \
     } while (0)
 // end of P_a(g): stage g+1 complete for this wave's pieces (see the header comment), then publish
@@ -847,7 +844,7 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp_kernel(
 // Epilogue of tile i for this wave (acc final).  See the header comment.
 #define ERH_PP_EPILOGUE()                                                                             \
     do {                                                                                              \
-        if (PABL == 7 || (PABL >= 11 && PABL <= 15)) {                                                \
+        if (PABL == 7 || PABL >= 11) {                                                \
             float keep_ = 0.f;                                                                        \
             _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                          \
                 _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                      \
@@ -943,7 +940,7 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp_kernel(
             }
             ERH_PP_EPILOGUE();
             ERH_PP_BARRIER();
-            if (PABL != 7 && !(PABL >= 11 && PABL <= 15)) flush_now = __builtin_amdgcn_readfirstlane(flag[i & 1]);
+            if (PABL != 7 && PABL < 11) flush_now = __builtin_amdgcn_readfirstlane(flag[i & 1]);
         }
     } else {
         for (int i = 0; i < n_tiles; ++i) {
@@ -955,7 +952,7 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp_kernel(
             }
             ERH_PP_EPILOGUE();
             ERH_PP_BARRIER();
-            if (PABL != 7 && !(PABL >= 11 && PABL <= 15)) flush_now = __builtin_amdgcn_readfirstlane(flag[i & 1]);
+            if (PABL != 7 && PABL < 11) flush_now = __builtin_amdgcn_readfirstlane(flag[i & 1]);
         }
     }
 #undef ERH_PP_ISSUE_A
@@ -969,7 +966,6 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp_kernel(
 using Cfg0 = ScanCfg<256, 256, 2, 4, 64, 3, 2>;   // one 8-wave workgroup per CU, 160 KiB LDS
 using Cfg1 = ScanCfg<128, 256, 1, 4, 32, 4, 3>;   // two 4-wave workgroups per CU, 80 KiB LDS each
 using Cfg2 = ScanCfg<256, 256, 2, 4, 32, 5, 5>;   // one workgroup per CU, BK 32, both operands 4 half-steps ahead
-using Cfg3 = ScanCfg<256, 256, 2, 4, 64, 2, 2>;   // BK 64, both rings 2 deep (128 KiB): measures what the third A stage buys
 static_assert(Cfg2::LDS_BYTES == 160 * 1024, "cfg2");
 static_assert(Cfg0::WAIT_N == 4 && Cfg0::LDS_BYTES == 160 * 1024, "cfg0");
 static_assert(Cfg1::LDS_BYTES == 80 * 1024, "cfg1");
@@ -983,7 +979,8 @@ hipError_t set_attrs() {
     e = hipFuncSetAttribute((const void *)dense_scan_append_kernel<C, A>,                                  \
                             hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);                      \
     if (e != hipSuccess) return e;
-    ERH_SET_ABL(0) ERH_SET_ABL(1) ERH_SET_ABL(2) ERH_SET_ABL(3) ERH_SET_ABL(4) ERH_SET_ABL(5)
+    ERH_SET_ABL(0)
+    if constexpr (C::MEASURE) { ERH_SET_ABL(1) ERH_SET_ABL(2) ERH_SET_ABL(3) ERH_SET_ABL(4) ERH_SET_ABL(5) }
 #undef ERH_SET_ABL
 #define ERH_SET_P(A)                                                                                       \
     e = hipFuncSetAttribute((const void *)dense_scan_persist_kernel<C, A, false>,                          \
@@ -994,7 +991,8 @@ hipError_t set_attrs() {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);                  \
         if (e != hipSuccess) return e;                                                                     \
     }
-    ERH_SET_P(0) ERH_SET_P(7) ERH_SET_P(8) ERH_SET_P(10)
+    ERH_SET_P(0)
+    if constexpr (C::MEASURE) { ERH_SET_P(7) ERH_SET_P(8) ERH_SET_P(10) }
 #undef ERH_SET_P
     return hipSuccess;
 }
@@ -1017,11 +1015,15 @@ hipError_t launch_persist(const _Float16 *X, int64_t N, int d, int64_t c0, int64
             hipLaunchKernelGGL((dense_scan_persist_kernel<C, A, false>), grid, block, C::LDS_BYTES, st, X, N, d, c0, c1, \
                                Q, Bpad, B, tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow);         \
     } while (0)
-    switch (pabl) {
-        case 7: ERH_LAUNCH_P(7); break;
-        case 8: ERH_LAUNCH_P(8); break;
-        case 10: ERH_LAUNCH_P(10); break;
-        default: ERH_LAUNCH_P(0); break;
+    if constexpr (C::MEASURE) {
+        switch (pabl) {
+            case 7: ERH_LAUNCH_P(7); break;
+            case 8: ERH_LAUNCH_P(8); break;
+            case 10: ERH_LAUNCH_P(10); break;
+            default: ERH_LAUNCH_P(0); break;
+        }
+    } else {
+        ERH_LAUNCH_P(0);
     }
 #undef ERH_LAUNCH_P
     return hipGetLastError();
@@ -1049,13 +1051,17 @@ hipError_t launch_append(const _Float16 *X, int64_t N, int d, int64_t c0, int64_
 #define ERH_LAUNCH_ABL(A)                                                                                  \
     hipLaunchKernelGGL((dense_scan_append_kernel<C, A>), grid, block, C::LDS_BYTES, st, X, N, d, c0, c1, Q, Bpad, B, \
                        tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow, dbg)
-    switch (ablate) {
-        case 1: ERH_LAUNCH_ABL(1); break;
-        case 2: ERH_LAUNCH_ABL(2); break;
-        case 3: ERH_LAUNCH_ABL(3); break;
-        case 4: ERH_LAUNCH_ABL(4); break;
-        case 5: ERH_LAUNCH_ABL(5); break;
-        default: ERH_LAUNCH_ABL(0); break;
+    if constexpr (C::MEASURE) {
+        switch (ablate) {
+            case 1: ERH_LAUNCH_ABL(1); break;
+            case 2: ERH_LAUNCH_ABL(2); break;
+            case 3: ERH_LAUNCH_ABL(3); break;
+            case 4: ERH_LAUNCH_ABL(4); break;
+            case 5: ERH_LAUNCH_ABL(5); break;
+            default: ERH_LAUNCH_ABL(0); break;
+        }
+    } else {
+        ERH_LAUNCH_ABL(0);
     }
 #undef ERH_LAUNCH_ABL
     return hipGetLastError();
@@ -1076,13 +1082,11 @@ hipError_t launch_pp(const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1
     switch (pabl) {
         case 7: ERH_LAUNCH_PP(7); break;
         case 8: ERH_LAUNCH_PP(8); break;
-        case 9: ERH_LAUNCH_PP(9); break;
         case 11: ERH_LAUNCH_PP(11); break;
         case 12: ERH_LAUNCH_PP(12); break;
         case 13: ERH_LAUNCH_PP(13); break;
         case 14: ERH_LAUNCH_PP(14); break;
         case 15: ERH_LAUNCH_PP(15); break;
-        case 16: ERH_LAUNCH_PP(16); break;
         default: ERH_LAUNCH_PP(0); break;
     }
 #undef ERH_LAUNCH_PP
@@ -1103,14 +1107,12 @@ hipError_t dense_scan_init() {
     if (e != hipSuccess) return e;
     e = set_attrs<Cfg2>();
     if (e != hipSuccess) return e;
-    e = set_attrs<Cfg3>();
-    if (e != hipSuccess) return e;
 #define ERH_SET_PP(A)                                                                                      \
     e = hipFuncSetAttribute((const void *)dense_scan_pp_kernel<A>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                             pp::LDS_BYTES);                                                                \
     if (e != hipSuccess) return e;
-    ERH_SET_PP(0) ERH_SET_PP(7) ERH_SET_PP(8) ERH_SET_PP(9) ERH_SET_PP(11) ERH_SET_PP(12) ERH_SET_PP(13) ERH_SET_PP(14)
-    ERH_SET_PP(15) ERH_SET_PP(16)
+    ERH_SET_PP(0) ERH_SET_PP(7) ERH_SET_PP(8) ERH_SET_PP(11) ERH_SET_PP(12) ERH_SET_PP(13) ERH_SET_PP(14)
+    ERH_SET_PP(15)
 #undef ERH_SET_PP
     return hipSuccess;
 }
@@ -1131,7 +1133,6 @@ hipError_t launch_dense_scan_store(int cfg, const _Float16 *Q, int Bpad, const _
     if (nc <= 0) return hipSuccess;
     if (cfg == 1) return launch_store<Cfg1>(Q, Bpad, X, N, d, c0, nc, S0, ld_s0, st);
     if (cfg == 2) return launch_store<Cfg2>(Q, Bpad, X, N, d, c0, nc, S0, ld_s0, st);
-    if (cfg == 3) return launch_store<Cfg3>(Q, Bpad, X, N, d, c0, nc, S0, ld_s0, st);
     return launch_store<Cfg0>(Q, Bpad, X, N, d, c0, nc, S0, ld_s0, st);
 }
 
@@ -1146,9 +1147,6 @@ hipError_t launch_dense_scan_append(int cfg, const _Float16 *X, int64_t N, int d
                                    ablate, dbg, st);
     if (cfg == 2)
         return launch_append<Cfg2>(X, N, d, c0, c1, Q, Bpad, B, tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow,
-                                   ablate, dbg, st);
-    if (cfg == 3)
-        return launch_append<Cfg3>(X, N, d, c0, c1, Q, Bpad, B, tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow,
                                    ablate, dbg, st);
     return launch_append<Cfg0>(X, N, d, c0, c1, Q, Bpad, B, tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow,
                                ablate, dbg, st);
@@ -1167,11 +1165,6 @@ hipError_t launch_dense_scan_persist(int cfg, const _Float16 *X, int64_t N, int 
         if (d / Cfg2::BK <= Cfg2::DA) return hipErrorInvalidValue;
         return launch_persist<Cfg2>(X, N, d, c0, c1, Q, Bpad, B, tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow,
                                     n_cus, pabl, readahead != 0, st);
-    }
-    if (cfg == 3) {
-        if (d / Cfg3::BK <= Cfg3::DA) return hipErrorInvalidValue;
-        return launch_persist<Cfg3>(X, N, d, c0, c1, Q, Bpad, B, tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow,
-                                    n_cus, pabl, false, st);
     }
     if (d / Cfg0::BK <= Cfg0::DA) return hipErrorInvalidValue;
     return launch_persist<Cfg0>(X, N, d, c0, c1, Q, Bpad, B, tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow, n_cus,
