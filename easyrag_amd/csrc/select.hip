@@ -255,15 +255,21 @@ __global__ __launch_bounds__(kSelThreads) void seed_select_full_kernel(
 
 // ---- refine: tighten tau from the candidates gathered so far --------------------------------------
 // grid = B, block = 1024, dynamic LDS = cp2 * 8 bytes.
+// Launched twice: with LDS for kRefineLight entries (two workgroups per CU; the usual few thousand candidates)
+// handling the queries whose list fits, and with LDS for the full capacity handling only the others.
+constexpr int kRefineLight = 4096;
+
 __global__ __launch_bounds__(kSelThreads) void cand_refine_kernel(
     int k, int cp2, const float *__restrict__ qnorm, float xnorm_max, int d,
-    float *__restrict__ tau, ErhCand *__restrict__ cand, uint32_t *__restrict__ cand_cnt, int cap) {
+    float *__restrict__ tau, ErhCand *__restrict__ cand, uint32_t *__restrict__ cand_cnt, int cap, int lo_excl,
+    int hi_incl /* this launch handles lists with lo_excl < count <= hi_incl */) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int &s_keep = *reinterpret_cast<int *>(smem);
     uint64_t *keys = reinterpret_cast<uint64_t *>(smem + 64);
     const int q = blockIdx.x, tid = threadIdx.x;
     int c = (int)cand_cnt[q];
     if (c > cap) c = cap;
+    if (c <= lo_excl || c > hi_incl) return;               // the other launch's query (uniform)
     if (c < k) return;                                     // nothing to learn yet (uniform)
     ErhCand *mine = cand + (int64_t)q * cap;
     const int ns = erh_next_pow2(c < 2 ? 2 : c);           // sort only what is there (ns <= cp2)
@@ -572,8 +578,12 @@ hipError_t launch_seed_select(const float *S0, int ld_s0, int n0, int64_t c0, in
 hipError_t launch_cand_refine(int B, int k, const float *qnorm, float xnorm_max, int d,
                               float *tau, ErhCand *cand, uint32_t *cand_cnt, int cap, hipStream_t st) {
     const int cp2 = pow2_ge(cap);
-    hipLaunchKernelGGL(cand_refine_kernel, dim3(B), dim3(kSelThreads), (size_t)cp2 * 8 + 64, st,
-                       k, cp2, qnorm, xnorm_max, d, tau, cand, cand_cnt, cap);
+    const int light = cp2 < kRefineLight ? cp2 : kRefineLight;
+    hipLaunchKernelGGL(cand_refine_kernel, dim3(B), dim3(kSelThreads), (size_t)light * 8 + 64, st,
+                       k, light, qnorm, xnorm_max, d, tau, cand, cand_cnt, cap, -1, light);
+    if (cp2 > light)
+        hipLaunchKernelGGL(cand_refine_kernel, dim3(B), dim3(kSelThreads), (size_t)cp2 * 8 + 64, st,
+                           k, cp2, qnorm, xnorm_max, d, tau, cand, cand_cnt, cap, light, cp2);
     return hipGetLastError();
 }
 

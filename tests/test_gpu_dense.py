@@ -50,6 +50,7 @@ CASES = [
     (5000, 768, 40, 288, 512, 0),           # no refine stage
     (20000, 1024, 300, 10, 2048, 8192),     # B > one query tile
     (20000, 256, 33, 50, 256, 1024),        # three append stages: boundaries 1024 and 4096 (x4 while 8x fits)
+    (60000, 256, 9, 100, 256, 32768),       # loose seed: ~12k candidates per query reach the refinement (full-capacity launch)
     (257, 64, 1, 288, 32768, 0),            # k > N
 ]
 
