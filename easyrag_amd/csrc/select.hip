@@ -325,6 +325,7 @@ __global__ __launch_bounds__(kFinThreads) void dense_finalize_kernel(
     __shared__ double r_s64[erh::kDenseRescoreMax];
     __shared__ int32_t r_idx[erh::kDenseRescoreMax];
     __shared__ float r_s32[erh::kDenseRescoreMax];
+    __shared__ int32_t r_pos[erh::kDenseRescoreMax];                    // stored position of the candidate (row of X)
     __shared__ int s_cnt, s_m;
     __shared__ unsigned int s_maxerr;
     const int q = blockIdx.x, tid = threadIdx.x;
@@ -389,8 +390,10 @@ __global__ __launch_bounds__(kFinThreads) void dense_finalize_kernel(
     bool uncertified = false;
     if (m > erh::kDenseRescoreMax) { m = erh::kDenseRescoreMax; uncertified = true; }
     for (int i = tid; i < m; i += kFinThreads) {
-        r_idx[i] = erh_key32_idx(buf[i]);
+        const int32_t o = erh_key32_idx(buf[i]);
+        r_idx[i] = o;
         r_s32[i] = erh_key32_score(buf[i]);
+        r_pos[i] = (int32_t)erh_mulmod(o, pos_mul, N);                  // once per candidate, not once per lane and row
     }
     __syncthreads();
     // one wave per pair of candidates: lane j accumulates elements 512*t + 8*j + e (e = 0..7) sequentially in fp64,
@@ -421,7 +424,7 @@ __global__ __launch_bounds__(kFinThreads) void dense_finalize_kernel(
     do {                                                                                              \
         _Pragma("unroll") for (int r = 0; r < RW; ++r) {                                              \
             const int e_ = ((E0) + r < m) ? (E0) + r : (E0);                                          \
-            const _Float16 *xr_ = X + erh_mulmod(r_idx[e_], pos_mul, N) * d;                          \
+            const _Float16 *xr_ = X + (int64_t)r_pos[e_] * d;                                         \
             _Pragma("unroll") for (int t = 0; t < QR; ++t) {                                          \
                 const int off_ = 512 * t + 8 * lane;                                                  \
                 if (off_ < d) DST[r][t] = *reinterpret_cast<const half8 *>(xr_ + off_);               \
@@ -454,7 +457,7 @@ __global__ __launch_bounds__(kFinThreads) void dense_finalize_kernel(
 #pragma unroll
             for (int r = 0; r < RW; ++r) {
                 const int e = (e0 + r < m) ? e0 + r : e0;
-                const _Float16 *xr = X + erh_mulmod(r_idx[e], pos_mul, N) * d;
+                const _Float16 *xr = X + (int64_t)r_pos[e] * d;
                 for (int off = 512 * QR + 8 * lane; off < d; off += 512) {
                     const half8 qv = *reinterpret_cast<const half8 *>(qrow + off);
                     const half8 xv = *reinterpret_cast<const half8 *>(xr + off);
