@@ -385,10 +385,10 @@ __global__ __launch_bounds__(kBmThreads) void bm25_scan_kernel(
                 bm_sweep<ST>(hdr, acc, cs, ci, TILE, base_doc, N, fd, dir_id, tau_s, tau_idx, tid);
                 ERH_SEC(3);
                 __syncthreads();
-                const int full = hdr->total;                          // uniform: read between two barriers
-                __syncthreads();
-                ERH_SEC(4);
+                const int full = hdr->total;                          // uniform; nobody writes it again before the next sweep,
+                ERH_SEC(4);                                           // which lies behind further barriers
                 if (!full) break;
+                __syncthreads();                                      // everyone has read it before it is cleared
                 if (tid == 0) hdr->total = 0;
                 bm_shrink<ST>(hdr, cs, ci, k);                        // list was full: cut to k, threshold becomes exact
                 ERH_SEC(2);

@@ -152,7 +152,7 @@ def main():
             queries = synth.token_queries(flat, lens, vocab, 1024, seed=9)
             qi, qt = queries_to_csr(queries)
             for k in (100, 192):
-                for abl in (0, 16, 0, 16):
+                for abl in (0, 0, 0):
                     eng.set_option("bm25_ablate", abl)
                     res[f"{name} B=1024 k={k} ablate={abl} #{len(res)}"] = timed(eng, lambda: eng.bm25_topk(qi, qt, k, device_out=True), 3)
                 eng.set_option("bm25_ablate", 0)
