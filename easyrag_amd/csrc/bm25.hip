@@ -182,32 +182,43 @@ __device__ __forceinline__ void bm_sweep(BmHdr *hdr, ST *acc, ST *cs, int32_t *c
     constexpr int VEC = 16 / (int)sizeof(ST);
     typedef ST VT __attribute__((ext_vector_type(VEC)));
     typedef uint32_t UT __attribute__((ext_vector_type(4)));
-    constexpr int UNR = 2;                                                  // vectors per thread per iteration
+    constexpr int UNR = 4;                                                  // vectors per thread per iteration (8 would spill at 128 VGPRs)
     // Common case per 16-byte vector: read, OR of the words (touched?), max, one compare, predicated zero store --
     // no jump.  Only a wave that holds a possible survivor (ballot) enters the per-element path.
+    // All reads of an iteration are issued BEFORE the first store: a store to the accumulators between two reads
+    // cannot be reordered by the compiler (same array), and a read-wait-store chain per vector costs one LDS latency
+    // each -- eight per tile with sixteen waves queueing on the LDS.
     for (int i0 = tid * VEC; i0 < tile_docs; i0 += kBmThreads * VEC * UNR) {
         VT v[UNR];
-        bool cand[UNR];
+        bool cand[UNR], touched[UNR];
         bool any = false;
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
             const int i = i0 + u * kBmThreads * VEC;
+            if (i < tile_docs) v[u] = *reinterpret_cast<VT *>(acc + i);
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int i = i0 + u * kBmThreads * VEC;
             cand[u] = false;
+            touched[u] = false;
             if (i < tile_docs) {
-                v[u] = *reinterpret_cast<VT *>(acc + i);
                 const UT bits = *reinterpret_cast<const UT *>(&v[u]);
-                const bool touched = (bits[0] | bits[1] | bits[2] | bits[3]) != 0u;
+                touched[u] = (bits[0] | bits[1] | bits[2] | bits[3]) != 0u;
                 ST m = v[u][0];
 #pragma unroll
                 for (int e = 1; e < VEC; ++e) m = v[u][e] > m ? v[u][e] : m;
-                cand[u] = touched && !(m < tau_s);                          // something here may reach the top k
-                if (touched && !cand[u]) {
-                    VT z;
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) z[e] = (ST)0;
-                    *reinterpret_cast<VT *>(acc + i) = z;
-                }
+                cand[u] = touched[u] && !(m < tau_s);                       // something here may reach the top k
                 any |= cand[u];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            if (touched[u] && !cand[u]) {
+                VT z;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) z[e] = (ST)0;
+                *reinterpret_cast<VT *>(acc + i0 + u * kBmThreads * VEC) = z;
             }
         }
         if (__builtin_amdgcn_ballot_w64(any) == 0) continue;                // wave-uniform
