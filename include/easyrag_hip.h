@@ -165,7 +165,16 @@ int erh_get_kernel_time(erh_handle *h, int kernel_class, double *total_ms, int64
 int erh_get_kernel_work(erh_handle *h, int kernel_class, double *bytes, double *flops);
 int erh_reset_kernel_time(erh_handle *h);
 
-/* Tuning knobs (defaults in DESIGN.md): name/value pairs, e.g. "dense_n0", "dense_n1". */
+/* Tuning knobs: name/value pairs.  None of them changes a result (except the measurement-only ones, which say so).
+ *   dense_n0 (32768)      rows of the stored prefix scored densely to seed the pruning thresholds (max 32768)
+ *   dense_n1 (131072)     first refinement boundary; 0 = never refine.  Further boundaries follow x4 while 8x fits.
+ *   dense_n1_auto (1)     snap the boundaries to whole rounds of the persistent scan
+ *   dense_shuffle (1)     golden-ratio row placement of the chunk matrix (takes effect at the next erh_set_dense);
+ *                         0 stores the rows in the caller's order
+ *   dense_pp (1)          ping-pong persistent append scan; 0 = lock-step kernels (dense_persist 1 / 0 = persistent /
+ *                         one workgroup per tile, dense_cfg 0..2 = their tile configuration, dense_readahead)
+ *   dense_ablate, bm25_ablate, debug_counters   MEASUREMENT ONLY: variants with parts of a kernel removed / section
+ *                         clocks; results are invalid while an ablate value is non-zero */
 int erh_set_option(erh_handle *h, const char *name, int64_t value);
 
 /* After a dense / hybrid call with DEVICE outputs: synchronise `stream`, read the call's flag words and
