@@ -222,6 +222,33 @@ def test_dense_fp32_inputs_normalised_on_device(engine):
         assert len(set(qi) & set(ids[i])) >= 18
 
 
+def test_dense_device_resident_inputs_all_dtypes(engine):
+    """erh_set_dense / erh_dense_topk with DEVICE pointers: fp16 rows (placement kernel straight from the caller's
+    buffer), fp32 rows (convert + normalise from the caller's buffer) and device queries give what the host paths give."""
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(41)
+    x32 = (rng.standard_normal((4000, 128)) * 2).astype(np.float32)
+    q32 = rng.standard_normal((7, 128)).astype(np.float32)
+    dev = torch.device("cuda", 0)
+    engine.set_dense(x32, normalize=True)
+    want = engine.dense_topk(q32, 25, normalize_q=True)
+    engine.set_dense(torch.from_numpy(x32).to(dev), normalize=True)
+    got = engine.dense_topk(torch.from_numpy(q32).to(dev), 25, normalize_q=True)
+    for a, b in zip(want, got):
+        assert np.array_equal(np.asarray(a), np.asarray(b))
+    x16 = to_f16_unit(x32)
+    q16 = to_f16_unit(q32)
+    engine.set_dense(x16)
+    want = engine.dense_topk(q16, 25)
+    engine.set_dense(torch.from_numpy(x16).to(dev))
+    got = engine.dense_topk(torch.from_numpy(q16).to(dev), 25)
+    for a, b in zip(want, got):
+        assert np.array_equal(np.asarray(a), np.asarray(b))
+    for i in (0, 6):
+        oid, osc = dense_exact_topk(x16, q16[i], 25)
+        assert np.array_equal(got[0][i], oid) and np.array_equal(got[1][i].view(np.uint64), osc.view(np.uint64))
+
+
 def test_dense_errors(engine):
     x = synth.dense_corpus(100, 64, seed=1)
     engine.set_dense(x)
