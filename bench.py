@@ -55,7 +55,7 @@ def cpu_baseline(x_dev, q16_dev, idx, payload, queries, k_dense, k_sparse, topk,
         threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
     except Exception:
         threads = os.cpu_count() or 1
-    n_sample = min(n_sample, len(queries))
+    n_sample = min(n_sample, len(queries) if queries else int(q16_dev.shape[0]))
     x32 = None
     if workload in ("hybrid", "dense"):
         x32 = x_dev.cpu().numpy().astype(np.float32)            # what a Qdrant local collection would hold (fp32)
@@ -64,6 +64,7 @@ def cpu_baseline(x_dev, q16_dev, idx, payload, queries, k_dense, k_sparse, topk,
     if workload in ("hybrid", "bm25"):
         ora = BM25SLucene()
         ora.data, ora.indices, ora.indptr, ora.num_docs = payload, idx.doc_ids, idx.indptr, idx.n_docs
+    top_ids = []
     t0 = time.perf_counter()
     for b in range(n_sample):
         sp = de = None
@@ -80,13 +81,18 @@ def cpu_baseline(x_dev, q16_dev, idx, payload, queries, k_dense, k_sparse, topk,
             did, dsc = qdrant_cosine_search(x32, q32[b], k_dense, prenormalized=True)
             de = list(zip(did.tolist(), dsc.tolist()))
         if workload == "hybrid":
-            reciprocal_rank_fusion([[Item(i, i, s) for i, s in sp], [Item(i, i, s) for i, s in de]], K=60, topk=topk)
+            fused = reciprocal_rank_fusion([[Item(i, i, s) for i, s in sp], [Item(i, i, s) for i, s in de]], K=60, topk=topk)
+            top_ids.append([it.idx for it in fused])
+        elif workload == "dense":
+            top_ids.append([i for i, _ in de][:topk])
+        else:
+            top_ids.append([i for i, _ in sp][:topk])
     dt = time.perf_counter() - t0
     what = {"hybrid": "BM25(add.at over CSR, argsort, walk) + dense(np.dot fp32 1Mx1024, argsort, walk) + RRF",
             "dense": "dense(np.dot fp32, argsort, walk)", "bm25": "BM25(add.at over CSR, argsort, walk)"}[workload]
     return {"value": n_sample / dt, "unit": "queries/s", "cores": int(threads), "kind": "port",
             "sample": f"{n_sample} queries of the same batch, one at a time as the reference does; {what}; "
-                      f"{dt:.1f} s of CPU work"}
+                      f"{dt:.1f} s of CPU work"}, top_ids
 
 
 def pmc_traffic(args, kernel_class, algorithmic_bytes):
@@ -217,7 +223,18 @@ def main():
         cpu = None
         if world == 1 and args.cpu_queries > 0:
             payload = eng.get_bm25_payload() if idx is not None else None
-            cpu = cpu_baseline(x, q16, idx, payload, queries, k_dense, k_sparse, topk, args.cpu_queries, args.workload)
+            cpu, ref_ids = cpu_baseline(x, q16, idx, payload, queries, k_dense, k_sparse, topk, args.cpu_queries,
+                                        args.workload)
+            # recall@topk of the GPU result against the CPU restatement on the same sample (sets: the CPU walk
+            # orders equal scores as numpy's argsort happens to, the GPU by index)
+            got = step()
+            torch.cuda.synchronize()
+            g_ids = got[0][: len(ref_ids)].cpu().numpy()
+            hit = tot = 0
+            for b, want in enumerate(ref_ids):
+                tot += len(want)
+                hit += len(set(want) & set(int(v) for v in g_ids[b] if v >= 0))
+            cpu["recall_at_topk_vs_cpu"] = (hit / tot) if tot else None
         total_q = B * world * args.steps
         workload_name = {
             "hybrid": f"configs[3]: 1M chunks, dual-route dense(top-{k_dense})+BM25(top-{k_sparse}) with RRF top-{topk}",
