@@ -1,0 +1,71 @@
+#!/usr/bin/env python
+"""Run the three bench workloads repeatedly on the same inputs and require bit-identical outputs every time: a missing
+wait or barrier in the pipelined kernels shows up as run-to-run differences long before it shows up as a wrong answer
+in a small parity test.  Usage: python scripts/determinism.py [repeats]"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from easyrag_amd import synth                                   # noqa: E402
+from easyrag_amd.engine import RetrievalEngine, queries_to_csr  # noqa: E402
+from easyrag_amd.index import BM25S, build_bm25_index_from_postings  # noqa: E402
+
+
+def main():
+    reps = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    dev = torch.device("cuda", 0)
+    n, d, vocab = 1_000_000, 1024, 262_144
+    eng = RetrievalEngine(0)
+    x = synth.dense_corpus_torch(n, d, seed=2, device=dev)
+    eng.set_dense(x)
+    indptr, doc, tf, lens, flat = synth.token_csr_torch(n, vocab, seed=3, device=dev)
+    idx = build_bm25_index_from_postings(indptr, doc, tf, lens, BM25S, compute_payload=False)
+    eng.set_bm25(idx, payload_on_device=True)
+    eng.set_doc_meta(n, None, None)
+    bad = 0
+    for B, name in ((1024, "hybrid"), (256, "dense"), (1024, "bm25")):
+        q16 = synth.dense_queries_torch(x, B, seed=77)
+        qi, qt = queries_to_csr(synth.token_queries(flat, lens, vocab, B, seed=78))
+        ref = None
+        for r in range(reps):
+            if name == "hybrid":
+                out = eng.hybrid_topk(q16, qi, qt, k_dense=288, k_sparse=192, K=60, topk=10, device_out=True)
+            elif name == "dense":
+                out = eng.dense_topk(q16, 100, device_out=True)
+            else:
+                out = eng.bm25_topk(qi, qt, 192, device_out=True)
+            torch.cuda.synchronize()
+            if name != "bm25":
+                eng.dense_check()
+            cur = [np.asarray(t.cpu()) for t in out]
+            if ref is None:
+                ref = cur
+            elif not all(np.array_equal(a.view(np.uint8), b.view(np.uint8)) for a, b in zip(ref, cur)):
+                bad += 1
+                print(f"{name}: repeat {r} differs from repeat 0")
+        if name != "bm25":                                    # the lock-step scan kernels must give the same exact result
+            for pp, persist in ((0, 1), (0, 0)):
+                eng.set_option("dense_pp", pp)
+                eng.set_option("dense_persist", persist)
+                if name == "hybrid":
+                    out = eng.hybrid_topk(q16, qi, qt, k_dense=288, k_sparse=192, K=60, topk=10, device_out=True)
+                else:
+                    out = eng.dense_topk(q16, 100, device_out=True)
+                torch.cuda.synchronize()
+                eng.dense_check()
+                cur = [np.asarray(t.cpu()) for t in out]
+                if not all(np.array_equal(a.view(np.uint8), b.view(np.uint8)) for a, b in zip(ref, cur)):
+                    bad += 1
+                    print(f"{name}: dense_pp={pp} dense_persist={persist} differs from the ping-pong kernel")
+            eng.set_option("dense_pp", 1)
+            eng.set_option("dense_persist", 1)
+        print(f"{name}: {reps} repeats (+ both lock-step kernels), B={B}: {'identical' if not bad else 'DIFFERENCES'}")
+    eng.close()
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
