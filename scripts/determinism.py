@@ -62,7 +62,8 @@ def main():
                     print(f"{name}: dense_pp={pp} dense_persist={persist} differs from the ping-pong kernel")
             eng.set_option("dense_pp", 1)
             eng.set_option("dense_persist", 1)
-        print(f"{name}: {reps} repeats{" (+ both lock-step kernels)" if name != "bm25" else ""}, B={B}: {'identical' if not bad else 'DIFFERENCES'}")
+        extra = "" if name == "bm25" else " (+ both lock-step kernels)"
+        print(f"{name}: {reps} repeats{extra}, B={B}: {'identical' if not bad else 'DIFFERENCES'}")
     eng.close()
     sys.exit(1 if bad else 0)
 
