@@ -26,6 +26,7 @@ ERH_ERR_NOMEM = -7
 ERH_F16, ERH_F32 = 0, 1
 ERH_BM25_OKAPI, ERH_BM25_BM25S = 0, 1
 ERH_DENSE_EXACT, ERH_DENSE_FAST = 0, 1
+ERH_BM25_SLOTS = 4
 ERH_K_DENSE_SCAN, ERH_K_DENSE_SELECT, ERH_K_BM25_SCAN, ERH_K_BM25_MERGE, ERH_K_FUSE = range(5)
 
 _vp, _i32, _i64, _dbl = C.c_void_p, C.c_int, C.c_int64, C.c_double
@@ -41,6 +42,7 @@ SIGNATURES = {
     "erh_set_dense": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i32]),
     "erh_set_bm25_csr": (_i32, [_vp, _i32, _i64, _i64, _i64, _vp, _vp, _vp]),
     "erh_set_bm25_tf": (_i32, [_vp, _i32, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl]),
+    "erh_bm25_select": (_i32, [_vp, _i32]),
     "erh_get_bm25_payload": (_i32, [_vp, _vp]),
     "erh_set_doc_meta": (_i32, [_vp, _i64, _vp, _vp]),
     "erh_dense_topk": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _vp]),
@@ -48,7 +50,7 @@ SIGNATURES = {
     "erh_bm25_scores": (_i32, [_vp, _vp, _i32, _vp]),
     "erh_rrf": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp]),
     "erh_fusion": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp]),
-    "erh_hybrid_topk": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp,
+    "erh_hybrid_topk": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp,
                                _vp, _vp, _vp, _i32, _vp]),
     "erh_set_profiling": (_i32, [_vp, _i32]),
     "erh_get_kernel_time": (_i32, [_vp, _i32, C.POINTER(_dbl), C.POINTER(_i64)]),
@@ -78,10 +80,10 @@ def load(build_if_missing: bool = True):
     except Exception:  # torch is plumbing only; the library works without it
         pass
     path = lib_path()
-    if not path.exists():
-        if not build_if_missing:
-            raise FileNotFoundError(f"{path} is missing; run `python -m easyrag_amd._build`")
-        _build.build()
+    if build_if_missing:
+        _build.build()                   # idempotent (source digest stamp): edited csrc never runs as a stale .so
+    elif not path.exists():
+        raise FileNotFoundError(f"{path} is missing; run `python -m easyrag_amd._build`")
     lib = C.CDLL(str(path), mode=getattr(os, "RTLD_NOW", 2))
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError = the library does not export what the header declares

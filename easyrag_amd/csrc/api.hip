@@ -35,6 +35,16 @@ struct DevBuf {
 
 struct EvPair { hipEvent_t a, b; int cls; };
 
+struct Bm25State {
+    int variant = -1;
+    int64_t V = 0, Nb = 0, nnz = 0;
+    DevBuf indptr, doc_ids, payload, tile_off, fine_off;
+    std::vector<int64_t> host_indptr;     // host copy: query validation + algorithmic-byte accounting
+    int n_tiles = 0, tile_docs = 0;
+    int n_fine = 0;                       // sub-ranges of the fine skip table (0 = not built: block scan only)
+    void release() { indptr.release(); doc_ids.release(); payload.release(); tile_off.release(); fine_off.release(); }
+};
+
 }  // namespace
 
 struct erh_handle {
@@ -53,18 +63,18 @@ struct erh_handle {
     int opt_dense_shuffle = 1;
     DevBuf dir_pos;                         // dir id by stored position (built on demand)
     bool dir_pos_valid = false;
-    // bm25 state
-    int variant = -1;
-    int64_t V = 0, Nb = 0, nnz = 0;
-    DevBuf indptr, doc_ids, payload, tile_off;
-    std::vector<int64_t> host_indptr;     // host copy: query validation + algorithmic-byte accounting
-    int n_tiles = 0, tile_docs = 0;
+    // bm25 state: up to ERH_BM25_SLOTS independent indices (e.g. the content route and the know_path route of the
+    // reference pipeline, pipeline.py:187-210); erh_bm25_select picks the one the set / query calls act on
+    Bm25State bm[ERH_BM25_SLOTS];
+    int cur = 0;
+    int opt_bm25_wscan = 1;               // wave-owned scan when the batch qualifies (bm25.hip), else the block scan
+    int64_t opt_bm25_fine_max_mb = 8192;  // largest fine skip table built for it
     // metadata
     int64_t Nmeta = 0;
     DevBuf content_id, dir_id;
     bool has_content = false, has_dir = false;
     // work space
-    DevBuf qin, Q16, qnorm, tau, S0, cand, cand_cnt, flags, filt, seed_need;
+    DevBuf qin, Q16, qnorm, tau, S0, cand, cand_cnt, flags, filt, filt2, seed_need;
     DevBuf o_ids, o_sc, o_len;              // staging for host outputs
     DevBuf qptr, qtok, part_sc, part_ids, part_len;
     DevBuf hy_sids, hy_ssc, hy_slen, hy_dids, hy_dsc, hy_dlen;
@@ -165,9 +175,10 @@ void choose_placement(int64_t n, int64_t *mul, int64_t *inv) {
 hipError_t scan_append(erh_handle *h, const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1, const _Float16 *Q16,
                        int Bpad, int B, const float *tau, const int16_t *filt, const int16_t *dir, ErhCand *cand,
                        uint32_t *cnt, int cap, uint32_t *flags, hipStream_t st) {
-    if (h->opt_dense_pp && (h->opt_dense_ablate == 0 || (h->opt_dense_ablate >= 7 && h->opt_dense_ablate <= 15 && h->opt_dense_ablate != 10 && h->opt_dense_ablate != 9))) {
+    if (h->opt_dense_pp && (h->opt_dense_ablate == 0 || h->opt_dense_ablate == 20 || (h->opt_dense_ablate >= 7 && h->opt_dense_ablate <= 15 && h->opt_dense_ablate != 10 && h->opt_dense_ablate != 9))) {
         hipError_t e = erh::launch_dense_scan_pp(X, N, d, c0, c1, Q16, Bpad, B, tau, filt, dir, cand, cnt, cap, flags,
-                                                 h->n_cus, h->opt_dense_ablate, st);
+                                                 h->n_cus, h->opt_dense_ablate,
+                                                 h->opt_debug_counters ? h->dbg.as<unsigned long long>() : nullptr, st);
         if (e != hipErrorInvalidValue) return e;
         (void)hipGetLastError();
     }
@@ -302,28 +313,36 @@ int dense_check_flags(erh_handle *h, hipStream_t st) {
 
 int bm25_topk_dev(erh_handle *h, const int32_t *qptr_dev, const int32_t *qtok_dev, int B, int k,
                   const int16_t *filter_dev, int32_t *d_ids, double *d_sc, int32_t *d_len, double postings_bytes,
-                  hipStream_t st) {
+                  int max_qlen, hipStream_t st) {
+    Bm25State &S = h->bm[h->cur];
     const int16_t *dir = h->has_dir ? h->dir_id.as<int16_t>() : nullptr;
     int segs = (512 + B - 1) / B;
-    segs = std::max(1, std::min(segs, h->n_tiles));
+    segs = std::max(1, std::min(segs, S.n_tiles));
     while (segs > 1 && (int64_t)segs * k > 8192) --segs;
+    // wave-owned scan (no per-token workgroup barrier) when the index has its fine skip table and lane j can own
+    // token j of every query; otherwise the block scan.  Both produce the same lists.
+    const bool wscan = h->opt_bm25_wscan && S.n_fine > 0 && max_qlen <= erh::bm25_wscan_max_tokens() &&
+                       h->opt_bm25_ablate == 0;
+    unsigned long long *dbg = h->opt_debug_counters ? h->dbg.as<unsigned long long>() : nullptr;
+    auto scan = [&](double *p_sc, int32_t *p_ids, int32_t *p_len) -> hipError_t {
+        if (wscan)
+            return erh::launch_bm25_wscan(S.variant, S.indptr.as<int64_t>(), S.doc_ids.as<int32_t>(), S.payload.p,
+                                          S.fine_off.as<int32_t>(), S.n_fine, S.n_tiles, S.Nb, qptr_dev, qtok_dev, B, k,
+                                          segs, filter_dev, dir, p_sc, p_ids, p_len, dbg, st);
+        return erh::launch_bm25_scan(S.variant, S.indptr.as<int64_t>(), S.doc_ids.as<int32_t>(), S.payload.p,
+                                     S.tile_off.as<int32_t>(), S.n_tiles, S.Nb, qptr_dev, qtok_dev, B, k, segs,
+                                     filter_dev, dir, p_sc, p_ids, p_len, h->opt_bm25_ablate, dbg, st);
+    };
     if (segs == 1) {
         ProfScope ps(h, st, ERH_K_BM25_SCAN, postings_bytes, 0);
-        HIPCHK(h, erh::launch_bm25_scan(h->variant, h->indptr.as<int64_t>(), h->doc_ids.as<int32_t>(), h->payload.p,
-                                        h->tile_off.as<int32_t>(), h->n_tiles, h->Nb, qptr_dev, qtok_dev, B, k, 1,
-                                        filter_dev, dir, d_sc, d_ids, d_len, h->opt_bm25_ablate,
-                                        h->opt_debug_counters ? h->dbg.as<unsigned long long>() : nullptr, st));
+        HIPCHK(h, scan(d_sc, d_ids, d_len));
         return ERH_OK;
     }
     HIPCHK(h, h->part_sc.ensure((size_t)B * segs * k * 8));
     HIPCHK(h, h->part_ids.ensure((size_t)B * segs * k * 4));
     HIPCHK(h, h->part_len.ensure((size_t)B * segs * 4));
     { ProfScope ps(h, st, ERH_K_BM25_SCAN, postings_bytes, 0);
-      HIPCHK(h, erh::launch_bm25_scan(h->variant, h->indptr.as<int64_t>(), h->doc_ids.as<int32_t>(), h->payload.p,
-                                      h->tile_off.as<int32_t>(), h->n_tiles, h->Nb, qptr_dev, qtok_dev, B, k, segs,
-                                      filter_dev, dir, h->part_sc.as<double>(), h->part_ids.as<int32_t>(),
-                                      h->part_len.as<int32_t>(), h->opt_bm25_ablate,
-                                      h->opt_debug_counters ? h->dbg.as<unsigned long long>() : nullptr, st)); }
+      HIPCHK(h, scan(h->part_sc.as<double>(), h->part_ids.as<int32_t>(), h->part_len.as<int32_t>())); }
     { ProfScope ps(h, st, ERH_K_BM25_MERGE, 0, 0);
       HIPCHK(h, erh::launch_bm25_merge(B, k, segs, h->part_sc.as<double>(), h->part_ids.as<int32_t>(),
                                        h->part_len.as<int32_t>(), d_ids, d_sc, d_len, st)); }
@@ -332,16 +351,20 @@ int bm25_topk_dev(erh_handle *h, const int32_t *qptr_dev, const int32_t *qtok_de
 
 // Upload the query CSR; returns the algorithmic posting bytes of the batch in *bytes (0 if an id is bad -> error).
 int upload_bm25_queries(erh_handle *h, const int32_t *q_indptr, const int32_t *q_tok, int B, hipStream_t st,
-                        const std::vector<int64_t> &host_indptr, double *bytes) {
+                        const std::vector<int64_t> &host_indptr, double *bytes, int *max_qlen) {
     if (q_indptr[0] != 0) return h->fail(ERH_ERR_INVALID, "q_indptr[0] must be 0");
-    for (int b = 0; b < B; ++b)
+    int longest = 0;
+    for (int b = 0; b < B; ++b) {
         if (q_indptr[b + 1] < q_indptr[b]) return h->fail(ERH_ERR_INVALID, "q_indptr must be non-decreasing");
+        longest = std::max(longest, q_indptr[b + 1] - q_indptr[b]);
+    }
+    *max_qlen = longest;
     const int nt = q_indptr[B];
-    const size_t per = (h->variant == ERH_BM25_OKAPI) ? 12 : 8;
+    const size_t per = (h->bm[h->cur].variant == ERH_BM25_OKAPI) ? 12 : 8;
     double total = 0;
     for (int i = 0; i < nt; ++i) {
         const int32_t t = q_tok[i];
-        if (t < 0 || t >= h->V) return h->fail(ERH_ERR_INVALID, "query term id out of range");
+        if (t < 0 || t >= h->bm[h->cur].V) return h->fail(ERH_ERR_INVALID, "query term id out of range");
         total += (double)(host_indptr[t + 1] - host_indptr[t]) * per;
     }
     *bytes = total;
@@ -356,7 +379,7 @@ int upload_bm25_queries(erh_handle *h, const int32_t *q_indptr, const int32_t *q
 
 extern "C" {
 
-int erh_version(void) { return 100; }
+int erh_version(void) { return 200; }
 
 const char *erh_status_str(int s) {
     switch (s) {
@@ -400,13 +423,14 @@ int erh_destroy(erh_handle *h) {
     (void)hipDeviceSynchronize();
     drain_events(h);
     for (auto &ev : h->pool) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
-    DevBuf *bufs[] = {&h->X, &h->indptr, &h->doc_ids, &h->payload, &h->tile_off, &h->content_id, &h->dir_id,
-                      &h->qin, &h->Q16, &h->qnorm, &h->tau, &h->S0, &h->cand, &h->cand_cnt, &h->flags, &h->filt,
+    DevBuf *bufs[] = {&h->X, &h->content_id, &h->dir_id,
+                      &h->qin, &h->Q16, &h->qnorm, &h->tau, &h->S0, &h->cand, &h->cand_cnt, &h->flags, &h->filt, &h->filt2,
                       &h->o_ids, &h->o_sc, &h->o_len, &h->qptr, &h->qtok, &h->part_sc, &h->part_ids, &h->part_len,
                       &h->hy_sids, &h->hy_ssc, &h->hy_slen, &h->hy_dids, &h->hy_dsc, &h->hy_dlen,
                       &h->fa_ids, &h->fa_sc, &h->fa_len, &h->fb_ids, &h->fb_sc, &h->fb_len,
                       &h->scores_tmp, &h->scores_wide, &h->dbg, &h->dir_pos, &h->seed_need};
     for (DevBuf *b : bufs) b->release();
+    for (auto &b : h->bm) b.release();
     delete h;
     return ERH_OK;
 }
@@ -432,6 +456,8 @@ int erh_set_option(erh_handle *h, const char *name, int64_t value) {
     if (!strcmp(name, "dense_persist")) { h->opt_dense_persist = value != 0; return ERH_OK; }
     if (!strcmp(name, "dense_ablate")) { h->opt_dense_ablate = (int)value; return ERH_OK; }
     if (!strcmp(name, "bm25_ablate")) { h->opt_bm25_ablate = (int)value; return ERH_OK; }
+    if (!strcmp(name, "bm25_wscan")) { h->opt_bm25_wscan = value != 0; return ERH_OK; }   // the fine table is built at the next erh_set_bm25_*
+    if (!strcmp(name, "bm25_fine_max_mb")) { if (value < 0) return h->fail(ERH_ERR_INVALID, "bm25_fine_max_mb < 0"); h->opt_bm25_fine_max_mb = value; return ERH_OK; }
     if (!strcmp(name, "debug_counters")) {
         h->opt_debug_counters = value != 0;
         if (value) {
@@ -573,20 +599,36 @@ static int bm25_common_upload(erh_handle *h, int variant, int64_t V, int64_t N, 
     }
     HIPCHK(h, hipSetDevice(h->device));
     hipStream_t st = nullptr;
-    HIPCHK(h, h->indptr.ensure((size_t)(V + 1) * 8));
-    HIPCHK(h, h->doc_ids.ensure((size_t)std::max<int64_t>(nnz, 1) * 4));
-    HIPCHK(h, hipMemcpyAsync(h->indptr.p, indptr, (size_t)(V + 1) * 8, hipMemcpyHostToDevice, st));
-    if (nnz) HIPCHK(h, hipMemcpyAsync(h->doc_ids.p, doc_ids, (size_t)nnz * 4, hipMemcpyHostToDevice, st));
-    h->tile_docs = (variant == ERH_BM25_OKAPI) ? erh::kBm25TileF64 : erh::kBm25TileF32;
-    h->n_tiles = (int)((N + h->tile_docs - 1) / h->tile_docs);
-    HIPCHK(h, h->tile_off.ensure((size_t)V * (h->n_tiles + 1) * 4));
-    HIPCHK(h, erh::launch_bm25_tile_off(h->indptr.as<int64_t>(), h->doc_ids.as<int32_t>(), V, h->tile_docs, h->n_tiles,
-                                        h->tile_off.as<int32_t>(), st));
-    h->host_indptr.assign(indptr, indptr + V + 1);
-    h->variant = variant;
-    h->V = V;
-    h->Nb = N;
-    h->nnz = nnz;
+    HIPCHK(h, h->bm[h->cur].indptr.ensure((size_t)(V + 1) * 8));
+    HIPCHK(h, h->bm[h->cur].doc_ids.ensure((size_t)std::max<int64_t>(nnz, 1) * 4));
+    HIPCHK(h, hipMemcpyAsync(h->bm[h->cur].indptr.p, indptr, (size_t)(V + 1) * 8, hipMemcpyHostToDevice, st));
+    if (nnz) HIPCHK(h, hipMemcpyAsync(h->bm[h->cur].doc_ids.p, doc_ids, (size_t)nnz * 4, hipMemcpyHostToDevice, st));
+    h->bm[h->cur].tile_docs = (variant == ERH_BM25_OKAPI) ? erh::kBm25TileF64 : erh::kBm25TileF32;
+    h->bm[h->cur].n_tiles = (int)((N + h->bm[h->cur].tile_docs - 1) / h->bm[h->cur].tile_docs);
+    HIPCHK(h, h->bm[h->cur].tile_off.ensure((size_t)V * (h->bm[h->cur].n_tiles + 1) * 4));
+    HIPCHK(h, erh::launch_bm25_tile_off(h->bm[h->cur].indptr.as<int64_t>(), h->bm[h->cur].doc_ids.as<int32_t>(), V, h->bm[h->cur].tile_docs, h->bm[h->cur].n_tiles,
+                                        h->bm[h->cur].tile_off.as<int32_t>(), st));
+    // fine skip table of the wave-owned scan: one int per (term, sub-range of tile_docs / 16 documents)
+    {
+        Bm25State &S = h->bm[h->cur];
+        S.n_fine = 0;
+        const int sub = erh::bm25_wscan_sub_docs(variant);
+        const int64_t nf = (N + sub - 1) / sub;
+        const double mb = (double)V * (double)(nf + 1) * 4.0 / (1024.0 * 1024.0);
+        if (h->opt_bm25_wscan && nf < (1 << 30) && mb <= (double)h->opt_bm25_fine_max_mb) {
+            HIPCHK(h, S.fine_off.ensure((size_t)V * (size_t)(nf + 1) * 4));
+            HIPCHK(h, erh::launch_bm25_tile_off(S.indptr.as<int64_t>(), S.doc_ids.as<int32_t>(), V, sub, (int)nf,
+                                                S.fine_off.as<int32_t>(), st));
+            S.n_fine = (int)nf;
+        } else {
+            S.fine_off.release();
+        }
+    }
+    h->bm[h->cur].host_indptr.assign(indptr, indptr + V + 1);
+    h->bm[h->cur].variant = variant;
+    h->bm[h->cur].V = V;
+    h->bm[h->cur].Nb = N;
+    h->bm[h->cur].nnz = nnz;
     return ERH_OK;
 }
 
@@ -594,12 +636,12 @@ int erh_set_bm25_csr(erh_handle *h, int variant, int64_t V, int64_t N, int64_t n
                      const int64_t *indptr, const int32_t *doc_ids, const void *payload) {
     if (!h) return ERH_ERR_INVALID;
     if (nnz > 0 && !payload) return h->fail(ERH_ERR_INVALID, "bm25 csr: null payload");
-    h->variant = -1;
+    h->bm[h->cur].variant = -1;
     int rc = bm25_common_upload(h, variant, V, N, nnz, indptr, doc_ids);
-    if (rc != ERH_OK) { h->variant = -1; return rc; }
+    if (rc != ERH_OK) { h->bm[h->cur].variant = -1; return rc; }
     const size_t es = (variant == ERH_BM25_OKAPI) ? 8 : 4;
-    HIPCHK(h, h->payload.ensure((size_t)std::max<int64_t>(nnz, 1) * es));
-    if (nnz) HIPCHK(h, hipMemcpyAsync(h->payload.p, payload, (size_t)nnz * es, hipMemcpyHostToDevice, nullptr));
+    HIPCHK(h, h->bm[h->cur].payload.ensure((size_t)std::max<int64_t>(nnz, 1) * es));
+    if (nnz) HIPCHK(h, hipMemcpyAsync(h->bm[h->cur].payload.p, payload, (size_t)nnz * es, hipMemcpyHostToDevice, nullptr));
     HIPCHK(h, hipStreamSynchronize(nullptr));
     return ERH_OK;
 }
@@ -609,12 +651,12 @@ int erh_set_bm25_tf(erh_handle *h, int variant, int64_t V, int64_t N, int64_t nn
                     const int32_t *doc_len, const void *idf, double avgdl, double k1, double b) {
     if (!h) return ERH_ERR_INVALID;
     if (!tf || !doc_len || !idf || !(avgdl > 0)) return h->fail(ERH_ERR_INVALID, "bm25 tf: null input or avgdl <= 0");
-    h->variant = -1;
+    h->bm[h->cur].variant = -1;
     int rc = bm25_common_upload(h, variant, V, N, nnz, indptr, doc_ids);
-    if (rc != ERH_OK) { h->variant = -1; return rc; }
+    if (rc != ERH_OK) { h->bm[h->cur].variant = -1; return rc; }
     const size_t es = (variant == ERH_BM25_OKAPI) ? 8 : 4;
     hipStream_t st = nullptr;
-    HIPCHK(h, h->payload.ensure((size_t)std::max<int64_t>(nnz, 1) * es));
+    HIPCHK(h, h->bm[h->cur].payload.ensure((size_t)std::max<int64_t>(nnz, 1) * es));
     DevBuf d_tf, d_dl, d_idf;
     auto cleanup = [&]() { d_tf.release(); d_dl.release(); d_idf.release(); };
     hipError_t e = d_tf.ensure((size_t)std::max<int64_t>(nnz, 1) * 4);
@@ -624,20 +666,27 @@ int erh_set_bm25_tf(erh_handle *h, int variant, int64_t V, int64_t N, int64_t nn
     if (e == hipSuccess) e = hipMemcpyAsync(d_dl.p, doc_len, (size_t)N * 4, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(d_idf.p, idf, (size_t)V * es, hipMemcpyHostToDevice, st);
     if (e == hipSuccess)
-        e = erh::launch_bm25_payload(variant, V, nnz, h->indptr.as<int64_t>(), h->doc_ids.as<int32_t>(), d_tf.as<int32_t>(),
-                                     d_dl.as<int32_t>(), d_idf.p, avgdl, k1, b, h->payload.p, st);
+        e = erh::launch_bm25_payload(variant, V, nnz, h->bm[h->cur].indptr.as<int64_t>(), h->bm[h->cur].doc_ids.as<int32_t>(), d_tf.as<int32_t>(),
+                                     d_dl.as<int32_t>(), d_idf.p, avgdl, k1, b, h->bm[h->cur].payload.p, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     cleanup();
-    if (e != hipSuccess) { h->variant = -1; return h->fail(ERH_ERR_HIP, "erh_set_bm25_tf", e); }
+    if (e != hipSuccess) { h->bm[h->cur].variant = -1; return h->fail(ERH_ERR_HIP, "erh_set_bm25_tf", e); }
+    return ERH_OK;
+}
+
+int erh_bm25_select(erh_handle *h, int slot) {
+    if (!h) return ERH_ERR_INVALID;
+    if (slot < 0 || slot >= ERH_BM25_SLOTS) return h->fail(ERH_ERR_INVALID, "erh_bm25_select: slot out of range");
+    h->cur = slot;
     return ERH_OK;
 }
 
 int erh_get_bm25_payload(erh_handle *h, void *out_payload) {
     if (!h || !out_payload) return ERH_ERR_INVALID;
-    if (h->variant < 0) return h->fail(ERH_ERR_STATE, "bm25 index not set");
+    if (h->bm[h->cur].variant < 0) return h->fail(ERH_ERR_STATE, "bm25 index not set");
     HIPCHK(h, hipSetDevice(h->device));
-    const size_t es = (h->variant == ERH_BM25_OKAPI) ? 8 : 4;
-    if (h->nnz) HIPCHK(h, hipMemcpy(out_payload, h->payload.p, (size_t)h->nnz * es, hipMemcpyDeviceToHost));
+    const size_t es = (h->bm[h->cur].variant == ERH_BM25_OKAPI) ? 8 : 4;
+    if (h->bm[h->cur].nnz) HIPCHK(h, hipMemcpy(out_payload, h->bm[h->cur].payload.p, (size_t)h->bm[h->cur].nnz * es, hipMemcpyDeviceToHost));
     return ERH_OK;
 }
 
@@ -664,16 +713,18 @@ int erh_set_doc_meta(erh_handle *h, int64_t N, const int32_t *content_id, const 
 
 // ---- queries ---------------------------------------------------------------------------------------
 
-static int stage_filter(erh_handle *h, const int16_t *filter_dir, int B, int64_t n_docs, hipStream_t st, const int16_t **dev) {
+static int stage_filter(erh_handle *h, const int16_t *filter_dir, int B, int64_t n_docs, hipStream_t st, const int16_t **dev,
+                        DevBuf *buf = nullptr) {
+    if (!buf) buf = &h->filt;
     *dev = nullptr;
     if (!filter_dir) return ERH_OK;
     bool any = false;
     for (int b = 0; b < B; ++b) any = any || filter_dir[b] >= 0;
     if (!any) return ERH_OK;
     if (!h->has_dir || h->Nmeta < n_docs) return h->fail(ERH_ERR_STATE, "filter given but erh_set_doc_meta(dir_id) not set for all documents");
-    HIPCHK(h, h->filt.ensure((size_t)B * 2));
-    HIPCHK(h, hipMemcpyAsync(h->filt.p, filter_dir, (size_t)B * 2, hipMemcpyHostToDevice, st));
-    *dev = h->filt.as<int16_t>();
+    HIPCHK(h, buf->ensure((size_t)B * 2));
+    HIPCHK(h, hipMemcpyAsync(buf->p, filter_dir, (size_t)B * 2, hipMemcpyHostToDevice, st));
+    *dev = buf->as<int16_t>();
     return ERH_OK;
 }
 
@@ -733,17 +784,18 @@ int erh_bm25_topk(erh_handle *h, const int32_t *q_indptr, const int32_t *q_tok, 
                   const int16_t *filter_dir,
                   int32_t *out_ids, double *out_scores, int32_t *out_len, int out_is_device, void *stream) {
     if (!h) return ERH_ERR_INVALID;
-    if (h->variant < 0) return h->fail(ERH_ERR_STATE, "erh_bm25_topk before erh_set_bm25_*");
+    if (h->bm[h->cur].variant < 0) return h->fail(ERH_ERR_STATE, "erh_bm25_topk before erh_set_bm25_*");
     if (!q_indptr || !out_ids || !out_scores || !out_len || B <= 0 || k <= 0) return h->fail(ERH_ERR_INVALID, "erh_bm25_topk: null pointer or non-positive B/k");
     if (q_indptr[B] > 0 && !q_tok) return h->fail(ERH_ERR_INVALID, "erh_bm25_topk: null q_tok");
     if (k > 1024) return h->fail(ERH_ERR_UNSUPPORTED, "erh_bm25_topk: k > 1024");
     HIPCHK(h, hipSetDevice(h->device));
     hipStream_t st = (hipStream_t)stream;
     const int16_t *filt = nullptr;
-    int rc = stage_filter(h, filter_dir, B, h->Nb, st, &filt);
+    int rc = stage_filter(h, filter_dir, B, h->bm[h->cur].Nb, st, &filt);
     if (rc != ERH_OK) return rc;
     double bytes = 0;
-    rc = upload_bm25_queries(h, q_indptr, q_tok, B, st, h->host_indptr, &bytes);
+    int max_qlen = 0;
+    rc = upload_bm25_queries(h, q_indptr, q_tok, B, st, h->bm[h->cur].host_indptr, &bytes, &max_qlen);
     if (rc != ERH_OK) return rc;
     int32_t *d_ids = out_ids; double *d_sc = out_scores; int32_t *d_len = out_len;
     if (!out_is_device) {
@@ -752,7 +804,7 @@ int erh_bm25_topk(erh_handle *h, const int32_t *q_indptr, const int32_t *q_tok, 
         HIPCHK(h, h->o_len.ensure((size_t)B * 4));
         d_ids = h->o_ids.as<int32_t>(); d_sc = h->o_sc.as<double>(); d_len = h->o_len.as<int32_t>();
     }
-    rc = bm25_topk_dev(h, h->qptr.as<int32_t>(), h->qtok.as<int32_t>(), B, k, filt, d_ids, d_sc, d_len, bytes, st);
+    rc = bm25_topk_dev(h, h->qptr.as<int32_t>(), h->qtok.as<int32_t>(), B, k, filt, d_ids, d_sc, d_len, bytes, max_qlen, st);
     if (rc != ERH_OK) return rc;
     if (!out_is_device) return copy_out(h, B, k, d_ids, d_sc, d_len, out_ids, out_scores, out_len, st);
     return ERH_OK;
@@ -760,25 +812,25 @@ int erh_bm25_topk(erh_handle *h, const int32_t *q_indptr, const int32_t *q_tok, 
 
 int erh_bm25_scores(erh_handle *h, const int32_t *q_tok, int n_tok, double *out_scores) {
     if (!h) return ERH_ERR_INVALID;
-    if (h->variant < 0) return h->fail(ERH_ERR_STATE, "erh_bm25_scores before erh_set_bm25_*");
+    if (h->bm[h->cur].variant < 0) return h->fail(ERH_ERR_STATE, "erh_bm25_scores before erh_set_bm25_*");
     if (!out_scores || n_tok < 0 || (n_tok > 0 && !q_tok)) return h->fail(ERH_ERR_INVALID, "erh_bm25_scores: null pointer");
     for (int i = 0; i < n_tok; ++i)
-        if (q_tok[i] < 0 || q_tok[i] >= h->V) return h->fail(ERH_ERR_INVALID, "erh_bm25_scores: term id out of range");
+        if (q_tok[i] < 0 || q_tok[i] >= h->bm[h->cur].V) return h->fail(ERH_ERR_INVALID, "erh_bm25_scores: term id out of range");
     HIPCHK(h, hipSetDevice(h->device));
     hipStream_t st = nullptr;
-    const size_t es = (h->variant == ERH_BM25_OKAPI) ? 8 : 4;
-    HIPCHK(h, h->scores_tmp.ensure((size_t)h->Nb * es));
-    HIPCHK(h, hipMemsetAsync(h->scores_tmp.p, 0, (size_t)h->Nb * es, st));
+    const size_t es = (h->bm[h->cur].variant == ERH_BM25_OKAPI) ? 8 : 4;
+    HIPCHK(h, h->scores_tmp.ensure((size_t)h->bm[h->cur].Nb * es));
+    HIPCHK(h, hipMemsetAsync(h->scores_tmp.p, 0, (size_t)h->bm[h->cur].Nb * es, st));
     for (int i = 0; i < n_tok; ++i)
-        HIPCHK(h, erh::launch_bm25_add_term(h->variant, h->indptr.as<int64_t>(), h->doc_ids.as<int32_t>(), h->payload.p,
+        HIPCHK(h, erh::launch_bm25_add_term(h->bm[h->cur].variant, h->bm[h->cur].indptr.as<int64_t>(), h->bm[h->cur].doc_ids.as<int32_t>(), h->bm[h->cur].payload.p,
                                             q_tok[i], h->scores_tmp.p, st));
     const double *src = h->scores_tmp.as<double>();
-    if (h->variant == ERH_BM25_BM25S) {
-        HIPCHK(h, h->scores_wide.ensure((size_t)h->Nb * 8));
-        HIPCHK(h, erh::launch_widen_f32(h->scores_tmp.as<float>(), h->Nb, h->scores_wide.as<double>(), st));
+    if (h->bm[h->cur].variant == ERH_BM25_BM25S) {
+        HIPCHK(h, h->scores_wide.ensure((size_t)h->bm[h->cur].Nb * 8));
+        HIPCHK(h, erh::launch_widen_f32(h->scores_tmp.as<float>(), h->bm[h->cur].Nb, h->scores_wide.as<double>(), st));
         src = h->scores_wide.as<double>();
     }
-    HIPCHK(h, hipMemcpyAsync(out_scores, src, (size_t)h->Nb * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipMemcpyAsync(out_scores, src, (size_t)h->bm[h->cur].Nb * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(h, hipStreamSynchronize(st));
     return ERH_OK;
 }
@@ -842,12 +894,13 @@ int erh_fusion(erh_handle *h, const int32_t *ids_a, const double *scores_a, cons
 
 int erh_hybrid_topk(erh_handle *h, const void *q, int q_dtype, int q_is_device, int normalize_q,
                     const int32_t *q_indptr, const int32_t *q_tok, int B,
-                    int k_dense, int k_sparse, int K, int topk, const int16_t *filter_dir,
+                    int k_dense, int k_sparse, int K, int topk, const int16_t *filter_sparse,
+                    const int16_t *filter_dense,
                     int32_t *out_ids, double *out_scores, int32_t *out_len, int out_is_device, void *stream) {
     if (!h) return ERH_ERR_INVALID;
     if (!h->X.p || h->N <= 0) return h->fail(ERH_ERR_STATE, "erh_hybrid_topk before erh_set_dense");
-    if (h->variant < 0) return h->fail(ERH_ERR_STATE, "erh_hybrid_topk before erh_set_bm25_*");
-    if (h->Nb != h->N) return h->fail(ERH_ERR_STATE, "erh_hybrid_topk: dense and bm25 corpora differ in size");
+    if (h->bm[h->cur].variant < 0) return h->fail(ERH_ERR_STATE, "erh_hybrid_topk before erh_set_bm25_*");
+    if (h->bm[h->cur].Nb != h->N) return h->fail(ERH_ERR_STATE, "erh_hybrid_topk: dense and bm25 corpora differ in size");
     if (!q || !q_indptr || !out_ids || !out_scores || !out_len || B <= 0 || k_dense <= 0 || k_sparse <= 0 || topk <= 0 || K < 0)
         return h->fail(ERH_ERR_INVALID, "erh_hybrid_topk: null pointer or non-positive size");
     if (q_dtype != ERH_F16 && q_dtype != ERH_F32) return h->fail(ERH_ERR_INVALID, "erh_hybrid_topk: q_dtype");
@@ -856,11 +909,20 @@ int erh_hybrid_topk(erh_handle *h, const void *q, int q_dtype, int q_is_device, 
     if (q_indptr[B] > 0 && !q_tok) return h->fail(ERH_ERR_INVALID, "erh_hybrid_topk: null q_tok");
     HIPCHK(h, hipSetDevice(h->device));
     hipStream_t st = (hipStream_t)stream;
-    const int16_t *filt = nullptr;
-    int rc = stage_filter(h, filter_dir, B, h->N, st, &filt);
+    // the two routes are filtered independently, as the reference does (filter_dict -> sparse, filters -> dense;
+    // retrievers.py:278,283); equal pointers / equal contents share one staged column
+    const int16_t *filt = nullptr, *filt_d = nullptr;
+    int rc = stage_filter(h, filter_sparse, B, h->N, st, &filt);
     if (rc != ERH_OK) return rc;
+    if (filter_dense == filter_sparse || (filter_dense && filter_sparse && !memcmp(filter_dense, filter_sparse, (size_t)B * 2))) {
+        filt_d = filt;
+    } else {
+        rc = stage_filter(h, filter_dense, B, h->N, st, &filt_d, &h->filt2);
+        if (rc != ERH_OK) return rc;
+    }
     double bytes = 0;
-    rc = upload_bm25_queries(h, q_indptr, q_tok, B, st, h->host_indptr, &bytes);
+    int max_qlen = 0;
+    rc = upload_bm25_queries(h, q_indptr, q_tok, B, st, h->bm[h->cur].host_indptr, &bytes, &max_qlen);
     if (rc != ERH_OK) return rc;
     const void *qd = nullptr;
     rc = stage_query_block(h, q, q_dtype, q_is_device, B, st, &qd);
@@ -873,9 +935,9 @@ int erh_hybrid_topk(erh_handle *h, const void *q, int q_dtype, int q_is_device, 
     HIPCHK(h, h->hy_dlen.ensure((size_t)B * 4));
     // sparse route (list a), dense route (list b), fusion -- all on the caller's stream, no host round trip
     rc = bm25_topk_dev(h, h->qptr.as<int32_t>(), h->qtok.as<int32_t>(), B, k_sparse, filt, h->hy_sids.as<int32_t>(),
-                       h->hy_ssc.as<double>(), h->hy_slen.as<int32_t>(), bytes, st);
+                       h->hy_ssc.as<double>(), h->hy_slen.as<int32_t>(), bytes, max_qlen, st);
     if (rc != ERH_OK) return rc;
-    rc = dense_topk_dev(h, qd, q_dtype, normalize_q, B, k_dense, filt, ERH_DENSE_EXACT, h->hy_dids.as<int32_t>(),
+    rc = dense_topk_dev(h, qd, q_dtype, normalize_q, B, k_dense, filt_d, ERH_DENSE_EXACT, h->hy_dids.as<int32_t>(),
                         h->hy_dsc.as<double>(), h->hy_dlen.as<int32_t>(), st);
     if (rc != ERH_OK) return rc;
     int32_t *d_ids = out_ids; double *d_sc = out_scores; int32_t *d_len = out_len;

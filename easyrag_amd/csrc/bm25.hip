@@ -103,7 +103,10 @@ struct BmHdr {
     int tau_idx;    // running k-th best: index part
     int pad;
     double tau_s;   // running k-th best: score part (0 => "score > 0" is the only condition)
+    int full[3];    // wave-owned scan: "list was full during sweep pass p" (p mod 3), see bm25_wscan_kernel
+    int want[3];    // wave-owned scan: "list grew past k + 512 during sweep pass p"
 };
+static_assert(sizeof(BmHdr) <= 64, "BmHdr must fit the 64-byte LDS header");
 
 template <typename ST>
 struct BmPre {
@@ -175,10 +178,14 @@ __device__ __forceinline__ void bm_shrink(BmHdr *hdr, ST *cs, int32_t *ci, int k
 // accumulator and hdr->total is raised: the caller shrinks the list (which tightens the threshold) and sweeps the
 // leftovers again.  The common case after the first tiles is "touched but nowhere near the threshold": one max,
 // one compare and one zero store per 16-byte vector.
+// The pass covers accumulators [i_begin, i_end) with `nthr` threads (ltid = this thread's rank among them): the whole
+// tile with the 1024 threads of the block scan, or one wave's own sub-range in the wave-owned scan.  *full_flag is
+// raised when the list is full; *want_flag (may be null) when it has grown past want_at entries.
 template <typename ST>
-__device__ __forceinline__ void bm_sweep(BmHdr *hdr, ST *acc, ST *cs, int32_t *ci, int tile_docs, int64_t base_doc,
-                                         int64_t N, int fd, const int16_t *__restrict__ dir_id, ST tau_s, int tau_idx,
-                                         int tid) {
+__device__ __forceinline__ void bm_sweep(BmHdr *hdr, ST *acc, ST *cs, int32_t *ci, int i_begin, int i_end, int nthr,
+                                         int ltid, int64_t base_doc, int64_t N, int fd,
+                                         const int16_t *__restrict__ dir_id, ST tau_s, int tau_idx, int *full_flag,
+                                         int *want_flag, int want_at) {
     constexpr int VEC = 16 / (int)sizeof(ST);
     typedef ST VT __attribute__((ext_vector_type(VEC)));
     typedef uint32_t UT __attribute__((ext_vector_type(4)));
@@ -188,21 +195,21 @@ __device__ __forceinline__ void bm_sweep(BmHdr *hdr, ST *acc, ST *cs, int32_t *c
     // All reads of an iteration are issued BEFORE the first store: a store to the accumulators between two reads
     // cannot be reordered by the compiler (same array), and a read-wait-store chain per vector costs one LDS latency
     // each -- eight per tile with sixteen waves queueing on the LDS.
-    for (int i0 = tid * VEC; i0 < tile_docs; i0 += kBmThreads * VEC * UNR) {
+    for (int i0 = i_begin + ltid * VEC; i0 < i_end; i0 += nthr * VEC * UNR) {
         VT v[UNR];
         bool cand[UNR], touched[UNR];
         bool any = false;
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
-            const int i = i0 + u * kBmThreads * VEC;
-            if (i < tile_docs) v[u] = *reinterpret_cast<VT *>(acc + i);
+            const int i = i0 + u * nthr * VEC;
+            if (i < i_end) v[u] = *reinterpret_cast<VT *>(acc + i);
         }
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
-            const int i = i0 + u * kBmThreads * VEC;
+            const int i = i0 + u * nthr * VEC;
             cand[u] = false;
             touched[u] = false;
-            if (i < tile_docs) {
+            if (i < i_end) {
                 const UT bits = *reinterpret_cast<const UT *>(&v[u]);
                 touched[u] = (bits[0] | bits[1] | bits[2] | bits[3]) != 0u;
                 ST m = v[u][0];
@@ -218,14 +225,14 @@ __device__ __forceinline__ void bm_sweep(BmHdr *hdr, ST *acc, ST *cs, int32_t *c
                 VT z;
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) z[e] = (ST)0;
-                *reinterpret_cast<VT *>(acc + i0 + u * kBmThreads * VEC) = z;
+                *reinterpret_cast<VT *>(acc + i0 + u * nthr * VEC) = z;
             }
         }
         if (__builtin_amdgcn_ballot_w64(any) == 0) continue;                // wave-uniform
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
             if (!cand[u]) continue;
-            const int i = i0 + u * kBmThreads * VEC;
+            const int i = i0 + u * nthr * VEC;
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
                 const ST sv = v[u][e];
@@ -239,8 +246,9 @@ __device__ __forceinline__ void bm_sweep(BmHdr *hdr, ST *acc, ST *cs, int32_t *c
                             cs[pos] = sv;
                             ci[pos] = (int32_t)doc;
                             v[u][e] = (ST)0;
+                            if (want_flag && pos >= want_at) *want_flag = 1;
                         } else {
-                            hdr->total = 1;                                 // list full: keep it for the next sweep
+                            *full_flag = 1;                                 // list full: keep it for the next sweep
                         }
                     } else {
                         v[u][e] = (ST)0;
@@ -393,7 +401,8 @@ __global__ __launch_bounds__(kBmThreads) void bm25_scan_kernel(
             for (;;) {
                 const ST tau_s = (ST)hdr->tau_s;
                 const int tau_idx = hdr->tau_idx;
-                bm_sweep<ST>(hdr, acc, cs, ci, TILE, base_doc, N, fd, dir_id, tau_s, tau_idx, tid);
+                bm_sweep<ST>(hdr, acc, cs, ci, 0, TILE, kBmThreads, tid, base_doc, N, fd, dir_id, tau_s, tau_idx,
+                             &hdr->total, nullptr, 0);
                 ERH_SEC(3);
                 __syncthreads();
                 const int full = hdr->total;                          // uniform; nobody writes it again before the next sweep,
@@ -418,6 +427,221 @@ __global__ __launch_bounds__(kBmThreads) void bm25_scan_kernel(
     }
     if (tid == 0) part_len[(int64_t)q * segs + seg] = n;
     ERH_SEC(6);
+    if (dbg && tid == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) atomicAdd(&dbg[i], (unsigned long long)t_sec[i]);
+    }
+#undef ERH_SEC
+}
+
+// ---- wave-owned scan (default for queries of up to kWsMaxTok tokens) ------------------------------------------------
+// Same tiles, accumulators, candidate list and results as bm25_scan_kernel; what changes is who applies a posting.
+// The tile is cut into 16 sub-ranges of TILE/16 documents and wave w owns sub-range w: it applies EVERY query token,
+// in query order, to its own documents only.  A document lives in exactly one sub-range and the LDS operations of one
+// wave execute in program order, so "token j before token j+1" holds per document without any workgroup barrier --
+// the token loop of the block scan (one exposed load latency plus one 16-wave barrier per (token, tile) step for
+// ~490 postings) becomes 16 independent streams whose latencies overlap each other.  A wave then sweeps its own
+// sub-range (nobody else wrote it) and meets the other waves once per tile, at the candidate-list bookkeeping.
+//   - posting ranges per (term, sub-range) come from a fine skip table fine_off[term][sub] (one int per term and
+//     sub-range, built once per index like tile_off); lane j holds the range of query token j for the current tile
+//     and fetches the next tile's while this one is processed;
+//   - a wave-uniform cursor walks the (token, 64-posting piece) sequence of the sub-range -- empty ranges cost
+//     nothing, a frequent term simply takes several pieces (postings of one term hit distinct documents, so their
+//     order is free) -- and fills 16 (fp32) / 8 (fp64) register slots per step: all requests of a step are issued before the
+//     first posting is applied, and the first step of the NEXT tile is requested before this tile is swept, so its
+//     latency hides behind the sweep and the bookkeeping barrier;
+//   - list-full / list-long decisions are taken once per sweep pass from flag words that rotate through three
+//     slots: pass p raises slot p % 3, every thread reads it after the barrier that ends pass p, thread 0 clears slot
+//     (p + 1) % 3 during pass p.  Waves are never more than one pass apart, so nobody reads a word while it changes.
+template <typename ST> constexpr int ws_slots() { return sizeof(ST) == 4 ? 16 : 8; }   // 64-posting pieces in flight per step (128-VGPR budget)
+constexpr int kWsMaxTok = 64;       // lane j owns token j
+constexpr int kWsWaves = kBmThreads / 64;
+
+template <typename ST>
+struct WsSet {
+    static constexpr int SLOTS = ws_slots<ST>();
+    int32_t d[SLOTS];               // document index or -1
+    ST v[SLOTS];
+    int used;                       // wave-uniform: slots filled
+};
+
+struct WsCursor {                   // wave-uniform
+    int j, off, nj;                 // token, postings of it already taken, its postings in this sub-range
+    int64_t loj;                    // its first posting
+};
+
+// Fill the slots from the cursor.  lo_lane / n_lane: lane j holds the posting range of token j (this sub-range, one tile).
+template <typename ST>
+__device__ __forceinline__ void ws_fill(WsSet<ST> &S, WsCursor &c, const int32_t *__restrict__ doc_ids,
+                                        const ST *__restrict__ payload, int64_t lo_lane, int n_lane, int nq, int lane) {
+    const int lo_l = (int)(uint32_t)lo_lane, lo_h = (int)(uint32_t)((uint64_t)lo_lane >> 32);
+    int used = 0;
+#pragma unroll
+    for (int u = 0; u < WsSet<ST>::SLOTS; ++u) {
+        while (c.j < nq && c.off >= c.nj) {                               // next token that has postings left
+            ++c.j;
+            c.off = 0;
+            c.nj = 0;
+            if (c.j < nq) {
+                c.nj = __builtin_amdgcn_readlane(n_lane, c.j);
+                c.loj = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(lo_h, c.j) << 32) |
+                                  (uint64_t)(uint32_t)__builtin_amdgcn_readlane(lo_l, c.j));
+            }
+        }
+        S.d[u] = -1;
+        S.v[u] = (ST)0;
+        if (c.j < nq) {                                                   // wave-uniform
+            const int at = c.off + lane;
+            if (at < c.nj) {
+                S.d[u] = doc_ids[c.loj + at];
+                S.v[u] = payload[c.loj + at];
+            }
+            c.off += 64;
+            used = u + 1;
+        }
+    }
+    S.used = used;
+}
+
+template <typename ST>
+__device__ __forceinline__ void ws_apply(const WsSet<ST> &S, ST *acc, int64_t base_doc) {
+#pragma unroll
+    for (int u = 0; u < WsSet<ST>::SLOTS; ++u) {
+        if (u < S.used && S.d[u] >= 0) {
+            const int slot = (int)((int64_t)S.d[u] - base_doc);
+            acc[slot] = acc[slot] + S.v[u];
+        }
+    }
+}
+
+// grid = (segs, B), block = 1024; every query of the batch has at most kWsMaxTok tokens (the host checks).
+template <typename ST>
+__global__ __launch_bounds__(kBmThreads) void bm25_wscan_kernel(
+    const int64_t *__restrict__ indptr, const int32_t *__restrict__ doc_ids, const ST *__restrict__ payload,
+    const int32_t *__restrict__ fine_off, int n_fine, int n_tiles, int64_t N,
+    const int32_t *__restrict__ q_indptr, const int32_t *__restrict__ q_tok, int k, int segs,
+    const int16_t *__restrict__ filter_dir, const int16_t *__restrict__ dir_id,
+    double *__restrict__ part_scores, int32_t *__restrict__ part_ids, int32_t *__restrict__ part_len,
+    unsigned long long *__restrict__ dbg /* measurement only: section clock sums of thread 0, or null */) {
+    using L = BmLds<ST>;
+    constexpr int TILE = L::TILE, SUB = TILE / kWsWaves;
+    static_assert(SUB % (64 * 16 / (int)sizeof(ST)) == 0, "a wave sweeps its sub-range in whole 16-byte rounds");
+    long long t_sec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long t_mark = dbg ? clock64() : 0;
+#define ERH_SEC(I) do { if (dbg) { const long long n_ = clock64(); t_sec[I] += n_ - t_mark; t_mark = n_; } } while (0)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    BmHdr *hdr = reinterpret_cast<BmHdr *>(smem);
+    ST *acc = reinterpret_cast<ST *>(smem + L::OFF_ACC);
+    ST *cs = reinterpret_cast<ST *>(smem + L::OFF_CS);
+    int32_t *ci = reinterpret_cast<int32_t *>(smem + L::OFF_CI);
+
+    const int seg = blockIdx.x, q = blockIdx.y, tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qs = q_indptr[q];
+    int nq = q_indptr[q + 1] - qs;
+    if (nq > kWsMaxTok) nq = kWsMaxTok;                                   // (never: the host routes longer queries to the block scan)
+    const int fd = filter_dir ? (int)filter_dir[q] : -1;
+    const int t_begin = (int)((int64_t)n_tiles * seg / segs);
+    const int t_end = (int)((int64_t)n_tiles * (seg + 1) / segs);
+    const int64_t out_base = ((int64_t)q * segs + seg) * k;
+
+    if (tid == 0) {
+        hdr->ncand = 0; hdr->total = 0; hdr->tau_idx = -1; hdr->tau_s = 0.0;
+        hdr->full[0] = hdr->full[1] = hdr->full[2] = 0;
+        hdr->want[0] = hdr->want[1] = hdr->want[2] = 0;
+    }
+    for (int i = tid; i < TILE; i += kBmThreads) acc[i] = (ST)0;
+    __syncthreads();
+
+    if (nq > 0 && t_begin < t_end) {
+        // lane j: query token j -- posting base and its row of the fine skip table
+        const bool has = lane < nq;
+        int64_t ip = 0;
+        const int32_t *fo = fine_off;
+        if (has) {
+            const int64_t tok = q_tok[qs + lane];
+            ip = indptr[tok];
+            fo = fine_off + tok * (int64_t)(n_fine + 1);
+        }
+        auto bounds = [&](int tile, int64_t &lo, int &n) {
+            int s0 = tile * kWsWaves + wave;
+            s0 = s0 < n_fine ? s0 : n_fine;
+            const int s1 = s0 < n_fine ? s0 + 1 : n_fine;
+            const int a = has ? fo[s0] : 0, b = has ? fo[s1] : 0;
+            lo = ip + a;
+            n = b - a;
+        };
+        int64_t lo_cur, lo_nxt = 0;
+        int n_cur, n_nxt = 0;
+        bounds(t_begin, lo_cur, n_cur);
+        WsSet<ST> S;
+        WsCursor cur;
+        cur.j = -1; cur.off = 0; cur.nj = 0; cur.loj = 0;
+        ws_fill<ST>(S, cur, doc_ids, payload, lo_cur, n_cur, nq, lane);
+        int ph = 0;                                                       // sweep pass counter (workgroup-uniform)
+        for (int tile = t_begin; tile < t_end; ++tile) {
+            const int64_t base_doc = (int64_t)tile * TILE;
+            const bool more = tile + 1 < t_end;
+            if (more) bounds(tile + 1, lo_nxt, n_nxt);                    // lands while this tile is processed
+            ERH_SEC(0);
+            // ---- all tokens, in order, onto this wave's documents ------------------------------------------------
+            for (;;) {
+                ws_apply<ST>(S, acc, base_doc);
+                if (cur.j >= nq) break;                                   // the sub-range's postings are exhausted
+                ws_fill<ST>(S, cur, doc_ids, payload, lo_cur, n_cur, nq, lane);
+            }
+            if (more) {                                                   // first step of the next tile: flies during the sweep
+                cur.j = -1; cur.off = 0; cur.nj = 0;
+                ws_fill<ST>(S, cur, doc_ids, payload, lo_nxt, n_nxt, nq, lane);
+            }
+            ERH_SEC(1);
+            // ---- first tile: seed the threshold from the per-thread maxima (see bm25_scan_kernel) --------------------
+            if (tile == t_begin && k <= kBmThreads && fd < 0) {
+                constexpr int VEC = 16 / (int)sizeof(ST);
+                typedef ST VT __attribute__((ext_vector_type(VEC)));
+                ST mx = (ST)0;
+                for (int i = wave * SUB + lane * VEC; i < (wave + 1) * SUB; i += 64 * VEC) {
+                    const VT v = *reinterpret_cast<const VT *>(acc + i);   // this wave's own sums: complete
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) mx = v[e] > mx ? v[e] : mx;
+                }
+                cs[tid] = mx;
+                erh_bitonic_desc<ST>(cs, kBmThreads);
+                const ST p = cs[k - 1];
+                __syncthreads();
+                if (tid == 0 && p > (ST)0) { hdr->tau_s = (double)p; hdr->tau_idx = 0x7fffffff; }
+                __syncthreads();
+            }
+            // ---- sweep the own sub-range; once per pass the workgroup decides about the candidate list -------------
+            for (;;) {
+                const int slot = ph % 3;
+                if (tid == 0) { hdr->full[(ph + 1) % 3] = 0; hdr->want[(ph + 1) % 3] = 0; }
+                const ST tau_s = (ST)hdr->tau_s;
+                const int tau_idx = hdr->tau_idx;
+                bm_sweep<ST>(hdr, acc, cs, ci, wave * SUB, (wave + 1) * SUB, 64, lane, base_doc, N, fd, dir_id, tau_s,
+                             tau_idx, &hdr->full[slot], &hdr->want[slot], k + kBmThreads / 2);
+                ERH_SEC(2);
+                __syncthreads();                                          // every sub-range swept
+                ERH_SEC(3);
+                const int full = hdr->full[slot], want = hdr->want[slot];
+                ++ph;
+                if (full || want) bm_shrink<ST>(hdr, cs, ci, k);          // uniform; cut to k, threshold becomes exact
+                ERH_SEC(4);
+                if (!full) break;                                         // (full: survivors were left behind -- sweep again)
+            }
+            lo_cur = lo_nxt;
+            n_cur = n_nxt;
+        }
+    }
+    bm_shrink<ST>(hdr, cs, ci, k);
+    const int n = hdr->ncand < k ? hdr->ncand : k;
+    for (int i = tid; i < k; i += kBmThreads) {
+        if (i < n) { part_scores[out_base + i] = (double)cs[i]; part_ids[out_base + i] = ci[i]; }
+        else { part_scores[out_base + i] = 0.0; part_ids[out_base + i] = -1; }
+    }
+    if (tid == 0) part_len[(int64_t)q * segs + seg] = n;
+    ERH_SEC(5);
     if (dbg && tid == 0) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) atomicAdd(&dbg[i], (unsigned long long)t_sec[i]);
@@ -487,6 +711,12 @@ hipError_t bm25_init() {
     e = hipFuncSetAttribute((const void *)bm25_scan_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)BmLds<double>::BYTES);
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void *)bm25_wscan_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)BmLds<float>::OFF_LO);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void *)bm25_wscan_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)BmLds<double>::OFF_LO);
+    if (e != hipSuccess) return e;
     return hipFuncSetAttribute((const void *)bm25_merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                8192 * 12 + 64);
 }
@@ -530,6 +760,28 @@ hipError_t launch_bm25_scan(int variant, const int64_t *indptr, const int32_t *d
         hipLaunchKernelGGL(bm25_scan_kernel<float>, grid, block, BmLds<float>::BYTES, st, indptr, doc_ids,
                            (const float *)payload, tile_off, n_tiles, N, q_indptr, q_tok, k, segs, filter_dir, dir_id,
                            part_scores, part_ids, part_len, ablate, dbg);
+    return hipGetLastError();
+}
+
+int bm25_wscan_max_tokens() { return kWsMaxTok; }
+int bm25_wscan_sub_docs(int variant) { return (variant == 0 ? kBm25TileF64 : kBm25TileF32) / kWsWaves; }
+
+hipError_t launch_bm25_wscan(int variant, const int64_t *indptr, const int32_t *doc_ids, const void *payload,
+                             const int32_t *fine_off, int n_fine, int n_tiles, int64_t N,
+                             const int32_t *q_indptr, const int32_t *q_tok, int B, int k, int segs,
+                             const int16_t *filter_dir, const int16_t *dir_id,
+                             double *part_scores, int32_t *part_ids, int32_t *part_len,
+                             unsigned long long *dbg, hipStream_t st) {
+    if (B <= 0) return hipSuccess;
+    dim3 grid(segs, B), block(kBmThreads);
+    if (variant == 0)
+        hipLaunchKernelGGL(bm25_wscan_kernel<double>, grid, block, BmLds<double>::OFF_LO, st, indptr, doc_ids,
+                           (const double *)payload, fine_off, n_fine, n_tiles, N, q_indptr, q_tok, k, segs, filter_dir,
+                           dir_id, part_scores, part_ids, part_len, dbg);
+    else
+        hipLaunchKernelGGL(bm25_wscan_kernel<float>, grid, block, BmLds<float>::OFF_LO, st, indptr, doc_ids,
+                           (const float *)payload, fine_off, n_fine, n_tiles, N, q_indptr, q_tok, k, segs, filter_dir,
+                           dir_id, part_scores, part_ids, part_len, dbg);
     return hipGetLastError();
 }
 

@@ -696,11 +696,17 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp_kernel(
     const _Float16 *__restrict__ X, int64_t N, int d, int64_t c0, int64_t c1,
     const _Float16 *__restrict__ Q, int Bpad, int B,
     const float *__restrict__ tau, const int16_t *__restrict__ filter_dir, const int16_t *__restrict__ dir_id,
-    ErhCand *__restrict__ cand, uint32_t *__restrict__ cand_cnt, int cap, uint32_t *__restrict__ overflow) {
+    ErhCand *__restrict__ cand, uint32_t *__restrict__ cand_cnt, int cap, uint32_t *__restrict__ overflow,
+    unsigned long long *__restrict__ dbg /* PABL == 20 only: phase clock sums of waves 0 and 4 */) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int grp = wave >> 2, wave_n = wave & 3;
+    // PABL 20 (measurement): shader-clock sums per phase kind -- 0 matrix segment, 1 counted wait, 2 barrier,
+    // 3 memory segment, 4 epilogue, 5 epilogue barrier
+    long long tph[6] = {0, 0, 0, 0, 0, 0};
+    long long t_mark = (PABL == 20) ? clock64() : 0;
+#define ERH_PH(I) do { if (PABL == 20) { const long long n_ = clock64(); tph[I] += n_ - t_mark; t_mark = n_; } } while (0)
     const int nk = d / pp::BK;
 
     const int n_qt = Bpad / pp::BN;
@@ -934,27 +940,45 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp_kernel(
         for (int i = 0; i < n_tiles; ++i) {
             for (int kt = 0; kt < nk; ++kt, ++g) {
                 ERH_PP_COMPUTE();
+                ERH_PH(0);
                 ERH_PP_WAIT();
+                ERH_PH(1);
                 ERH_PP_BARRIER();                                      // barrier g
+                ERH_PH(2);
                 ERH_PP_MEM();                                          // M(g)
+                ERH_PH(3);
             }
             ERH_PP_EPILOGUE();
+            ERH_PH(4);
             ERH_PP_BARRIER();
+            ERH_PH(5);
             if (PABL != 7 && PABL < 11) flush_now = __builtin_amdgcn_readfirstlane(flag[i & 1]);
         }
     } else {
         for (int i = 0; i < n_tiles; ++i) {
             for (int kt = 0; kt < nk; ++kt, ++g) {
                 ERH_PP_MEM();                                          // M(g-1)
+                ERH_PH(3);
                 ERH_PP_WAIT();
+                ERH_PH(1);
                 ERH_PP_BARRIER();                                      // barrier g
+                ERH_PH(2);
                 ERH_PP_COMPUTE();
+                ERH_PH(0);
             }
             ERH_PP_EPILOGUE();
+            ERH_PH(4);
             ERH_PP_BARRIER();
+            ERH_PH(5);
             if (PABL != 7 && PABL < 11) flush_now = __builtin_amdgcn_readfirstlane(flag[i & 1]);
         }
     }
+    if (PABL == 20 && dbg && lane == 0 && (wave == 0 || wave == 4)) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) atomicAdd(&dbg[grp * 8 + i], (unsigned long long)tph[i]);
+        atomicAdd(&dbg[grp * 8 + 6], (unsigned long long)total);
+    }
+#undef ERH_PH
 #undef ERH_PP_ISSUE_A
 #undef ERH_PP_ISSUE_B
 #undef ERH_PP_MEM
@@ -1069,7 +1093,8 @@ hipError_t launch_append(const _Float16 *X, int64_t N, int d, int64_t c0, int64_
 
 hipError_t launch_pp(const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1, const _Float16 *Q, int Bpad, int B,
                      const float *tau, const int16_t *filter_dir, const int16_t *dir_id, ErhCand *cand,
-                     uint32_t *cand_cnt, int cap, uint32_t *overflow, int ctas, int pabl, hipStream_t st) {
+                     uint32_t *cand_cnt, int cap, uint32_t *overflow, int ctas, int pabl, unsigned long long *dbg,
+                     hipStream_t st) {
     const int n_qt = Bpad / pp::BN;
     const int grid_n = ctas / (8 * n_qt) * (8 * n_qt);
     if (grid_n <= 0) return hipErrorInvalidValue;
@@ -1078,8 +1103,9 @@ hipError_t launch_pp(const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1
     dim3 grid((unsigned)grid_n), block(pp::NT);
 #define ERH_LAUNCH_PP(A)                                                                                   \
     hipLaunchKernelGGL((dense_scan_pp_kernel<A>), grid, block, pp::LDS_BYTES, st, X, N, d, c0, c1, Q, Bpad, B, tau, \
-                       filter_dir, dir_id, cand, cand_cnt, cap, overflow)
+                       filter_dir, dir_id, cand, cand_cnt, cap, overflow, dbg)
     switch (pabl) {
+        case 20: ERH_LAUNCH_PP(20); break;
         case 7: ERH_LAUNCH_PP(7); break;
         case 8: ERH_LAUNCH_PP(8); break;
         case 11: ERH_LAUNCH_PP(11); break;
@@ -1112,7 +1138,7 @@ hipError_t dense_scan_init() {
                             pp::LDS_BYTES);                                                                \
     if (e != hipSuccess) return e;
     ERH_SET_PP(0) ERH_SET_PP(7) ERH_SET_PP(8) ERH_SET_PP(11) ERH_SET_PP(12) ERH_SET_PP(13) ERH_SET_PP(14)
-    ERH_SET_PP(15)
+    ERH_SET_PP(15) ERH_SET_PP(20)
 #undef ERH_SET_PP
     return hipSuccess;
 }
@@ -1122,10 +1148,11 @@ hipError_t dense_scan_init() {
 hipError_t launch_dense_scan_pp(const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1, const _Float16 *Q,
                                 int Bpad, int B, const float *tau, const int16_t *filter_dir, const int16_t *dir_id,
                                 ErhCand *cand, uint32_t *cand_cnt, int cap, uint32_t *overflow, int n_cus, int pabl,
-                                hipStream_t st) {
+                                unsigned long long *dbg, hipStream_t st) {
     if (c1 <= c0) return hipSuccess;
     if (d % (2 * pp::BK) != 0 || d / pp::BK < 8) return hipErrorInvalidValue;   // stage pairs never straddle a tile
-    return launch_pp(X, N, d, c0, c1, Q, Bpad, B, tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow, n_cus, pabl, st);
+    return launch_pp(X, N, d, c0, c1, Q, Bpad, B, tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow, n_cus, pabl,
+                     dbg, st);
 }
 
 hipError_t launch_dense_scan_store(int cfg, const _Float16 *Q, int Bpad, const _Float16 *X, int64_t N, int d,

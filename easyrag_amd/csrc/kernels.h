@@ -19,7 +19,7 @@ hipError_t launch_dense_scan_append(int cfg, const _Float16 *X, int64_t N, int d
 hipError_t launch_dense_scan_pp(const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1, const _Float16 *Q,
                                 int Bpad, int B, const float *tau, const int16_t *filter_dir, const int16_t *dir_id,
                                 ErhCand *cand, uint32_t *cand_cnt, int cap, uint32_t *overflow, int n_cus, int pabl,
-                                hipStream_t st);
+                                unsigned long long *dbg, hipStream_t st);
 hipError_t launch_dense_scan_persist(int cfg, const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1,
                                      const _Float16 *Q, int Bpad, int B, const float *tau,
                                      const int16_t *filter_dir, const int16_t *dir_id,
@@ -80,6 +80,15 @@ hipError_t launch_bm25_scan(int variant, const int64_t *indptr, const int32_t *d
                             const int16_t *filter_dir, const int16_t *dir_id,
                             double *part_scores, int32_t *part_ids, int32_t *part_len, int ablate,
                             unsigned long long *dbg, hipStream_t st);
+// wave-owned scan (bm25.hip: bm25_wscan_kernel): fine_off = skip table at bm25_wscan_sub_docs() granularity
+int bm25_wscan_max_tokens();
+int bm25_wscan_sub_docs(int variant);
+hipError_t launch_bm25_wscan(int variant, const int64_t *indptr, const int32_t *doc_ids, const void *payload,
+                             const int32_t *fine_off, int n_fine, int n_tiles, int64_t N,
+                             const int32_t *q_indptr, const int32_t *q_tok, int B, int k, int segs,
+                             const int16_t *filter_dir, const int16_t *dir_id,
+                             double *part_scores, int32_t *part_ids, int32_t *part_len,
+                             unsigned long long *dbg, hipStream_t st);
 hipError_t launch_bm25_merge(int B, int k, int segs, const double *part_scores, const int32_t *part_ids,
                              const int32_t *part_len, int32_t *out_ids, double *out_scores, int32_t *out_len,
                              hipStream_t st);

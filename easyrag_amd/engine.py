@@ -55,8 +55,15 @@ class RetrievalEngine:
         self.device = int(device)
         self.n_dense = 0
         self.d = 0
-        self.bm25: Optional[BM25Index] = None
+        self._bm25_slots: List[Optional[BM25Index]] = [None] * _lib.ERH_BM25_SLOTS
+        self._bm25_cur = 0
         self.n_meta = 0
+        self.corpus = None                   # retrievers.py keeps its per-engine node bookkeeping here
+
+    @property
+    def bm25(self) -> Optional[BM25Index]:
+        """The BM25 index of the selected slot."""
+        return self._bm25_slots[self._bm25_cur]
 
     # -- lifetime ---------------------------------------------------------------------------
     def close(self):
@@ -103,8 +110,29 @@ class RetrievalEngine:
         self._check(self._lib.erh_set_dense(self._h, _ptr(x), n, d, dt, is_dev, 1 if normalize else 0))
         self.n_dense, self.d = int(n), int(d)
 
-    def set_bm25(self, index: BM25Index, payload_on_device: bool = False):
-        """Upload CSR postings.  payload_on_device=True lets the GPU evaluate IDF*TF/(TF+k1*lenNorm)."""
+    # A handle holds ERH_BM25_SLOTS independent BM25 indices (content route + know_path route of the reference
+    # pipeline share one engine); every BM25 call names its slot, default 0.
+    def alloc_bm25_slot(self) -> int:
+        for i, v in enumerate(self._bm25_slots):
+            if v is None:
+                return i
+        raise RuntimeError(f"all {_lib.ERH_BM25_SLOTS} BM25 index slots of this engine are in use")
+
+    def free_bm25_slot(self, slot: int):
+        self._bm25_slots[slot] = None
+
+    def _select(self, slot: Optional[int]) -> int:
+        slot = self._bm25_cur if slot is None else int(slot)
+        if not 0 <= slot < _lib.ERH_BM25_SLOTS:
+            raise ValueError("BM25 slot out of range")
+        if slot != self._bm25_cur:
+            self._check(self._lib.erh_bm25_select(self._h, slot))
+            self._bm25_cur = slot
+        return slot
+
+    def set_bm25(self, index: BM25Index, payload_on_device: bool = False, slot: Optional[int] = None):
+        """Upload CSR postings into `slot`.  payload_on_device=True lets the GPU evaluate IDF*TF/(TF+k1*lenNorm)."""
+        slot = self._select(slot)
         indptr = _np(index.indptr, np.int64)
         doc_ids = _np(index.doc_ids, np.int32)
         if payload_on_device:
@@ -121,9 +149,10 @@ class RetrievalEngine:
             rc = self._lib.erh_set_bm25_csr(self._h, index.variant, index.n_vocab, index.n_docs, index.nnz,
                                             _ptr(indptr), _ptr(doc_ids), _ptr(pay))
         self._check(rc)
-        self.bm25 = index
+        self._bm25_slots[slot] = index
 
-    def get_bm25_payload(self) -> np.ndarray:
+    def get_bm25_payload(self, slot: Optional[int] = None) -> np.ndarray:
+        self._select(slot)
         assert self.bm25 is not None
         out = np.empty(self.bm25.nnz, np.float64 if self.bm25.variant == OKAPI else np.float32)
         self._check(self._lib.erh_get_bm25_payload(self._h, _ptr(out)))
@@ -132,28 +161,35 @@ class RetrievalEngine:
     def set_doc_meta(self, n_docs: int, content_id=None, dir_id=None):
         cid = None if content_id is None else _np(content_id, np.int32)
         did = None if dir_id is None else _np(dir_id, np.int16)
+        for name, a in (("content_id", cid), ("dir_id", did)):
+            if a is not None and a.shape != (int(n_docs),):
+                raise ValueError(f"{name} must have one entry per document ({n_docs}), got shape {a.shape}")
         self._check(self._lib.erh_set_doc_meta(self._h, int(n_docs), _ptr(cid), _ptr(did)))
         self.n_meta = int(n_docs)
 
     # -- helpers ------------------------------------------------------------------------------
-    @staticmethod
-    def _q_desc(q):
+    def _q_desc(self, q):
+        """(array, dtype code, is_device, B); the C ABI takes no query dimension, so the shape is checked here."""
         if _is_torch(q):
             import torch
             q = q.contiguous()
             dt = {torch.float16: _lib.ERH_F16, torch.float32: _lib.ERH_F32}.get(q.dtype)
             if dt is None:
                 raise TypeError("queries must be float16 or float32")
-            return q, dt, (1 if q.is_cuda else 0), int(q.shape[0])
-        q = np.ascontiguousarray(q)
-        if q.ndim == 1:
-            q = q[None, :]
-        if q.dtype == np.float16:
-            dt = _lib.ERH_F16
+            is_dev = 1 if q.is_cuda else 0
         else:
-            q = np.ascontiguousarray(q, dtype=np.float32)
-            dt = _lib.ERH_F32
-        return q, dt, 0, int(q.shape[0])
+            q = np.ascontiguousarray(q)
+            if q.ndim == 1:
+                q = q[None, :]
+            if q.dtype == np.float16:
+                dt = _lib.ERH_F16
+            else:
+                q = np.ascontiguousarray(q, dtype=np.float32)
+                dt = _lib.ERH_F32
+            is_dev = 0
+        if q.ndim != 2 or int(q.shape[1]) != self.d:
+            raise ValueError(f"queries must be [B, {self.d}] (the chunk matrix's dimension), got {tuple(q.shape)}")
+        return q, dt, is_dev, int(q.shape[0])
 
     @staticmethod
     def _filter(filter_dir, B):
@@ -193,7 +229,9 @@ class RetrievalEngine:
                                              1 if device_out else 0, self._stream(stream)))
         return ids, sc, ln
 
-    def bm25_topk(self, q_indptr, q_tok, k: int, filter_dir=None, device_out: bool = False, stream=None):
+    def bm25_topk(self, q_indptr, q_tok, k: int, filter_dir=None, device_out: bool = False, stream=None,
+                  slot: Optional[int] = None):
+        self._select(slot)
         q_indptr = _np(q_indptr, np.int32)
         q_tok = _np(q_tok, np.int32)
         B = q_indptr.shape[0] - 1
@@ -204,16 +242,24 @@ class RetrievalEngine:
                                             self._stream(stream)))
         return ids, sc, ln
 
-    def bm25_scores(self, q_tok) -> np.ndarray:
+    def bm25_scores(self, q_tok, slot: Optional[int] = None) -> np.ndarray:
+        self._select(slot)
         assert self.bm25 is not None
         q_tok = _np(q_tok, np.int32)
         out = np.empty(self.bm25.n_docs, np.float64)
         self._check(self._lib.erh_bm25_scores(self._h, _ptr(q_tok), int(q_tok.shape[0]), _ptr(out)))
         return out
 
+    def _check_ids(self, *arrays):
+        """Fusion kernels index content_id[id]: ids must be -1 (padding) or a document of the uploaded metadata."""
+        for a in arrays:
+            if a.size and (int(a.max()) >= self.n_meta or int(a.min()) < -1):
+                raise ValueError(f"fusion ids must lie in [-1, {self.n_meta}) (erh_set_doc_meta size)")
+
     def rrf(self, ids_a, len_a, ids_b, len_b, K: int = 60, topk: int = 256):
         ids_a = _np(ids_a, np.int32)
         ids_b = _np(ids_b, np.int32)
+        self._check_ids(ids_a, ids_b)
         B = ids_a.shape[0]
         la = None if len_a is None else _np(len_a, np.int32)
         lb = None if len_b is None else _np(len_b, np.int32)
@@ -227,6 +273,7 @@ class RetrievalEngine:
         ids_b = _np(ids_b, np.int32)
         sc_a = _np(sc_a, np.float64)
         sc_b = _np(sc_b, np.float64)
+        self._check_ids(ids_a, ids_b)
         B = ids_a.shape[0]
         la = None if len_a is None else _np(len_a, np.int32)
         lb = None if len_b is None else _np(len_b, np.int32)
@@ -237,17 +284,22 @@ class RetrievalEngine:
         return ids, sc, ln
 
     def hybrid_topk(self, q, q_indptr, q_tok, k_dense: int = 288, k_sparse: int = 192, K: int = 60, topk: int = 256,
-                    filter_dir=None, normalize_q: bool = False, device_out: bool = False, stream=None):
+                    filter_dir=None, normalize_q: bool = False, device_out: bool = False, stream=None,
+                    slot: Optional[int] = None, filter_dense="same"):
+        """filter_dir restricts the sparse route; the dense route uses filter_dense (default: the same column) --
+        the reference keeps the two knobs apart (filter_dict -> BM25, filters -> Qdrant; retrievers.py:278,283)."""
+        self._select(slot)
         q, dt, is_dev, B = self._q_desc(q)
         q_indptr = _np(q_indptr, np.int32)
         q_tok = _np(q_tok, np.int32)
         if q_indptr.shape[0] - 1 != B:
             raise ValueError("dense and sparse query batches differ in size")
         f = self._filter(filter_dir, B)
+        fdn = f if isinstance(filter_dense, str) else self._filter(filter_dense, B)
         ids, sc, ln = self._outs(B, topk, device_out)
         self._check(self._lib.erh_hybrid_topk(self._h, _ptr(q), dt, is_dev, 1 if normalize_q else 0,
                                               _ptr(q_indptr), _ptr(q_tok), B, int(k_dense), int(k_sparse), int(K),
-                                              int(topk), _ptr(f), _ptr(ids), _ptr(sc), _ptr(ln),
+                                              int(topk), _ptr(f), _ptr(fdn), _ptr(ids), _ptr(sc), _ptr(ln),
                                               1 if device_out else 0, self._stream(stream)))
         return ids, sc, ln
 

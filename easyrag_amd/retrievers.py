@@ -14,7 +14,14 @@ What differs, deliberately: nodes are addressed by their integer position in the
 HipVectorStore (the fp16 chunk matrix resident in HBM); equal scores are ordered by node index
 (numpy's argsort()[::-1] tie order is implementation-defined); and every retriever also offers a
 batched entry point (retrieve_batch) because the GPU path is built for batches.  Scores, cut-offs,
-filters, fusion keys and list order follow the reference.
+filters, fusion keys and list order follow the reference -- including HybridRetriever's two faces:
+`aretrieve` (what the pipeline calls) selects the route and fuses with RRF, `retrieve` is the reference's
+unmaintained sync path (sparse + dense concatenated, de-duplicated by node_id, no fusion, no filter push-down).
+
+Engine sharing: retrievers built over the same node list may share one RetrievalEngine (one GPU replica of
+the corpus): the vector store holds the chunk matrix, every BM25Retriever takes its own BM25 index slot of the
+engine (4 per engine), and the node bookkeeping (content ids, filter classes) lives on the engine.  Passing an
+engine that already serves a DIFFERENT node list raises.
 
 No retrieval arithmetic happens in this file except BM25Retriever.filter(scores), which the reference
 exposes as a host-side helper over a caller-supplied score vector; _retrieve does not use it.
@@ -23,6 +30,7 @@ from __future__ import annotations
 
 import asyncio
 import logging
+import threading
 from typing import Any, Callable, Dict, Hashable, List, Optional, Sequence
 
 import numpy as np
@@ -66,15 +74,20 @@ def tokenize_and_remove_stopwords(tokenizer, text, stopwords):
     return [w for w in tokenizer.cut(text) if w not in stopwords and w != " "]
 
 
-def _unit_f16(v) -> np.ndarray:
+def _unit_f16(v, slab_rows: int = 65536) -> np.ndarray:
     """L2-normalise rows in float64, round once to float16: the query / chunk representation the kernels score.
-    (Qdrant normalises both sides for Distance.COSINE; doing it here pins the fp16 rounding on the host.)"""
-    v64 = np.asarray(v, dtype=np.float32).astype(np.float64)
-    if v64.ndim == 1:
-        v64 = v64[None, :]
-    n = np.sqrt(np.sum(v64 * v64, axis=-1, keepdims=True))
-    n = np.where(n != 0.0, n, 1e-12)
-    return (v64 / n).astype(np.float16)
+    (Qdrant normalises both sides for Distance.COSINE; doing it here pins the fp16 rounding on the host.)
+    Rows go through float64 in slabs, so a 1M x 1024 matrix needs ~0.5 GB of temporaries, not 24."""
+    v = np.asarray(v)
+    if v.ndim == 1:
+        v = v[None, :]
+    out = np.empty(v.shape, np.float16)
+    for r0 in range(0, v.shape[0], slab_rows):
+        v64 = v[r0:r0 + slab_rows].astype(np.float32).astype(np.float64)
+        n = np.sqrt(np.sum(v64 * v64, axis=-1, keepdims=True))
+        n = np.where(n != 0.0, n, 1e-12)
+        out[r0:r0 + slab_rows] = (v64 / n).astype(np.float16)
+    return out
 
 
 def _as_bundle(q) -> QueryBundle:
@@ -147,15 +160,18 @@ class _FilteredCorpus:
         return self._classes.class_of(filter_dict)
 
 
-_CORPORA: Dict[int, _FilteredCorpus] = {}
-
-
 def _corpus_for(nodes, engine: Optional[RetrievalEngine]) -> _FilteredCorpus:
-    """Retrievers built over the same engine share one _FilteredCorpus (and so one metadata upload)."""
-    if engine is not None and id(engine) in _CORPORA and len(_CORPORA[id(engine)].nodes) == len(nodes):
-        return _CORPORA[id(engine)]
+    """Retrievers built over the same engine share one _FilteredCorpus (and so one metadata upload).  The
+    bookkeeping lives on the engine object (no process-global cache pinning engines); an engine serves ONE node
+    list -- the same node objects in the same order -- and anything else is an error, not a silent reuse."""
+    if engine is not None and engine.corpus is not None:
+        c = engine.corpus
+        nodes = list(nodes)
+        if len(c.nodes) != len(nodes) or any(a is not b for a, b in zip(c.nodes, nodes)):
+            raise ValueError("this RetrievalEngine already serves a different node list; use one engine per corpus")
+        return c
     c = _FilteredCorpus(nodes, engine)
-    _CORPORA[id(c.engine)] = c
+    c.engine.corpus = c
     return c
 
 
@@ -243,8 +259,17 @@ class BM25Retriever(_RetrieverBase):
         self.bm25: BM25Index = build_bm25_index(self._corpus, variant=1 if bm25_type == 1 else 0, k1=self.k1,
                                                 b=self.b, epsilon=self.epsilon,
                                                 compute_payload=not payload_on_device)
-        self.engine.set_bm25(self.bm25, payload_on_device=payload_on_device)
+        # every retriever owns one BM25 index slot of the (possibly shared) engine: the content retriever and the
+        # know_path retriever of the reference pipeline (pipeline.py:187-210) live side by side
+        self._slot = self.engine.alloc_bm25_slot()
+        self.engine.set_bm25(self.bm25, payload_on_device=payload_on_device, slot=self._slot)
         self.filter_dict = None
+
+    def close(self):
+        """Give the BM25 slot back to the engine."""
+        if getattr(self, "_slot", None) is not None:
+            self.engine.free_bm25_slot(self._slot)
+            self._slot = None
 
     @classmethod
     def from_defaults(cls, index=None, nodes=None, docstore=None, tokenizer=None,
@@ -271,15 +296,18 @@ class BM25Retriever(_RetrieverBase):
         """Score vector over all nodes (float64; float32 values widened for bm25_type 1).  With `docs` a
         throw-away index over those strings is built first (ref retrievers.py:131-147)."""
         if docs is None:
-            return self._cast(self.engine.bm25_scores(self._query_ids(query)))
+            return self._cast(self.engine.bm25_scores(self._query_ids(query), slot=self._slot))
         corpus = [tokenize_and_remove_stopwords(self._tokenizer, d, self.stopwords) for d in docs]
         idx = build_bm25_index(corpus, variant=1 if self.bm25_type == 1 else 0, k1=self.k1, b=self.b, epsilon=self.epsilon)
-        tmp = RetrievalEngine(self.engine.device)
-        try:
-            tmp.set_bm25(idx)
-            return self._cast(tmp.bm25_scores(self._query_ids(query, idx)))
-        finally:
-            tmp.close()
+        # the throw-away index of a handful of sentences goes into a scratch slot of the SAME handle (no handle
+        # creation, no kernel-attribute setup per call: this sits on the per-query path of the compressor)
+        with _SCRATCH_LOCK:
+            scratch = self.engine.alloc_bm25_slot()
+            try:
+                self.engine.set_bm25(idx, slot=scratch)
+                return self._cast(self.engine.bm25_scores(self._query_ids(query, idx), slot=scratch))
+            finally:
+                self.engine.free_bm25_slot(scratch)
 
     def _cast(self, s: np.ndarray) -> np.ndarray:
         return s.astype(np.float32) if self.bm25_type == 1 else s
@@ -310,12 +338,14 @@ class BM25Retriever(_RetrieverBase):
         qi, qt = queries_to_csr([self._query_ids(q) for q in queries])
         cls = self._corpus_state.filter_class(self.filter_dict)
         filt = None if cls < 0 else np.full(len(queries), cls, np.int16)
-        ids, sc, ln = self.engine.bm25_topk(qi, qt, self._similarity_top_k, filter_dir=filt)
+        ids, sc, ln = self.engine.bm25_topk(qi, qt, self._similarity_top_k, filter_dir=filt, slot=self._slot)
         return [[NodeWithScore(node=self._nodes[i], score=float(s)) for i, s in zip(ids[b, :ln[b]], sc[b, :ln[b]])]
                 for b in range(len(queries))]
 
 
+_SCRATCH_LOCK = threading.Lock()
 _FUSION_ENGINE: Optional[RetrievalEngine] = None
+_FUSION_LOCK = threading.Lock()
 
 
 def _fusion_engine() -> RetrievalEngine:
@@ -361,8 +391,6 @@ class HybridRetriever(_RetrieverBase):
         items, cid, per_list = _lists_to_device_form(lists)
         if not items:
             return []
-        eng = _fusion_engine()
-        eng.set_doc_meta(len(items), cid, None)
         da, db = max(len(per_list[0]), 1), max(len(per_list[1]), 1)
         ia = np.full((1, da), -1, np.int32)
         ib = np.full((1, db), -1, np.int32)
@@ -370,14 +398,17 @@ class HybridRetriever(_RetrieverBase):
         ib[0, :len(per_list[1])] = per_list[1]
         la = np.asarray([len(per_list[0])], np.int32)
         lb = np.asarray([len(per_list[1])], np.int32)
-        if rrf:
-            ids, sc, ln = eng.rrf(ia, la, ib, lb, K=K, topk=topk)
-        else:
-            sa = np.zeros((1, da), np.float64)
-            sb = np.zeros((1, db), np.float64)
-            sa[0, :la[0]] = [items[i].score for i in per_list[0]]
-            sb[0, :lb[0]] = [items[i].score for i in per_list[1]]
-            ids, sc, ln = eng.fusion(ia, sa, la, ib, sb, lb, topk=topk)
+        with _FUSION_LOCK:                       # the classmethods share one small handle (item ids are list-local)
+            eng = _fusion_engine()
+            eng.set_doc_meta(len(items), cid, None)
+            if rrf:
+                ids, sc, ln = eng.rrf(ia, la, ib, lb, K=K, topk=topk)
+            else:
+                sa = np.zeros((1, da), np.float64)
+                sb = np.zeros((1, db), np.float64)
+                sa[0, :la[0]] = [items[i].score for i in per_list[0]]
+                sb[0, :lb[0]] = [items[i].score for i in per_list[1]]
+                ids, sc, ln = eng.fusion(ia, sa, la, ib, sb, lb, topk=topk)
         out = []
         for i, s in zip(ids[0, :ln[0]], sc[0, :ln[0]]):
             node = items[i]
@@ -401,9 +432,24 @@ class HybridRetriever(_RetrieverBase):
                 and len(vs.nodes) == len(self.sparse_retriever._nodes))
 
     def _retrieve(self, query_bundle: QueryBundle) -> List[NodeWithScore]:
+        """The reference's sync path (retrievers.py:293-305, marked unmaintained there): both routes with whatever
+        filters the child retrievers currently hold, sparse list then dense list, de-duplicated by node_id; no
+        route selection, no RRF, no filter push-down.  The pipeline calls `aretrieve`."""
+        sparse_nodes = self.sparse_retriever.retrieve(query_bundle)
+        dense_nodes = self.dense_retriever.retrieve(query_bundle)
+        all_nodes, node_ids = [], set()
+        for n in sparse_nodes + dense_nodes:
+            if n.node.node_id not in node_ids:
+                all_nodes.append(n)
+                node_ids.add(n.node.node_id)
+        return all_nodes
+
+    async def _aretrieve(self, query_bundle: QueryBundle) -> List[NodeWithScore]:
+        """Route selection + filter push-down + RRF (retrievers.py:276-291)."""
         return self.retrieve_batch([query_bundle.query_str])[0]
 
     def retrieve_batch(self, queries: Sequence[str]) -> List[List[NodeWithScore]]:
+        """`_aretrieve` for a batch of query strings."""
         sp, de = self.sparse_retriever, self.dense_retriever
         if self.retrieval_type != 1:
             sp.filter_dict = self.filter_dict
@@ -413,18 +459,25 @@ class HybridRetriever(_RetrieverBase):
             de.filters = self.filters
             if self.retrieval_type == 1:
                 return de.retrieve_batch(queries)
-        if not self._fused_possible():
+        # filter_dict restricts the sparse route only, filters the dense route only (retrievers.py:278,283)
+        fd_sparse = self.filter_dict or None
+        fd_dense = _filter_to_dict(self.filters)
+        same_column = (not fd_sparse or not fd_dense or tuple(sorted(fd_sparse)) == tuple(sorted(fd_dense)))
+        if not self._fused_possible() or not same_column:
             sparse, dense = sp.retrieve_batch(queries), de.retrieve_batch(queries)
             return [self.reciprocal_rank_fusion([s, d], topk=self.topk) for s, d in zip(sparse, dense)]
         # both routes share one engine: BM25 -> dense -> RRF([sparse, dense]) in a single device pipeline
-        fd = self.filter_dict if self.filter_dict is not None else _filter_to_dict(self.filters)
-        cls = sp._corpus_state.filter_class(fd)
-        filt = None if cls < 0 else np.full(len(queries), cls, np.int16)
+        cstate = sp._corpus_state
+        cls_s, cls_d = cstate.filter_class(fd_sparse), cstate.filter_class(fd_dense)
+        if fd_sparse and fd_dense:                  # same key set: one class table serves both lookups
+            cls_s = cstate.filter_class(fd_sparse)
+        filt_s = None if cls_s < 0 else np.full(len(queries), cls_s, np.int16)
+        filt_d = None if cls_d < 0 else np.full(len(queries), cls_d, np.int16)
         qi, qt = queries_to_csr([sp._query_ids(q) for q in queries])
         embs = _unit_f16(np.asarray([de._embed_model.get_query_embedding(q) for q in queries], dtype=np.float32))
         ids, sc, ln = sp.engine.hybrid_topk(embs, qi, qt, k_dense=de._similarity_top_k,
                                             k_sparse=sp._similarity_top_k, K=60, topk=self.topk,
-                                            filter_dir=filt)
+                                            filter_dir=filt_s, filter_dense=filt_d, slot=sp._slot)
         nodes = sp._nodes
         return [[NodeWithScore(node=nodes[i], score=float(s)) for i, s in zip(ids[b, :ln[b]], sc[b, :ln[b]])]
                 for b in range(len(queries))]

@@ -100,6 +100,13 @@ int erh_set_bm25_tf(erh_handle *h, int variant, int64_t V, int64_t N, int64_t nn
                     const int64_t *indptr, const int32_t *doc_ids, const int32_t *tf,
                     const int32_t *doc_len, const void *idf, double avgdl, double k1, double b);
 
+/* A handle holds up to ERH_BM25_SLOTS independent BM25 indices (the reference pipeline builds two over the same
+ * nodes: node text with embed_type 2 and know_path with embed_type 5, src/easyrag/pipeline/pipeline.py:187-210).
+ * erh_bm25_select chooses the slot that erh_set_bm25_*, erh_bm25_topk, erh_bm25_scores, erh_get_bm25_payload and
+ * erh_hybrid_topk act on (default 0).  Document metadata (erh_set_doc_meta) is shared by all slots. */
+#define ERH_BM25_SLOTS 4
+int erh_bm25_select(erh_handle *h, int slot);
+
 /* Copy the payload the handle holds back to the host (float32 or float64 [nnz]); parity/debug. */
 int erh_get_bm25_payload(erh_handle *h, void *out_payload);
 
@@ -142,10 +149,14 @@ int erh_fusion(erh_handle *h, const int32_t *ids_a, const double *scores_a, cons
                int32_t *out_ids, double *out_scores, int32_t *out_len, int io_is_device, void *stream);
 
 /* Dual route fused on the device: BM25 top-k_sparse and dense top-k_dense (ERH_DENSE_EXACT),
- * then RRF([sparse, dense], K) -> topk, without a host round trip between the stages. */
+ * then RRF([sparse, dense], K) -> topk, without a host round trip between the stages.
+ * filter_sparse / filter_dense: host int16[B] class per query (-1 = unfiltered) or NULL, one per route -- the
+ * reference pushes filter_dict to the sparse retriever and filters to the dense one independently
+ * (retrievers.py:278, 283). */
 int erh_hybrid_topk(erh_handle *h, const void *q, int q_dtype, int q_is_device, int normalize_q,
                     const int32_t *q_indptr, const int32_t *q_tok, int B,
-                    int k_dense, int k_sparse, int K, int topk, const int16_t *filter_dir,
+                    int k_dense, int k_sparse, int K, int topk, const int16_t *filter_sparse,
+                    const int16_t *filter_dense,
                     int32_t *out_ids, double *out_scores, int32_t *out_len, int out_is_device, void *stream);
 
 /* ---- measurement / diagnostics --------------------------------------------------------- */
@@ -173,6 +184,9 @@ int erh_reset_kernel_time(erh_handle *h);
  *                         0 stores the rows in the caller's order
  *   dense_pp (1)          ping-pong persistent append scan; 0 = lock-step kernels (dense_persist 1 / 0 = persistent /
  *                         one workgroup per tile, dense_cfg 0..2 = their tile configuration, dense_readahead)
+ *   bm25_wscan (1)        wave-owned BM25 scan (no per-token workgroup barrier) for batches whose queries have at most
+ *                         64 tokens; 0 = block scan for everything.  Needs a fine skip table (4 bytes per term and per
+ *                         2048 / 1024 documents), built by erh_set_bm25_* unless it would exceed bm25_fine_max_mb (8192)
  *   dense_ablate, bm25_ablate, debug_counters   MEASUREMENT ONLY: variants with parts of a kernel removed / section
  *                         clocks; results are invalid while an ablate value is non-zero */
 int erh_set_option(erh_handle *h, const char *name, int64_t value);

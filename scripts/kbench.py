@@ -100,6 +100,51 @@ def main():
                     res[f"dense B={B} k={k} pp={pp} pabl={abl} (run {rep})"] = timed(eng, lambda: eng.dense_topk(q, k, device_out=True))
             eng.set_option("dense_ablate", 0)
             eng.set_option("dense_pp", 1)
+    if what == "pp2":                                        # ping-pong kernel: operand-side ablations and phase clocks
+        x = synth.dense_corpus_torch(n, d, seed=2, device=dev)
+        eng.set_dense(x)
+        for B, k in ((256, 100), (1024, 288)):
+            q = synth.dense_queries_torch(x, B, seed=7)
+            for rep in "ab":
+                for abl in (0, 7, 12, 13, 15, 11):
+                    eng.set_option("dense_ablate", abl)
+                    res[f"dense B={B} k={k} pp pabl={abl} (run {rep})"] = timed(eng, lambda: eng.dense_topk(q, k, device_out=True))
+            eng.set_option("debug_counters", 1)
+            eng.set_option("dense_ablate", 20)
+            eng.dense_topk(q, k, device_out=True)
+            torch.cuda.synchronize()
+            c = eng.debug_counters().astype(np.float64)
+            eng.set_option("dense_ablate", 0)
+            eng.set_option("debug_counters", 0)
+            names = ["matrix", "wait", "barrier", "memory", "epilogue", "epi_barrier"]
+            for g in (0, 1):
+                stages = c[g * 8 + 6]
+                res[f"dense B={B} pp phase clocks per stage, group {g}"] = {
+                    n_: round(v / stages, 1) for n_, v in zip(names, c[g * 8:g * 8 + 6])} if stages else {}
+        del x
+    if what == "bm25w":                                      # wave-owned scan vs block scan, section clocks
+        indptr, doc, tf, lens, flat = synth.token_csr_torch(n, vocab, seed=3, device=dev)
+        for variant, name in ((BM25S, "bm25s"), (OKAPI, "okapi")):
+            idx = build_bm25_index_from_postings(indptr, doc, tf, lens, variant, compute_payload=False)
+            queries = synth.token_queries(flat, lens, vocab, 1024, seed=9)
+            for ws in (1, 0, 1, 0):
+                eng.set_option("bm25_wscan", ws)
+                eng.set_bm25(idx, payload_on_device=True)
+                for Bq, k in ((1024, 192), (256, 100), (16, 192), (1, 192)):
+                    qi, qt = queries_to_csr(queries[:Bq])
+                    res[f"{name} wscan={ws} B={Bq} k={k} #{len(res)}"] = timed(eng, lambda: eng.bm25_topk(qi, qt, k, device_out=True), 3)
+            eng.set_option("bm25_wscan", 1)
+            eng.set_bm25(idx, payload_on_device=True)
+            qi, qt = queries_to_csr(queries)
+            eng.set_option("debug_counters", 1)
+            eng.bm25_topk(qi, qt, 192, device_out=True)
+            torch.cuda.synchronize()
+            c = eng.debug_counters().astype(np.float64)
+            eng.set_option("debug_counters", 0)
+            names = ["bounds+misc", "apply(+next fetch)", "sweep", "sweep_barrier", "shrink", "final"]
+            tot = c[:6].sum()
+            res[f"{name} wscan sections (% of thread-0 cycles, k=192)"] = {n_: round(100 * v / tot, 1) for n_, v in zip(names, c[:6])}
+            res[f"{name} wscan cycles per query (thread 0)"] = {"total": round(tot / 1024)}
     if what in ("all", "dense"):
         x = synth.dense_corpus_torch(n, d, seed=2, device=dev)
         eng.set_dense(x)

@@ -107,10 +107,19 @@ def test_dense_and_hybrid_retrievers(corpus, tokenizer):
         for rt, exp in ((1, [nodes[i].node_id for i in did]), (2, [nodes[i].node_id for i, _ in sp]),
                         (3, [nodes[w.idx].node_id for w in want])):
             hy = HybridRetriever(dense, sparse, retrieval_type=rt, topk=256)
-            assert [g.node.node_id for g in hy.retrieve(query)] == exp
+            assert [g.node.node_id for g in asyncio.run(hy.aretrieve(query))] == exp   # what the pipeline calls
+            assert [g.node.node_id for g in hy.retrieve_batch([query])[0]] == exp
         hy = HybridRetriever(dense, sparse, retrieval_type=3, topk=256)
         got3 = asyncio.run(hy.aretrieve(query))
         assert [g.score for g in got3] == [w.score for w in want]
+        # the reference's sync path (retrievers.py:293-305): sparse + dense, de-duplicated by node_id, no fusion
+        sync = hy.retrieve(query)
+        exp_sync, seen = [], set()
+        for i in [i for i, _ in sp] + [int(i) for i in did]:
+            if nodes[i].node_id not in seen:
+                seen.add(nodes[i].node_id)
+                exp_sync.append(nodes[i].node_id)
+        assert [g.node.node_id for g in sync] == exp_sync
         # classmethods over already-retrieved lists (pipeline.py:362, 408)
         s_nodes, d_nodes = sparse.retrieve(query), dense.retrieve(query)
         rr = HybridRetriever.reciprocal_rank_fusion([s_nodes, d_nodes], topk=10)
@@ -120,9 +129,87 @@ def test_dense_and_hybrid_retrievers(corpus, tokenizer):
         wantf = fusion([[Item(i, cid[i], s) for i, s in sp], Bl], topk=256)
         fu = HybridRetriever.fusion([s_nodes, d_nodes], topk=256)
         assert [g.node.node_id for g in fu] == [nodes[w.idx].node_id for w in wantf]
-    # filters pushed down through the hybrid retriever (retrievers.py:278, 283)
-    hy = HybridRetriever(dense, sparse, retrieval_type=3, topk=50)
-    hy.filter_dict = {"dir": "umac"}
-    hy.filters = {"dir": "umac"}
-    out = hy.retrieve("w5 w9 w3")
-    assert out and all(g.node.metadata["dir"] == "umac" for g in out)
+    # filters pushed down through the hybrid retriever (retrievers.py:278, 283): filter_dict -> sparse route only,
+    # filters -> dense route only; every combination against the oracle composition
+    query = "w5 w9 w3"
+    q16 = to_f16_unit(np.asarray(emb.get_query_embedding(query), np.float32))
+    qtok = tokenize_and_remove_stopwords(tokenizer, query, STOP)
+    dirs = np.array([n.metadata["dir"] for n in nodes])
+    for fdict, filters in (({"dir": "umac"}, {"dir": "umac"}), ({"dir": "umac"}, None), (None, {"dir": "rcp"}),
+                           ({"dir": "umac"}, {"dir": "rcp"}), ({"dir": "umac"}, {"know_path": "kp 3"})):
+        hy = HybridRetriever(dense, sparse, retrieval_type=3, topk=50)
+        hy.filter_dict, hy.filters = fdict, filters
+        m_s = None if fdict is None else dirs == fdict["dir"]
+        if filters is None:
+            m_d = None
+        elif "dir" in filters:
+            m_d = dirs == filters["dir"]
+        else:
+            m_d = np.array([n.metadata["know_path"] == filters["know_path"] for n in nodes])
+        sp = bm25_filter(ora.get_scores(qtok), 192, m_s)
+        did, dsc = dense_exact_topk(x16, q16, 288, m_d)
+        want = reciprocal_rank_fusion([[Item(i, cid[i], s) for i, s in sp],
+                                       [Item(int(i), cid[int(i)], float(s)) for i, s in zip(did, dsc)]], topk=50)
+        out = asyncio.run(hy.aretrieve(query))
+        assert [g.node.node_id for g in out] == [nodes[w.idx].node_id for w in want], (fdict, filters)
+        assert [g.score for g in out] == [w.score for w in want]
+    sparse.filter_dict = None
+    dense.filters = None
+
+
+def test_path_route_composition(corpus, tokenizer):
+    """What the shipped yaml executes (retrieval_type 2; pipeline.py:187-210, 357-365): a content BM25 retriever
+    (embed_type 2, top 192) and a know_path BM25 retriever (embed_type 5, top 6) over the same nodes, both with the
+    query's `dir` filter, merged by HybridRetriever.fusion([content, path]).  The two retrievers share one engine
+    (two index slots)."""
+    from easyrag_amd.retrievers import get_node_content
+    nodes, _, _ = corpus
+    for bm25_type in (0, 1):
+        content_r = BM25Retriever.from_defaults(nodes=nodes, tokenizer=tokenizer, similarity_top_k=192,
+                                                stopwords=STOP, embed_type=2, bm25_type=bm25_type)
+        path_r = BM25Retriever.from_defaults(nodes=nodes, tokenizer=tokenizer, similarity_top_k=6, stopwords=STOP,
+                                             embed_type=5, bm25_type=bm25_type, engine=content_r.engine)
+        assert path_r.engine is content_r.engine and path_r._slot != content_r._slot
+        mk = (lambda t: BM25Okapi(t, 1.5, 0.75, 0.25)) if bm25_type == 0 else (lambda t: BM25SLucene(1.5, 0.75).index(t))
+        toks_c = [tokenize_and_remove_stopwords(tokenizer, get_node_content(n, 2), STOP) for n in nodes]
+        toks_p = [tokenize_and_remove_stopwords(tokenizer, get_node_content(n, 5), STOP) for n in nodes]
+        ora_c, ora_p = mk(toks_c), mk(toks_p)
+        key = {}
+        cid = [key.setdefault(n.get_content(), i) for i, n in enumerate(nodes)]
+        dirs = np.array([n.metadata["dir"] for n in nodes])
+        for query, d in (("w5 w9 kp 3", "umac"), ("kp 7 w2 w40 w8", "rcp"), ("w77 w3", "emsplus"), ("kp 1", None)):
+            fd = None if d is None else {"dir": d}
+            content_r.filter_dict = fd
+            path_r.filter_dict = fd
+            qt = tokenize_and_remove_stopwords(tokenizer, query, STOP)
+            mask = None if d is None else dirs == d
+            sc_c, sc_p = ora_c.get_scores(qt), ora_p.get_scores(qt)
+            want_c, want_p = bm25_filter(sc_c, 192, mask), bm25_filter(sc_p, 6, mask)
+            got_c, got_p = content_r.retrieve(query), path_r.retrieve(query)
+            assert [(g.node.node_id, g.score) for g in got_c] == [(nodes[i].node_id, s) for i, s in want_c]
+            assert [(g.node.node_id, g.score) for g in got_p] == [(nodes[i].node_id, s) for i, s in want_p]
+            wantf = fusion([[Item(i, cid[i], s) for i, s in want_c], [Item(i, cid[i], s) for i, s in want_p]], topk=256)
+            fu = HybridRetriever.fusion([got_c, got_p], topk=256)
+            assert [g.node.node_id for g in fu] == [nodes[w.idx].node_id for w in wantf]
+            assert [g.score for g in fu] == [w.score for w in wantf]
+            # the content retriever still answers from ITS index after the path retriever was used
+            assert [g.node.node_id for g in content_r.retrieve(query)] == [nodes[i].node_id for i, _ in want_c]
+        path_r.close()
+        content_r.close()
+
+
+def test_engine_sharing_rules(corpus, tokenizer):
+    nodes, vecs, _ = corpus
+    r = BM25Retriever.from_defaults(nodes=nodes, tokenizer=tokenizer, similarity_top_k=5, stopwords=STOP)
+    with pytest.raises(ValueError):                       # a different node list on the same engine
+        BM25Retriever.from_defaults(nodes=nodes[:100], tokenizer=tokenizer, stopwords=STOP, engine=r.engine)
+    with pytest.raises(ValueError):                       # wrong embedding dimension at query time
+        HipVectorStore(nodes, vecs, engine=r.engine).query_batch(np.zeros((1, 64), np.float32), 3)
+    extra = [BM25Retriever.from_defaults(nodes=nodes, tokenizer=tokenizer, stopwords=STOP, embed_type=5, engine=r.engine)
+             for _ in range(3)]
+    with pytest.raises(RuntimeError):                     # the handle's four index slots are taken
+        BM25Retriever.from_defaults(nodes=nodes, tokenizer=tokenizer, stopwords=STOP, engine=r.engine)
+    for e in extra:
+        e.close()
+    assert r.retrieve("w5 w9")
+    r.close()

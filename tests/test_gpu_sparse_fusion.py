@@ -13,6 +13,14 @@ from oracle.retrievers import Item
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=[1, 0], ids=["wave-owned-scan", "block-scan"])
+def bm25_kernel(request, engine):
+    """Both BM25 scan kernels must satisfy every parity test (the option takes effect at the next set_bm25)."""
+    engine.set_option("bm25_wscan", request.param)
+    yield request.param
+    engine.set_option("bm25_wscan", 1)
+
+
 def _oracle_for(variant, docs):
     if variant == OKAPI:
         return BM25Okapi(docs, k1=1.5, b=0.75, epsilon=0.25)
@@ -27,7 +35,7 @@ def _oracle_scores(ora, variant, q):
 
 @pytest.mark.parametrize("variant", [OKAPI, BM25S])
 @pytest.mark.parametrize("n_docs,vocab,seed", [(60, 10, 0), (3000, 500, 1), (40000, 2000, 2)])
-def test_bm25_scores_and_topk_match_oracle(engine, variant, n_docs, vocab, seed):
+def test_bm25_scores_and_topk_match_oracle(engine, bm25_kernel, variant, n_docs, vocab, seed):
     flat, lens = synth.token_corpus(n_docs, vocab, seed=seed, mean_len=20)
     docs = [list(map(int, d)) for d in synth.split_docs(flat, lens)]
     ora = _oracle_for(variant, docs)
@@ -56,7 +64,7 @@ def test_bm25_scores_and_topk_match_oracle(engine, variant, n_docs, vocab, seed)
 
 
 @pytest.mark.parametrize("variant", [OKAPI, BM25S])
-def test_bm25_ties_and_filter(engine, variant):
+def test_bm25_ties_and_filter(engine, bm25_kernel, variant):
     # 16 distinct documents repeated 40 times each: exact score ties across the whole corpus, ordered by index
     rng = np.random.default_rng(4)
     base = [list(map(int, rng.integers(0, 12, size=rng.integers(3, 9)))) for _ in range(16)]
@@ -86,7 +94,7 @@ def test_bm25_payload_evaluated_on_gpu_is_bit_identical(engine, variant):
     assert got.dtype == idx.payload.dtype and np.array_equal(got, idx.payload)
 
 
-def test_bm25_single_query_uses_segments_and_merge(engine):
+def test_bm25_single_query_uses_segments_and_merge(engine, bm25_kernel):
     # B = 1 splits the document range over several workgroups and merges the partial lists
     flat, lens = synth.token_corpus(150000, 3000, seed=5, mean_len=16)
     idx = build_bm25_index_from_ids(flat=flat, doc_lens=lens, n_vocab=3000, variant=BM25S)
@@ -103,6 +111,71 @@ def test_bm25_single_query_uses_segments_and_merge(engine):
         s, e = idx.indptr[t], idx.indptr[t + 1]
         np.add.at(acc, idx.doc_ids[s:e], idx.payload[s:e])
     assert np.array_equal(scores, acc.astype(np.float64))
+
+
+@pytest.mark.parametrize("variant", [OKAPI, BM25S])
+def test_bm25_long_queries_frequent_terms_and_list_flood(engine, bm25_kernel, variant):
+    """Cases the wave-owned scan treats specially: a term with far more than 64 postings per 2048-document
+    sub-range (several pieces per step, several steps per tile), queries longer than 64 tokens (routed to the block
+    scan), a batch mixing both, and an unseeded first tile (dir filter active) whose touched documents overflow the
+    2048-entry candidate list, so the list-full / re-sweep path runs."""
+    rng = np.random.default_rng(77)
+    n_docs, vocab = 70000, 400
+    lens = rng.integers(6, 30, size=n_docs)
+    # ids 0..3 are very frequent (each in ~half of the documents), the rest Zipfian
+    flat = rng.integers(4, vocab, size=int(lens.sum()))
+    common = rng.random(flat.shape[0]) < 0.25
+    flat[common] = rng.integers(0, 4, size=int(common.sum()))
+    docs = [list(map(int, d)) for d in synth.split_docs(flat.astype(np.int64), lens.astype(np.int64))]
+    ora = _oracle_for(variant, docs)
+    idx = build_bm25_index(docs, variant)
+    engine.set_bm25(idx)
+    dir_id = (np.arange(n_docs) % 2).astype(np.int16)
+    engine.set_doc_meta(n_docs, None, dir_id)
+    queries = [[0, 1, 2, 3, 7], [3, 3, 0, 9, 11, 12, 200], list(range(4, 80)) + [1, 1],        # 78 tokens
+               [int(t) for t in rng.integers(0, vocab, size=40)], [5], [0] * 20 + list(range(30, 70))]
+    qi, qt = queries_to_csr([idx.tokens_to_ids(q) for q in queries])
+    osc = [_oracle_scores(ora, variant, q) for q in queries]
+    short = [b for b, q in enumerate(queries) if len(q) <= 64]
+    for filt in (None, np.array([1, 0, 1, -1, 0, 1], np.int16)):
+        for k in (5, 192, 1024):
+            for sel in (list(range(len(queries))), short):                    # mixed batch / all-short batch
+                qi2, qt2 = queries_to_csr([idx.tokens_to_ids(queries[b]) for b in sel])
+                f2 = None if filt is None else filt[sel]
+                ids, sc, ln = engine.bm25_topk(qi2, qt2, k, filter_dir=f2)
+                for r, b in enumerate(sel):
+                    mask = None if (filt is None or filt[b] < 0) else dir_id == filt[b]
+                    want = bm25_filter(osc[b], k, mask)
+                    assert ln[r] == len(want)
+                    assert list(ids[r, :ln[r]]) == [w[0] for w in want], f"k={k} query {b}: ids differ"
+                    assert list(sc[r, :ln[r]]) == [w[1] for w in want], f"k={k} query {b}: scores differ"
+
+
+def test_bm25_two_indices_on_one_handle(engine):
+    """Index slots: two BM25 indices over the same documents live side by side on one handle and answer
+    independently (content route + know_path route of the reference pipeline, pipeline.py:187-210)."""
+    flat_a, lens_a = synth.token_corpus(5000, 300, seed=31, mean_len=20)
+    flat_b, lens_b = synth.token_corpus(5000, 40, seed=32, mean_len=3)
+    docs_a = [list(map(int, d)) for d in synth.split_docs(flat_a, lens_a)]
+    docs_b = [list(map(int, d)) for d in synth.split_docs(flat_b, lens_b)]
+    ia, ib = build_bm25_index(docs_a, OKAPI), build_bm25_index(docs_b, BM25S)
+    oa, ob = _oracle_for(OKAPI, docs_a), _oracle_for(BM25S, docs_b)
+    engine.set_bm25(ia, slot=1)
+    engine.set_bm25(ib, slot=2)
+    try:
+        qa = [list(map(int, q)) for q in synth.token_queries(flat_a, lens_a, 300, 6, seed=1)]
+        qb = [list(map(int, q)) for q in synth.token_queries(flat_b, lens_b, 40, 6, seed=2, from_doc=2, random_extra=1)]
+        for rep in range(2):                                                  # alternate between the slots
+            for slot, idx, ora, qs, var, k in ((1, ia, oa, qa, OKAPI, 192), (2, ib, ob, qb, BM25S, 6)):
+                qi, qt = queries_to_csr([idx.tokens_to_ids(q) for q in qs])
+                ids, sc, ln = engine.bm25_topk(qi, qt, k, slot=slot)
+                for b, q in enumerate(qs):
+                    want = bm25_filter(_oracle_scores(ora, var, q), k)
+                    assert list(ids[b, :ln[b]]) == [w[0] for w in want] and list(sc[b, :ln[b]]) == [w[1] for w in want]
+                assert np.array_equal(engine.bm25_scores(idx.tokens_to_ids(qs[0]), slot=slot),
+                                      _oracle_scores(ora, var, qs[0]).astype(np.float64))
+    finally:
+        engine._select(0)
 
 
 def _random_lists(rng, n_items, la, lb, dup_rate):
