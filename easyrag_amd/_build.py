@@ -10,8 +10,11 @@ from pathlib import Path
 PKG_DIR = Path(__file__).resolve().parent
 CSRC = PKG_DIR / "csrc"
 INCLUDE = PKG_DIR.parent / "include"
-LIB_PATH = PKG_DIR / "libeasyrag_hip.so"
-STAMP = PKG_DIR / ".libeasyrag_hip.stamp"
+MEASURE = os.environ.get("ERH_MEASURE", "0") not in ("", "0")
+# the measurement build (kernel ablations, section clocks; scripts/kbench.py) is a separate library file, so the
+# product library in the tree is never the one with measurement variants inside
+LIB_PATH = PKG_DIR / ("libeasyrag_hip_measure.so" if MEASURE else "libeasyrag_hip.so")
+STAMP = PKG_DIR / (".libeasyrag_hip_measure.stamp" if MEASURE else ".libeasyrag_hip.stamp")
 
 SOURCES = ["api.hip", "dense_scan.hip", "select.hip", "bm25.hip", "fuse.hip"]
 HEADERS = ["common.h", "kernels.h"]
@@ -28,6 +31,12 @@ HIPCC_FLAGS = [
 ]
 
 
+def _flags():
+    """ERH_MEASURE=1 in the environment builds the measurement variants (kernel ablations, section clocks) that
+    scripts/kbench.py drives; the product build carries none of them."""
+    return HIPCC_FLAGS + (["-DERH_MEASURE"] if MEASURE else [])
+
+
 def _hipcc() -> str:
     for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):
@@ -40,7 +49,7 @@ def _digest() -> str:
     for name in SOURCES + HEADERS:
         h.update((CSRC / name).read_bytes())
     h.update((INCLUDE / "easyrag_hip.h").read_bytes())
-    h.update(" ".join(HIPCC_FLAGS).encode())
+    h.update(" ".join(_flags()).encode())
     return h.hexdigest()
 
 
@@ -50,13 +59,13 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     if not force and LIB_PATH.exists() and STAMP.exists() and STAMP.read_text().strip() == dig:
         return LIB_PATH
     hipcc = _hipcc()
-    obj_dir = PKG_DIR / "build"
+    obj_dir = PKG_DIR / ("build_measure" if MEASURE else "build")
     obj_dir.mkdir(exist_ok=True)
     objs = []
     procs = []
     for src in SOURCES:
         obj = obj_dir / (src.replace(".hip", ".o"))
-        cmd = [hipcc, *HIPCC_FLAGS, "-I", str(INCLUDE), "-I", str(CSRC), "-c", str(CSRC / src), "-o", str(obj)]
+        cmd = [hipcc, *_flags(), "-I", str(INCLUDE), "-I", str(CSRC), "-c", str(CSRC / src), "-o", str(obj)]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

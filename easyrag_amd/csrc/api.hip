@@ -175,7 +175,9 @@ void choose_placement(int64_t n, int64_t *mul, int64_t *inv) {
 hipError_t scan_append(erh_handle *h, const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1, const _Float16 *Q16,
                        int Bpad, int B, const float *tau, const int16_t *filt, const int16_t *dir, ErhCand *cand,
                        uint32_t *cnt, int cap, uint32_t *flags, hipStream_t st) {
-    if (h->opt_dense_pp && (h->opt_dense_ablate == 0 || h->opt_dense_ablate == 20 || (h->opt_dense_ablate >= 7 && h->opt_dense_ablate <= 15 && h->opt_dense_ablate != 10 && h->opt_dense_ablate != 9))) {
+    const int abl = h->opt_dense_ablate;
+    const bool pp_code = abl == 0 || abl == 7 || abl == 8 || (abl >= 11 && abl <= 18) || abl == 20 || abl == 21;
+    if (h->opt_dense_pp && pp_code) {
         hipError_t e = erh::launch_dense_scan_pp(X, N, d, c0, c1, Q16, Bpad, B, tau, filt, dir, cand, cnt, cap, flags,
                                                  h->n_cus, h->opt_dense_ablate,
                                                  h->opt_debug_counters ? h->dbg.as<unsigned long long>() : nullptr, st);
@@ -454,8 +456,13 @@ int erh_set_option(erh_handle *h, const char *name, int64_t value) {
     if (!strcmp(name, "dense_n1_auto")) { h->opt_n1_auto = value != 0; return ERH_OK; }
     if (!strcmp(name, "dense_pp")) { h->opt_dense_pp = value != 0; return ERH_OK; }
     if (!strcmp(name, "dense_persist")) { h->opt_dense_persist = value != 0; return ERH_OK; }
+#ifdef ERH_MEASURE
     if (!strcmp(name, "dense_ablate")) { h->opt_dense_ablate = (int)value; return ERH_OK; }
     if (!strcmp(name, "bm25_ablate")) { h->opt_bm25_ablate = (int)value; return ERH_OK; }
+#else
+    if (!strcmp(name, "dense_ablate") || !strcmp(name, "bm25_ablate") || !strcmp(name, "debug_counters"))
+        return value == 0 ? ERH_OK : h->fail(ERH_ERR_UNSUPPORTED, "measurement option: rebuild the library with ERH_MEASURE=1");
+#endif
     if (!strcmp(name, "bm25_wscan")) { h->opt_bm25_wscan = value != 0; return ERH_OK; }   // the fine table is built at the next erh_set_bm25_*
     if (!strcmp(name, "bm25_fine_max_mb")) { if (value < 0) return h->fail(ERH_ERR_INVALID, "bm25_fine_max_mb < 0"); h->opt_bm25_fine_max_mb = value; return ERH_OK; }
     if (!strcmp(name, "debug_counters")) {

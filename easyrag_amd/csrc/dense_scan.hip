@@ -50,7 +50,11 @@ struct ScanCfg {
     // read-ahead variant (needs DA == DB >= 2): stage kt+1 must have landed too, so only the loads issued after
     // A(kt+1) -- the later (DB - 2) steps -- may stay in flight
     static constexpr bool CAN_RA = (AST_ == BST_) && (BST_ >= 3);
+#ifdef ERH_MEASURE
     static constexpr bool MEASURE = (BK_ == 64) && (AST_ == 3);   // ablation variants are built for the default lock-step config only
+#else
+    static constexpr bool MEASURE = false;                        // product build: no measurement instantiations
+#endif
     static constexpr int WAIT_RA = (DB - 2) * (A_ITERS + B_ITERS);
     static_assert(BK == 32 || BK == 64, "BK");
     static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile must be a multiple of the 32x32 MFMA tile");
@@ -689,24 +693,26 @@ static_assert(LDS_BYTES == 160 * 1024, "pp LDS");
         __builtin_amdgcn_sched_barrier(0);                 \
     } while (0)
 
-// PABL (measurement only): 0 full, 7 no epilogue, 8 thresholds forced to +inf;
-// without epilogue AND: 11 no MFMA, 12 no LDS-DMA, 13 no chunk-side DMA, 14 no fragment reads, 15 no query-side DMA
+// PABL (measurement builds only, -DERH_MEASURE): bit mask -- 1 no epilogue, 2 thresholds forced to +inf, 4 no MFMA,
+// 8 no chunk-side DMA, 16 no query-side DMA, 32 no fragment reads, 64 phase clocks.  Anything but 0 and 64 gives
+// invalid results.  The option "dense_ablate" keeps its round-1 codes (pp_mask_of below maps them).
+constexpr int kPpNoEpi = 1, kPpTauInf = 2, kPpNoMfma = 4, kPpNoDmaA = 8, kPpNoDmaB = 16, kPpNoFrag = 32, kPpClocks = 64;
 template <int PABL>
 __global__ __launch_bounds__(pp::NT) void dense_scan_pp_kernel(
     const _Float16 *__restrict__ X, int64_t N, int d, int64_t c0, int64_t c1,
     const _Float16 *__restrict__ Q, int Bpad, int B,
     const float *__restrict__ tau, const int16_t *__restrict__ filter_dir, const int16_t *__restrict__ dir_id,
     ErhCand *__restrict__ cand, uint32_t *__restrict__ cand_cnt, int cap, uint32_t *__restrict__ overflow,
-    unsigned long long *__restrict__ dbg /* PABL == 20 only: phase clock sums of waves 0 and 4 */) {
+    unsigned long long *__restrict__ dbg /* kPpClocks only: phase clock sums of waves 0 and 4 */) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int grp = wave >> 2, wave_n = wave & 3;
-    // PABL 20 (measurement): shader-clock sums per phase kind -- 0 matrix segment, 1 counted wait, 2 barrier,
+    // kPpClocks (measurement): shader-clock sums per phase kind -- 0 matrix segment, 1 counted wait, 2 barrier,
     // 3 memory segment, 4 epilogue, 5 epilogue barrier
     long long tph[6] = {0, 0, 0, 0, 0, 0};
-    long long t_mark = (PABL == 20) ? clock64() : 0;
-#define ERH_PH(I) do { if (PABL == 20) { const long long n_ = clock64(); tph[I] += n_ - t_mark; t_mark = n_; } } while (0)
+    long long t_mark = (PABL & kPpClocks) ? clock64() : 0;
+#define ERH_PH(I) do { if (PABL & kPpClocks) { const long long n_ = clock64(); tph[I] += n_ - t_mark; t_mark = n_; } } while (0)
     const int nk = d / pp::BK;
 
     const int n_qt = Bpad / pp::BN;
@@ -727,7 +733,7 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp_kernel(
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const int q = (int)q_row0 + wave_n * 64 + nt * 32 + l31;
-        t_q[nt] = (q < B && PABL != 8) ? tau[q] : INFINITY;
+        t_q[nt] = (q < B && !(PABL & kPpTauInf)) ? tau[q] : INFINITY;
     }
     asm volatile("" ::"v"(t_q[0]), "v"(t_q[1]));                      // loaded before the DMA stream starts (keeps vmcnt countable)
 
@@ -755,7 +761,7 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp_kernel(
 // 70 GB/s per CU when the halves are a stage apart).
 #define ERH_PP_ISSUE_B()                                                                              \
     do {                                                                                              \
-        if (gb < total && PABL != 12 && PABL != 15) {                                                 \
+        if (gb < total && !(PABL & kPpNoDmaB)) {                                                 \
             char *d0_ = lds + pp::B_BASE + sb * pp::B_BYTES;                                          \
             char *d1_ = lds + pp::B_BASE + ((sb + 1) & (pp::BST - 1)) * pp::B_BYTES;                  \
             tb.issue_part(kb, pp::BK, d0_, wave, 0, 1);                                               \
@@ -767,7 +773,7 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp_kernel(
     } while (0)
 #define ERH_PP_ISSUE_A()                                                                              \
     do {                                                                                              \
-        if (ga < total && PABL != 12 && PABL != 13) {                                                 \
+        if (ga < total && !(PABL & kPpNoDmaA)) {                                                 \
             if (ka == 0 && ga > 0) {                                                                  \
                 ++ta_tile;                                                                            \
                 ta.init(X, c0 + ((int64_t)stream + (int64_t)ta_tile * n_streams) * pp::BM, N, d, wave, lane); \
@@ -784,7 +790,7 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp_kernel(
 // memory phase M(h): the fragments of stage h+1, then the A pair (h+4, h+5) for even h / the B pair (h+3, h+4) for odd h
 #define ERH_PP_MEM()                                                                                  \
     do {                                                                                              \
-        if (gf < total && (PABL != 14 || gf == 0)) {                                                  \
+        if (gf < total && (!(PABL & kPpNoFrag) || gf == 0)) {                                                  \
             const char *pa_ = lds + fa_slot * pp::A_BYTES + a_lane_off;                               \
             const char *pb_ = lds + fb_slot * pp::B_BYTES + b_lane_off;                               \
             _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                        \
@@ -804,7 +810,7 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp_kernel(
     } while (0)
 #define ERH_PP_COMPUTE()                                                                              \
     do {                                                                                              \
-        if (PABL == 11) {                                                                             \
+        if (PABL & kPpNoMfma) {                                                                       \
             _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) asm volatile("" ::"v"(fa[mt][0]), "v"(fa[mt][1])); \
             _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) asm volatile("" ::"v"(fb[nt][0]), "v"(fb[nt][1])); \
             if (kt == 0) { _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) \
@@ -850,7 +856,7 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp_kernel(
 // Epilogue of tile i for this wave (acc final).  See the header comment.
 #define ERH_PP_EPILOGUE()                                                                             \
     do {                                                                                              \
-        if (PABL == 7 || PABL >= 11) {                                                \
+        if (PABL & kPpNoEpi) {                                                        \
             float keep_ = 0.f;                                                                        \
             _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                          \
                 _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                      \
@@ -952,7 +958,7 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp_kernel(
             ERH_PH(4);
             ERH_PP_BARRIER();
             ERH_PH(5);
-            if (PABL != 7 && PABL < 11) flush_now = __builtin_amdgcn_readfirstlane(flag[i & 1]);
+            if (!(PABL & kPpNoEpi)) flush_now = __builtin_amdgcn_readfirstlane(flag[i & 1]);
         }
     } else {
         for (int i = 0; i < n_tiles; ++i) {
@@ -970,10 +976,10 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp_kernel(
             ERH_PH(4);
             ERH_PP_BARRIER();
             ERH_PH(5);
-            if (PABL != 7 && PABL < 11) flush_now = __builtin_amdgcn_readfirstlane(flag[i & 1]);
+            if (!(PABL & kPpNoEpi)) flush_now = __builtin_amdgcn_readfirstlane(flag[i & 1]);
         }
     }
-    if (PABL == 20 && dbg && lane == 0 && (wave == 0 || wave == 4)) {
+    if ((PABL & kPpClocks) && dbg && lane == 0 && (wave == 0 || wave == 4)) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) atomicAdd(&dbg[grp * 8 + i], (unsigned long long)tph[i]);
         atomicAdd(&dbg[grp * 8 + 6], (unsigned long long)total);
@@ -1091,6 +1097,28 @@ hipError_t launch_append(const _Float16 *X, int64_t N, int d, int64_t c0, int64_
     return hipGetLastError();
 }
 
+#ifdef ERH_MEASURE
+// option code -> ablation mask of the ping-pong kernel (round-1 codes kept; 16..18, 21 new)
+constexpr int pp_mask_of(int code) {
+    switch (code) {
+        case 7: return kPpNoEpi;
+        case 8: return kPpTauInf;
+        case 11: return kPpNoEpi | kPpNoMfma;
+        case 12: return kPpNoEpi | kPpNoDmaA | kPpNoDmaB;
+        case 13: return kPpNoEpi | kPpNoDmaA;
+        case 14: return kPpNoEpi | kPpNoFrag;
+        case 15: return kPpNoEpi | kPpNoDmaB;
+        case 16: return kPpNoEpi | kPpNoMfma | kPpNoFrag;                          // LDS-DMA + barriers only
+        case 17: return kPpNoEpi | kPpNoMfma | kPpNoDmaA | kPpNoDmaB;             // fragment reads + barriers only
+        case 18: return kPpNoEpi | kPpNoMfma | kPpNoDmaA | kPpNoDmaB | kPpNoFrag; // barriers only
+        case 20: return kPpNoEpi | kPpClocks;
+        case 21: return kPpClocks;
+        default: return 0;
+    }
+}
+#define ERH_PP_MASKS(X) X(1) X(2) X(5) X(25) X(9) X(33) X(17) X(37) X(29) X(61) X(65) X(64)
+#endif
+
 hipError_t launch_pp(const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1, const _Float16 *Q, int Bpad, int B,
                      const float *tau, const int16_t *filter_dir, const int16_t *dir_id, ErhCand *cand,
                      uint32_t *cand_cnt, int cap, uint32_t *overflow, int ctas, int pabl, unsigned long long *dbg,
@@ -1104,17 +1132,17 @@ hipError_t launch_pp(const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1
 #define ERH_LAUNCH_PP(A)                                                                                   \
     hipLaunchKernelGGL((dense_scan_pp_kernel<A>), grid, block, pp::LDS_BYTES, st, X, N, d, c0, c1, Q, Bpad, B, tau, \
                        filter_dir, dir_id, cand, cand_cnt, cap, overflow, dbg)
-    switch (pabl) {
-        case 20: ERH_LAUNCH_PP(20); break;
-        case 7: ERH_LAUNCH_PP(7); break;
-        case 8: ERH_LAUNCH_PP(8); break;
-        case 11: ERH_LAUNCH_PP(11); break;
-        case 12: ERH_LAUNCH_PP(12); break;
-        case 13: ERH_LAUNCH_PP(13); break;
-        case 14: ERH_LAUNCH_PP(14); break;
-        case 15: ERH_LAUNCH_PP(15); break;
+#ifdef ERH_MEASURE
+    switch (pp_mask_of(pabl)) {
+#define ERH_PP_CASE(M) case M: ERH_LAUNCH_PP(M); break;
+        ERH_PP_MASKS(ERH_PP_CASE)
+#undef ERH_PP_CASE
         default: ERH_LAUNCH_PP(0); break;
     }
+#else
+    (void)pabl;
+    ERH_LAUNCH_PP(0);
+#endif
 #undef ERH_LAUNCH_PP
     return hipGetLastError();
 }
@@ -1137,8 +1165,10 @@ hipError_t dense_scan_init() {
     e = hipFuncSetAttribute((const void *)dense_scan_pp_kernel<A>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                             pp::LDS_BYTES);                                                                \
     if (e != hipSuccess) return e;
-    ERH_SET_PP(0) ERH_SET_PP(7) ERH_SET_PP(8) ERH_SET_PP(11) ERH_SET_PP(12) ERH_SET_PP(13) ERH_SET_PP(14)
-    ERH_SET_PP(15) ERH_SET_PP(20)
+    ERH_SET_PP(0)
+#ifdef ERH_MEASURE
+    ERH_PP_MASKS(ERH_SET_PP)
+#endif
 #undef ERH_SET_PP
     return hipSuccess;
 }

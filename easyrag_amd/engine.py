@@ -187,7 +187,7 @@ class RetrievalEngine:
                 q = np.ascontiguousarray(q, dtype=np.float32)
                 dt = _lib.ERH_F32
             is_dev = 0
-        if q.ndim != 2 or int(q.shape[1]) != self.d:
+        if self.d and (q.ndim != 2 or int(q.shape[1]) != self.d):   # (before set_dense the library reports the state error)
             raise ValueError(f"queries must be [B, {self.d}] (the chunk matrix's dimension), got {tuple(q.shape)}")
         return q, dt, is_dev, int(q.shape[0])
 

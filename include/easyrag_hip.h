@@ -187,8 +187,10 @@ int erh_reset_kernel_time(erh_handle *h);
  *   bm25_wscan (1)        wave-owned BM25 scan (no per-token workgroup barrier) for batches whose queries have at most
  *                         64 tokens; 0 = block scan for everything.  Needs a fine skip table (4 bytes per term and per
  *                         2048 / 1024 documents), built by erh_set_bm25_* unless it would exceed bm25_fine_max_mb (8192)
- *   dense_ablate, bm25_ablate, debug_counters   MEASUREMENT ONLY: variants with parts of a kernel removed / section
- *                         clocks; results are invalid while an ablate value is non-zero */
+ *   dense_ablate, bm25_ablate, debug_counters   MEASUREMENT BUILDS ONLY (library compiled with -DERH_MEASURE, i.e.
+ *                         ERH_MEASURE=1 python -m easyrag_amd._build): variants with parts of a kernel removed /
+ *                         section clocks; results are invalid while an ablate value is non-zero.  The product
+ *                         build contains none of these variants and rejects non-zero values (ERH_ERR_UNSUPPORTED). */
 int erh_set_option(erh_handle *h, const char *name, int64_t value);
 
 /* After a dense / hybrid call with DEVICE outputs: synchronise `stream`, read the call's flag words and

@@ -5,6 +5,8 @@ import json
 import os
 import sys
 
+os.environ["ERH_MEASURE"] = "1"          # measurement variants of the kernels (see easyrag_amd/_build.py)
+
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -106,7 +108,7 @@ def main():
         for B, k in ((256, 100), (1024, 288)):
             q = synth.dense_queries_torch(x, B, seed=7)
             for rep in "ab":
-                for abl in (0, 7, 12, 13, 15, 11):
+                for abl in (0, 7, 12, 13, 15, 14, 11, 16, 17, 18):
                     eng.set_option("dense_ablate", abl)
                     res[f"dense B={B} k={k} pp pabl={abl} (run {rep})"] = timed(eng, lambda: eng.dense_topk(q, k, device_out=True))
             eng.set_option("debug_counters", 1)
