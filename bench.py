@@ -1,12 +1,14 @@
 #!/usr/bin/env python
 """bench.py -- queries/sec of the dual-route coarse ranker (dense + BM25 + RRF top-10) at 1M x 1024 chunks.
 
-Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched under
-torch.distributed.run, one rank per GPU (RCCL).  A "step" is one pass of the hot path over one batch of
-synthetic queries: BM25 top-192 over ~50M CSR postings + dense cosine top-288 over the fp16 chunk matrix +
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it runs one rank per GPU (RCCL):
+either launched under torch.distributed.run by the caller, or -- when WORLD_SIZE is not set -- bench.py starts its
+own N ranks the same way.  A "step" is one pass of the hot path over one batch of synthetic queries: BM25 top-192 over ~50M CSR postings + dense cosine top-288 over the fp16 chunk matrix +
 RRF(K=60) -> top-10 (BASELINE.json configs[3]; the depths are the reference's yaml defaults f_topk_2 / f_topk_1).
-Per-GPU work is fixed (1024 queries per rank, corpus replicated) and the fused top-k blocks are all-gathered
-(configs[4] at N = 8): weak scaling.  Inputs are resident in HBM before the timed region; rank 0 prints ONE
+Per-GPU work is fixed (1024 queries per rank, corpus replicated): the global batch of N x 1024 queries is sharded
+contiguously over the ranks (easyrag_amd.dist.QueryShards) and the fused top-k rows are all-gathered (configs[4] at
+N = 8): weak scaling.  Consecutive steps use different query batches (a small rotating pool), so no step finds its
+predecessor's postings or query tiles warm in L2 / MALL.  Inputs are resident in HBM before the timed region; rank 0 prints ONE
 JSON line with the whole-job aggregate, the roofline of the dominant kernel (dense MFMA scan, timed with HIP
 events on the launch stream inside the library) and the CPU baseline (oracle port, rank 0, N = 1 only).
 """
@@ -38,7 +40,9 @@ def parse_args():
     ap.add_argument("--chunks", type=int, default=1_000_000)
     ap.add_argument("--dim", type=int, default=1024)
     ap.add_argument("--vocab", type=int, default=262_144)
-    ap.add_argument("--batch", type=int, default=0, help="queries per GPU per step (default 1024; dense-only 256)")
+    ap.add_argument("--batch", type=int, default=0, help="queries per GPU per step (default: hybrid 1024 = configs[3]; dense / bm25 256 = configs[1] / configs[2])")
+    ap.add_argument("--pool", type=int, default=4, help="distinct query batches rotated through the steps")
+    ap.add_argument("--gather", default=None, choices=["torch", "native"], help="multi-GPU gather: torch.distributed around the library's pack/unpack kernels (default) or erh_allgather_topk (RCCL inside the library)")
     ap.add_argument("--variant", default="bm25s", choices=["bm25s", "okapi"])
     ap.add_argument("--cpu-queries", type=int, default=96, help="queries in the bounded CPU-baseline sample, ~15 s of host work (0 = skip)")
     ap.add_argument("--option", action="append", default=[], help="library option name=value (e.g. dense_n1=131072)")
@@ -102,11 +106,15 @@ def pmc_traffic(args, kernel_class, algorithmic_bytes):
     sizes, no option overrides); otherwise traffic stays null."""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
     default_shape = (args.chunks == 1_000_000 and args.dim == 1024 and args.vocab == 262_144 and args.batch == 0
-                     and not args.option and args.variant == "bm25s")
+                     and not args.option and args.variant == "bm25s" and args.gpus == 1)
     try:
-        rec = json.load(open(path))[args.workload]
+        table = json.load(open(path))
+        rec = table[args.workload]
     except (OSError, KeyError, ValueError):
         return {"traffic": None}
+    from easyrag_amd import _build
+    if table.get("_lib_digest") != _build._digest():
+        return {"traffic": None, "traffic_note": "profiles/pmc_traffic.json was collected on different kernel sources (stale)"}
     if not default_shape or rec.get("kernel_class") != kernel_class:
         return {"traffic": None}
     t = float(rec["hbm_bytes_per_launch"])
@@ -114,8 +122,31 @@ def pmc_traffic(args, kernel_class, algorithmic_bytes):
             "traffic_source": "profiles/pmc_traffic.json (" + rec["command"] + "; " + rec["correction"] + ")"}
 
 
+def spawn_ranks(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks under torch.distributed.run on this node (what
+    the driver's wrapped form does) and relay their output."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} needs {args.gpus} GPUs on this node, found {have} "
+              f"(one rank per GPU; RCCL does not share a device between ranks)", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL needs it on this driver
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args))
     import torch
     from easyrag_amd import dist as erd
     from easyrag_amd import synth
@@ -125,47 +156,63 @@ def main():
 
     rank, world = erd.init_from_env()
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     n, d, vocab = args.chunks, args.dim, args.vocab
-    B = args.batch or (256 if args.workload == "dense" else 1024)
+    B = args.batch or (1024 if args.workload == "hybrid" else 256)
     k_dense, k_sparse, topk = (100, 0, 100) if args.workload == "dense" else (288, 192, 10)
     if args.workload == "bm25":
         k_dense, k_sparse, topk = 0, 100, 100
     variant = BM25S if args.variant == "bm25s" else OKAPI
+    n_global = B * world
+    pool = max(1, args.pool)
 
-    # ---- synthetic corpus, replicated on every rank (same seeds); queries differ per rank -------------------
+    # ---- synthetic corpus, replicated on every rank (same seeds); the global query batches are the same on every
+    # rank too, and each rank answers its contiguous shard of them -------------------------------------------------
     eng = RetrievalEngine(local)
     for opt in args.option:
         name, val = opt.split("=")
         eng.set_option(name, int(val))
-    x = q16 = idx = None
-    queries = []
+    shards = erd.QueryShards(n_global, rank, world, engine=eng, mode=args.gather)
+    lo, hi = shards.bounds
+    x = idx = None
+    q16_pool, csr_pool, tok_pool = [], [], []
     if args.workload in ("hybrid", "dense"):
         x = synth.dense_corpus_torch(n, d, seed=2, device=dev)
-        q16 = synth.dense_queries_torch(x, B, seed=1000 + rank)
+        q16_pool = [synth.dense_queries_torch(x, n_global, seed=1000 + p)[lo:hi].contiguous() for p in range(pool)]
         eng.set_dense(x)
     if args.workload in ("hybrid", "bm25"):
         indptr, doc, tf, lens, flat = synth.token_csr_torch(n, vocab, seed=3, device=dev)
         idx = build_bm25_index_from_postings(indptr, doc, tf, lens, variant, compute_payload=False)
         eng.set_bm25(idx, payload_on_device=True)            # IDF*TF/(TF + k1*lenNorm) evaluated by the GPU
-        queries = synth.token_queries(flat, lens, vocab, B, seed=2000 + rank)
+        for p in range(pool):
+            tok_pool.append(synth.token_queries(flat, lens, vocab, n_global, seed=2000 + p)[lo:hi])
+            csr_pool.append(queries_to_csr(tok_pool[-1]))
         del flat
     eng.set_doc_meta(n, None, None)
-    qi, qt = queries_to_csr(queries) if queries else (None, None)
     torch.cuda.synchronize()
+    q16 = q16_pool[0] if q16_pool else None
+    queries = tok_pool[0] if tok_pool else []
+
+    def local_step(p):
+        if args.workload == "hybrid":
+            qi, qt = csr_pool[p]
+            return eng.hybrid_topk(q16_pool[p], qi, qt, k_dense=k_dense, k_sparse=k_sparse, K=60, topk=topk, device_out=True)
+        if args.workload == "dense":
+            return eng.dense_topk(q16_pool[p], k_dense, device_out=True)
+        qi, qt = csr_pool[p]
+        return eng.bm25_topk(qi, qt, k_sparse, device_out=True)
+
+    counter = [0]
 
     def step():
-        if args.workload == "hybrid":
-            out = eng.hybrid_topk(q16, qi, qt, k_dense=k_dense, k_sparse=k_sparse, K=60, topk=topk, device_out=True)
-        elif args.workload == "dense":
-            out = eng.dense_topk(q16, k_dense, device_out=True)
-        else:
-            out = eng.bm25_topk(qi, qt, k_sparse, device_out=True)
+        p = counter[0] % pool
+        counter[0] += 1
+        out = local_step(p)
         if world > 1:
-            out = erd.allgather_topk(out[0], out[1], out[2], B * world)
+            out = shards.gather(*out)
         return out
 
     for _ in range(args.warmup):
@@ -227,7 +274,7 @@ def main():
                                         args.workload)
             # recall@topk of the GPU result against the CPU restatement on the same sample (sets: the CPU walk
             # orders equal scores as numpy's argsort happens to, the GPU by index)
-            got = step()
+            got = local_step(0)
             torch.cuda.synchronize()
             g_ids = got[0][: len(ref_ids)].cpu().numpy()
             hit = tot = 0
@@ -239,7 +286,7 @@ def main():
         workload_name = {
             "hybrid": f"configs[3]: 1M chunks, dual-route dense(top-{k_dense})+BM25(top-{k_sparse}) with RRF top-{topk}",
             "dense": f"configs[1]: 1M chunks x 1024-d fp16, dense cosine top-{k_dense} only",
-            "bm25": f"configs[2]: 1M chunks, BM25 only top-{k_sparse}"}[args.workload]
+            "bm25": f"configs[2]: 1M chunks, BM25 only top-{k_sparse}, batch {B}"}[args.workload]
         rec = {
             "metric": "queries/sec (dense+BM25+RRF top-10) at 1Mx1024 chunks" if args.workload == "hybrid"
                       else f"queries/sec ({args.workload} only) at 1Mx1024 chunks",
@@ -251,7 +298,9 @@ def main():
                        "postings": int(idx.nnz) if idx is not None else 0,
                        "queries_per_gpu": B, "global_batch": B * world,
                        "bm25_variant": args.variant if idx is not None else None,
-                       "parallelism": f"query-sharded x{world}, corpus replicated, all-gather of fused top-k"},
+                       "query_batches_rotated": pool,
+                       "parallelism": f"query-sharded x{world}, corpus replicated, all-gather of fused top-k"
+                                      + (f" ({shards.mode})" if world > 1 else "")},
             "roofline": roof,
             "cpu_baseline": cpu,
             "kernel_ms_per_step": per_step,

@@ -52,6 +52,13 @@ SIGNATURES = {
     "erh_fusion": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp]),
     "erh_hybrid_topk": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp,
                                _vp, _vp, _vp, _i32, _vp]),
+    "erh_comm_unique_id": (_i32, [_vp]),
+    "erh_comm_init": (_i32, [_vp, _i32, _i32, _vp]),
+    "erh_comm_destroy": (_i32, [_vp]),
+    "erh_allgather_topk": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "erh_topk_row_bytes": (_i32, [_i32]),
+    "erh_pack_topk": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
+    "erh_unpack_topk": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "erh_set_profiling": (_i32, [_vp, _i32]),
     "erh_get_kernel_time": (_i32, [_vp, _i32, C.POINTER(_dbl), C.POINTER(_i64)]),
     "erh_get_kernel_work": (_i32, [_vp, _i32, C.POINTER(_dbl), C.POINTER(_dbl)]),

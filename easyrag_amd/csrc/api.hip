@@ -3,6 +3,7 @@
 #include "../../include/easyrag_hip.h"
 
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cstdio>
@@ -82,6 +83,10 @@ struct erh_handle {
     DevBuf scores_tmp, scores_wide;
     DevBuf dbg;                              // 16 x u64 section counters (measurement only)
     int opt_debug_counters = 0;
+    // multi-GPU exchange (erh_comm_* / erh_allgather_topk): RCCL communicator + packed send / receive rows
+    void *comm = nullptr;
+    int comm_rank = 0, comm_world = 1;
+    DevBuf gather_send, gather_recv;
     // options
     int64_t opt_n0 = 32768, opt_n1 = 131072;
     int opt_n1_auto = 1;                   // snap n1 to a whole number of persistent-scan rounds (performance only)
@@ -433,6 +438,9 @@ int erh_destroy(erh_handle *h) {
                       &h->scores_tmp, &h->scores_wide, &h->dbg, &h->dir_pos, &h->seed_need};
     for (DevBuf *b : bufs) b->release();
     for (auto &b : h->bm) b.release();
+    if (h->comm) (void)erh_comm_destroy(h);
+    h->gather_send.release();
+    h->gather_recv.release();
     delete h;
     return ERH_OK;
 }
@@ -997,6 +1005,146 @@ int erh_debug_dense_scores(erh_handle *h, const void *q_f16_host, int B, int64_t
         HIPCHK(h, hipMemcpyAsync(out, h->S0.p, (size_t)B * rows * 4, hipMemcpyDeviceToHost, st));
     }
     HIPCHK(h, hipStreamSynchronize(st));
+    return ERH_OK;
+}
+
+}  // extern "C"
+
+// ---- multi-GPU: all-gather of the fused top-k over RCCL ---------------------------------------------------------------
+// The corpus is replicated and the query batch sharded contiguously over the ranks (north_star),
+// so the only exchange is one all-gather of [B_local x k] (score, id, len) rows.  RCCL is bound at run time with
+// dlopen("librccl.so.1") -- the instance torch already mapped when the caller uses torch, the ROCm one otherwise --
+// so the library has no link-time dependency on it and single-GPU users never load it.
+namespace {
+
+typedef struct { char internal[128]; } rccl_unique_id;                 // = ncclUniqueId (rccl.h)
+struct Rccl {
+    void *dl = nullptr;
+    int (*GetUniqueId)(rccl_unique_id *) = nullptr;
+    int (*CommInitRank)(void **, int, rccl_unique_id, int) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    bool ok = false;
+};
+
+Rccl &rccl() {
+    static Rccl r;
+    if (r.dl) return r;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *n : names) {
+        r.dl = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (r.dl) break;
+    }
+    if (!r.dl) return r;
+    r.GetUniqueId = (int (*)(rccl_unique_id *))dlsym(r.dl, "ncclGetUniqueId");
+    r.CommInitRank = (int (*)(void **, int, rccl_unique_id, int))dlsym(r.dl, "ncclCommInitRank");
+    r.AllGather = (int (*)(const void *, void *, size_t, int, void *, hipStream_t))dlsym(r.dl, "ncclAllGather");
+    r.CommDestroy = (int (*)(void *))dlsym(r.dl, "ncclCommDestroy");
+    r.GetErrorString = (const char *(*)(int))dlsym(r.dl, "ncclGetErrorString");
+    r.ok = r.GetUniqueId && r.CommInitRank && r.AllGather && r.CommDestroy;
+    return r;
+}
+
+int rccl_fail(erh_handle *h, const char *what, int rc) {
+    char buf[256];
+    Rccl &r = rccl();
+    snprintf(buf, sizeof buf, "%s: RCCL error %d (%s)", what, rc, r.GetErrorString ? r.GetErrorString(rc) : "?");
+    return h->fail(ERH_ERR_HIP, buf);
+}
+
+}  // namespace
+
+extern "C" {
+
+int erh_comm_unique_id(void *out128) {
+    if (!out128) return ERH_ERR_INVALID;
+    Rccl &r = rccl();
+    if (!r.ok) return ERH_ERR_UNSUPPORTED;
+    rccl_unique_id id;
+    if (r.GetUniqueId(&id) != 0) return ERH_ERR_HIP;
+    memcpy(out128, &id, sizeof id);
+    return ERH_OK;
+}
+
+int erh_comm_init(erh_handle *h, int rank, int world, const void *id128) {
+    if (!h) return ERH_ERR_INVALID;
+    if (!id128 || world < 1 || rank < 0 || rank >= world) return h->fail(ERH_ERR_INVALID, "erh_comm_init: bad rank / world / id");
+    if (h->comm) return h->fail(ERH_ERR_STATE, "erh_comm_init: communicator already initialised");
+    Rccl &r = rccl();
+    if (!r.ok) return h->fail(ERH_ERR_UNSUPPORTED, "erh_comm_init: librccl.so.1 not found or incomplete");
+    HIPCHK(h, hipSetDevice(h->device));
+    rccl_unique_id id;
+    memcpy(&id, id128, sizeof id);
+    void *c = nullptr;
+    const int rc = r.CommInitRank(&c, world, id, rank);
+    if (rc != 0) return rccl_fail(h, "ncclCommInitRank", rc);
+    h->comm = c;
+    h->comm_rank = rank;
+    h->comm_world = world;
+    return ERH_OK;
+}
+
+int erh_comm_destroy(erh_handle *h) {
+    if (!h) return ERH_ERR_INVALID;
+    if (h->comm) {
+        (void)hipSetDevice(h->device);
+        (void)rccl().CommDestroy(h->comm);
+        h->comm = nullptr;
+    }
+    h->comm_rank = 0;
+    h->comm_world = 1;
+    return ERH_OK;
+}
+
+int erh_topk_row_bytes(int k) { return k > 0 ? erh::topk_row_bytes(k) : 0; }
+
+int erh_pack_topk(erh_handle *h, const int32_t *ids, const double *scores, const int32_t *lens, int b_local, int k,
+                  int rows, void *out_rows, void *stream) {
+    if (!h) return ERH_ERR_INVALID;
+    if (!ids || !scores || !lens || !out_rows || b_local < 0 || k <= 0 || rows < b_local)
+        return h->fail(ERH_ERR_INVALID, "erh_pack_topk: null pointer or bad sizes");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, erh::launch_pack_topk(ids, scores, lens, b_local, k, rows, out_rows, (hipStream_t)stream));
+    return ERH_OK;
+}
+
+int erh_unpack_topk(erh_handle *h, const void *gathered_rows, int n_queries, int world, int k,
+                    int32_t *out_ids, double *out_scores, int32_t *out_len, void *stream) {
+    if (!h) return ERH_ERR_INVALID;
+    if (!gathered_rows || !out_ids || !out_scores || !out_len || n_queries <= 0 || world <= 0 || k <= 0)
+        return h->fail(ERH_ERR_INVALID, "erh_unpack_topk: null pointer or bad sizes");
+    HIPCHK(h, hipSetDevice(h->device));
+    const int m = (n_queries + world - 1) / world;
+    HIPCHK(h, erh::launch_unpack_topk(gathered_rows, n_queries, world, k, m, out_ids, out_scores, out_len,
+                                      (hipStream_t)stream));
+    return ERH_OK;
+}
+
+int erh_allgather_topk(erh_handle *h, const int32_t *ids, const double *scores, const int32_t *lens, int b_local, int k,
+                       int n_queries, int32_t *out_ids, double *out_scores, int32_t *out_len, void *stream) {
+    if (!h) return ERH_ERR_INVALID;
+    if (!ids || !scores || !lens || !out_ids || !out_scores || !out_len || k <= 0 || n_queries <= 0 || b_local < 0)
+        return h->fail(ERH_ERR_INVALID, "erh_allgather_topk: null pointer or bad sizes");
+    const int world = h->comm_world, rank = h->comm_rank;
+    const int base = n_queries / world, rem = n_queries % world;
+    if (b_local != base + (rank < rem ? 1 : 0))
+        return h->fail(ERH_ERR_INVALID, "erh_allgather_topk: b_local is not this rank's contiguous shard of n_queries");
+    if (world > 1 && !h->comm) return h->fail(ERH_ERR_STATE, "erh_allgather_topk before erh_comm_init");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int m = (n_queries + world - 1) / world;
+    const size_t row = (size_t)erh::topk_row_bytes(k);
+    HIPCHK(h, h->gather_send.ensure(row * m));
+    HIPCHK(h, h->gather_recv.ensure(row * m * world));
+    HIPCHK(h, erh::launch_pack_topk(ids, scores, lens, b_local, k, m, h->gather_send.p, st));
+    if (world > 1) {
+        const int rc = rccl().AllGather(h->gather_send.p, h->gather_recv.p, row * m, /*ncclChar*/ 0, h->comm, st);
+        if (rc != 0) return rccl_fail(h, "ncclAllGather", rc);
+    } else {
+        HIPCHK(h, hipMemcpyAsync(h->gather_recv.p, h->gather_send.p, row * m, hipMemcpyDeviceToDevice, st));
+    }
+    HIPCHK(h, erh::launch_unpack_topk(h->gather_recv.p, n_queries, world, k, m, out_ids, out_scores, out_len, st));
     return ERH_OK;
 }
 

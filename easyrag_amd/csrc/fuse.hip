@@ -112,6 +112,46 @@ __global__ __launch_bounds__(kFuseThreads) void fuse_kernel(
     if (tid == 0) out_len[q] = kk;
 }
 
+
+// ---- multi-GPU exchange: one packed row per query -----------------------------------------------------------------
+// The query batch is sharded contiguously over the ranks (corpus replicated); the only
+// exchange is the all-gather of the fused top-k.  Three arrays (scores f64[k], ids i32[k], len i32) travel as ONE
+// buffer: row = [k x f64 | k x i32 | i32 len | pad to 8 bytes], every rank contributing `m` = ceil(n / world) rows
+// (padding rows: len 0).  pack / unpack are the only per-step work besides the collective, and allocate nothing.
+__global__ void pack_topk_kernel(const int32_t *__restrict__ ids, const double *__restrict__ sc,
+                                 const int32_t *__restrict__ len, int b_local, int k, int m, int row_bytes,
+                                 char *__restrict__ out) {
+    const int r = blockIdx.x;
+    char *row = out + (size_t)r * row_bytes;
+    double *o_sc = reinterpret_cast<double *>(row);
+    int32_t *o_id = reinterpret_cast<int32_t *>(row + (size_t)k * 8);
+    const bool live = r < b_local;
+    for (int i = threadIdx.x; i < k; i += blockDim.x) {
+        o_sc[i] = live ? sc[(size_t)r * k + i] : 0.0;
+        o_id[i] = live ? ids[(size_t)r * k + i] : -1;
+    }
+    if (threadIdx.x == 0) o_id[k] = live ? len[r] : 0;
+}
+
+// Global query g lives in rank r's block at row g - lo(r); shards differ by at most one query (dist.py: shard_bounds).
+__global__ void unpack_topk_kernel(const char *__restrict__ gathered, int n_queries, int world, int k, int m,
+                                   int row_bytes, int32_t *__restrict__ ids, double *__restrict__ sc,
+                                   int32_t *__restrict__ len) {
+    const int g = blockIdx.x;
+    const int base = n_queries / world, rem = n_queries % world;
+    int r, lo;
+    if (g < (base + 1) * rem) { r = g / (base + 1); lo = r * (base + 1); }
+    else { r = rem + (base ? (g - (base + 1) * rem) / base : 0); lo = r * base + rem; }
+    const char *row = gathered + ((size_t)r * m + (g - lo)) * row_bytes;
+    const double *i_sc = reinterpret_cast<const double *>(row);
+    const int32_t *i_id = reinterpret_cast<const int32_t *>(row + (size_t)k * 8);
+    for (int i = threadIdx.x; i < k; i += blockDim.x) {
+        sc[(size_t)g * k + i] = i_sc[i];
+        ids[(size_t)g * k + i] = i_id[i];
+    }
+    if (threadIdx.x == 0) len[g] = i_id[k];
+}
+
 }  // namespace
 
 namespace erh {
@@ -147,6 +187,24 @@ hipError_t launch_fusion(const int32_t *ids_a, const double *sc_a, const int32_t
     hipLaunchKernelGGL(fuse_kernel<false>, dim3(B), dim3(kFuseThreads), fuse_lds_bytes(P), st,
                        ids_a, sc_a, len_a, depth_a, ids_b, sc_b, len_b, depth_b,
                        content_id, 0, topk, P, out_ids, out_scores, out_len);
+    return hipGetLastError();
+}
+
+int topk_row_bytes(int k) { return (k * 12 + 4 + 7) / 8 * 8; }
+
+hipError_t launch_pack_topk(const int32_t *ids, const double *sc, const int32_t *len, int b_local, int k, int m,
+                            void *out, hipStream_t st) {
+    if (m <= 0) return hipSuccess;
+    hipLaunchKernelGGL(pack_topk_kernel, dim3(m), dim3(64), 0, st, ids, sc, len, b_local, k, m, topk_row_bytes(k),
+                       (char *)out);
+    return hipGetLastError();
+}
+
+hipError_t launch_unpack_topk(const void *gathered, int n_queries, int world, int k, int m, int32_t *ids, double *sc,
+                              int32_t *len, hipStream_t st) {
+    if (n_queries <= 0) return hipSuccess;
+    hipLaunchKernelGGL(unpack_topk_kernel, dim3(n_queries), dim3(64), 0, st, (const char *)gathered, n_queries, world, k,
+                       m, topk_row_bytes(k), ids, sc, len);
     return hipGetLastError();
 }
 

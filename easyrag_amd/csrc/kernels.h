@@ -109,4 +109,11 @@ hipError_t launch_fusion(const int32_t *ids_a, const double *sc_a, const int32_t
                          const int32_t *content_id, int B, int topk,
                          int32_t *out_ids, double *out_scores, int32_t *out_len, hipStream_t st);
 
+// packed top-k rows for the multi-GPU all-gather (fuse.hip)
+int topk_row_bytes(int k);
+hipError_t launch_pack_topk(const int32_t *ids, const double *sc, const int32_t *len, int b_local, int k, int m,
+                            void *out, hipStream_t st);
+hipError_t launch_unpack_topk(const void *gathered, int n_queries, int world, int k, int m, int32_t *ids, double *sc,
+                              int32_t *len, hipStream_t st);
+
 }  // namespace erh

@@ -2,15 +2,23 @@
 ranks, one all-gather of the fused top-k (BASELINE.json north_star).
 
 Queries are independent units, so there is no data-path collective inside the retrieval itself; the only
-exchange is the final gather of [B_local x k] (id, score) blocks -- ~120 KB per rank at 1024 x 10, i.e. pure
-latency on xGMI.  One process per GPU, `torch.distributed` backend "nccl" (= RCCL on ROCm); the same code
-runs on CPU tensors with "gloo" (tests/test_dist_gloo.py).  The reference has no counterpart (single
-process, one query at a time: src/main.py:48-52).
+exchange is the final gather of [B_local x k] (score, id, len) rows -- ~120 KB per rank at 1024 x 10, i.e. pure
+latency on xGMI.  One process per GPU.  Three ways to run the gather, same result:
+
+  "torch"   (default on GPUs) the library packs the rows (erh_pack_topk), `torch.distributed`
+            all_gather_into_tensor (backend "nccl" = RCCL) moves ONE preallocated uint8 buffer, the library
+            unpacks into preallocated global arrays (erh_unpack_topk): two tiny kernels + one collective, no
+            per-step allocation, no torch.cat.
+  "native"  erh_allgather_topk: pack + ncclAllGather + unpack inside the library on the caller's stream (its own
+            RCCL communicator, bootstrapped by broadcasting erh_comm_unique_id through torch.distributed).
+  "host"    CPU tensors / no engine: padded blocks through all_gather_into_tensor ("gloo" in the CPU tests).
+
+The reference has no counterpart (single process, one query at a time: src/main.py:48-52).
 """
 from __future__ import annotations
 
 import os
-from typing import Optional, Tuple
+from typing import Callable, Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -49,10 +57,9 @@ def init_from_env(device_index: Optional[int] = None) -> Tuple[int, int]:
 
 def allgather_topk(ids: torch.Tensor, scores: torch.Tensor, lens: torch.Tensor, n_queries: int,
                    group=None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-    """Gather every rank's [B_local x k] fused top-k into the global [n_queries x k] result, in query order.
-
-    Shards are padded to max_shard rows so that all ranks contribute equal-sized blocks (one
-    all_gather_into_tensor per array); the padding rows are dropped afterwards."""
+    """"host" gather: every rank's [B_local x k] fused top-k -> the global [n_queries x k] result, in query order.
+    Shards are padded to max_shard rows so that all ranks contribute equal-sized blocks; the padding rows are
+    dropped afterwards.  (GPU runs use QueryShards below, which packs in the library and allocates nothing.)"""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return ids[:n_queries], scores[:n_queries], lens[:n_queries]
     world = dist.get_world_size(group)
@@ -69,8 +76,6 @@ def allgather_topk(ids: torch.Tensor, scores: torch.Tensor, lens: torch.Tensor, 
         return out
 
     p_ids, p_sc, p_ln = pad(ids, -1), pad(scores, 0), pad(lens, 0)
-    # one collective instead of three (the exchange is pure latency): rows packed as [scores | ids | len] bytes,
-    # widest type first so that every field stays aligned inside a row
     nb_sc, nb_id, nb_ln = k * p_sc.element_size(), k * p_ids.element_size(), p_ln.element_size()
     packed = torch.cat([p_sc.view(torch.uint8).reshape(m, nb_sc), p_ids.view(torch.uint8).reshape(m, nb_id),
                         p_ln.reshape(m, 1).view(torch.uint8).reshape(m, nb_ln)], dim=1).contiguous()
@@ -84,3 +89,65 @@ def allgather_topk(ids: torch.Tensor, scores: torch.Tensor, lens: torch.Tensor, 
     keep = torch.cat([torch.arange(r * m, r * m + (shard_bounds(n_queries, r, world)[1] - shard_bounds(n_queries, r, world)[0]),
                                    device=ids.device) for r in range(world)])
     return g_ids[keep], g_sc[keep], g_ln[keep]
+
+
+class QueryShards:
+    """One rank's view of a sharded global query batch: its contiguous shard and the gather of the results.
+
+        sh = QueryShards(n_queries, rank, world, engine=eng)          # engine=None -> "host" gather (CPU tests)
+        lo, hi = sh.bounds
+        ids, sc, ln = sh.step(lambda lo, hi: eng.hybrid_topk(q[lo:hi], ..., device_out=True))
+
+    `step` runs the local retrieval on [lo, hi) and returns the GLOBAL result on every rank.  bench.py --gpus N and
+    the tests drive exactly this code."""
+
+    def __init__(self, n_queries: int, rank: int, world: int, engine=None, mode: Optional[str] = None, group=None):
+        self.n, self.rank, self.world, self.engine, self.group = int(n_queries), int(rank), int(world), engine, group
+        self.bounds = shard_bounds(self.n, self.rank, self.world)
+        self.m = max_shard(self.n, self.world)
+        if mode is None:
+            mode = os.environ.get("ERH_GATHER", "torch") if engine is not None else "host"
+        if mode not in ("torch", "native", "host"):
+            raise ValueError("gather mode must be torch, native or host")
+        if mode != "host" and engine is None:
+            raise ValueError("the packed gathers need the engine (the library packs and unpacks)")
+        self.mode = mode
+        self._k = None
+        self._send = self._recv = self._out = None
+        if mode == "native" and world > 1:
+            uid = [engine.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0, group=group)
+            engine.comm_init(rank, world, uid[0])
+
+    def _buffers(self, k: int, device):
+        if self._k != k:
+            row = self.engine.topk_row_bytes(k)
+            self._send = torch.empty((self.m, row), dtype=torch.uint8, device=device)
+            self._recv = torch.empty((self.m * self.world, row), dtype=torch.uint8, device=device)
+            self._out = (torch.empty((self.n, k), dtype=torch.int32, device=device),
+                         torch.empty((self.n, k), dtype=torch.float64, device=device),
+                         torch.empty((self.n,), dtype=torch.int32, device=device))
+            self._k = k
+        return self._send, self._recv, self._out
+
+    def gather(self, ids, sc, ln):
+        lo, hi = self.bounds
+        if ids.shape[0] != hi - lo:
+            raise ValueError(f"rank {self.rank} must contribute its shard of {hi - lo} queries, got {ids.shape[0]}")
+        if self.mode == "host":
+            return allgather_topk(ids, sc, ln, self.n, self.group)
+        k = int(ids.shape[1])
+        send, recv, out = self._buffers(k, ids.device)
+        if self.mode == "native":
+            return self.engine.allgather_topk(ids, sc, ln, self.n, out=out)
+        self.engine.pack_topk(ids, sc, ln, send)
+        if self.world > 1:
+            dist.all_gather_into_tensor(recv, send, group=self.group)
+        else:
+            recv.copy_(send)
+        self.engine.unpack_topk(recv, self.n, self.world, k, out)
+        return out
+
+    def step(self, run_local: Callable[[int, int], Tuple[torch.Tensor, torch.Tensor, torch.Tensor]]):
+        lo, hi = self.bounds
+        return self.gather(*run_local(lo, hi))

@@ -58,6 +58,7 @@ class RetrievalEngine:
         self._bm25_slots: List[Optional[BM25Index]] = [None] * _lib.ERH_BM25_SLOTS
         self._bm25_cur = 0
         self.n_meta = 0
+        self.rank, self.world = 0, 1
         self.corpus = None                   # retrievers.py keeps its per-engine node bookkeeping here
 
     @property
@@ -302,6 +303,55 @@ class RetrievalEngine:
                                               int(topk), _ptr(f), _ptr(fdn), _ptr(ids), _ptr(sc), _ptr(ln),
                                               1 if device_out else 0, self._stream(stream)))
         return ids, sc, ln
+
+    # -- multi-GPU exchange (one handle = one rank) ------------------------------------------------------------
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """128-byte RCCL id; rank 0 creates it and the caller hands it to every rank (any side channel)."""
+        buf = C.create_string_buffer(128)
+        rc = _lib.load().erh_comm_unique_id(buf)
+        if rc != 0:
+            raise _lib.ErhError(rc, "erh_comm_unique_id failed (librccl.so.1 not loadable?)")
+        return buf.raw
+
+    def comm_init(self, rank: int, world: int, unique_id: bytes):
+        """Join the RCCL communicator of erh_allgather_topk (collective: every rank calls it)."""
+        if len(unique_id) != 128:
+            raise ValueError("unique_id must be the 128 bytes of comm_unique_id()")
+        self._check(self._lib.erh_comm_init(self._h, int(rank), int(world), C.c_char_p(unique_id)))
+        self.rank, self.world = int(rank), int(world)
+
+    def comm_destroy(self):
+        self._check(self._lib.erh_comm_destroy(self._h))
+        self.rank, self.world = 0, 1
+
+    def topk_row_bytes(self, k: int) -> int:
+        return int(self._lib.erh_topk_row_bytes(int(k)))
+
+    def allgather_topk(self, ids, sc, ln, n_queries: int, out=None, stream=None):
+        """Device tensors of this rank's shard -> the global [n_queries x k] result (RCCL all-gather inside the
+        library, on `stream`).  `out` = preallocated (ids, scores, len) device tensors, or None to allocate."""
+        import torch
+        k = int(ids.shape[1])
+        if out is None:
+            dev = ids.device
+            out = (torch.empty((n_queries, k), dtype=torch.int32, device=dev),
+                   torch.empty((n_queries, k), dtype=torch.float64, device=dev),
+                   torch.empty((n_queries,), dtype=torch.int32, device=dev))
+        self._check(self._lib.erh_allgather_topk(self._h, _ptr(ids), _ptr(sc), _ptr(ln), int(ids.shape[0]), k,
+                                                 int(n_queries), _ptr(out[0]), _ptr(out[1]), _ptr(out[2]),
+                                                 self._stream(stream)))
+        return out
+
+    def pack_topk(self, ids, sc, ln, rows_out, stream=None):
+        """[b_local x k] device result -> packed rows (uint8 tensor [m, row_bytes], padding rows have len 0)."""
+        self._check(self._lib.erh_pack_topk(self._h, _ptr(ids), _ptr(sc), _ptr(ln), int(ids.shape[0]),
+                                            int(ids.shape[1]), int(rows_out.shape[0]), _ptr(rows_out),
+                                            self._stream(stream)))
+
+    def unpack_topk(self, gathered, n_queries: int, world: int, k: int, out, stream=None):
+        self._check(self._lib.erh_unpack_topk(self._h, _ptr(gathered), int(n_queries), int(world), int(k),
+                                              _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), self._stream(stream)))
 
     # -- measurement ------------------------------------------------------------------------------
     def sync(self, stream=None):

@@ -159,6 +159,30 @@ int erh_hybrid_topk(erh_handle *h, const void *q, int q_dtype, int q_is_device, 
                     const int16_t *filter_dense,
                     int32_t *out_ids, double *out_scores, int32_t *out_len, int out_is_device, void *stream);
 
+/* ---- multi-GPU: query batch sharded over ranks, corpus replicated, one all-gather of the fused top-k ----------
+ * (north_star / SURVEY.md section 8(e); the reference is single-process: src/main.py:48-52.)  One process and one
+ * handle per GPU.  Rank r owns the contiguous shard [lo, hi) of the n_queries global queries, shards differing by at
+ * most one query: base = n / world, rem = n % world, lo = r*base + min(r, rem), size = base + (r < rem).
+ *
+ * erh_comm_unique_id: rank 0 obtains the 128-byte RCCL id and the caller distributes it (any side channel);
+ * erh_comm_init: every rank joins (collective call); RCCL is bound at run time (dlopen "librccl.so.1").
+ * erh_allgather_topk: DEVICE buffers.  Packs this rank's [b_local x k] result into rows
+ * [k x f64 score | k x i32 id | i32 len], runs ncclAllGather on `stream`, and unpacks the world's rows into the
+ * global [n_queries x k] arrays in query order -- no host round trip, no allocation after the first call.
+ * world == 1 (no erh_comm_init) degenerates to a device copy.
+ * erh_pack_topk / erh_unpack_topk / erh_topk_row_bytes expose the two kernels for callers that run the
+ * collective themselves (easyrag_amd/dist.py uses them around torch.distributed.all_gather_into_tensor). */
+int erh_comm_unique_id(void *out128);
+int erh_comm_init(erh_handle *h, int rank, int world, const void *id128);
+int erh_comm_destroy(erh_handle *h);
+int erh_allgather_topk(erh_handle *h, const int32_t *ids, const double *scores, const int32_t *lens, int b_local, int k,
+                       int n_queries, int32_t *out_ids, double *out_scores, int32_t *out_len, void *stream);
+int erh_topk_row_bytes(int k);
+int erh_pack_topk(erh_handle *h, const int32_t *ids, const double *scores, const int32_t *lens, int b_local, int k,
+                  int rows, void *out_rows, void *stream);
+int erh_unpack_topk(erh_handle *h, const void *gathered_rows, int n_queries, int world, int k,
+                    int32_t *out_ids, double *out_scores, int32_t *out_len, void *stream);
+
 /* ---- measurement / diagnostics --------------------------------------------------------- */
 
 /* Kernel timing with HIP events on the launch stream.  Kernel classes: */

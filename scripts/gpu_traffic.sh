@@ -14,8 +14,10 @@ for wl in hybrid dense bm25; do
 done
 cd $GRAFT_REPO_ROOT
 python - <<'PY'
-import csv, glob, json, collections
-out = {}
+import csv, glob, json, collections, sys
+sys.path.insert(0, ".")
+from easyrag_amd import _build
+out = {"_lib_digest": _build._digest()}      # bench.py attaches the figures only to runs of exactly these kernels
 for wl, match in (("hybrid", "dense_scan"), ("dense", "dense_scan"), ("bm25", "bm25_scan")):
     f = glob.glob(f"gpurun_out/traffic/{wl}/**/*counter_collection.csv", recursive=True)
     if not f:

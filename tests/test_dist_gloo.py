@@ -40,6 +40,48 @@ def _worker(rank, world, port, n_q, k, out_dir):
     torch.distributed.destroy_process_group()
 
 
+class _FakeEngine:
+    """What bench.step() hands to QueryShards.step on a GPU rank, minus the GPU: a local retrieval over [lo, hi)."""
+
+    def __init__(self, n_q, k):
+        self.ids, self.sc, self.ln = _fused_oracle(n_q, k)
+
+    def local(self, lo, hi):
+        return torch.from_numpy(self.ids[lo:hi]), torch.from_numpy(self.sc[lo:hi]), torch.from_numpy(self.ln[lo:hi])
+
+
+def _worker_shards(rank, world, port, n_q, k, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    erd.init_from_env()
+    fake = _FakeEngine(n_q, k)
+    sh = erd.QueryShards(n_q, rank, world, engine=None)              # "host" gather: same step() code path as bench.py
+    assert sh.mode == "host" and sh.bounds == erd.shard_bounds(n_q, rank, world)
+    for _ in range(2):                                               # a second step reuses the object
+        g = sh.step(fake.local)
+    np.savez(os.path.join(out_dir, f"s{rank}.npz"), ids=g[0].numpy(), sc=g[1].numpy(), ln=g[2].numpy())
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_query_shards_step(tmp_path):
+    """The code path of bench.py --gpus N (QueryShards.step) on two gloo ranks with a fake engine."""
+    for n_q in (32, 29):
+        port = _free_port()
+        mp.spawn(_worker_shards, args=(2, port, n_q, 10, str(tmp_path)), nprocs=2, join=True)
+        ids, sc, ln = _fused_oracle(n_q, 10)
+        for r in range(2):
+            z = np.load(tmp_path / f"s{r}.npz")
+            assert np.array_equal(z["ids"], ids) and np.array_equal(z["sc"], sc) and np.array_equal(z["ln"], ln)
+
+
+def test_query_shards_rejects_wrong_shard():
+    sh = erd.QueryShards(10, 0, 1, engine=None)
+    import pytest
+    with pytest.raises(ValueError):
+        sh.gather(torch.zeros((3, 4), dtype=torch.int32), torch.zeros((3, 4), dtype=torch.float64),
+                  torch.zeros((3,), dtype=torch.int32))
+
+
 def test_shard_bounds_cover_everything():
     for n in (0, 1, 7, 8, 1024, 8191):
         for w in (1, 2, 3, 8):

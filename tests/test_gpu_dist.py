@@ -1,0 +1,82 @@
+"""GPU side of the multi-GPU layout on ONE device: the world's shards are run one after the other through the same
+sharding arithmetic and the library's pack / unpack kernels, and the gathered result must equal the unsharded call
+("with < 8 devices run shards sequentially").  RCCL itself needs >= 2 GPUs; what a single GPU
+can check is everything around the collective, and erh_allgather_topk at world size 1 (pack -> copy -> unpack)."""
+import numpy as np
+import pytest
+
+from easyrag_amd import dist as erd
+from easyrag_amd import synth
+from easyrag_amd.engine import queries_to_csr
+from easyrag_amd.index import BM25S, build_bm25_index
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def workload(engine):
+    import torch
+    n, d, vocab, B = 30000, 256, 3000, 1003                        # 1003 queries: ragged over 8 ranks (126 / 125)
+    x = synth.dense_corpus(n, d, seed=11)
+    q = synth.dense_queries(x, B, seed=12).astype(np.float16)
+    flat, lens = synth.token_corpus(n, vocab, seed=13, mean_len=24)
+    docs = [list(map(int, t)) for t in synth.split_docs(flat, lens)]
+    idx = build_bm25_index(docs, BM25S)
+    queries = [idx.tokens_to_ids(list(map(int, t))) for t in synth.token_queries(flat, lens, vocab, B, seed=14)]
+    engine.set_dense(x)
+    engine.set_bm25(idx)
+    engine.set_doc_meta(n, None, None)
+    return torch.from_numpy(q).cuda(), queries
+
+
+def _local(engine, q, queries, lo, hi, topk):
+    qi, qt = queries_to_csr(queries[lo:hi])
+    return engine.hybrid_topk(q[lo:hi], qi, qt, k_dense=288, k_sparse=192, K=60, topk=topk, device_out=True)
+
+
+@pytest.mark.parametrize("world", [8, 3, 1])
+def test_sequential_shards_equal_unsharded(engine, workload, world):
+    import torch
+    q, queries = workload
+    B, topk = q.shape[0], 10
+    full = _local(engine, q, queries, 0, B, topk)
+    m = erd.max_shard(B, world)
+    row = engine.topk_row_bytes(topk)
+    recv = torch.zeros((world * m, row), dtype=torch.uint8, device=q.device)
+    for r in range(world):                                            # what rank r would contribute to the all-gather
+        lo, hi = erd.shard_bounds(B, r, world)
+        ids, sc, ln = _local(engine, q, queries, lo, hi, topk)
+        engine.pack_topk(ids, sc, ln, recv[r * m:(r + 1) * m])
+    out = (torch.empty((B, topk), dtype=torch.int32, device=q.device),
+           torch.empty((B, topk), dtype=torch.float64, device=q.device),
+           torch.empty((B,), dtype=torch.int32, device=q.device))
+    engine.unpack_topk(recv, B, world, topk, out)
+    torch.cuda.synchronize()
+    for a, b in zip(out, full):
+        assert torch.equal(a, b)
+
+
+def test_query_shards_world1_torch_and_native(engine, workload):
+    """QueryShards at world size 1 in both GPU gather modes: "torch" (pack, copy, unpack) and "native"
+    (erh_allgather_topk without a communicator)."""
+    import torch
+    q, queries = workload
+    B = 200
+    want = _local(engine, q, queries, 0, B, 10)
+    for mode in ("torch", "native"):
+        sh = erd.QueryShards(B, 0, 1, engine=engine, mode=mode)
+        got = sh.step(lambda lo, hi: _local(engine, q, queries, lo, hi, 10))
+        torch.cuda.synchronize()
+        for a, b in zip(got, want):
+            assert torch.equal(a, b)
+    # a one-rank RCCL communicator: init, gather through ncclAllGather's single-rank path, destroy
+    uid = engine.comm_unique_id()
+    assert len(uid) == 128
+    engine.comm_init(0, 1, uid)
+    try:
+        got = engine.allgather_topk(*want, B)
+        torch.cuda.synchronize()
+        for a, b in zip(got, want):
+            assert torch.equal(a, b)
+    finally:
+        engine.comm_destroy()

@@ -1,0 +1,135 @@
+"""GPU parity at BASELINE.json's full sizes (1M chunks x 1024, ~60M postings): EXACT ids and scores against the oracle
+composition on sampled queries, for the configurations round 1 only property-checked:
+
+  configs[3]  dense(288) + BM25(192) + RRF -> top-10, B = 1024, both BM25 variants      (32 sampled queries each)
+  configs[2]  BM25 only, B = 256 (two document segments per query + merge), k = 100 / 192 (32 sampled queries)
+  Okapi       float64 accumulation, 61 tiles of 16384 documents                          (12 sampled queries)
+
+How the oracle stays affordable at 1M documents without weakening it:
+  sparse  the per-posting payload comes from the host index (easyrag_amd/index.py, bit-equal to the dict-loop
+          rank_bm25 / bm25s restatements on small corpora: tests/test_index_vs_oracle.py); a query's score vector is
+          the oracle's scatter-add over the postings in token order (numpy, accumulation type of the variant), then
+          oracle.bm25_filter.
+  dense   an independent fp32 GEMM (torch, not this library) proposes every row within 2e-3 of the k-th best fp32
+          score -- |fp32 - exact| <= d * 2^-23 * |x||q| ~ 1.2e-4 for these unit vectors, so the proposal provably
+          contains the exact top-k -- and the oracle's pinned-order float64 scores of those rows decide.
+"""
+import numpy as np
+import pytest
+
+from easyrag_amd import synth
+from easyrag_amd.engine import queries_to_csr
+from easyrag_amd.index import BM25S, OKAPI, build_bm25_index_from_postings
+from oracle import bm25_filter, dense_exact_scores, reciprocal_rank_fusion
+from oracle.retrievers import Item
+
+pytestmark = pytest.mark.gpu
+
+N, D, VOCAB = 1_000_000, 1024, 262_144
+
+
+@pytest.fixture(scope="module")
+def dense_data():
+    import torch
+    dev = torch.device("cuda", 0)
+    x = synth.dense_corpus_torch(N, D, seed=2, device=dev)
+    q = synth.dense_queries_torch(x, 1024, seed=1000)
+    return x, q
+
+
+@pytest.fixture(scope="module")
+def sparse_data():
+    import torch
+    dev = torch.device("cuda", 0)
+    indptr, doc, tf, lens, flat = synth.token_csr_torch(N, VOCAB, seed=3, device=dev)
+    queries = synth.token_queries(flat, lens, VOCAB, 1024, seed=2000)
+    del flat
+    torch.cuda.empty_cache()
+    return indptr, doc, tf, lens, queries
+
+
+_INDEX = {}
+
+
+def host_index(sparse_data, variant):
+    """Host-built index (payload included) per variant, built once per session."""
+    if variant not in _INDEX:
+        indptr, doc, tf, lens, _ = sparse_data
+        _INDEX[variant] = build_bm25_index_from_postings(indptr, doc, tf, lens, variant)
+    return _INDEX[variant]
+
+
+def sparse_oracle_scores(idx, q_tokens):
+    """The variant's get_scores over the CSR postings: contributions added in query-token order, repeats included,
+    in the variant's accumulation type."""
+    acc = np.zeros(idx.n_docs, np.float64 if idx.variant == OKAPI else np.float32)
+    for t in q_tokens:
+        s, e = idx.indptr[t], idx.indptr[t + 1]
+        np.add.at(acc, idx.doc_ids[s:e], idx.payload[s:e])
+    return acc
+
+
+def dense_oracle_topk(x, q16_rows, k):
+    """Exact (pinned-order fp64, index-ascending ties) top-k of each query row over the whole matrix."""
+    import torch
+    out = []
+    qf = q16_rows.float()
+    s32 = torch.empty((qf.shape[0], x.shape[0]), dtype=torch.float32, device=x.device)
+    for s in range(0, x.shape[0], 131072):
+        s32[:, s:s + 131072] = qf @ x[s:s + 131072].float().T
+    kth = torch.topk(s32, k, dim=1).values[:, -1]
+    for i in range(qf.shape[0]):
+        cand = torch.nonzero(s32[i] >= kth[i] - 2e-3).reshape(-1)
+        rows = x[cand].cpu().numpy()
+        sc = dense_exact_scores(rows, q16_rows[i].cpu().numpy())
+        ids = cand.cpu().numpy()
+        order = np.lexsort((ids, -sc))[:k]
+        out.append((ids[order].astype(np.int64), sc[order]))
+    return out
+
+
+@pytest.mark.parametrize("variant", [BM25S, OKAPI], ids=["bm25s", "okapi"])
+def test_hybrid_configs3_exact(engine, dense_data, sparse_data, variant):
+    x, q = dense_data
+    queries = sparse_data[4]
+    idx = host_index(sparse_data, variant)                                          # host payload = the oracle's data
+    engine.set_dense(x)
+    engine.set_bm25(idx, payload_on_device=True)                                    # the GPU evaluates its own payload
+    assert np.array_equal(engine.get_bm25_payload(), idx.payload)
+    engine.set_doc_meta(N, None, None)
+    qi, qt = queries_to_csr(queries)
+    ids, sc, ln = engine.hybrid_topk(q, qi, qt, k_dense=288, k_sparse=192, K=60, topk=10)
+    assert np.all(ln == 10)
+    sample = list(range(0, 1024, 33))[:32]
+    dense_want = dense_oracle_topk(x, q[sample], 288)
+    for (did, dsc), b in zip(dense_want, sample):
+        sp = bm25_filter(sparse_oracle_scores(idx, queries[b]), 192)
+        want = reciprocal_rank_fusion([[Item(i, i, s) for i, s in sp],
+                                       [Item(int(i), int(i), float(s)) for i, s in zip(did, dsc)]], K=60, topk=10)
+        assert list(ids[b, :ln[b]]) == [w.idx for w in want], f"query {b}: fused ids differ"
+        assert list(sc[b, :ln[b]]) == [w.score for w in want], f"query {b}: fused scores differ"
+    # the two routes on their own, same sample (what feeds the fusion)
+    d_ids, d_sc, d_ln = engine.dense_topk(q[sample], 288)
+    for r, (did, dsc) in enumerate(dense_want):
+        assert np.array_equal(d_ids[r], did) and np.array_equal(d_sc[r], dsc)
+
+
+@pytest.mark.parametrize("variant,k,n_sample", [(BM25S, 100, 32), (BM25S, 192, 32), (OKAPI, 100, 12), (OKAPI, 192, 12)],
+                         ids=["bm25s-k100", "bm25s-k192", "okapi-k100", "okapi-k192"])
+@pytest.mark.parametrize("wscan", [1, 0], ids=["wave-owned-scan", "block-scan"])
+def test_bm25_configs2_exact(engine, sparse_data, variant, k, n_sample, wscan):
+    """B = 256: the document range of every query is split over two workgroups (segments) whose lists are merged."""
+    queries = sparse_data[4]
+    idx = host_index(sparse_data, variant)
+    engine.set_option("bm25_wscan", wscan)
+    try:
+        engine.set_bm25(idx)
+        qi, qt = queries_to_csr(queries[:256])
+        ids, sc, ln = engine.bm25_topk(qi, qt, k)
+    finally:
+        engine.set_option("bm25_wscan", 1)
+    assert np.all(ln == k)
+    for b in list(range(0, 256, 256 // n_sample))[:n_sample]:
+        want = bm25_filter(sparse_oracle_scores(idx, queries[b]), k)
+        assert list(ids[b, :ln[b]]) == [w[0] for w in want], f"query {b}: ids differ"
+        assert list(sc[b, :ln[b]]) == [w[1] for w in want], f"query {b}: scores differ"
