@@ -67,6 +67,7 @@ SIGNATURES = {
     "erh_dense_check": (_i32, [_vp, _vp]),
     "erh_debug_counters": (_i32, [_vp, _vp]),
     "erh_dense_diag": (_i32, [_vp, C.POINTER(_dbl), C.POINTER(_dbl), C.POINTER(_i32)]),
+    "erh_dense_exhaustive_count": (_i32, [_vp, C.POINTER(_i32)]),
     "erh_debug_dense_scores": (_i32, [_vp, _vp, _i32, _i64, _i32, _i32, _vp]),
 }
 

@@ -107,6 +107,19 @@ struct erh_handle {
     // diag of the last dense call
     double diag_maxerr = 0, diag_margin = 0;
     int32_t diag_uncert = 0;
+    int32_t diag_exhaustive = 0;            // queries of the last call answered by the exhaustive path
+    // exhaustive path (select.hip): per-query "not certifiable from the candidate list" flags, work space, and what
+    // the last dense call needs for further rounds from the host (more than dense_exhaustive_max() flagged queries)
+    DevBuf bad, ex_ws;
+    struct LastDense {
+        bool valid = false, hybrid = false;
+        int B = 0, k = 0;
+        const int16_t *filter_dev = nullptr;
+        int32_t *d_ids = nullptr; double *d_sc = nullptr; int32_t *d_len = nullptr;
+        // hybrid: the fusion to redo after the dense lists changed
+        int k_sparse = 0, K = 0, topk = 0;
+        int32_t *f_ids = nullptr; double *f_sc = nullptr; int32_t *f_len = nullptr;
+    } last;
 
     int fail(int code, const char *what, hipError_t e = hipSuccess) {
         char buf[512];
@@ -215,6 +228,10 @@ int dense_topk_dev(erh_handle *h, const void *q_dev, int q_dtype, int normalize_
     HIPCHK(h, h->cand_cnt.ensure((size_t)B * 4));
     HIPCHK(h, h->flags.ensure(64));
     HIPCHK(h, h->seed_need.ensure((size_t)B * 4));
+    HIPCHK(h, h->bad.ensure((size_t)B * 4));
+    HIPCHK(h, h->ex_ws.ensure(erh::dense_exhaustive_bytes(N)));
+    HIPCHK(h, hipMemsetAsync(h->bad.p, 0, (size_t)B * 4, st));
+    uint32_t *bad = h->bad.as<uint32_t>();
     int64_t n0 = std::min<int64_t>(std::min<int64_t>(h->opt_n0, erh::kDenseN0Max), N);
     if (n0 < 1) n0 = 1;
     const int ld = round_up((int)n0, 256);
@@ -252,7 +269,7 @@ int dense_topk_dev(erh_handle *h, const void *q_dev, int q_dtype, int normalize_
     { ProfScope ps(h, st, ERH_K_DENSE_SELECT, 0, 0);
       HIPCHK(h, erh::launch_seed_select(h->S0.as<float>(), ld, (int)n0, 0, B, k, h->qnorm.as<float>(), h->xnorm_max, d,
                                         filter_dev, dir, h->tau.as<float>(), h->cand.as<ErhCand>(),
-                                        h->cand_cnt.as<uint32_t>(), cap, flags, h->seed_need.as<uint32_t>(), st)); }
+                                        h->cand_cnt.as<uint32_t>(), cap, bad, h->seed_need.as<uint32_t>(), st)); }
     if (N > n0) {
         // Stage boundaries n0 < b1 < b2 < ... < N: the threshold is refined (and the candidate list cut back to what
         // still matters) at every boundary, so a stage adds about k * (b_next - b) / b candidates however large N is.
@@ -291,7 +308,7 @@ int dense_topk_dev(erh_handle *h, const void *q_dev, int q_dtype, int normalize_
             if (next < N) {
                 ProfScope ps(h, st, ERH_K_DENSE_SELECT, 0, 0);
                 HIPCHK(h, erh::launch_cand_refine(B, k, h->qnorm.as<float>(), h->xnorm_max, d, h->tau.as<float>(),
-                                                  h->cand.as<ErhCand>(), h->cand_cnt.as<uint32_t>(), cap, st));
+                                                  h->cand.as<ErhCand>(), h->cand_cnt.as<uint32_t>(), cap, bad, st));
                 want = (N >= 8 * next) ? 4 * next : 0;                  // another boundary only if plenty of corpus remains
             }
             cur = next;
@@ -300,21 +317,51 @@ int dense_topk_dev(erh_handle *h, const void *q_dev, int q_dtype, int normalize_
     { ProfScope ps(h, st, ERH_K_DENSE_SELECT, 0, 0);
       HIPCHK(h, erh::launch_dense_finalize(B, k, mode, h->qnorm.as<float>(), h->xnorm_max, d, X, Q16,
                                            h->cand.as<ErhCand>(), h->cand_cnt.as<uint32_t>(), cap, d_ids, d_sc, d_len,
-                                           reinterpret_cast<float *>(flags + 1), flags + 2, flags, N, h->pos_mul, h->pos_inv, st)); }
+                                           reinterpret_cast<float *>(flags + 1), flags + 2, bad, N, h->pos_mul, h->pos_inv, st));
+      // queries the candidate budgets could not certify get their exact answer from the exhaustive path (two empty
+      // launches when there are none); it also settles the overflow word: set only if more than
+      // dense_exhaustive_max() queries were flagged, in which case dense_check_flags runs further rounds
+      HIPCHK(h, erh::launch_dense_exhaustive(bad, B, 0, k, X, N, d, Q16, filter_dev,
+                                             h->has_dir ? h->dir_id.as<int16_t>() : nullptr, h->pos_inv, h->ex_ws.p,
+                                             flags, h->n_cus, d_ids, d_sc, d_len, st)); }
+    h->last = erh_handle::LastDense();
+    h->last.valid = true;
+    h->last.B = B; h->last.k = k; h->last.filter_dev = filter_dev;
+    h->last.d_ids = d_ids; h->last.d_sc = d_sc; h->last.d_len = d_len;
     return ERH_OK;
 }
 
-// Read the flag words of the last dense call (synchronises the stream).
+// Read the flag words of the last dense call (synchronises the stream).  If more queries were flagged than one
+// device-side round of the exhaustive path handles, the remaining rounds run here (and a fused call's RRF is redone
+// over the corrected dense lists), so the caller always gets an answer.
 int dense_check_flags(erh_handle *h, hipStream_t st) {
     uint32_t f[4] = {0, 0, 0, 0};
     HIPCHK(h, hipMemcpyAsync(f, h->flags.p, sizeof f, hipMemcpyDeviceToHost, st));
     HIPCHK(h, hipStreamSynchronize(st));
+    if (f[0] && h->last.valid) {
+        const int total = (int)f[3], per = erh::dense_exhaustive_max();
+        const erh_handle::LastDense &L = h->last;
+        for (int skip = per; skip < total; skip += per)
+            HIPCHK(h, erh::launch_dense_exhaustive(h->bad.as<uint32_t>(), L.B, skip, L.k, h->X.as<_Float16>(), h->N, h->d,
+                                                   h->Q16.as<_Float16>(), L.filter_dev,
+                                                   h->has_dir ? h->dir_id.as<int16_t>() : nullptr, h->pos_inv,
+                                                   h->ex_ws.p, h->flags.as<uint32_t>(), h->n_cus, L.d_ids, L.d_sc,
+                                                   L.d_len, st));
+        if (L.hybrid) {
+            const int32_t *cid = h->has_content ? h->content_id.as<int32_t>() : nullptr;
+            HIPCHK(h, erh::launch_rrf(h->hy_sids.as<int32_t>(), h->hy_slen.as<int32_t>(), L.k_sparse, L.d_ids, L.d_len,
+                                      L.k, cid, L.B, L.K, L.topk, L.f_ids, L.f_sc, L.f_len, st));
+        }
+        HIPCHK(h, hipMemcpyAsync(f, h->flags.p, sizeof f, hipMemcpyDeviceToHost, st));
+        HIPCHK(h, hipStreamSynchronize(st));
+    }
     float me;
     memcpy(&me, &f[1], 4);
     h->diag_maxerr = me;
     h->diag_uncert = (int32_t)f[2];
+    h->diag_exhaustive = (int32_t)f[3];
     h->diag_margin = 2.0 * (double)h->d * 1.1920929e-7 * (double)h->xnorm_max;   // for a unit-norm query
-    if (f[0]) return h->fail(ERH_ERR_OVERFLOW, "dense candidate list overflowed (too many near-threshold chunks)");
+    if (f[0]) return h->fail(ERH_ERR_OVERFLOW, "dense candidate list overflowed and the exhaustive path could not finish");
     return ERH_OK;
 }
 
@@ -435,7 +482,7 @@ int erh_destroy(erh_handle *h) {
                       &h->o_ids, &h->o_sc, &h->o_len, &h->qptr, &h->qtok, &h->part_sc, &h->part_ids, &h->part_len,
                       &h->hy_sids, &h->hy_ssc, &h->hy_slen, &h->hy_dids, &h->hy_dsc, &h->hy_dlen,
                       &h->fa_ids, &h->fa_sc, &h->fa_len, &h->fb_ids, &h->fb_sc, &h->fb_len,
-                      &h->scores_tmp, &h->scores_wide, &h->dbg, &h->dir_pos, &h->seed_need};
+                      &h->scores_tmp, &h->scores_wide, &h->dbg, &h->dir_pos, &h->seed_need, &h->bad, &h->ex_ws};
     for (DevBuf *b : bufs) b->release();
     for (auto &b : h->bm) b.release();
     if (h->comm) (void)erh_comm_destroy(h);
@@ -537,6 +584,12 @@ int erh_dense_diag(erh_handle *h, double *max_abs_err, double *margin, int32_t *
     if (max_abs_err) *max_abs_err = h->diag_maxerr;
     if (margin) *margin = h->diag_margin;
     if (uncertified) *uncertified = h->diag_uncert;
+    return ERH_OK;
+}
+
+int erh_dense_exhaustive_count(erh_handle *h, int32_t *count) {
+    if (!h || !count) return ERH_ERR_INVALID;
+    *count = h->diag_exhaustive;
     return ERH_OK;
 }
 
@@ -788,9 +841,9 @@ int erh_dense_topk(erh_handle *h, const void *q, int q_dtype, int q_is_device, i
     rc = dense_topk_dev(h, qd, q_dtype, normalize_q, B, k, filt, mode, d_ids, d_sc, d_len, st);
     if (rc != ERH_OK) return rc;
     if (!out_is_device) {
-        rc = copy_out(h, B, k, d_ids, d_sc, d_len, out_ids, out_scores, out_len, st);
+        rc = dense_check_flags(h, st);                  // (may run further exhaustive rounds before the copy)
         if (rc != ERH_OK) return rc;
-        return dense_check_flags(h, st);
+        return copy_out(h, B, k, d_ids, d_sc, d_len, out_ids, out_scores, out_len, st);
     }
     return ERH_OK;
 }
@@ -967,10 +1020,13 @@ int erh_hybrid_topk(erh_handle *h, const void *q, int q_dtype, int q_is_device, 
       HIPCHK(h, erh::launch_rrf(h->hy_sids.as<int32_t>(), h->hy_slen.as<int32_t>(), k_sparse,
                                 h->hy_dids.as<int32_t>(), h->hy_dlen.as<int32_t>(), k_dense, cid, B, K, topk,
                                 d_ids, d_sc, d_len, st)); }
+    h->last.hybrid = true;
+    h->last.k_sparse = k_sparse; h->last.K = K; h->last.topk = topk;
+    h->last.f_ids = d_ids; h->last.f_sc = d_sc; h->last.f_len = d_len;
     if (!out_is_device) {
-        rc = copy_out(h, B, topk, d_ids, d_sc, d_len, out_ids, out_scores, out_len, st);
+        rc = dense_check_flags(h, st);
         if (rc != ERH_OK) return rc;
-        return dense_check_flags(h, st);
+        return copy_out(h, B, topk, d_ids, d_sc, d_len, out_ids, out_scores, out_len, st);
     }
     return ERH_OK;
 }

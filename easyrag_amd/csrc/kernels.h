@@ -51,18 +51,25 @@ hipError_t launch_row_norm_max(const _Float16 *x, int64_t n, int d, float *out, 
 hipError_t launch_seed_select(const float *S0, int ld_s0, int n0, int64_t c0, int B, int k,
                               const float *qnorm, float xnorm_max, int d,
                               const int16_t *filter_dir, const int16_t *dir_id,
-                              float *tau, ErhCand *cand, uint32_t *cand_cnt, int cap, uint32_t *overflow, uint32_t *need_full,
+                              float *tau, ErhCand *cand, uint32_t *cand_cnt, int cap, uint32_t *bad, uint32_t *need_full,
                               hipStream_t st);
 // Refine: k-th best over the current candidates -> tighter tau; candidates below it are dropped.
 hipError_t launch_cand_refine(int B, int k, const float *qnorm, float xnorm_max, int d,
-                              float *tau, ErhCand *cand, uint32_t *cand_cnt, int cap, hipStream_t st);
+                              float *tau, ErhCand *cand, uint32_t *cand_cnt, int cap, uint32_t *bad, hipStream_t st);
 // Final: sort candidates, (EXACT) re-score the margin set in pinned fp64, rank, write top-k.
 hipError_t launch_dense_finalize(int B, int k, int mode, const float *qnorm, float xnorm_max, int d,
                                  const _Float16 *X, const _Float16 *Q16,
                                  const ErhCand *cand, const uint32_t *cand_cnt, int cap,
                                  int32_t *out_ids, double *out_scores, int32_t *out_len,
-                                 float *diag_maxerr, uint32_t *diag_uncert, uint32_t *overflow, int64_t N, int64_t pos_mul,
+                                 float *diag_maxerr, uint32_t *diag_uncert, uint32_t *bad, int64_t N, int64_t pos_mul,
                                  int64_t pos_inv, hipStream_t st);
+// Exhaustive path for the queries flagged in bad[] (select.hip): exact fp64 scores of every chunk + streaming top-k.
+int dense_exhaustive_max();
+size_t dense_exhaustive_bytes(int64_t N);
+hipError_t launch_dense_exhaustive(const uint32_t *bad, int B, int skip, int k, const _Float16 *X, int64_t N, int d,
+                                   const _Float16 *Q16, const int16_t *filter_dir, const int16_t *dir_id,
+                                   int64_t pos_inv, void *ws, uint32_t *flags, int n_cus,
+                                   int32_t *out_ids, double *out_scores, int32_t *out_len, hipStream_t st);
 
 // ---- bm25.hip --------------------------------------------------------------------------------
 constexpr int kBm25TileF32 = 32768;   // documents per LDS accumulator tile (fp32 sums)

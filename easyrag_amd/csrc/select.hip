@@ -148,7 +148,7 @@ __device__ __forceinline__ uint32_t seed_key(const float *__restrict__ row, int 
 __device__ __forceinline__ void seed_emit(const float *__restrict__ row, int n0, int64_t c0, int fd,
                                           const int16_t *__restrict__ dir_id, float prune, int q,
                                           float *__restrict__ tau, ErhCand *__restrict__ cand,
-                                          uint32_t *__restrict__ cand_cnt, int cap, uint32_t *__restrict__ overflow,
+                                          uint32_t *__restrict__ cand_cnt, int cap, uint32_t *__restrict__ bad,
                                           int *s_cnt) {
     const int tid = threadIdx.x;
     if (tid == 0) tau[q] = prune;
@@ -170,7 +170,7 @@ __device__ __forceinline__ void seed_emit(const float *__restrict__ row, int n0,
     if (tid == 0) {
         const int c = *s_cnt;
         cand_cnt[q] = (uint32_t)(c < cap ? c : cap);
-        if (c > cap) atomicOr(overflow, 1u);
+        if (c > cap) bad[q] = 1u;                        // list too short for this query: the exhaustive path answers it
     }
 }
 
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(kSelThreads) void seed_select_kernel(
     const float *__restrict__ qnorm, float xnorm_max, int d,
     const int16_t *__restrict__ filter_dir, const int16_t *__restrict__ dir_id,
     float *__restrict__ tau, ErhCand *__restrict__ cand, uint32_t *__restrict__ cand_cnt, int cap,
-    uint32_t *__restrict__ overflow, uint32_t *__restrict__ need_full) {
+    uint32_t *__restrict__ bad, uint32_t *__restrict__ need_full) {
     __shared__ int s_nvalid, s_cnt, s_cnt2;
     __shared__ uint32_t tmax[kSelThreads];
     __shared__ uint32_t buf[kSeedBuf];
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(kSelThreads) void seed_select_kernel(
             return;
         }
     }
-    seed_emit(row, n0, c0, fd, dir_id, prune, q, tau, cand, cand_cnt, cap, overflow, &s_cnt);
+    seed_emit(row, n0, c0, fd, dir_id, prune, q, tau, cand, cand_cnt, cap, bad, &s_cnt);
 }
 
 // Full-sort fallback for the queries flagged by seed_select_kernel.  dynamic LDS = 64 + np2*4 bytes.
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(kSelThreads) void seed_select_full_kernel(
     const float *__restrict__ qnorm, float xnorm_max, int d,
     const int16_t *__restrict__ filter_dir, const int16_t *__restrict__ dir_id,
     float *__restrict__ tau, ErhCand *__restrict__ cand, uint32_t *__restrict__ cand_cnt, int cap,
-    uint32_t *__restrict__ overflow, const uint32_t *__restrict__ need_full) {
+    uint32_t *__restrict__ bad, const uint32_t *__restrict__ need_full) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int q = blockIdx.x, tid = threadIdx.x;
     if (!need_full[q]) return;                       // uniform
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(kSelThreads) void seed_select_full_kernel(
     erh_bitonic_desc<uint32_t>(keys, np2);
     const float prune = erh_ord2f(keys[k - 1]) - margin_of(qnorm[q], xnorm_max, d);
     __syncthreads();
-    seed_emit(row, n0, c0, fd, dir_id, prune, q, tau, cand, cand_cnt, cap, overflow, &s_cnt);
+    seed_emit(row, n0, c0, fd, dir_id, prune, q, tau, cand, cand_cnt, cap, bad, &s_cnt);
 }
 
 // ---- refine: tighten tau from the candidates gathered so far --------------------------------------
@@ -262,13 +262,16 @@ constexpr int kRefineLight = 4096;
 __global__ __launch_bounds__(kSelThreads) void cand_refine_kernel(
     int k, int cp2, const float *__restrict__ qnorm, float xnorm_max, int d,
     float *__restrict__ tau, ErhCand *__restrict__ cand, uint32_t *__restrict__ cand_cnt, int cap, int lo_excl,
-    int hi_incl /* this launch handles lists with lo_excl < count <= hi_incl */) {
+    int hi_incl /* this launch handles lists with lo_excl < count <= hi_incl */, uint32_t *__restrict__ bad) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int &s_keep = *reinterpret_cast<int *>(smem);
     uint64_t *keys = reinterpret_cast<uint64_t *>(smem + 64);
     const int q = blockIdx.x, tid = threadIdx.x;
     int c = (int)cand_cnt[q];
-    if (c > cap) c = cap;
+    if (c > cap) {                                         // appends were dropped in the stage before this boundary
+        if (threadIdx.x == 0 && hi_incl >= cap) bad[q] = 1u;
+        c = cap;
+    }
     if (c <= lo_excl || c > hi_incl) return;               // the other launch's query (uniform)
     if (c < k) return;                                     // nothing to learn yet (uniform)
     ErhCand *mine = cand + (int64_t)q * cap;
@@ -318,7 +321,7 @@ __global__ __launch_bounds__(kFinThreads) void dense_finalize_kernel(
     const _Float16 *__restrict__ X, const _Float16 *__restrict__ Q16,
     const ErhCand *__restrict__ cand, const uint32_t *__restrict__ cand_cnt, int cap,
     int32_t *__restrict__ out_ids, double *__restrict__ out_scores, int32_t *__restrict__ out_len,
-    float *__restrict__ diag_maxerr, uint32_t *__restrict__ diag_uncert, uint32_t *__restrict__ overflow,
+    float *__restrict__ diag_maxerr, uint32_t *__restrict__ diag_uncert, uint32_t *__restrict__ bad,
     int64_t N, int64_t pos_mul, int64_t pos_inv /* candidates carry stored positions: orig = pos * pos_inv mod N */) {
     __shared__ __attribute__((aligned(16))) uint64_t buf[kFinBuf];
     __shared__ uint32_t tmax[kFinSlots];
@@ -330,7 +333,10 @@ __global__ __launch_bounds__(kFinThreads) void dense_finalize_kernel(
     __shared__ unsigned int s_maxerr;
     const int q = blockIdx.x, tid = threadIdx.x;
     int c = (int)cand_cnt[q];
-    if (c > cap) c = cap;
+    if (c > cap) {                                                      // appends were dropped: not answerable from the list
+        if (tid == 0) bad[q] = 1u;
+        c = cap;
+    }
     const ErhCand *mine = cand + (int64_t)q * cap;
     const int kk = k < c ? k : c;
     int32_t *o_ids = out_ids + (int64_t)q * k;
@@ -363,7 +369,7 @@ __global__ __launch_bounds__(kFinThreads) void dense_finalize_kernel(
     __syncthreads();
     int g = s_cnt;
     if (g > kFinBuf) {                                                  // uniform; pathological tie clusters only
-        if (tid == 0) { atomicOr(overflow, 1u); atomicAdd(diag_uncert, 1u); }
+        if (tid == 0) { bad[q] = 1u; atomicAdd(diag_uncert, 1u); }
         g = kFinBuf;
     }
     const int ns = erh_next_pow2(g < 2 ? 2 : g);
@@ -494,8 +500,167 @@ __global__ __launch_bounds__(kFinThreads) void dense_finalize_kernel(
     if (tid == 0) {
         const float me = __uint_as_float(s_maxerr);
         atomicMax((unsigned int *)diag_maxerr, __float_as_uint(me));
-        if (uncertified || me > delta) atomicAdd(diag_uncert, 1u);
+        if (uncertified || me > delta) { atomicAdd(diag_uncert, 1u); bad[q] = 1u; }   // re-score set cut, or the error bound failed
     }
+}
+
+// ---- exhaustive path: queries the pruned pipeline could not certify ----------------------------------------------
+// The reference always answers (Qdrant's exact scan has no candidate budget).  The pruned pipeline has three: a
+// 16384-entry candidate list per query, a 2048-entry gather and a 1024-row fp64 re-score set -- a corpus with tens of
+// thousands of (near-)duplicates of what a query asks for exhausts them.  Every such query is flagged in bad[q]
+// and answered here instead, with the same contract and no budget at all:
+//   1. dense_exact_all_kernel   the pinned-order fp64 score of EVERY chunk (one more pass over the matrix per group
+//                               of kExGroup flagged queries; products of fp16 values are exact in fp64, the sum order
+//                               is dense_finalize_kernel's) -> S64[slot][position];
+//   2. dense_exact_select_kernel one workgroup per flagged query streams its S64 row through a 2048-entry list kept
+//                               under an exact (score, index) threshold -- ties resolve by original index as always --
+//                               and writes the query's final top-k over whatever the pruned pipeline wrote.
+// Both are always enqueued (they cost two empty launches when nothing is flagged) so device-output pipelines such
+// as erh_hybrid_topk stay free of host round trips.  kExMax flagged queries are handled per call on the device; more
+// than that (a batch that is pathological as a whole) is finished by further rounds from the host at the next
+// synchronisation point (api.hip: dense_check_flags).
+constexpr int kExGroup = 4;
+constexpr int kExMax = 16;
+constexpr int kExCap = 2048;
+
+// list[0 .. kExMax) = flagged queries of rank skip .. skip + kExMax - 1 (ascending), count[0] = how many, count[1] = all flagged
+__global__ __launch_bounds__(1024) void dense_bad_collect_kernel(const uint32_t *__restrict__ bad, int B, int skip,
+                                                                int32_t *__restrict__ list, int32_t *__restrict__ count,
+                                                                uint32_t *__restrict__ flags) {
+    __shared__ int s_base, s_taken;
+    const int tid = threadIdx.x;
+    if (tid == 0) { s_base = 0; s_taken = 0; }
+    __syncthreads();
+    for (int q0 = 0; q0 < B; q0 += 1024) {                               // ascending order by construction
+        const int q = q0 + tid;
+        const bool f = q < B && bad[q] != 0u;
+        // rank of q among the flagged: block-wide exclusive scan by wave ballots
+        __shared__ int wsum[16];
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(f);
+        const int lane = tid & 63, w = tid >> 6;
+        const int within = __builtin_popcountll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[w] = __builtin_popcountll(m);
+        __syncthreads();
+        int before = s_base;
+        for (int i = 0; i < w; ++i) before += wsum[i];
+        if (f) {
+            const int r = before + within - skip;
+            if (r >= 0 && r < kExMax) { list[r] = q; atomicAdd(&s_taken, 1); }
+        }
+        __syncthreads();
+        if (tid == 0) { int t = 0; for (int i = 0; i < 16; ++i) t += wsum[i]; s_base += t; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        count[0] = s_taken;
+        count[1] = s_base;
+        flags[0] = (s_base > skip + kExMax) ? 1u : 0u;                   // still unanswered after this round
+        flags[3] = (uint32_t)s_base;
+        if (s_base <= skip + kExMax) flags[2] = 0u;                      // every flagged query gets its exact answer
+    }
+}
+
+// grid = any, block = 256 (4 waves), dynamic LDS = kExGroup * d * 2 bytes.  One wave per row and iteration.
+__global__ __launch_bounds__(256) void dense_exact_all_kernel(const _Float16 *__restrict__ X, int64_t N, int d,
+                                                            const _Float16 *__restrict__ Q16,
+                                                            const int32_t *__restrict__ list,
+                                                            const int32_t *__restrict__ count, double *__restrict__ S64) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    _Float16 *qs = reinterpret_cast<_Float16 *>(smem);
+    const int n_bad = count[0];
+    if (n_bad <= 0) return;                                              // the normal case: nothing to do
+    const int lane = threadIdx.x & 63;
+    const int64_t wave_g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * 4;
+    for (int g0 = 0; g0 < n_bad; g0 += kExGroup) {
+        const int ng = (n_bad - g0 < kExGroup) ? n_bad - g0 : kExGroup;
+        __syncthreads();
+        for (int i = threadIdx.x; i < ng * (d / 8); i += 256) {
+            const int g = i / (d / 8), o = i % (d / 8);
+            reinterpret_cast<half8 *>(qs)[g * (d / 8) + o] =
+                reinterpret_cast<const half8 *>(Q16 + (int64_t)list[g0 + g] * d)[o];
+        }
+        __syncthreads();
+        for (int64_t pos = wave_g; pos < N; pos += n_waves) {
+            const _Float16 *xr = X + pos * d;
+            double acc[kExGroup];
+#pragma unroll
+            for (int g = 0; g < kExGroup; ++g) acc[g] = 0.0;
+            for (int off = 8 * lane; off < d; off += 512) {               // lane j: elements 512*t + 8*j + e, sequentially
+                const half8 xv = *reinterpret_cast<const half8 *>(xr + off);
+#pragma unroll
+                for (int g = 0; g < kExGroup; ++g) {
+                    if (g < ng) {
+                        const half8 qv = *reinterpret_cast<const half8 *>(qs + g * d + off);
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) acc[g] = acc[g] + (double)((float)xv[u] * (float)qv[u]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < kExGroup; ++g)
+                for (int o = 32; o >= 1; o >>= 1) acc[g] = acc[g] + __shfl_xor(acc[g], o);
+            if (lane == 0) {
+#pragma unroll
+                for (int g = 0; g < kExGroup; ++g)
+                    if (g < ng) S64[(int64_t)(g0 + g) * N + pos] = acc[g];
+            }
+        }
+    }
+}
+
+// grid = kExMax, block = 1024.
+__global__ __launch_bounds__(1024) void dense_exact_select_kernel(
+    const double *__restrict__ S64, int64_t N, int k, const int32_t *__restrict__ list, const int32_t *__restrict__ count,
+    const int16_t *__restrict__ filter_dir, const int16_t *__restrict__ dir_id /* by ORIGINAL index */, int64_t pos_inv,
+    int32_t *__restrict__ out_ids, double *__restrict__ out_scores, int32_t *__restrict__ out_len) {
+    __shared__ double cs[kExCap];
+    __shared__ int32_t ci[kExCap];
+    __shared__ int s_n;
+    __shared__ double s_tau;
+    __shared__ int s_tau_idx, s_have_tau;
+    const int slot = blockIdx.x, tid = threadIdx.x;
+    if (slot >= count[0]) return;                                        // uniform
+    const int q = list[slot];
+    const int fd = filter_dir ? (int)filter_dir[q] : -1;
+    const double *row = S64 + (int64_t)slot * N;
+    if (tid == 0) { s_n = 0; s_have_tau = 0; s_tau = 0.0; s_tau_idx = 0; }
+    __syncthreads();
+    auto shrink = [&]() {                                                // uniform call: sort, keep k, refresh the threshold
+        __syncthreads();
+        const int n = s_n;
+        const int np2 = erh_next_pow2(n < 2 ? 2 : n);
+        for (int i = n + tid; i < np2; i += 1024) { cs[i] = -INFINITY; ci[i] = 0x7fffffff; }
+        erh_bitonic_rec_desc<double>(cs, ci, np2);
+        if (tid == 0) {
+            s_n = n < k ? n : k;
+            if (n >= k) { s_have_tau = 1; s_tau = cs[k - 1]; s_tau_idx = ci[k - 1]; }
+        }
+        __syncthreads();
+    };
+    for (int64_t p0 = 0; p0 < N; p0 += 1024) {
+        if (s_n > kExCap - 1024) shrink();                               // uniform (read after a barrier): appends below always fit
+        const int64_t pos = p0 + tid;
+        if (pos < N) {
+            const double s = row[pos];
+            const int32_t orig = (int32_t)erh_mulmod(pos, pos_inv, N);
+            bool pass = !s_have_tau || s > s_tau || (s == s_tau && orig < s_tau_idx);
+            if (pass && fd >= 0 && (int)dir_id[orig] != fd) pass = false;
+            if (pass) {
+                const int at = atomicAdd(&s_n, 1);
+                cs[at] = s;
+                ci[at] = orig;
+            }
+        }
+        __syncthreads();
+    }
+    shrink();
+    const int n = s_n < k ? s_n : k;
+    for (int i = tid; i < k; i += 1024) {
+        out_ids[(int64_t)q * k + i] = i < n ? ci[i] : -1;
+        out_scores[(int64_t)q * k + i] = i < n ? cs[i] : 0.0;
+    }
+    if (tid == 0) out_len[q] = n;
 }
 
 }  // namespace
@@ -566,27 +731,27 @@ hipError_t launch_row_norm_max(const _Float16 *x, int64_t n, int d, float *out, 
 hipError_t launch_seed_select(const float *S0, int ld_s0, int n0, int64_t c0, int B, int k,
                               const float *qnorm, float xnorm_max, int d,
                               const int16_t *filter_dir, const int16_t *dir_id,
-                              float *tau, ErhCand *cand, uint32_t *cand_cnt, int cap, uint32_t *overflow,
+                              float *tau, ErhCand *cand, uint32_t *cand_cnt, int cap, uint32_t *bad,
                               uint32_t *need_full, hipStream_t st) {
     const int np2 = pow2_ge(n0 < 2 ? 2 : n0);
     hipLaunchKernelGGL(seed_select_kernel, dim3(B), dim3(kSelThreads), 0, st,
                        S0, ld_s0, n0, np2, c0, k, qnorm, xnorm_max, d, filter_dir, dir_id, tau, cand, cand_cnt, cap,
-                       overflow, need_full);
+                       bad, need_full);
     hipLaunchKernelGGL(seed_select_full_kernel, dim3(B), dim3(kSelThreads), (size_t)np2 * 4 + 64, st,
                        S0, ld_s0, n0, np2, c0, k, qnorm, xnorm_max, d, filter_dir, dir_id, tau, cand, cand_cnt, cap,
-                       overflow, need_full);
+                       bad, need_full);
     return hipGetLastError();
 }
 
 hipError_t launch_cand_refine(int B, int k, const float *qnorm, float xnorm_max, int d,
-                              float *tau, ErhCand *cand, uint32_t *cand_cnt, int cap, hipStream_t st) {
+                              float *tau, ErhCand *cand, uint32_t *cand_cnt, int cap, uint32_t *bad, hipStream_t st) {
     const int cp2 = pow2_ge(cap);
     const int light = cp2 < kRefineLight ? cp2 : kRefineLight;
     hipLaunchKernelGGL(cand_refine_kernel, dim3(B), dim3(kSelThreads), (size_t)light * 8 + 64, st,
-                       k, light, qnorm, xnorm_max, d, tau, cand, cand_cnt, cap, -1, light);
+                       k, light, qnorm, xnorm_max, d, tau, cand, cand_cnt, cap, -1, light, bad);
     if (cp2 > light)
         hipLaunchKernelGGL(cand_refine_kernel, dim3(B), dim3(kSelThreads), (size_t)cp2 * 8 + 64, st,
-                           k, cp2, qnorm, xnorm_max, d, tau, cand, cand_cnt, cap, light, cp2);
+                           k, cp2, qnorm, xnorm_max, d, tau, cand, cand_cnt, cap, light, cp2, bad);
     return hipGetLastError();
 }
 
@@ -594,11 +759,34 @@ hipError_t launch_dense_finalize(int B, int k, int mode, const float *qnorm, flo
                                  const _Float16 *X, const _Float16 *Q16,
                                  const ErhCand *cand, const uint32_t *cand_cnt, int cap,
                                  int32_t *out_ids, double *out_scores, int32_t *out_len,
-                                 float *diag_maxerr, uint32_t *diag_uncert, uint32_t *overflow, int64_t N,
+                                 float *diag_maxerr, uint32_t *diag_uncert, uint32_t *bad, int64_t N,
                                  int64_t pos_mul, int64_t pos_inv, hipStream_t st) {
     hipLaunchKernelGGL(dense_finalize_kernel, dim3(B), dim3(kFinThreads), 0, st,
                        k, mode, qnorm, xnorm_max, d, X, Q16, cand, cand_cnt, cap,
-                       out_ids, out_scores, out_len, diag_maxerr, diag_uncert, overflow, N, pos_mul, pos_inv);
+                       out_ids, out_scores, out_len, diag_maxerr, diag_uncert, bad, N, pos_mul, pos_inv);
+    return hipGetLastError();
+}
+
+int dense_exhaustive_max() { return kExMax; }
+size_t dense_exhaustive_bytes(int64_t N) { return (size_t)kExMax * (size_t)N * 8 + 64 * 4; }
+
+// ws = [S64 kExMax x N doubles | list int32[kExMax] | count int32[2]]; flags = the call's flag words.
+hipError_t launch_dense_exhaustive(const uint32_t *bad, int B, int skip, int k, const _Float16 *X, int64_t N, int d,
+                                   const _Float16 *Q16, const int16_t *filter_dir, const int16_t *dir_id,
+                                   int64_t pos_inv, void *ws, uint32_t *flags, int n_cus,
+                                   int32_t *out_ids, double *out_scores, int32_t *out_len, hipStream_t st) {
+    double *S64 = reinterpret_cast<double *>(ws);
+    int32_t *list = reinterpret_cast<int32_t *>(S64 + (size_t)kExMax * (size_t)N);
+    int32_t *count = list + kExMax;
+    hipLaunchKernelGGL(dense_bad_collect_kernel, dim3(1), dim3(1024), 0, st, bad, B, skip, list, count, flags);
+    const size_t lds = (size_t)kExGroup * d * 2;
+    hipError_t e = hipFuncSetAttribute((const void *)dense_exact_all_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(dense_exact_all_kernel, dim3((unsigned)(n_cus * 8)), dim3(256), lds, st, X, N, d, Q16, list, count,
+                       S64);
+    hipLaunchKernelGGL(dense_exact_select_kernel, dim3(kExMax), dim3(1024), 0, st, S64, N, k, list, count, filter_dir,
+                       dir_id, pos_inv, out_ids, out_scores, out_len);
     return hipGetLastError();
 }
 

@@ -384,7 +384,9 @@ class RetrievalEngine:
     def dense_diag(self):
         e, m, u = C.c_double(), C.c_double(), C.c_int()
         self._check(self._lib.erh_dense_diag(self._h, C.byref(e), C.byref(m), C.byref(u)))
-        return {"max_abs_err": e.value, "margin": m.value, "uncertified": u.value}
+        x = C.c_int()
+        self._check(self._lib.erh_dense_exhaustive_count(self._h, C.byref(x)))
+        return {"max_abs_err": e.value, "margin": m.value, "uncertified": u.value, "exhaustive": x.value}
 
     def debug_dense_scores(self, q16: np.ndarray, row0: int, rows: int, use_mfma: bool) -> np.ndarray:
         q16 = np.ascontiguousarray(q16, dtype=np.float16)

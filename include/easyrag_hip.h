@@ -52,7 +52,7 @@ typedef struct erh_handle erh_handle;
 #define ERH_ERR_HIP         (-3)  /* a HIP runtime call failed (see erh_last_error) */
 #define ERH_ERR_STATE       (-4)  /* required data not set (e.g. dense search before erh_set_dense) */
 #define ERH_ERR_UNSUPPORTED (-5)  /* shape outside the supported range */
-#define ERH_ERR_OVERFLOW    (-6)  /* candidate work space overflowed; result not produced */
+#define ERH_ERR_OVERFLOW    (-6)  /* candidate work space overflowed and the exhaustive path could not finish */
 #define ERH_ERR_NOMEM       (-7)  /* device allocation failed */
 
 /* element types */
@@ -217,8 +217,10 @@ int erh_reset_kernel_time(erh_handle *h);
  *                         build contains none of these variants and rejects non-zero values (ERH_ERR_UNSUPPORTED). */
 int erh_set_option(erh_handle *h, const char *name, int64_t value);
 
-/* After a dense / hybrid call with DEVICE outputs: synchronise `stream`, read the call's flag words and
- * return ERH_ERR_OVERFLOW if a candidate list overflowed (host-output calls do this themselves). */
+/* After a dense / hybrid call with DEVICE outputs: synchronise `stream` and read the call's flag words (host-output
+ * calls do this themselves).  Queries whose candidate budgets overflowed are answered by the exhaustive path on the
+ * device, up to 16 per call without any host involvement; if a call flagged more, the remaining rounds (and, for a
+ * fused call, the RRF over the corrected lists) are run here, so that the results are complete when this returns. */
 int erh_dense_check(erh_handle *h, void *stream);
 
 /* Measurement only: with option "debug_counters" = 1 the scan kernels add per-section shader-clock sums
@@ -228,6 +230,12 @@ int erh_debug_counters(erh_handle *h, uint64_t *out16);
 /* Diagnostics of the last dense EXACT call: max |fp64 - fp32| over re-scored candidates, the
  * margin used, and the number of queries whose exactness certificate failed. */
 int erh_dense_diag(erh_handle *h, double *max_abs_err, double *margin, int32_t *uncertified);
+
+/* Queries of the last dense / hybrid call (as of its erh_dense_check or host-output return) that the pruned
+ * pipeline could not certify -- candidate list, gather or re-score budget exhausted, e.g. tens of thousands of
+ * near-duplicate chunks around the k-th score -- and that were answered by the exhaustive path instead (exact fp64
+ * score of every chunk, streaming top-k; same results contract).  Normally 0. */
+int erh_dense_exhaustive_count(erh_handle *h, int32_t *count);
 
 /* Debug: plain (non-MFMA) fp32 scores of B fp16 queries against rows [row0, row0+rows) of the stored
  * matrix, out float32[B*rows] on the host; and the MFMA scores of the same block. */

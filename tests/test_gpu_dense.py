@@ -171,8 +171,8 @@ def test_dense_corpus_sorted_by_topic(engine):
     """A corpus ordered by topic: the queries' topic fills the LAST 60 % of the rows, so a threshold seeded from the
     first rows of the caller's order would admit tens of thousands of candidates per query (more than the candidate
     lists hold).  Rows are stored in a golden-ratio placement, which makes every stored prefix an even sample of
-    the caller's order: the result is exact and no list overflows; with dense_shuffle=0 the same call reports the
-    overflow instead of returning a wrong answer."""
+    the caller's order: the result is exact and no list overflows; with dense_shuffle=0 the candidate lists do
+    overflow, and every query (12 of them) is then answered by the exhaustive path -- same ids, same scores."""
     rng = np.random.default_rng(31)
     n, d, b, k = 60000, 256, 12, 50
     topic_a = rng.standard_normal(d)
@@ -200,14 +200,83 @@ def test_dense_corpus_sorted_by_topic(engine):
         ids, sc, ln = engine.dense_topk(q16, k, filter_dir=filt)
         oid, osc = dense_exact_topk(x, q16[2], k, dir_id == 3)
         assert np.array_equal(ids[2], oid) and np.array_equal(sc[2].view(np.uint64), osc.view(np.uint64))
+        assert engine.dense_diag()["exhaustive"] == 0
         engine.set_option("dense_shuffle", 0)
         engine.set_dense(x)
-        with pytest.raises(_lib.ErhError):
-            engine.dense_topk(q16, k)
+        engine.set_doc_meta(n, None, dir_id)
+        for f, mask in ((None, None), (filt, dir_id == 3)):
+            ids, sc, ln = engine.dense_topk(q16, k, filter_dir=f)
+            assert engine.dense_diag()["exhaustive"] == b          # the reference always answers; so does this
+            for i in (0, 5, b - 1):
+                oid, osc = dense_exact_topk(x, q16[i], k, mask)
+                assert np.array_equal(ids[i, :ln[i]], oid)
+                assert np.array_equal(sc[i, :ln[i]].view(np.uint64), osc.view(np.uint64))
     finally:
         engine.set_option("dense_shuffle", 1)
         engine.set_option("dense_n0", 32768)
         engine.set_option("dense_n1", 131072)
+
+
+def test_dense_budgets_exhausted_still_answers(engine):
+    """Corpora that exhaust the pruned pipeline's budgets (boilerplate-heavy manuals are exactly EasyRAG's
+    data): 20000 exact copies of the chunk a query asks for (the 16384-entry candidate list cannot hold the tie
+    block), 3000 near-copies whose fp32 scores all sit inside the pruning margin (the 1024-row fp64 re-score set is
+    too small), and a batch in which 40 queries need the exhaustive path at once (more than one device-side round),
+    alone and inside the fused dual route."""
+    from easyrag_amd.engine import queries_to_csr
+    from easyrag_amd.index import BM25S, build_bm25_index
+    from oracle import BM25SLucene, bm25_filter, reciprocal_rank_fusion
+    from oracle.retrievers import Item
+    rng = np.random.default_rng(41)
+    n, d, k = 50000, 128, 60
+    x = to_f16_unit(rng.standard_normal((n, d)))
+    hot = to_f16_unit(rng.standard_normal(d))[0]
+    copies = np.sort(rng.choice(n, size=20000, replace=False))
+    x[copies] = hot
+    near = to_f16_unit(rng.standard_normal(d))[0]
+    near_rows = np.setdiff1d(np.arange(n), copies)[:3000]
+    x[near_rows] = near
+    # flip the last mantissa bit of one component in half of the near-copies: fp32 scores differ by ~1e-6 (inside the
+    # margin), fp64 scores differ for real, so the ranking among them must come from the exact re-score
+    flip = near_rows[::2]
+    col = int(np.argmax(np.abs(near.astype(np.float32))))
+    x[flip, col] = np.nextafter(x[flip, col], np.float16(0))
+    engine.set_dense(x)
+    q16 = np.stack([hot, near] + [to_f16_unit(rng.standard_normal(d))[0] for _ in range(3)])
+    ids, sc, ln = engine.dense_topk(q16, k)
+    assert engine.dense_diag()["exhaustive"] >= 2
+    assert np.array_equal(ids[0], copies[:k])                          # the tie block: lowest indices first
+    for i in range(q16.shape[0]):
+        oid, osc = dense_exact_topk(x, q16[i], k)
+        assert np.array_equal(ids[i], oid) and np.array_equal(sc[i].view(np.uint64), osc.view(np.uint64)), i
+    # 40 flagged queries in one batch, with a dir filter on some
+    dir_id = (np.arange(n) % 3).astype(np.int16)
+    engine.set_doc_meta(n, None, dir_id)
+    qb = np.stack([hot if i % 2 == 0 else near for i in range(40)] + [q16[3]])
+    filt = np.full(41, -1, np.int16)
+    filt[5], filt[6] = 1, 2
+    ids, sc, ln = engine.dense_topk(qb, k, filter_dir=filt)
+    assert engine.dense_diag()["exhaustive"] == 40
+    for i in (0, 1, 5, 6, 38, 39, 40):
+        mask = None if filt[i] < 0 else dir_id == filt[i]
+        oid, osc = dense_exact_topk(x, qb[i], k, mask)
+        assert np.array_equal(ids[i], oid) and np.array_equal(sc[i].view(np.uint64), osc.view(np.uint64)), i
+    # the fused dual route over the same batch: RRF must see the corrected dense lists
+    flat, lens = synth.token_corpus(n, 500, seed=3, mean_len=12)
+    docs = [list(map(int, t)) for t in synth.split_docs(flat, lens)]
+    idx = build_bm25_index(docs, BM25S)
+    engine.set_bm25(idx)
+    queries = [list(map(int, t)) for t in synth.token_queries(flat, lens, 500, 41, seed=5)]
+    qi, qt = queries_to_csr([idx.tokens_to_ids(t) for t in queries])
+    engine.set_doc_meta(n, None, None)
+    fid, fsc, fln = engine.hybrid_topk(qb, qi, qt, k_dense=k, k_sparse=50, K=60, topk=10)
+    ora = BM25SLucene(1.5, 0.75).index(docs)
+    for i in (0, 1, 39, 40):
+        sp = bm25_filter(ora.get_scores(queries[i]), 50)
+        oid, osc = dense_exact_topk(x, qb[i], k)
+        want = reciprocal_rank_fusion([[Item(a, a, s) for a, s in sp],
+                                       [Item(int(a), int(a), float(s)) for a, s in zip(oid, osc)]], K=60, topk=10)
+        assert list(fid[i, :fln[i]]) == [w.idx for w in want] and list(fsc[i, :fln[i]]) == [w.score for w in want], i
 
 
 def test_dense_fp32_inputs_normalised_on_device(engine):
