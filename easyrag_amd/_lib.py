@@ -42,6 +42,8 @@ SIGNATURES = {
     "erh_set_dense": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i32]),
     "erh_set_bm25_csr": (_i32, [_vp, _i32, _i64, _i64, _i64, _vp, _vp, _vp]),
     "erh_set_bm25_tf": (_i32, [_vp, _i32, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl]),
+    "erh_build_bm25_index": (_i32, [_vp, _i32, _i64, _i64, _i64, _vp, _vp, _i32, _dbl, _dbl, _dbl, C.POINTER(_i64)]),
+    "erh_get_bm25_csr": (_i32, [_vp, _vp, _vp, _vp, _vp, C.POINTER(_dbl), C.POINTER(_dbl)]),
     "erh_bm25_select": (_i32, [_vp, _i32]),
     "erh_get_bm25_payload": (_i32, [_vp, _vp]),
     "erh_set_doc_meta": (_i32, [_vp, _i64, _vp, _vp]),

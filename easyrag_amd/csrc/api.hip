@@ -6,6 +6,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -40,10 +41,14 @@ struct Bm25State {
     int variant = -1;
     int64_t V = 0, Nb = 0, nnz = 0;
     DevBuf indptr, doc_ids, payload, tile_off, fine_off;
+    DevBuf tf;                            // kept by erh_build_bm25_index (what erh_get_bm25_csr returns)
+    std::vector<double> idf_host;         // idem (float32 values widened exactly for the bm25s variant)
+    double avgdl = 0, average_idf = 0;
+    bool built_on_device = false;
     std::vector<int64_t> host_indptr;     // host copy: query validation + algorithmic-byte accounting
     int n_tiles = 0, tile_docs = 0;
     int n_fine = 0;                       // sub-ranges of the fine skip table (0 = not built: block scan only)
-    void release() { indptr.release(); doc_ids.release(); payload.release(); tile_off.release(); fine_off.release(); }
+    void release() { indptr.release(); doc_ids.release(); payload.release(); tile_off.release(); fine_off.release(); tf.release(); }
 };
 
 }  // namespace
@@ -93,6 +98,8 @@ struct erh_handle {
     int opt_dense_ablate = 0, opt_bm25_ablate = 0;   // measurement only (results invalid when non-zero)
     int opt_dense_cfg = 0;                 // dense scan tile configuration (dense_scan.hip)
     int opt_dense_readahead = 1;           // cfg 2 only: fragments of the next K-step are read before its barrier
+    int opt_small_single = 1;              // small batches: skip the refinement boundaries when the lists can take it
+    int opt_dense_gemv = 1;                // batches of <= 16 queries: skinny-GEMM stream instead of the padded 256-query scan
     int opt_dense_pp = 1;                  // ping-pong persistent append scan (falls back to the kernels below when it does not apply)
     int opt_dense_persist = 1;             // persistent append scan (falls back to the plain launch when it does not apply)
     int n_cus = 0;                         // compute units of the device (persistent grids = one workgroup per CU)
@@ -193,6 +200,13 @@ void choose_placement(int64_t n, int64_t *mul, int64_t *inv) {
 hipError_t scan_append(erh_handle *h, const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1, const _Float16 *Q16,
                        int Bpad, int B, const float *tau, const int16_t *filt, const int16_t *dir, ErhCand *cand,
                        uint32_t *cnt, int cap, uint32_t *flags, hipStream_t st) {
+    // small batches: the skinny-GEMM stream (dense_gemv.hip) instead of a 256-query tile that is mostly padding
+    if (h->opt_dense_gemv && h->opt_dense_ablate == 0 && B <= erh::dense_gemv_max_queries()) {
+        hipError_t e = erh::launch_dense_gemv_append(X, N, d, c0, c1, Q16, B, tau, filt, dir, cand, cnt, cap, flags,
+                                                     h->n_cus, st);
+        if (e != hipErrorInvalidValue) return e;
+        (void)hipGetLastError();
+    }
     const int abl = h->opt_dense_ablate;
     const bool pp_code = abl == 0 || abl == 7 || abl == 8 || (abl >= 11 && abl <= 18) || abl == 20 || abl == 21;
     if (h->opt_dense_pp && pp_code) {
@@ -264,8 +278,15 @@ int dense_topk_dev(erh_handle *h, const void *q_dev, int q_dtype, int normalize_
     double wb, wf;
     // stage A: score the seed prefix densely, k-th best -> pruning threshold
     scan_work(n0, &wb, &wf);
+    const bool small = h->opt_dense_gemv && h->opt_dense_ablate == 0 && B <= erh::dense_gemv_max_queries();
     { ProfScope ps(h, st, ERH_K_DENSE_SCAN, wb, wf);
-      HIPCHK(h, erh::launch_dense_scan_store(h->opt_dense_cfg, Q16, Bpad, X, N, d, 0, (int)n0, h->S0.as<float>(), ld, st)); }
+      hipError_t e = hipErrorInvalidValue;
+      if (small) e = erh::launch_dense_gemv_store(X, N, d, 0, (int)n0, Q16, B, h->S0.as<float>(), ld, h->n_cus, st);
+      if (e == hipErrorInvalidValue) {
+          (void)hipGetLastError();
+          e = erh::launch_dense_scan_store(h->opt_dense_cfg, Q16, Bpad, X, N, d, 0, (int)n0, h->S0.as<float>(), ld, st);
+      }
+      HIPCHK(h, e); }
     { ProfScope ps(h, st, ERH_K_DENSE_SELECT, 0, 0);
       HIPCHK(h, erh::launch_seed_select(h->S0.as<float>(), ld, (int)n0, 0, B, k, h->qnorm.as<float>(), h->xnorm_max, d,
                                         filter_dev, dir, h->tau.as<float>(), h->cand.as<ErhCand>(),
@@ -295,6 +316,9 @@ int dense_topk_dev(erh_handle *h, const void *q_dev, int q_dtype, int normalize_
         int64_t cur = n0;
         int64_t want = h->opt_n1;
         if (want <= n0) want = 0;
+        // small batches: one stage when the candidates a seed-only threshold admits (about k * N / n0 per query) fit
+        // the lists comfortably -- the refinement launches cost more than they save when there are 16 lists to cut
+        if (small && h->opt_small_single && (double)k * (double)N / (double)n0 <= 0.5 * cap) want = 0;
         while (cur < N) {
             int64_t next = N;
             if (want > cur && want < N) {
@@ -510,6 +534,10 @@ int erh_set_option(erh_handle *h, const char *name, int64_t value) {
     if (!strcmp(name, "dense_shuffle")) { h->opt_dense_shuffle = value != 0; return ERH_OK; }   // takes effect at the next erh_set_dense
     if (!strcmp(name, "dense_n1_auto")) { h->opt_n1_auto = value != 0; return ERH_OK; }
     if (!strcmp(name, "dense_pp")) { h->opt_dense_pp = value != 0; return ERH_OK; }
+    if (!strcmp(name, "dense_gemv")) { h->opt_dense_gemv = value != 0; return ERH_OK; }
+    if (!strcmp(name, "dense_gemv_kb")) { erh::dense_gemv_tune((int)value, 0); return ERH_OK; }       // process-wide tuning
+    if (!strcmp(name, "dense_gemv_wgs")) { erh::dense_gemv_tune(0, (int)value); return ERH_OK; }
+    if (!strcmp(name, "dense_small_single_stage")) { h->opt_small_single = value != 0; return ERH_OK; }
     if (!strcmp(name, "dense_persist")) { h->opt_dense_persist = value != 0; return ERH_OK; }
 #ifdef ERH_MEASURE
     if (!strcmp(name, "dense_ablate")) { h->opt_dense_ablate = (int)value; return ERH_OK; }
@@ -650,6 +678,31 @@ int erh_set_dense(erh_handle *h, const void *x, int64_t n, int d, int dtype, int
     return ERH_OK;
 }
 
+// Skip tables over device-resident CSR postings (indptr / doc_ids of the selected slot): the 32768 / 16384-document
+// tile table of the block scan and the fine table of the wave-owned scan.
+static int bm25_finish_tables(erh_handle *h, int variant, int64_t V, int64_t N, hipStream_t st) {
+    Bm25State &S = h->bm[h->cur];
+    S.tile_docs = (variant == ERH_BM25_OKAPI) ? erh::kBm25TileF64 : erh::kBm25TileF32;
+    S.n_tiles = (int)((N + S.tile_docs - 1) / S.tile_docs);
+    HIPCHK(h, S.tile_off.ensure((size_t)V * (S.n_tiles + 1) * 4));
+    HIPCHK(h, erh::launch_bm25_tile_off(S.indptr.as<int64_t>(), S.doc_ids.as<int32_t>(), V, S.tile_docs, S.n_tiles,
+                                        S.tile_off.as<int32_t>(), st));
+    // fine skip table of the wave-owned scan: one int per (term, sub-range of tile_docs / 16 documents)
+    S.n_fine = 0;
+    const int sub = erh::bm25_wscan_sub_docs(variant);
+    const int64_t nf = (N + sub - 1) / sub;
+    const double mb = (double)V * (double)(nf + 1) * 4.0 / (1024.0 * 1024.0);
+    if (h->opt_bm25_wscan && nf < (1 << 30) && mb <= (double)h->opt_bm25_fine_max_mb) {
+        HIPCHK(h, S.fine_off.ensure((size_t)V * (size_t)(nf + 1) * 4));
+        HIPCHK(h, erh::launch_bm25_tile_off(S.indptr.as<int64_t>(), S.doc_ids.as<int32_t>(), V, sub, (int)nf,
+                                            S.fine_off.as<int32_t>(), st));
+        S.n_fine = (int)nf;
+    } else {
+        S.fine_off.release();
+    }
+    return ERH_OK;
+}
+
 static int bm25_common_upload(erh_handle *h, int variant, int64_t V, int64_t N, int64_t nnz,
                               const int64_t *indptr, const int32_t *doc_ids) {
     if (variant != ERH_BM25_OKAPI && variant != ERH_BM25_BM25S) return h->fail(ERH_ERR_INVALID, "bm25 variant");
@@ -671,27 +724,8 @@ static int bm25_common_upload(erh_handle *h, int variant, int64_t V, int64_t N, 
     HIPCHK(h, h->bm[h->cur].doc_ids.ensure((size_t)std::max<int64_t>(nnz, 1) * 4));
     HIPCHK(h, hipMemcpyAsync(h->bm[h->cur].indptr.p, indptr, (size_t)(V + 1) * 8, hipMemcpyHostToDevice, st));
     if (nnz) HIPCHK(h, hipMemcpyAsync(h->bm[h->cur].doc_ids.p, doc_ids, (size_t)nnz * 4, hipMemcpyHostToDevice, st));
-    h->bm[h->cur].tile_docs = (variant == ERH_BM25_OKAPI) ? erh::kBm25TileF64 : erh::kBm25TileF32;
-    h->bm[h->cur].n_tiles = (int)((N + h->bm[h->cur].tile_docs - 1) / h->bm[h->cur].tile_docs);
-    HIPCHK(h, h->bm[h->cur].tile_off.ensure((size_t)V * (h->bm[h->cur].n_tiles + 1) * 4));
-    HIPCHK(h, erh::launch_bm25_tile_off(h->bm[h->cur].indptr.as<int64_t>(), h->bm[h->cur].doc_ids.as<int32_t>(), V, h->bm[h->cur].tile_docs, h->bm[h->cur].n_tiles,
-                                        h->bm[h->cur].tile_off.as<int32_t>(), st));
-    // fine skip table of the wave-owned scan: one int per (term, sub-range of tile_docs / 16 documents)
-    {
-        Bm25State &S = h->bm[h->cur];
-        S.n_fine = 0;
-        const int sub = erh::bm25_wscan_sub_docs(variant);
-        const int64_t nf = (N + sub - 1) / sub;
-        const double mb = (double)V * (double)(nf + 1) * 4.0 / (1024.0 * 1024.0);
-        if (h->opt_bm25_wscan && nf < (1 << 30) && mb <= (double)h->opt_bm25_fine_max_mb) {
-            HIPCHK(h, S.fine_off.ensure((size_t)V * (size_t)(nf + 1) * 4));
-            HIPCHK(h, erh::launch_bm25_tile_off(S.indptr.as<int64_t>(), S.doc_ids.as<int32_t>(), V, sub, (int)nf,
-                                                S.fine_off.as<int32_t>(), st));
-            S.n_fine = (int)nf;
-        } else {
-            S.fine_off.release();
-        }
-    }
+    int rc_t = bm25_finish_tables(h, variant, V, N, st);
+    if (rc_t != ERH_OK) return rc_t;
     h->bm[h->cur].host_indptr.assign(indptr, indptr + V + 1);
     h->bm[h->cur].variant = variant;
     h->bm[h->cur].V = V;
@@ -739,6 +773,167 @@ int erh_set_bm25_tf(erh_handle *h, int variant, int64_t V, int64_t N, int64_t nn
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     cleanup();
     if (e != hipSuccess) { h->bm[h->cur].variant = -1; return h->fail(ERH_ERR_HIP, "erh_set_bm25_tf", e); }
+    return ERH_OK;
+}
+
+
+// ---- index build on the device (first half) --------------------------------------------------
+int erh_build_bm25_index(erh_handle *h, int variant, int64_t V, int64_t N, int64_t n_tokens, const int32_t *token_ids,
+                         const int32_t *doc_len, int is_device_ptr, double k1, double b, double epsilon,
+                         int64_t *out_nnz) {
+    if (!h) return ERH_ERR_INVALID;
+    if (variant != ERH_BM25_OKAPI && variant != ERH_BM25_BM25S) return h->fail(ERH_ERR_INVALID, "bm25 variant");
+    if (V <= 0 || N <= 0 || n_tokens < 0 || !doc_len || (n_tokens > 0 && !token_ids))
+        return h->fail(ERH_ERR_INVALID, "erh_build_bm25_index: null pointer or non-positive shape");
+    if (N > 2147483647LL || V > 2147483647LL || n_tokens > 2147483647LL)
+        return h->fail(ERH_ERR_UNSUPPORTED, "erh_build_bm25_index: N, V and the token count must fit int32");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t st = nullptr;
+    Bm25State &S = h->bm[h->cur];
+    S.variant = -1;
+    S.built_on_device = false;
+    const int64_t T = n_tokens;
+    // document lengths: host copy (offsets, avgdl) + device copy (payload kernel)
+    std::vector<int32_t> dl((size_t)N);
+    if (is_device_ptr) HIPCHK(h, hipMemcpy(dl.data(), doc_len, (size_t)N * 4, hipMemcpyDeviceToHost));
+    else memcpy(dl.data(), doc_len, (size_t)N * 4);
+    std::vector<int64_t> off((size_t)N + 1);
+    off[0] = 0;
+    for (int64_t i = 0; i < N; ++i) {
+        if (dl[i] < 0) return h->fail(ERH_ERR_INVALID, "erh_build_bm25_index: negative document length");
+        off[i + 1] = off[i] + dl[i];
+    }
+    if (off[N] != T) return h->fail(ERH_ERR_INVALID, "erh_build_bm25_index: document lengths do not sum to the token count");
+    DevBuf d_tok, d_off, d_keys, d_sorted, d_uniq, d_cnt, d_first, d_misc, d_temp, d_df, d_dl, d_idf;
+    auto cleanup = [&]() {
+        for (DevBuf *x : {&d_tok, &d_off, &d_keys, &d_sorted, &d_uniq, &d_cnt, &d_first, &d_misc, &d_temp, &d_df, &d_dl, &d_idf})
+            x->release();
+    };
+#define BUILD_CHK(call)                                                                     \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess) { cleanup(); return h->fail(e_ == hipErrorOutOfMemory ? ERH_ERR_NOMEM : ERH_ERR_HIP, #call, e_); } \
+    } while (0)
+    const size_t Tn = (size_t)std::max<int64_t>(T, 1);
+    const int32_t *tok_dev = token_ids;
+    if (!is_device_ptr) {
+        BUILD_CHK(d_tok.ensure(Tn * 4));
+        if (T) BUILD_CHK(hipMemcpyAsync(d_tok.p, token_ids, (size_t)T * 4, hipMemcpyHostToDevice, st));
+        tok_dev = d_tok.as<int32_t>();
+    }
+    BUILD_CHK(d_off.ensure((size_t)(N + 1) * 8));
+    BUILD_CHK(hipMemcpyAsync(d_off.p, off.data(), (size_t)(N + 1) * 8, hipMemcpyHostToDevice, st));
+    BUILD_CHK(d_keys.ensure(Tn * 8));
+    BUILD_CHK(d_sorted.ensure(Tn * 8));
+    BUILD_CHK(d_uniq.ensure(Tn * 8));
+    BUILD_CHK(d_cnt.ensure(Tn * 4));
+    BUILD_CHK(d_first.ensure((size_t)V * 8));
+    BUILD_CHK(d_misc.ensure(64));
+    BUILD_CHK(hipMemsetAsync(d_misc.p, 0, 64, st));
+    uint32_t *bad_tok = d_misc.as<uint32_t>();
+    int32_t *num_runs = d_misc.as<int32_t>() + 4;
+    BUILD_CHK(erh::launch_csr_keys(tok_dev, d_off.as<int64_t>(), T, N, V, d_keys.as<uint64_t>(),
+                                   d_first.as<unsigned long long>(), bad_tok, st));
+    int key_bits = 32;
+    while (key_bits < 64 && (1ll << (key_bits - 32)) < V) ++key_bits;
+    int64_t nnz = 0;
+    if (T > 0) {
+        size_t tb = 0;
+        BUILD_CHK(erh::csr_sort_rle(d_keys.as<uint64_t>(), d_sorted.as<uint64_t>(), T, key_bits, d_uniq.as<uint64_t>(),
+                                    d_cnt.as<int32_t>(), num_runs, nullptr, &tb, st));
+        BUILD_CHK(d_temp.ensure(tb + 256));
+        tb = d_temp.cap;
+        BUILD_CHK(erh::csr_sort_rle(d_keys.as<uint64_t>(), d_sorted.as<uint64_t>(), T, key_bits, d_uniq.as<uint64_t>(),
+                                    d_cnt.as<int32_t>(), num_runs, d_temp.p, &tb, st));
+    }
+    uint32_t misc[8] = {0};
+    BUILD_CHK(hipMemcpyAsync(misc, d_misc.p, sizeof misc, hipMemcpyDeviceToHost, st));
+    BUILD_CHK(hipStreamSynchronize(st));
+    if (misc[0]) { cleanup(); return h->fail(ERH_ERR_INVALID, "erh_build_bm25_index: token id out of range"); }
+    nnz = T > 0 ? (int64_t)(int32_t)misc[4] : 0;
+    d_keys.release();
+    d_sorted.release();
+    d_temp.release();
+    BUILD_CHK(S.doc_ids.ensure((size_t)std::max<int64_t>(nnz, 1) * 4));
+    BUILD_CHK(S.tf.ensure((size_t)std::max<int64_t>(nnz, 1) * 4));
+    BUILD_CHK(d_df.ensure((size_t)V * 8));
+    BUILD_CHK(erh::launch_csr_split(d_uniq.as<uint64_t>(), d_cnt.as<int32_t>(), nnz, V, S.doc_ids.as<int32_t>(),
+                                    S.tf.as<int32_t>(), d_df.as<unsigned long long>(), st));
+    std::vector<unsigned long long> df((size_t)V), first((size_t)V);
+    BUILD_CHK(hipMemcpyAsync(df.data(), d_df.p, (size_t)V * 8, hipMemcpyDeviceToHost, st));
+    BUILD_CHK(hipMemcpyAsync(first.data(), d_first.p, (size_t)V * 8, hipMemcpyDeviceToHost, st));
+    BUILD_CHK(hipStreamSynchronize(st));
+    // ---- V-sized host work: indptr, idf (+ epsilon floor), avgdl -- the libraries' arithmetic, libm's log --------
+    std::vector<int64_t> indptr((size_t)V + 1);
+    indptr[0] = 0;
+    for (int64_t t = 0; t < V; ++t) indptr[t + 1] = indptr[t] + (int64_t)df[t];
+    if (indptr[V] != nnz) { cleanup(); return h->fail(ERH_ERR_HIP, "erh_build_bm25_index: posting count mismatch"); }
+    S.idf_host.assign((size_t)V, 0.0);
+    S.average_idf = 0.0;
+    const double total_len = (double)off[N];                               // < 2^53: exact
+    S.avgdl = total_len / (double)N;                                       // rank_bm25: num_doc / corpus_size; bm25s: mean(len)
+    if (variant == ERH_BM25_OKAPI) {
+        for (int64_t t = 0; t < V; ++t)
+            if (df[t]) S.idf_host[t] = std::log((double)(N - (int64_t)df[t]) + 0.5) - std::log((double)df[t] + 0.5);
+        // average over the terms in first-appearance order (the order rank_bm25's `nd` dict was filled), sequentially
+        std::vector<int64_t> order;
+        order.reserve((size_t)V);
+        for (int64_t t = 0; t < V; ++t) if (df[t]) order.push_back(t);
+        std::sort(order.begin(), order.end(), [&](int64_t a, int64_t c) { return first[a] < first[c]; });
+        double sum = 0.0;
+        for (int64_t t : order) sum += S.idf_host[t];
+        S.average_idf = sum / (double)std::max<size_t>(order.size(), 1);
+        const double eps = epsilon * S.average_idf;
+        for (int64_t t = 0; t < V; ++t) if (S.idf_host[t] < 0) S.idf_host[t] = eps;
+    } else {
+        for (int64_t t = 0; t < V; ++t)
+            if (df[t]) S.idf_host[t] = (double)(float)std::log(1.0 + ((double)(N - (int64_t)df[t]) + 0.5) / ((double)df[t] + 0.5));
+    }
+    // ---- device: indptr, per-posting payload, skip tables ----------------------------------------------------------
+    BUILD_CHK(S.indptr.ensure((size_t)(V + 1) * 8));
+    BUILD_CHK(hipMemcpyAsync(S.indptr.p, indptr.data(), (size_t)(V + 1) * 8, hipMemcpyHostToDevice, st));
+    const size_t es = (variant == ERH_BM25_OKAPI) ? 8 : 4;
+    BUILD_CHK(S.payload.ensure((size_t)std::max<int64_t>(nnz, 1) * es));
+    BUILD_CHK(d_dl.ensure((size_t)N * 4));
+    BUILD_CHK(hipMemcpyAsync(d_dl.p, dl.data(), (size_t)N * 4, hipMemcpyHostToDevice, st));
+    BUILD_CHK(d_idf.ensure((size_t)V * es));
+    std::vector<float> idf32;
+    if (variant == ERH_BM25_OKAPI) {
+        BUILD_CHK(hipMemcpyAsync(d_idf.p, S.idf_host.data(), (size_t)V * 8, hipMemcpyHostToDevice, st));
+    } else {
+        idf32.resize((size_t)V);
+        for (int64_t t = 0; t < V; ++t) idf32[t] = (float)S.idf_host[t];
+        BUILD_CHK(hipMemcpyAsync(d_idf.p, idf32.data(), (size_t)V * 4, hipMemcpyHostToDevice, st));
+    }
+    BUILD_CHK(erh::launch_bm25_payload(variant, V, nnz, S.indptr.as<int64_t>(), S.doc_ids.as<int32_t>(), S.tf.as<int32_t>(),
+                                       d_dl.as<int32_t>(), d_idf.p, S.avgdl, k1, b, S.payload.p, st));
+    int rc = bm25_finish_tables(h, variant, V, N, st);
+    if (rc != ERH_OK) { cleanup(); return rc; }
+    BUILD_CHK(hipStreamSynchronize(st));
+#undef BUILD_CHK
+    cleanup();
+    S.host_indptr = std::move(indptr);
+    S.variant = variant;
+    S.V = V;
+    S.Nb = N;
+    S.nnz = nnz;
+    S.built_on_device = true;
+    if (out_nnz) *out_nnz = nnz;
+    return ERH_OK;
+}
+
+int erh_get_bm25_csr(erh_handle *h, int64_t *indptr, int32_t *doc_ids, int32_t *tf, double *idf, double *avgdl,
+                     double *average_idf) {
+    if (!h) return ERH_ERR_INVALID;
+    Bm25State &S = h->bm[h->cur];
+    if (S.variant < 0 || !S.built_on_device) return h->fail(ERH_ERR_STATE, "erh_get_bm25_csr: the selected slot was not built by erh_build_bm25_index");
+    HIPCHK(h, hipSetDevice(h->device));
+    if (indptr) memcpy(indptr, S.host_indptr.data(), (size_t)(S.V + 1) * 8);
+    if (doc_ids && S.nnz) HIPCHK(h, hipMemcpy(doc_ids, S.doc_ids.p, (size_t)S.nnz * 4, hipMemcpyDeviceToHost));
+    if (tf && S.nnz) HIPCHK(h, hipMemcpy(tf, S.tf.p, (size_t)S.nnz * 4, hipMemcpyDeviceToHost));
+    if (idf) memcpy(idf, S.idf_host.data(), (size_t)S.V * 8);
+    if (avgdl) *avgdl = S.avgdl;
+    if (average_idf) *average_idf = S.average_idf;
     return ERH_OK;
 }
 

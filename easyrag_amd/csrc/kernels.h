@@ -28,6 +28,16 @@ hipError_t launch_dense_scan_persist(int cfg, const _Float16 *X, int64_t N, int 
 hipError_t launch_dense_naive(const _Float16 *Q, int B, const _Float16 *X, int64_t row0, int rows, int d,
                               float *out, hipStream_t st);
 
+// ---- dense_gemv.hip: append scan for batches of at most dense_gemv_max_queries() queries ----------------------------
+int dense_gemv_max_queries();
+void dense_gemv_tune(int kb, int wgs);   // loads in flight per wave (16 / 32 steps), workgroups per CU
+hipError_t launch_dense_gemv_append(const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1, const _Float16 *Q, int B,
+                                    const float *tau, const int16_t *filter_dir, const int16_t *dir_id, ErhCand *cand,
+                                    uint32_t *cand_cnt, int cap, uint32_t *overflow, int n_cus, hipStream_t st);
+
+hipError_t launch_dense_gemv_store(const _Float16 *X, int64_t N, int d, int64_t c0, int nc, const _Float16 *Q, int B,
+                                   float *S0, int ld_s0, int n_cus, hipStream_t st);
+
 // ---- select.hip ------------------------------------------------------------------------------
 constexpr int kDenseN0Max = 32768;    // seed prefix: one fp32 score row must fit LDS for the k-th select
 constexpr int kDenseCapMax = 16384;   // candidates per query that the LDS sort can hold (64-bit keys)
@@ -103,6 +113,14 @@ hipError_t launch_bm25_merge(int B, int k, int segs, const double *part_scores, 
 hipError_t launch_bm25_add_term(int variant, const int64_t *indptr, const int32_t *doc_ids, const void *payload,
                                 int32_t term, void *scores, hipStream_t st);
 hipError_t launch_widen_f32(const float *in, int64_t n, double *out, hipStream_t st);
+
+// ---- index_build.hip: token stream -> CSR postings on the device ----------------------------------------------------
+hipError_t launch_csr_keys(const int32_t *tok, const int64_t *doc_off, int64_t T, int64_t N, int64_t V, uint64_t *keys,
+                           unsigned long long *first_pos, uint32_t *bad_token, hipStream_t st);
+hipError_t csr_sort_rle(const uint64_t *keys_in, uint64_t *keys_sorted, int64_t T, int key_bits, uint64_t *uniq,
+                        int32_t *counts, int32_t *num_runs, void *temp, size_t *temp_bytes, hipStream_t st);
+hipError_t launch_csr_split(const uint64_t *uniq, const int32_t *counts, int64_t nnz, int64_t V, int32_t *doc_ids,
+                            int32_t *tf, unsigned long long *df, hipStream_t st);
 
 // ---- fuse.hip --------------------------------------------------------------------------------
 constexpr int kFuseMaxItems = 2048;   // depth_a + depth_b

@@ -100,6 +100,19 @@ int erh_set_bm25_tf(erh_handle *h, int variant, int64_t V, int64_t N, int64_t nn
                     const int64_t *indptr, const int32_t *doc_ids, const int32_t *tf,
                     const int32_t *doc_len, const void *idf, double avgdl, double k1, double b);
 
+/* Index build on the device (BM25Retriever.__init__, retrievers.py:94-118, minus the tokeniser): the corpus as one
+ * flat stream of term ids, token_ids int32[n_tokens] in document order, with doc_len int32[N] tokens per document
+ * (host or device pointers).  Builds the CSR postings of the selected slot -- 64-bit (term, doc) keys, radix sort,
+ * run-length tf, df -- then idf / epsilon floor / avgdl exactly as the variant's library computes them and the
+ * per-posting payload as erh_set_bm25_tf does.  *out_nnz = number of postings.  Bit-identical to the host builder
+ * (easyrag_amd/index.py).  erh_get_bm25_csr copies the result back (any pointer may be NULL): indptr int64[V+1],
+ * doc_ids / tf int32[nnz], idf float64[V] (float32 values widened for ERH_BM25_BM25S), avgdl, average_idf. */
+int erh_build_bm25_index(erh_handle *h, int variant, int64_t V, int64_t N, int64_t n_tokens, const int32_t *token_ids,
+                         const int32_t *doc_len, int is_device_ptr, double k1, double b, double epsilon,
+                         int64_t *out_nnz);
+int erh_get_bm25_csr(erh_handle *h, int64_t *indptr, int32_t *doc_ids, int32_t *tf, double *idf, double *avgdl,
+                     double *average_idf);
+
 /* A handle holds up to ERH_BM25_SLOTS independent BM25 indices (the reference pipeline builds two over the same
  * nodes: node text with embed_type 2 and know_path with embed_type 5, src/easyrag/pipeline/pipeline.py:187-210).
  * erh_bm25_select chooses the slot that erh_set_bm25_*, erh_bm25_topk, erh_bm25_scores, erh_get_bm25_payload and
@@ -208,6 +221,8 @@ int erh_reset_kernel_time(erh_handle *h);
  *                         0 stores the rows in the caller's order
  *   dense_pp (1)          ping-pong persistent append scan; 0 = lock-step kernels (dense_persist 1 / 0 = persistent /
  *                         one workgroup per tile, dense_cfg 0..2 = their tile configuration, dense_readahead)
+ *   dense_gemv (1)        batches of at most 16 queries stream the chunk matrix through a 16x16x32 skinny-GEMM kernel
+ *                         (the reference's one-query-at-a-time call pattern) instead of the padded 256-query scan
  *   bm25_wscan (1)        wave-owned BM25 scan (no per-token workgroup barrier) for batches whose queries have at most
  *                         64 tokens; 0 = block scan for everything.  Needs a fine skip table (4 bytes per term and per
  *                         2048 / 1024 documents), built by erh_set_bm25_* unless it would exceed bm25_fine_max_mb (8192)

