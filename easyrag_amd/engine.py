@@ -152,6 +152,53 @@ class RetrievalEngine:
         self._check(rc)
         self._bm25_slots[slot] = index
 
+    def build_bm25(self, flat, doc_lens, n_vocab: int, variant: int = OKAPI, k1: float = 1.5, b: float = 0.75,
+                   epsilon: float = 0.25, slot: Optional[int] = None, fetch: bool = True) -> BM25Index:
+        """Index a corpus given as one flat stream of term ids (document order) + tokens per document, ON THE DEVICE
+        (erh_build_bm25_index: radix sort of (term, doc) keys, run-length tf, df, payload).  `flat` / `doc_lens` may
+        be numpy arrays or device tensors (int32).  fetch=True copies the CSR arrays back into the returned BM25Index
+        (tests, cpu baselines); fetch=False returns an index object that only carries the sizes and parameters."""
+        slot = self._select(slot)
+        if _is_torch(flat):
+            import torch
+            flat = flat.contiguous().to(torch.int32)
+            doc_lens = doc_lens.contiguous().to(torch.int32)
+            is_dev = 1 if flat.is_cuda else 0
+            if is_dev and not doc_lens.is_cuda:
+                doc_lens = doc_lens.to(flat.device)
+            if is_dev:
+                torch.cuda.current_stream(flat.device).synchronize()
+            n_tok, n_docs = int(flat.shape[0]), int(doc_lens.shape[0])
+        else:
+            flat = _np(flat, np.int32)
+            doc_lens = _np(doc_lens, np.int32)
+            is_dev = 0
+            n_tok, n_docs = int(flat.shape[0]), int(doc_lens.shape[0])
+        nnz = C.c_int64()
+        self._check(self._lib.erh_build_bm25_index(self._h, int(variant), int(n_vocab), n_docs, n_tok, _ptr(flat),
+                                                   _ptr(doc_lens), is_dev, float(k1), float(b), float(epsilon),
+                                                   C.byref(nnz)))
+        n = int(nnz.value)
+        idx = BM25Index(variant=int(variant), n_docs=n_docs, n_vocab=int(n_vocab), indptr=np.zeros(0, np.int64),
+                        doc_ids=np.zeros(0, np.int32), tf=np.zeros(0, np.int32),
+                        doc_len=np.zeros(0, np.int32), idf=np.zeros(0), avgdl=0.0, k1=k1, b=b, epsilon=epsilon,
+                        payload=np.zeros(0), n_postings=n)
+        if fetch:
+            idx.indptr = np.empty(int(n_vocab) + 1, np.int64)
+            idx.doc_ids = np.empty(n, np.int32)
+            idx.tf = np.empty(n, np.int32)
+            idf = np.empty(int(n_vocab), np.float64)
+            avgdl, avg_idf = C.c_double(), C.c_double()
+            self._check(self._lib.erh_get_bm25_csr(self._h, _ptr(idx.indptr), _ptr(idx.doc_ids), _ptr(idx.tf), _ptr(idf),
+                                                   C.byref(avgdl), C.byref(avg_idf)))
+            idx.idf = idf if variant == OKAPI else idf.astype(np.float32)
+            idx.avgdl, idx.average_idf = avgdl.value, avg_idf.value
+            idx.doc_len = (doc_lens.cpu().numpy() if _is_torch(doc_lens) else doc_lens).astype(np.int32)
+        self._bm25_slots[slot] = idx
+        if fetch:
+            idx.payload = self.get_bm25_payload(slot)
+        return idx
+
     def get_bm25_payload(self, slot: Optional[int] = None) -> np.ndarray:
         self._select(slot)
         assert self.bm25 is not None

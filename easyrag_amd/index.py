@@ -46,10 +46,11 @@ class BM25Index:
     payload: np.ndarray        # float64[nnz] (Okapi) / float32[nnz] (bm25s)
     vocab: Dict[Hashable, int] = field(default_factory=dict)
     average_idf: float = 0.0
+    n_postings: Optional[int] = None     # set when the arrays live only on the device (RetrievalEngine.build_bm25(fetch=False))
 
     @property
     def nnz(self) -> int:
-        return int(self.doc_ids.shape[0])
+        return int(self.doc_ids.shape[0]) if self.n_postings is None else int(self.n_postings)
 
     def tokens_to_ids(self, tokens: Sequence[Hashable]) -> np.ndarray:
         """Query tokens -> term ids, order and repeats kept, out-of-vocabulary tokens dropped (they add
@@ -169,20 +170,29 @@ def build_bm25_index_from_ids(corpus_ids: Optional[Sequence[Sequence[int]]] = No
     return _finish(variant, n_docs, n_vocab, indptr, doc, tf, doc_lens, order, k1, b, epsilon, compute_payload)
 
 
-def build_bm25_index(corpus: Sequence[Sequence[Hashable]], variant: int = OKAPI, k1: float = 1.5, b: float = 0.75,
-                     epsilon: float = 0.25, compute_payload: bool = True) -> BM25Index:
-    """Index a tokenised corpus (list of token lists); vocabulary ids follow first appearance."""
+def vocab_ids(corpus: Sequence[Sequence[Hashable]]):
+    """Tokenised corpus -> (vocab {token: id by first appearance}, flat int32 id stream, int32 tokens per document):
+    the only O(corpus) Python loop left on this side (dictionary lookups of the tokeniser's output strings)."""
     vocab: Dict[Hashable, int] = {}
-    ids: List[np.ndarray] = []
+    lens = np.fromiter((len(d) for d in corpus), dtype=np.int32, count=len(corpus))
+    flat = np.empty(int(lens.sum()), np.int32)
+    p = 0
     for docu in corpus:
-        row = np.empty(len(docu), np.int64)
-        for i, tok in enumerate(docu):
+        for tok in docu:
             j = vocab.get(tok)
             if j is None:
                 j = len(vocab)
                 vocab[tok] = j
-            row[i] = j
-        ids.append(row)
-    idx = build_bm25_index_from_ids(ids, max(len(vocab), 1), variant, k1, b, epsilon, compute_payload=compute_payload)
+            flat[p] = j
+            p += 1
+    return vocab, flat, lens
+
+
+def build_bm25_index(corpus: Sequence[Sequence[Hashable]], variant: int = OKAPI, k1: float = 1.5, b: float = 0.75,
+                     epsilon: float = 0.25, compute_payload: bool = True) -> BM25Index:
+    """Index a tokenised corpus (list of token lists) on the host; vocabulary ids follow first appearance."""
+    vocab, flat, lens = vocab_ids(corpus)
+    idx = build_bm25_index_from_ids(None, max(len(vocab), 1), variant, k1, b, epsilon, flat=flat, doc_lens=lens,
+                                    compute_payload=compute_payload)
     idx.vocab = vocab
     return idx

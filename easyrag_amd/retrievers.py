@@ -37,7 +37,7 @@ import numpy as np
 
 from . import _lib
 from .engine import RetrievalEngine, queries_to_csr
-from .index import BM25Index, build_bm25_index
+from .index import BM25Index, build_bm25_index, vocab_ids
 from .schema import NodeWithScore, QueryBundle
 
 logger = logging.getLogger(__name__)
@@ -244,7 +244,8 @@ class BM25Retriever(_RetrieverBase):
     def __init__(self, nodes, tokenizer: Optional[Callable], similarity_top_k: int = DEFAULT_SIMILARITY_TOP_K,
                  callback_manager=None, objects=None, object_map=None, verbose: bool = False,
                  stopwords=("",), embed_type: int = 0, bm25_type: int = 0,
-                 engine: Optional[RetrievalEngine] = None, payload_on_device: bool = False) -> None:
+                 engine: Optional[RetrievalEngine] = None, payload_on_device: bool = False,
+                 device_build: bool = True) -> None:
         self._nodes = list(nodes)
         self._tokenizer = tokenizer
         self._similarity_top_k = similarity_top_k
@@ -256,13 +257,21 @@ class BM25Retriever(_RetrieverBase):
         self.k1, self.b, self.epsilon = 1.5, 0.75, 0.25          # ref retrievers.py:103-105
         self._corpus_state = _corpus_for(self._nodes, engine)
         self.engine = self._corpus_state.engine
-        self.bm25: BM25Index = build_bm25_index(self._corpus, variant=1 if bm25_type == 1 else 0, k1=self.k1,
-                                                b=self.b, epsilon=self.epsilon,
-                                                compute_payload=not payload_on_device)
         # every retriever owns one BM25 index slot of the (possibly shared) engine: the content retriever and the
         # know_path retriever of the reference pipeline (pipeline.py:187-210) live side by side
         self._slot = self.engine.alloc_bm25_slot()
-        self.engine.set_bm25(self.bm25, payload_on_device=payload_on_device, slot=self._slot)
+        variant = 1 if bm25_type == 1 else 0
+        if device_build:
+            # tokens -> ids on the host (dictionary lookups), everything else of the index build on the GPU
+            # (erh_build_bm25_index: sort, run lengths, df, idf, payload); nothing but the vocabulary stays here
+            vocab, flat, lens = vocab_ids(self._corpus)
+            self.bm25: BM25Index = self.engine.build_bm25(flat, lens, max(len(vocab), 1), variant=variant, k1=self.k1,
+                                                          b=self.b, epsilon=self.epsilon, slot=self._slot, fetch=False)
+            self.bm25.vocab = vocab
+        else:
+            self.bm25 = build_bm25_index(self._corpus, variant=variant, k1=self.k1, b=self.b, epsilon=self.epsilon,
+                                         compute_payload=not payload_on_device)
+            self.engine.set_bm25(self.bm25, payload_on_device=payload_on_device, slot=self._slot)
         self.filter_dict = None
 
     def close(self):

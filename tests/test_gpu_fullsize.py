@@ -43,9 +43,8 @@ def sparse_data():
     dev = torch.device("cuda", 0)
     indptr, doc, tf, lens, flat = synth.token_csr_torch(N, VOCAB, seed=3, device=dev)
     queries = synth.token_queries(flat, lens, VOCAB, 1024, seed=2000)
-    del flat
     torch.cuda.empty_cache()
-    return indptr, doc, tf, lens, queries
+    return indptr, doc, tf, lens, queries, flat
 
 
 _INDEX = {}
@@ -54,7 +53,7 @@ _INDEX = {}
 def host_index(sparse_data, variant):
     """Host-built index (payload included) per variant, built once per session."""
     if variant not in _INDEX:
-        indptr, doc, tf, lens, _ = sparse_data
+        indptr, doc, tf, lens = sparse_data[:4]
         _INDEX[variant] = build_bm25_index_from_postings(indptr, doc, tf, lens, variant)
     return _INDEX[variant]
 
@@ -133,3 +132,19 @@ def test_bm25_configs2_exact(engine, sparse_data, variant, k, n_sample, wscan):
         want = bm25_filter(sparse_oracle_scores(idx, queries[b]), k)
         assert list(ids[b, :ln[b]]) == [w[0] for w in want], f"query {b}: ids differ"
         assert list(sc[b, :ln[b]]) == [w[1] for w in want], f"query {b}: scores differ"
+
+
+@pytest.mark.parametrize("variant", [BM25S, OKAPI], ids=["bm25s", "okapi"])
+def test_device_index_build_full_size(engine, sparse_data, variant):
+    """f3: 1M documents / ~56M tokens indexed on the device (erh_build_bm25_index): CSR, tf, idf and payload equal the
+    host builder's bit for bit (the postings themselves also equal the torch-sorted CSR the other tests use)."""
+    import time
+    indptr, doc, tf, lens, _, flat = sparse_data
+    want = host_index(sparse_data, variant)
+    t0 = time.perf_counter()
+    got = engine.build_bm25(flat.astype(np.int32), lens.astype(np.int32), VOCAB, variant=variant)
+    dt = time.perf_counter() - t0
+    print(f"device index build, {flat.shape[0]} tokens -> {got.nnz} postings: {dt:.2f} s (including the copies back)")
+    assert np.array_equal(got.indptr, indptr) and np.array_equal(got.doc_ids, doc) and np.array_equal(got.tf, tf)
+    assert np.array_equal(got.idf, want.idf) and got.avgdl == want.avgdl
+    assert np.array_equal(got.payload, want.payload)

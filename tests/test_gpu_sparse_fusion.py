@@ -178,6 +178,41 @@ def test_bm25_two_indices_on_one_handle(engine):
         engine._select(0)
 
 
+@pytest.mark.parametrize("variant", [OKAPI, BM25S])
+@pytest.mark.parametrize("n_docs,vocab,seed,mean_len", [(50, 12, 0, 6), (4000, 700, 1, 25), (60000, 5000, 2, 40)])
+def test_device_index_build_is_bit_identical_to_host_builder(engine, variant, n_docs, vocab, seed, mean_len):
+    """erh_build_bm25_index (sort / run-length / df on the GPU, idf on the host with libm's log) against the numpy
+    builder that is itself checked against the rank_bm25 / bm25s restatements (tests/test_index_vs_oracle.py): CSR,
+    tf, idf, avgdl, average_idf and the per-posting payload, bit for bit; and the built index answers queries."""
+    flat, lens = synth.token_corpus(n_docs, vocab, seed=seed, mean_len=mean_len)
+    if n_docs == 4000:
+        lens = lens.copy()
+        empty = lens[7]
+        flat = np.concatenate([flat[:lens[:7].sum()], flat[lens[:8].sum():]])     # document 7 becomes empty
+        lens[7] = 0
+        assert empty > 0
+    want = build_bm25_index_from_ids(flat=flat, doc_lens=lens, n_vocab=vocab + 3, variant=variant)   # ids vocab..vocab+2 never occur
+    got = engine.build_bm25(flat, lens, vocab + 3, variant=variant)
+    assert got.nnz == want.nnz
+    assert np.array_equal(got.indptr, want.indptr) and np.array_equal(got.doc_ids, want.doc_ids)
+    assert np.array_equal(got.tf, want.tf)
+    assert got.idf.dtype == want.idf.dtype and np.array_equal(got.idf, want.idf)
+    assert got.avgdl == want.avgdl and got.average_idf == want.average_idf
+    assert got.payload.dtype == want.payload.dtype and np.array_equal(got.payload, want.payload)
+    queries = [list(map(int, q)) for q in synth.token_queries(flat, lens, vocab, 6, seed=seed + 3)]
+    qi, qt = queries_to_csr(queries)
+    ids, sc, ln = engine.bm25_topk(qi, qt, 20)
+    for b, q in enumerate(queries):
+        acc = np.zeros(n_docs, want.payload.dtype)
+        for t in q:
+            s, e = want.indptr[t], want.indptr[t + 1]
+            np.add.at(acc, want.doc_ids[s:e], want.payload[s:e])
+        w = bm25_filter(acc, 20)
+        assert list(ids[b, :ln[b]]) == [x[0] for x in w] and list(sc[b, :ln[b]]) == [x[1] for x in w]
+    with pytest.raises(Exception):
+        engine.build_bm25(np.array([0, vocab + 99], np.int32), np.array([2], np.int32), vocab, variant=variant)
+
+
 def _random_lists(rng, n_items, la, lb, dup_rate):
     ids_a = rng.choice(n_items, size=la, replace=False)
     ids_b = rng.choice(n_items, size=lb, replace=False)
