@@ -100,7 +100,7 @@ struct erh_handle {
     int opt_dense_readahead = 1;           // cfg 2 only: fragments of the next K-step are read before its barrier
     int opt_small_single = 1;              // small batches: skip the refinement boundaries when the lists can take it
     int opt_dense_gemv = 1;                // batches of <= 16 queries: skinny-GEMM stream instead of the padded 256-query scan
-    int opt_dense_pp = 1;                  // ping-pong persistent append scan (falls back to the kernels below when it does not apply)
+    int opt_dense_pp = 2;                  // ping-pong persistent append scan (falls back to the kernels below when it does not apply)
     int opt_dense_persist = 1;             // persistent append scan (falls back to the plain launch when it does not apply)
     int n_cus = 0;                         // compute units of the device (persistent grids = one workgroup per CU)
     // profiling
@@ -212,7 +212,8 @@ hipError_t scan_append(erh_handle *h, const _Float16 *X, int64_t N, int d, int64
     if (h->opt_dense_pp && pp_code) {
         hipError_t e = erh::launch_dense_scan_pp(X, N, d, c0, c1, Q16, Bpad, B, tau, filt, dir, cand, cnt, cap, flags,
                                                  h->n_cus, h->opt_dense_ablate,
-                                                 h->opt_debug_counters ? h->dbg.as<unsigned long long>() : nullptr, st);
+                                                 h->opt_debug_counters ? h->dbg.as<unsigned long long>() : nullptr,
+                                                 (h->opt_dense_pp >= 2 && X == h->X.as<_Float16>()) ? 1 : 0, st);
         if (e != hipErrorInvalidValue) return e;
         (void)hipGetLastError();
     }
@@ -533,7 +534,7 @@ int erh_set_option(erh_handle *h, const char *name, int64_t value) {
     if (!strcmp(name, "dense_readahead")) { h->opt_dense_readahead = value != 0; return ERH_OK; }
     if (!strcmp(name, "dense_shuffle")) { h->opt_dense_shuffle = value != 0; return ERH_OK; }   // takes effect at the next erh_set_dense
     if (!strcmp(name, "dense_n1_auto")) { h->opt_n1_auto = value != 0; return ERH_OK; }
-    if (!strcmp(name, "dense_pp")) { h->opt_dense_pp = value != 0; return ERH_OK; }
+    if (!strcmp(name, "dense_pp")) { if (value < 0 || value > 2) return h->fail(ERH_ERR_INVALID, "dense_pp"); h->opt_dense_pp = (int)value; return ERH_OK; }
     if (!strcmp(name, "dense_gemv")) { h->opt_dense_gemv = value != 0; return ERH_OK; }
     if (!strcmp(name, "dense_gemv_kb")) { erh::dense_gemv_tune((int)value, 0); return ERH_OK; }       // process-wide tuning
     if (!strcmp(name, "dense_gemv_wgs")) { erh::dense_gemv_tune(0, (int)value); return ERH_OK; }
@@ -633,7 +634,9 @@ int erh_set_dense(erh_handle *h, const void *x, int64_t n, int d, int dtype, int
         return h->fail(ERH_ERR_UNSUPPORTED, "erh_set_dense: normalize=1 needs fp32 rows (fp16 rows are taken as stored)");
     HIPCHK(h, hipSetDevice(h->device));
     hipStream_t st = nullptr;
-    HIPCHK(h, h->X.ensure((size_t)n * d * 2));
+    hipStream_t st_pad = nullptr;
+    HIPCHK(h, h->X.ensure((size_t)(n + erh::kDensePadRows) * d * 2));   // zero rows behind the matrix: tiles may run past N
+    HIPCHK(h, hipMemsetAsync(h->X.as<char>() + (size_t)n * d * 2, 0, (size_t)erh::kDensePadRows * d * 2, st_pad));
     const hipMemcpyKind kind = is_device_ptr ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     int64_t mul = 1, inv = 1;
     if (h->opt_dense_shuffle && n > 2) choose_placement(n, &mul, &inv);

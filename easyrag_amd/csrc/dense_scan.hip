@@ -693,6 +693,102 @@ static_assert(LDS_BYTES == 160 * 1024, "pp LDS");
         __builtin_amdgcn_sched_barrier(0);                 \
     } while (0)
 
+// Epilogue of tile i for this wave (acc final); shared by both ping-pong kernels (it uses their local names).  See the
+// header comment of the ping-pong scan above.
+#define ERH_PP_EPILOGUE()                                                                             \
+    do {                                                                                              \
+        if (PABL & kPpNoEpi) {                                                        \
+            float keep_ = 0.f;                                                                        \
+            _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                          \
+                _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                      \
+                    _Pragma("unroll") for (int r = 0; r < 16; ++r) keep_ += acc[mt][nt][r];           \
+            if (keep_ == 1.2345e-30f) *overflow = 7u;                                                 \
+            break;                                                                                    \
+        }                                                                                             \
+        if (threadIdx.x == 0) flag[(i + 1) & 1] = 0;                                                  \
+        const bool last_ = (i + 1 == n_tiles);                                                        \
+        const int fill0_ = fill;                                                                      \
+        for (int shift_ = 0;; shift_ += pp::CAPW) {                                                   \
+            int cnt_ = fill0_;                                                                        \
+            float tt_[2] = {t_q[0], t_q[1]};                                                          \
+            asm volatile("" : "+v"(tt_[0]), "+v"(tt_[1]));   /* opaque per pass: nothing of the pass is hoisted out of the loop */ \
+            _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                                        \
+                const float t_ = tt_[nt];                                                             \
+                uint32_t pk_l_ = (uint32_t)(nt * 32 + l31) | ((uint32_t)(grp * 128 + 4 * hh) << 6) |     \
+                                 ((uint32_t)i << 14);                                                 \
+                asm volatile("" : "+v"(pk_l_));                                                       \
+                _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                    \
+                    /* four accumulator registers per wave-uniform test: two issue slots per register in the   \
+                       common no-survivor case (a compare and its share of the OR / branch) instead of a       \
+                       compare, a ballot test and a branch for every register */                               \
+                    _Pragma("unroll") for (int r4 = 0; r4 < 16; r4 += 4) {                            \
+                        const bool any_ = (acc[mt][nt][r4] >= t_) | (acc[mt][nt][r4 + 1] >= t_) |     \
+                                          (acc[mt][nt][r4 + 2] >= t_) | (acc[mt][nt][r4 + 3] >= t_);  \
+                        if (__builtin_amdgcn_ballot_w64(any_)) {                                      \
+                            _Pragma("unroll") for (int r = r4; r < r4 + 4; ++r) {                     \
+                                const float sc_ = acc[mt][nt][r];                                     \
+                                const bool hit_ = sc_ >= t_;                                          \
+                                const unsigned long long m_ = __builtin_amdgcn_ballot_w64(hit_);      \
+                                if (m_) {                                                             \
+                                    const int pos_ = cnt_ - shift_ +                                  \
+                                        (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m_ >> 32),          \
+                                                                       __builtin_amdgcn_mbcnt_lo((uint32_t)m_, 0u)); \
+                                    if (hit_ && (unsigned)pos_ < (unsigned)pp::CAPW) {                \
+                                        *reinterpret_cast<float *>(rec + pos_ * 4) = sc_;             \
+                                        *reinterpret_cast<uint32_t *>(rec + 1024 + pos_ * 4) =        \
+                                            pk_l_ + ((uint32_t)(mt * 32 + (r & 3) + 8 * (r >> 2)) << 6); \
+                                    }                                                                 \
+                                    cnt_ += __builtin_popcountll(m_);                                 \
+                                }                                                                     \
+                                __builtin_amdgcn_sched_barrier(0);   /* keeps one ballot mask live at a time */ \
+                            }                                                                         \
+                        }                                                                             \
+                        __builtin_amdgcn_sched_barrier(0);                                            \
+                    }                                                                                 \
+                }                                                                                     \
+            }                                                                                         \
+            const int avail_ = cnt_ - shift_;                                                         \
+            const bool over_ = avail_ > pp::CAPW;                                                     \
+            const int nrec_ = over_ ? pp::CAPW : avail_;                                              \
+            if (over_ || flush_now || last_) {                                                        \
+                for (int base_ = 0; base_ < nrec_; base_ += 64) {                                     \
+                    const int j_ = base_ + lane;                                                      \
+                    if (j_ < nrec_) {                                                                 \
+                        uint2 rc_;                                                                    \
+                        rc_.x = *reinterpret_cast<const uint32_t *>(rec + j_ * 4);                    \
+                        rc_.y = *reinterpret_cast<const uint32_t *>(rec + 1024 + j_ * 4);             \
+                        const int q_ = (int)q_row0 + wave_n * 64 + (int)(rc_.y & 63u);                \
+                        const int64_t chunk_ = c0 + ((int64_t)stream + (int64_t)(rc_.y >> 14) * n_streams) * pp::BM + \
+                                               (int64_t)((rc_.y >> 6) & 255u);                        \
+                        bool ok_ = chunk_ < lim;                                                      \
+                        if (ok_ && filter_dir) {                                                      \
+                            const int fd_ = (int)filter_dir[q_];                                      \
+                            ok_ = fd_ < 0 || (int)dir_id[chunk_] == fd_;                              \
+                        }                                                                             \
+                        if (ok_) {                                                                    \
+                            const uint32_t p_ = atomicAdd(&cand_cnt[q_], 1u);                         \
+                            if (p_ < (uint32_t)cap) {                                                 \
+                                ErhCand c_;                                                           \
+                                c_.s = __uint_as_float(rc_.x);                                        \
+                                c_.idx = (int32_t)chunk_;                                             \
+                                cand[(int64_t)q_ * cap + p_] = c_;                                    \
+                            } else {                                                                  \
+                                atomicOr(overflow, 1u);                                               \
+                            }                                                                         \
+                        }                                                                             \
+                    }                                                                                 \
+                }                                                                                     \
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                      \
+                fill = 0;                                                                             \
+            } else {                                                                                  \
+                fill = nrec_;                                                                         \
+            }                                                                                         \
+            if (!over_) break;                                                                        \
+        }                                                                                             \
+        if (fill > pp::CAPW / 2 && lane == 0) flag[i & 1] = 1;                                        \
+    } while (0)
+
+
 // PABL (measurement builds only, -DERH_MEASURE): bit mask -- 1 no epilogue, 2 thresholds forced to +inf, 4 no MFMA,
 // 8 no chunk-side DMA, 16 no query-side DMA, 32 no fragment reads, 64 phase clocks.  Anything but 0 and 64 gives
 // invalid results.  The option "dense_ablate" keeps its round-1 codes (pp_mask_of below maps them).
@@ -853,90 +949,6 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp_kernel(
     int flush_now = 0;                                                 // workgroup-uniform, decided one tile ahead
     int g = 0;
 
-// Epilogue of tile i for this wave (acc final).  See the header comment.
-#define ERH_PP_EPILOGUE()                                                                             \
-    do {                                                                                              \
-        if (PABL & kPpNoEpi) {                                                        \
-            float keep_ = 0.f;                                                                        \
-            _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                          \
-                _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                      \
-                    _Pragma("unroll") for (int r = 0; r < 16; ++r) keep_ += acc[mt][nt][r];           \
-            if (keep_ == 1.2345e-30f) *overflow = 7u;                                                 \
-            break;                                                                                    \
-        }                                                                                             \
-        if (threadIdx.x == 0) flag[(i + 1) & 1] = 0;                                                  \
-        const bool last_ = (i + 1 == n_tiles);                                                        \
-        const int fill0_ = fill;                                                                      \
-        for (int shift_ = 0;; shift_ += pp::CAPW) {                                                   \
-            int cnt_ = fill0_;                                                                        \
-            float tt_[2] = {t_q[0], t_q[1]};                                                          \
-            asm volatile("" : "+v"(tt_[0]), "+v"(tt_[1]));   /* opaque per pass: nothing of the pass is hoisted out of the loop */ \
-            _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                                        \
-                const float t_ = tt_[nt];                                                             \
-                uint32_t pk_l_ = (uint32_t)(nt * 32 + l31) | ((uint32_t)(grp * 128 + 4 * hh) << 6) |     \
-                                 ((uint32_t)i << 14);                                                 \
-                asm volatile("" : "+v"(pk_l_));                                                       \
-                _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                    \
-                    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                  \
-                        const float sc_ = acc[mt][nt][r];                                             \
-                        const bool hit_ = sc_ >= t_;                                                  \
-                        const unsigned long long m_ = __builtin_amdgcn_ballot_w64(hit_);              \
-                        if (m_) {                                                                     \
-                            const int pos_ = cnt_ - shift_ +                                          \
-                                (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m_ >> 32),                  \
-                                                               __builtin_amdgcn_mbcnt_lo((uint32_t)m_, 0u)); \
-                            if (hit_ && (unsigned)pos_ < (unsigned)pp::CAPW) {                        \
-                                *reinterpret_cast<float *>(rec + pos_ * 4) = sc_;                     \
-                                *reinterpret_cast<uint32_t *>(rec + 1024 + pos_ * 4) =                \
-                                    pk_l_ + ((uint32_t)(mt * 32 + (r & 3) + 8 * (r >> 2)) << 6);      \
-                            }                                                                         \
-                            cnt_ += __builtin_popcountll(m_);                                         \
-                        }                                                                             \
-                        __builtin_amdgcn_sched_barrier(0);   /* keeps one ballot mask live at a time */ \
-                    }                                                                                 \
-                }                                                                                     \
-            }                                                                                         \
-            const int avail_ = cnt_ - shift_;                                                         \
-            const bool over_ = avail_ > pp::CAPW;                                                     \
-            const int nrec_ = over_ ? pp::CAPW : avail_;                                              \
-            if (over_ || flush_now || last_) {                                                        \
-                for (int base_ = 0; base_ < nrec_; base_ += 64) {                                     \
-                    const int j_ = base_ + lane;                                                      \
-                    if (j_ < nrec_) {                                                                 \
-                        uint2 rc_;                                                                    \
-                        rc_.x = *reinterpret_cast<const uint32_t *>(rec + j_ * 4);                    \
-                        rc_.y = *reinterpret_cast<const uint32_t *>(rec + 1024 + j_ * 4);             \
-                        const int q_ = (int)q_row0 + wave_n * 64 + (int)(rc_.y & 63u);                \
-                        const int64_t chunk_ = c0 + ((int64_t)stream + (int64_t)(rc_.y >> 14) * n_streams) * pp::BM + \
-                                               (int64_t)((rc_.y >> 6) & 255u);                        \
-                        bool ok_ = chunk_ < lim;                                                      \
-                        if (ok_ && filter_dir) {                                                      \
-                            const int fd_ = (int)filter_dir[q_];                                      \
-                            ok_ = fd_ < 0 || (int)dir_id[chunk_] == fd_;                              \
-                        }                                                                             \
-                        if (ok_) {                                                                    \
-                            const uint32_t p_ = atomicAdd(&cand_cnt[q_], 1u);                         \
-                            if (p_ < (uint32_t)cap) {                                                 \
-                                ErhCand c_;                                                           \
-                                c_.s = __uint_as_float(rc_.x);                                        \
-                                c_.idx = (int32_t)chunk_;                                             \
-                                cand[(int64_t)q_ * cap + p_] = c_;                                    \
-                            } else {                                                                  \
-                                atomicOr(overflow, 1u);                                               \
-                            }                                                                         \
-                        }                                                                             \
-                    }                                                                                 \
-                }                                                                                     \
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                      \
-                fill = 0;                                                                             \
-            } else {                                                                                  \
-                fill = nrec_;                                                                         \
-            }                                                                                         \
-            if (!over_) break;                                                                        \
-        }                                                                                             \
-        if (fill > pp::CAPW / 2 && lane == 0) flag[i & 1] = 1;                                        \
-    } while (0)
-
     // One barrier per stage: between barrier g and barrier g+1 group 0 runs M(g) then C(g+1), group 1 runs C(g) then
     // M(g) -- opposite order, so on every SIMD one wave is in its matrix segment while its partner does the memory
     // segment.  (The barrier is only needed where a stage changes hands: before it every read of stage g is done
@@ -990,7 +1002,271 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp_kernel(
 #undef ERH_PP_MEM
 #undef ERH_PP_COMPUTE
 #undef ERH_PP_WAIT
-#undef ERH_PP_EPILOGUE
+}
+
+// ---------------------------------------------------------------------------------------------
+// Ping-pong scan, lean issue stream (option "dense_pp" = 2, the default).  Same tiles, rings, schedule, epilogue and
+// results as dense_scan_pp_kernel.  What changed is the instruction count of the memory segment: a wave issues at
+// most one instruction every ~4 cycles, and the phase clocks showed M(h) at 760-1130 cycles against 515-650 for the 16
+// MFMAs it is supposed to hide behind (profiles/r02a_kbench_pp_ablations.log) -- with ~140 instructions in it, most
+// of them bookkeeping (64-bit address arithmetic per DMA instruction, stage -> ring-slot arithmetic, the A/B parity
+// and tail tests).  Here
+//   - the per-lane source pointers ADVANCE (128 bytes per stage pair; one uniform-increment add per pointer, the jump
+//     to the stream's next tile folded into the same add) instead of being recomputed from (tile, stage);
+//     rows past N are read from the zero padding erh_set_dense allocates behind the matrix, so nothing is clamped;
+//   - ring positions are byte offsets that wrap by compare-and-subtract; the stage loop is unrolled by two, so the
+//     A-pair / B-pair alternation and the vmcnt(8) / vmcnt(4) alternation are compile-time;
+//   - fragment addresses are one VGPR add per operand and stage plus immediate offsets.
+template <int PABL>
+__global__ __launch_bounds__(pp::NT) void dense_scan_pp2_kernel(
+    const _Float16 *__restrict__ X, int64_t N, int d, int64_t c0, int64_t c1,
+    const _Float16 *__restrict__ Q, int Bpad, int B,
+    const float *__restrict__ tau, const int16_t *__restrict__ filter_dir, const int16_t *__restrict__ dir_id,
+    ErhCand *__restrict__ cand, uint32_t *__restrict__ cand_cnt, int cap, uint32_t *__restrict__ overflow,
+    unsigned long long *__restrict__ dbg /* kPpClocks only */) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp = wave >> 2, wave_n = wave & 3;
+    long long tph[6] = {0, 0, 0, 0, 0, 0};
+    long long t_mark = (PABL & kPpClocks) ? clock64() : 0;
+#define ERH_PH(I) do { if (PABL & kPpClocks) { const long long n_ = clock64(); tph[I] += n_ - t_mark; t_mark = n_; } } while (0)
+    const int nk = d / pp::BK;
+
+    const int n_qt = Bpad / pp::BN;
+    const int64_t n_ct = (c1 - c0 + pp::BM - 1) / pp::BM;
+    const int xcd = blockIdx.x & 7;
+    const int jx = blockIdx.x >> 3;
+    const int qt = jx % n_qt;
+    const int stream = (jx / n_qt) * 8 + xcd;
+    const int n_streams = (gridDim.x / (8 * n_qt)) * 8;
+    if (stream >= n_ct) return;                                        // whole workgroup, before any barrier
+    const int n_tiles = (int)((n_ct - stream + n_streams - 1) / n_streams);
+    const int total = n_tiles * nk;                                    // flattened (tile, stage) sequence
+    const int64_t q_row0 = (int64_t)qt * pp::BN;
+    const int64_t lim = (c1 < N) ? c1 : N;
+
+    const int l31 = lane & 31, hh = lane >> 5;
+    float t_q[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int q = (int)q_row0 + wave_n * 64 + nt * 32 + l31;
+        t_q[nt] = (q < B && !(PABL & kPpTauInf)) ? tau[q] : INFINITY;
+    }
+    asm volatile("" ::"v"(t_q[0]), "v"(t_q[1]));                      // loaded before the DMA stream starts (keeps vmcnt countable)
+
+    // per-lane source pointers of this wave's two 1-KiB DMA instructions per operand and stage: piece = 16-byte unit,
+    // 4 per row; instruction `it` of wave w moves pieces [(it * 8 + w) * 64, +64) of the 256-row stage image
+    const _Float16 *pa[2], *pb[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int piece = (it * pp::NW + wave) * 64 + lane;
+        const int r = piece >> 2, p4 = piece & 3;
+        const int ls = p4 ^ row_swizzle<pp::PR>(r);                    // logical 16-byte slot stored at physical slot p4
+        pa[it] = X + (c0 + (int64_t)stream * pp::BM + r) * (int64_t)d + ls * 8;
+        pb[it] = Q + (q_row0 + r) * (int64_t)d + ls * 8;
+    }
+    const int64_t a_jump = ((int64_t)n_streams * pp::BM - 1) * (int64_t)d;   // end of a tile row -> same row of the stream's next tile
+    const int sw = row_swizzle<pp::PR>(l31);
+    const int a_rd0 = (grp * 128 + l31) * pp::RB + ((hh ^ sw) << 4);
+    const int a_rd1 = (grp * 128 + l31) * pp::RB + (((2 + hh) ^ sw) << 4);
+    const int b_rd0 = pp::B_BASE + (wave_n * 64 + l31) * pp::RB + ((hh ^ sw) << 4);
+    const int b_rd1 = pp::B_BASE + (wave_n * 64 + l31) * pp::RB + (((2 + hh) ^ sw) << 4);
+    char *const rec = lds + pp::REC_BASE + wave * pp::REC_BYTES;
+    volatile int *const flag = reinterpret_cast<volatile int *>(lds + pp::FLAG_OFF);
+    if (threadIdx.x == 0) { flag[0] = 0; flag[1] = 0; }
+
+    // issue state: ring byte offsets of the next pair's first slot, stage-in-tile counters, pair issues left
+    constexpr int kABytes = pp::AST * pp::A_BYTES, kBBytes = pp::BST * pp::B_BYTES;
+    int a_dst = 0, b_dst = 0, ka = 0, kb = 0;
+    int a_left = total >> 1, b_left = total >> 1;                      // (nk is even: pairs never straddle a tile)
+    // fragment-read state
+    int fa_off = 0, fb_off = 0, f_left = total;
+    half8 fa[4][2], fb[2][2];
+    char *const my_dst = lds + wave * 1024;                            // + it * 8192 + ring offset
+
+#define ERH_PP2_GLDS(SRC, DST) __builtin_amdgcn_global_load_lds((const void *)(SRC), ERH_LDS_PTR(DST), 16, 0, 0)
+#define ERH_PP2_ISSUE_A()                                                                             \
+    do {                                                                                              \
+        if (a_left > 0) {                                                                             \
+            if (!(PABL & kPpNoDmaA)) {                                                                \
+                int d1_ = a_dst + pp::A_BYTES;                                                        \
+                if (d1_ == kABytes) d1_ = 0;                                                          \
+                ERH_PP2_GLDS(pa[0], my_dst + a_dst);                                                  \
+                ERH_PP2_GLDS(pa[0] + 32, my_dst + d1_);                                               \
+                ERH_PP2_GLDS(pa[1], my_dst + a_dst + 8192);                                           \
+                ERH_PP2_GLDS(pa[1] + 32, my_dst + d1_ + 8192);                                        \
+            }                                                                                         \
+            ka += 2;                                                                                  \
+            int64_t inc_ = 64;                                                                        \
+            if (ka == nk) { ka = 0; inc_ = 64 + a_jump; }                                             \
+            pa[0] += inc_; pa[1] += inc_;                                                             \
+            a_dst += 2 * pp::A_BYTES;                                                                 \
+            if (a_dst >= kABytes) a_dst -= kABytes;                                                   \
+            --a_left;                                                                                 \
+        }                                                                                             \
+    } while (0)
+#define ERH_PP2_ISSUE_B()                                                                             \
+    do {                                                                                              \
+        if (b_left > 0) {                                                                             \
+            if (!(PABL & kPpNoDmaB)) {                                                                \
+                const int d0_ = pp::B_BASE + b_dst, d1_ = pp::B_BASE + ((b_dst + pp::B_BYTES) & (kBBytes - 1)); \
+                ERH_PP2_GLDS(pb[0], my_dst + d0_);                                                    \
+                ERH_PP2_GLDS(pb[0] + 32, my_dst + d1_);                                               \
+                ERH_PP2_GLDS(pb[1], my_dst + d0_ + 8192);                                             \
+                ERH_PP2_GLDS(pb[1] + 32, my_dst + d1_ + 8192);                                        \
+            }                                                                                         \
+            kb += 2;                                                                                  \
+            int64_t inc_ = 64;                                                                        \
+            if (kb == nk) { kb = 0; inc_ = 64 - (int64_t)d; }       /* same query rows for every tile */ \
+            pb[0] += inc_; pb[1] += inc_;                                                             \
+            b_dst = (b_dst + 2 * pp::B_BYTES) & (kBBytes - 1);                                        \
+            --b_left;                                                                                 \
+        }                                                                                             \
+    } while (0)
+// fragments of the next stage to read (the stage after the one the matrix segment is working on)
+#define ERH_PP2_READ()                                                                                \
+    do {                                                                                              \
+        if (f_left > 0) {                                                                             \
+            if (!(PABL & kPpNoFrag) || f_left == total) {                                             \
+                const char *pa0_ = lds + (a_rd0 + fa_off), *pa1_ = lds + (a_rd1 + fa_off);            \
+                const char *pb0_ = lds + (b_rd0 + fb_off), *pb1_ = lds + (b_rd1 + fb_off);            \
+                _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                    \
+                    fa[mt][0] = *reinterpret_cast<const half8 *>(pa0_ + mt * 32 * pp::RB);            \
+                    fa[mt][1] = *reinterpret_cast<const half8 *>(pa1_ + mt * 32 * pp::RB);            \
+                }                                                                                     \
+                _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                                    \
+                    fb[nt][0] = *reinterpret_cast<const half8 *>(pb0_ + nt * 32 * pp::RB);            \
+                    fb[nt][1] = *reinterpret_cast<const half8 *>(pb1_ + nt * 32 * pp::RB);            \
+                }                                                                                     \
+            }                                                                                         \
+            fa_off += pp::A_BYTES;                                                                    \
+            if (fa_off == kABytes) fa_off = 0;                                                        \
+            fb_off = (fb_off + pp::B_BYTES) & (kBBytes - 1);                                          \
+            --f_left;                                                                                 \
+        }                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);   /* reads first: the DMA issue below covers their latency */ \
+    } while (0)
+#define ERH_PP2_COMPUTE(FIRST)                                                                        \
+    do {                                                                                              \
+        if (PABL & kPpNoMfma) {                                                                       \
+            _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) asm volatile("" ::"v"(fa[mt][0]), "v"(fa[mt][1])); \
+            _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) asm volatile("" ::"v"(fb[nt][0]), "v"(fb[nt][1])); \
+            if (FIRST) { _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f; }                \
+            break;                                                                                    \
+        }                                                                                             \
+        if (FIRST) {                                                                                  \
+            const f32x16 z_ = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; \
+            _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                          \
+                _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                      \
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mt][0], fb[nt][0], z_, 0, 0, 0); \
+        } else {                                                                                      \
+            _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                          \
+                _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                      \
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mt][0], fb[nt][0], acc[mt][nt], 0, 0, 0); \
+        }                                                                                             \
+        _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                              \
+            _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                          \
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mt][1], fb[nt][1], acc[mt][nt], 0, 0, 0); \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+    } while (0)
+// before barrier g: everything this wave issued up to B(g+1) has landed (see the header of the ping-pong scan)
+#define ERH_PP2_WAIT(G, ODD)                                                                          \
+    do {                                                                                              \
+        if ((G) + 4 >= total) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        \
+        else if (ODD) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                \
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                         \
+    } while (0)
+
+    // prologue: A(0,1) B(0,1) A(2,3); stage 0 complete = the last 4 instructions may stay in flight
+    ERH_PP2_ISSUE_A();
+    ERH_PP2_ISSUE_B();
+    ERH_PP2_ISSUE_A();
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    ERH_PP_BARRIER();
+
+    f32x16 acc[4][2];
+    int fill = 0;                                                      // records buffered in this wave's area
+    int flush_now = 0;                                                 // workgroup-uniform, decided one tile ahead
+    int g = 0;
+
+    if (grp == 0) {
+        ERH_PP2_READ();                                                // M(-1): fragments of stage 0, B(2,3)
+        ERH_PP2_ISSUE_B();
+        __builtin_amdgcn_sched_barrier(0);
+        for (int i = 0; i < n_tiles; ++i) {
+            for (int kt = 0; kt < nk; kt += 2, g += 2) {
+                ERH_PP2_COMPUTE(kt == 0);                              // C(g), g even
+                ERH_PH(0);
+                ERH_PP2_WAIT(g, false);
+                ERH_PH(1);
+                ERH_PP_BARRIER();                                      // barrier g
+                ERH_PH(2);
+                ERH_PP2_READ();                                        // M(g): fragments of g+1, A(g+4, g+5)
+                ERH_PP2_ISSUE_A();
+                __builtin_amdgcn_sched_barrier(0);
+                ERH_PH(3);
+                ERH_PP2_COMPUTE(false);                                // C(g), g odd
+                ERH_PH(0);
+                ERH_PP2_WAIT(g + 1, true);
+                ERH_PH(1);
+                ERH_PP_BARRIER();
+                ERH_PH(2);
+                ERH_PP2_READ();                                        // M(g): fragments of g+1, B(g+3, g+4)
+                ERH_PP2_ISSUE_B();
+                __builtin_amdgcn_sched_barrier(0);
+                ERH_PH(3);
+            }
+            ERH_PP_EPILOGUE();
+            ERH_PH(4);
+            ERH_PP_BARRIER();
+            ERH_PH(5);
+            if (!(PABL & kPpNoEpi)) flush_now = __builtin_amdgcn_readfirstlane(flag[i & 1]);
+        }
+    } else {
+        for (int i = 0; i < n_tiles; ++i) {
+            for (int kt = 0; kt < nk; kt += 2, g += 2) {
+                ERH_PP2_READ();                                        // M(g-1), g even: fragments of g, B(g+2, g+3)
+                ERH_PP2_ISSUE_B();
+                __builtin_amdgcn_sched_barrier(0);
+                ERH_PH(3);
+                ERH_PP2_WAIT(g, false);
+                ERH_PH(1);
+                ERH_PP_BARRIER();                                      // barrier g
+                ERH_PH(2);
+                ERH_PP2_COMPUTE(kt == 0);
+                ERH_PH(0);
+                ERH_PP2_READ();                                        // M(g-1), g odd: fragments of g, A(g+3, g+4)
+                ERH_PP2_ISSUE_A();
+                __builtin_amdgcn_sched_barrier(0);
+                ERH_PH(3);
+                ERH_PP2_WAIT(g + 1, true);
+                ERH_PH(1);
+                ERH_PP_BARRIER();
+                ERH_PH(2);
+                ERH_PP2_COMPUTE(false);
+                ERH_PH(0);
+            }
+            ERH_PP_EPILOGUE();
+            ERH_PH(4);
+            ERH_PP_BARRIER();
+            ERH_PH(5);
+            if (!(PABL & kPpNoEpi)) flush_now = __builtin_amdgcn_readfirstlane(flag[i & 1]);
+        }
+    }
+    if ((PABL & kPpClocks) && dbg && lane == 0 && (wave == 0 || wave == 4)) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) atomicAdd(&dbg[grp * 8 + i], (unsigned long long)tph[i]);
+        atomicAdd(&dbg[grp * 8 + 6], (unsigned long long)total);
+    }
+#undef ERH_PH
+#undef ERH_PP2_GLDS
+#undef ERH_PP2_ISSUE_A
+#undef ERH_PP2_ISSUE_B
+#undef ERH_PP2_READ
+#undef ERH_PP2_COMPUTE
+#undef ERH_PP2_WAIT
 }
 
 using Cfg0 = ScanCfg<256, 256, 2, 4, 64, 3, 2>;   // one 8-wave workgroup per CU, 160 KiB LDS
@@ -1122,7 +1398,7 @@ constexpr int pp_mask_of(int code) {
 hipError_t launch_pp(const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1, const _Float16 *Q, int Bpad, int B,
                      const float *tau, const int16_t *filter_dir, const int16_t *dir_id, ErhCand *cand,
                      uint32_t *cand_cnt, int cap, uint32_t *overflow, int ctas, int pabl, unsigned long long *dbg,
-                     hipStream_t st) {
+                     int lean, hipStream_t st) {
     const int n_qt = Bpad / pp::BN;
     const int grid_n = ctas / (8 * n_qt) * (8 * n_qt);
     if (grid_n <= 0) return hipErrorInvalidValue;
@@ -1130,8 +1406,14 @@ hipError_t launch_pp(const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1
     if (n_ct / (grid_n / n_qt) + 1 >= (1ll << pp::TILE_BITS)) return hipErrorInvalidValue;   // tile index must fit the record
     dim3 grid((unsigned)grid_n), block(pp::NT);
 #define ERH_LAUNCH_PP(A)                                                                                   \
-    hipLaunchKernelGGL((dense_scan_pp_kernel<A>), grid, block, pp::LDS_BYTES, st, X, N, d, c0, c1, Q, Bpad, B, tau, \
-                       filter_dir, dir_id, cand, cand_cnt, cap, overflow, dbg)
+    do {                                                                                                   \
+        if (lean)                                                                                          \
+            hipLaunchKernelGGL((dense_scan_pp2_kernel<A>), grid, block, pp::LDS_BYTES, st, X, N, d, c0, c1, Q, Bpad, B, \
+                               tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow, dbg);                \
+        else                                                                                               \
+            hipLaunchKernelGGL((dense_scan_pp_kernel<A>), grid, block, pp::LDS_BYTES, st, X, N, d, c0, c1, Q, Bpad, B, \
+                               tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow, dbg);                \
+    } while (0)
 #ifdef ERH_MEASURE
     switch (pp_mask_of(pabl)) {
 #define ERH_PP_CASE(M) case M: ERH_LAUNCH_PP(M); break;
@@ -1164,6 +1446,9 @@ hipError_t dense_scan_init() {
 #define ERH_SET_PP(A)                                                                                      \
     e = hipFuncSetAttribute((const void *)dense_scan_pp_kernel<A>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                             pp::LDS_BYTES);                                                                \
+    if (e != hipSuccess) return e;                                                                         \
+    e = hipFuncSetAttribute((const void *)dense_scan_pp2_kernel<A>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                            pp::LDS_BYTES);                                                                \
     if (e != hipSuccess) return e;
     ERH_SET_PP(0)
 #ifdef ERH_MEASURE
@@ -1178,11 +1463,11 @@ hipError_t dense_scan_init() {
 hipError_t launch_dense_scan_pp(const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1, const _Float16 *Q,
                                 int Bpad, int B, const float *tau, const int16_t *filter_dir, const int16_t *dir_id,
                                 ErhCand *cand, uint32_t *cand_cnt, int cap, uint32_t *overflow, int n_cus, int pabl,
-                                unsigned long long *dbg, hipStream_t st) {
+                                unsigned long long *dbg, int lean, hipStream_t st) {
     if (c1 <= c0) return hipSuccess;
     if (d % (2 * pp::BK) != 0 || d / pp::BK < 8) return hipErrorInvalidValue;   // stage pairs never straddle a tile
     return launch_pp(X, N, d, c0, c1, Q, Bpad, B, tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow, n_cus, pabl,
-                     dbg, st);
+                     dbg, lean, st);
 }
 
 hipError_t launch_dense_scan_store(int cfg, const _Float16 *Q, int Bpad, const _Float16 *X, int64_t N, int d,

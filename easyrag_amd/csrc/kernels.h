@@ -19,7 +19,9 @@ hipError_t launch_dense_scan_append(int cfg, const _Float16 *X, int64_t N, int d
 hipError_t launch_dense_scan_pp(const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1, const _Float16 *Q,
                                 int Bpad, int B, const float *tau, const int16_t *filter_dir, const int16_t *dir_id,
                                 ErhCand *cand, uint32_t *cand_cnt, int cap, uint32_t *overflow, int n_cus, int pabl,
-                                unsigned long long *dbg, hipStream_t st);
+                                unsigned long long *dbg, int lean /* the lean-issue kernel: X must be padded by kDensePadRows zero rows */,
+                                hipStream_t st);
+constexpr int kDensePadRows = 256;   // zero rows erh_set_dense keeps behind the matrix (tiles past N read them)
 hipError_t launch_dense_scan_persist(int cfg, const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1,
                                      const _Float16 *Q, int Bpad, int B, const float *tau,
                                      const int16_t *filter_dir, const int16_t *dir_id,

@@ -219,7 +219,7 @@ int erh_reset_kernel_time(erh_handle *h);
  *   dense_n1_auto (1)     snap the boundaries to whole rounds of the persistent scan
  *   dense_shuffle (1)     golden-ratio row placement of the chunk matrix (takes effect at the next erh_set_dense);
  *                         0 stores the rows in the caller's order
- *   dense_pp (1)          ping-pong persistent append scan; 0 = lock-step kernels (dense_persist 1 / 0 = persistent /
+ *   dense_pp (2)          ping-pong persistent append scan: 2 = lean-issue kernel, 1 = the round-1 kernel; 0 = lock-step kernels (dense_persist 1 / 0 = persistent /
  *                         one workgroup per tile, dense_cfg 0..2 = their tile configuration, dense_readahead)
  *   dense_gemv (1)        batches of at most 16 queries stream the chunk matrix through a 16x16x32 skinny-GEMM kernel
  *                         (the reference's one-query-at-a-time call pattern) instead of the padded 256-query scan

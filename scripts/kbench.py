@@ -102,15 +102,17 @@ def main():
                     res[f"dense B={B} k={k} pp={pp} pabl={abl} (run {rep})"] = timed(eng, lambda: eng.dense_topk(q, k, device_out=True))
             eng.set_option("dense_ablate", 0)
             eng.set_option("dense_pp", 1)
-    if what == "pp2":                                        # ping-pong kernel: operand-side ablations and phase clocks
+    if what in ("pp2", "pp2q"):                              # ping-pong kernels: operand-side ablations and phase clocks
         x = synth.dense_corpus_torch(n, d, seed=2, device=dev)
         eng.set_dense(x)
+        lean = int(os.environ.get("KB_PP", "2"))
+        eng.set_option("dense_pp", lean)
         for B, k in ((256, 100), (1024, 288)):
             q = synth.dense_queries_torch(x, B, seed=7)
             for rep in "ab":
-                for abl in (0, 7, 12, 13, 15, 14, 11, 16, 17, 18):
+                for abl in ((0, 7, 12, 11, 16, 17, 18) if what == "pp2q" else (0, 7, 12, 13, 15, 14, 11, 16, 17, 18)):
                     eng.set_option("dense_ablate", abl)
-                    res[f"dense B={B} k={k} pp pabl={abl} (run {rep})"] = timed(eng, lambda: eng.dense_topk(q, k, device_out=True))
+                    res[f"dense B={B} k={k} pp{lean} pabl={abl} (run {rep})"] = timed(eng, lambda: eng.dense_topk(q, k, device_out=True))
             eng.set_option("debug_counters", 1)
             eng.set_option("dense_ablate", 20)
             eng.dense_topk(q, k, device_out=True)
@@ -121,7 +123,7 @@ def main():
             names = ["matrix", "wait", "barrier", "memory", "epilogue", "epi_barrier"]
             for g in (0, 1):
                 stages = c[g * 8 + 6]
-                res[f"dense B={B} pp phase clocks per stage, group {g}"] = {
+                res[f"dense B={B} pp{lean} phase clocks per stage, group {g}"] = {
                     n_: round(v / stages, 1) for n_, v in zip(names, c[g * 8:g * 8 + 6])} if stages else {}
         del x
     if what == "bm25w":                                      # wave-owned scan vs block scan, section clocks

@@ -12,9 +12,9 @@ from oracle import dense_exact_scores, dense_exact_topk, qdrant_cosine_search, t
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[(0, 1, 1, 0), (0, 1, 0, 0), (0, 0, 0, 0), (1, 0, 0, 0), (2, 1, 0, 0), (0, 1, 1, 1)],
-                ids=["pingpong-256x256x32", "cfg0-256x256x64-persistent", "cfg0-per-tile", "cfg1-128x256x32-per-tile",
-                     "cfg2-256x256x32-persistent", "gemv-16x16x32-small-batch"])
+@pytest.fixture(params=[(0, 1, 2, 0), (0, 1, 1, 0), (0, 1, 0, 0), (0, 0, 0, 0), (1, 0, 0, 0), (2, 1, 0, 0), (0, 1, 2, 1)],
+                ids=["pingpong-lean-256x256x32", "pingpong-256x256x32", "cfg0-256x256x64-persistent", "cfg0-per-tile",
+                     "cfg1-128x256x32-per-tile", "cfg2-256x256x32-persistent", "gemv-16x16x32-small-batch"])
 def scan_cfg(request, engine):
     """Every dense-scan kernel / tile configuration / launch style must satisfy every parity test.  The last arm
     lets batches of at most 16 queries take the skinny-GEMM stream (larger batches use the ping-pong scan); the
@@ -26,7 +26,7 @@ def scan_cfg(request, engine):
     yield request.param
     engine.set_option("dense_cfg", 0)
     engine.set_option("dense_persist", 1)
-    engine.set_option("dense_pp", 1)
+    engine.set_option("dense_pp", 2)
     engine.set_option("dense_gemv", 1)
 
 
