@@ -18,13 +18,15 @@ import csv, glob, json, collections, sys
 sys.path.insert(0, ".")
 from easyrag_amd import _build
 out = {"_lib_digest": _build._digest()}      # bench.py attaches the figures only to runs of exactly these kernels
-for wl, match in (("hybrid", "dense_scan"), ("dense", "dense_scan"), ("bm25", "bm25_scan")):
+import re
+for wl, match, pat in (("hybrid", "dense_scan", r"dense_(scan|gemv)"), ("dense", "dense_scan", r"dense_(scan|gemv)"),
+                       ("bm25", "bm25_scan", r"bm25_w?scan")):
     f = glob.glob(f"gpurun_out/traffic/{wl}/**/*counter_collection.csv", recursive=True)
     if not f:
         continue
     per = collections.defaultdict(list)
     for r in csv.DictReader(open(f[0])):
-        if match in r["Kernel_Name"] and r["Counter_Name"] == "FETCH_SIZE":
+        if re.search(pat, r["Kernel_Name"]) and r["Counter_Name"] == "FETCH_SIZE":
             per[r["Kernel_Name"].split("(")[0][:80]].append(float(r["Counter_Value"]))
     vals = [v for vs in per.values() for v in vs]
     if not vals:

@@ -4,8 +4,9 @@ import csv
 import re
 import sys
 
-OURS = ("dense_scan", "dense_naive", "bm25_", "seed_select", "cand_refine", "dense_finalize", "fuse_kernel",
-        "prep_queries", "convert_rows", "row_norm", "widen_f32")
+OURS = ("dense_scan", "dense_gemv", "dense_exact", "dense_bad", "dense_naive", "bm25_", "seed_select", "cand_refine",
+        "dense_finalize", "fuse_kernel", "pack_topk", "unpack_topk", "csr_", "prep_queries", "convert_rows",
+        "permute_rows", "row_norm", "widen_f32")
 
 
 def short(name: str) -> str:
