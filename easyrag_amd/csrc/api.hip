@@ -100,7 +100,10 @@ struct erh_handle {
     int opt_dense_readahead = 1;           // cfg 2 only: fragments of the next K-step are read before its barrier
     int opt_small_single = 1;              // small batches: skip the refinement boundaries when the lists can take it
     int opt_dense_gemv = 1;                // batches of <= 16 queries: skinny-GEMM stream instead of the padded 256-query scan
-    int opt_dense_pp = 2;                  // ping-pong persistent append scan (falls back to the kernels below when it does not apply)
+    int opt_dense_speculate = 1;           // speculative (verified) first threshold + a single scan stage; 0: guaranteed bounds, refined in stages
+    int opt_dense_var = 0;                 // dense_scan_pp2_kernel VAR (bit 0: two barriers per stage, bit 1: static priority)
+    int opt_dense_rot = 0;                 // K-rotation between the query tiles of a stream, in stages per query tile (-1: nk / n_qt)
+    int opt_dense_pp = 3;                  // ping-pong persistent append scan (falls back to the kernels below when it does not apply)
     int opt_dense_persist = 1;             // persistent append scan (falls back to the plain launch when it does not apply)
     int n_cus = 0;                         // compute units of the device (persistent grids = one workgroup per CU)
     // profiling
@@ -196,6 +199,13 @@ void choose_placement(int64_t n, int64_t *mul, int64_t *inv) {
     *mul = ((t0 % n) + n) % n;
 }
 
+// K-rotation of the ping-pong scan in stages of 32 halves per query tile (see dense_scan_pp2_kernel)
+static int dense_rot_stages(const erh_handle *h, int d, int Bpad) {
+    const int nk = d / 32, n_qt = Bpad / erh::dense_scan_q_tile();
+    if (h->opt_dense_rot >= 0) return h->opt_dense_rot % (nk > 0 ? nk : 1);
+    return n_qt > 1 ? (nk / n_qt) & ~1 : 0;
+}
+
 // Append-stage scan: persistent kernel when enabled and applicable, else one workgroup per tile.
 hipError_t scan_append(erh_handle *h, const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1, const _Float16 *Q16,
                        int Bpad, int B, const float *tau, const int16_t *filt, const int16_t *dir, ErhCand *cand,
@@ -208,12 +218,13 @@ hipError_t scan_append(erh_handle *h, const _Float16 *X, int64_t N, int d, int64
         (void)hipGetLastError();
     }
     const int abl = h->opt_dense_ablate;
-    const bool pp_code = abl == 0 || abl == 7 || abl == 8 || (abl >= 11 && abl <= 18) || abl == 20 || abl == 21;
+    const bool pp_code = abl == 0 || abl == 7 || abl == 8 || (abl >= 11 && abl <= 18) || (abl >= 20 && abl <= 24);
     if (h->opt_dense_pp && pp_code) {
         hipError_t e = erh::launch_dense_scan_pp(X, N, d, c0, c1, Q16, Bpad, B, tau, filt, dir, cand, cnt, cap, flags,
                                                  h->n_cus, h->opt_dense_ablate,
                                                  h->opt_debug_counters ? h->dbg.as<unsigned long long>() : nullptr,
-                                                 (h->opt_dense_pp >= 2 && X == h->X.as<_Float16>()) ? 1 : 0, st);
+                                                 (h->opt_dense_pp >= 2 && X == h->X.as<_Float16>())
+                                                     ? (1 | (h->opt_dense_var << 1) | (h->opt_dense_pp >= 3 ? 8 : 0) | (dense_rot_stages(h, d, Bpad) << 8)) : 0, st);
         if (e != hipErrorInvalidValue) return e;
         (void)hipGetLastError();
     }
@@ -288,8 +299,19 @@ int dense_topk_dev(erh_handle *h, const void *q_dev, int q_dtype, int normalize_
           e = erh::launch_dense_scan_store(h->opt_dense_cfg, Q16, Bpad, X, N, d, 0, (int)n0, h->S0.as<float>(), ld, st);
       }
       HIPCHK(h, e); }
+    // Rank of the prefix score that seeds the threshold.  Guaranteed: k.  Speculative: the prefix is an even sample of
+    // the corpus (erh_set_dense's row placement), so the number of true top-k members inside it is ~Poisson(mu),
+    // mu = k * n0 / N; the rank mu + 6.5 sqrt(mu) + 3 is exceeded with probability ~1e-9, i.e. the rank-th prefix score
+    // is below the corpus' k-th best -- which dense_finalize_kernel verifies for every query (exhaustive path if not).
+    int rank = k;
+    bool speculate = false;
+    if (h->opt_dense_speculate && N > n0) {
+        const double mu = (double)k * (double)n0 / (double)N;
+        const double r = std::ceil(mu + 6.5 * std::sqrt(mu) + 3.0);
+        if (r < (double)k) { rank = (int)r; speculate = true; }
+    }
     { ProfScope ps(h, st, ERH_K_DENSE_SELECT, 0, 0);
-      HIPCHK(h, erh::launch_seed_select(h->S0.as<float>(), ld, (int)n0, 0, B, k, h->qnorm.as<float>(), h->xnorm_max, d,
+      HIPCHK(h, erh::launch_seed_select(h->S0.as<float>(), ld, (int)n0, 0, B, k, rank, h->qnorm.as<float>(), h->xnorm_max, d,
                                         filter_dev, dir, h->tau.as<float>(), h->cand.as<ErhCand>(),
                                         h->cand_cnt.as<uint32_t>(), cap, bad, h->seed_need.as<uint32_t>(), st)); }
     if (N > n0) {
@@ -317,6 +339,7 @@ int dense_topk_dev(erh_handle *h, const void *q_dev, int q_dtype, int normalize_
         int64_t cur = n0;
         int64_t want = h->opt_n1;
         if (want <= n0) want = 0;
+        if (speculate) want = 0;                 // already tighter than any refinement of a guaranteed bound: one stage
         // small batches: one stage when the candidates a seed-only threshold admits (about k * N / n0 per query) fit
         // the lists comfortably -- the refinement launches cost more than they save when there are 16 lists to cut
         if (small && h->opt_small_single && (double)k * (double)N / (double)n0 <= 0.5 * cap) want = 0;
@@ -342,7 +365,8 @@ int dense_topk_dev(erh_handle *h, const void *q_dev, int q_dtype, int normalize_
     { ProfScope ps(h, st, ERH_K_DENSE_SELECT, 0, 0);
       HIPCHK(h, erh::launch_dense_finalize(B, k, mode, h->qnorm.as<float>(), h->xnorm_max, d, X, Q16,
                                            h->cand.as<ErhCand>(), h->cand_cnt.as<uint32_t>(), cap, d_ids, d_sc, d_len,
-                                           reinterpret_cast<float *>(flags + 1), flags + 2, bad, N, h->pos_mul, h->pos_inv, st));
+                                           reinterpret_cast<float *>(flags + 1), flags + 2, bad, N, h->pos_mul, h->pos_inv,
+                                           speculate ? h->tau.as<float>() : nullptr, st));
       // queries the candidate budgets could not certify get their exact answer from the exhaustive path (two empty
       // launches when there are none); it also settles the overflow word: set only if more than
       // dense_exhaustive_max() queries were flagged, in which case dense_check_flags runs further rounds
@@ -534,7 +558,10 @@ int erh_set_option(erh_handle *h, const char *name, int64_t value) {
     if (!strcmp(name, "dense_readahead")) { h->opt_dense_readahead = value != 0; return ERH_OK; }
     if (!strcmp(name, "dense_shuffle")) { h->opt_dense_shuffle = value != 0; return ERH_OK; }   // takes effect at the next erh_set_dense
     if (!strcmp(name, "dense_n1_auto")) { h->opt_n1_auto = value != 0; return ERH_OK; }
-    if (!strcmp(name, "dense_pp")) { if (value < 0 || value > 2) return h->fail(ERH_ERR_INVALID, "dense_pp"); h->opt_dense_pp = (int)value; return ERH_OK; }
+    if (!strcmp(name, "dense_pp")) { if (value < 0 || value > 3) return h->fail(ERH_ERR_INVALID, "dense_pp"); h->opt_dense_pp = (int)value; return ERH_OK; }
+    if (!strcmp(name, "dense_speculate")) { h->opt_dense_speculate = value != 0; return ERH_OK; }
+    if (!strcmp(name, "dense_var")) { if (value < 0 || value > 3) return h->fail(ERH_ERR_INVALID, "dense_var"); h->opt_dense_var = (int)value; return ERH_OK; }
+    if (!strcmp(name, "dense_rot")) { if (value < -1 || value > 4096) return h->fail(ERH_ERR_INVALID, "dense_rot"); h->opt_dense_rot = (int)value; return ERH_OK; }
     if (!strcmp(name, "dense_gemv")) { h->opt_dense_gemv = value != 0; return ERH_OK; }
     if (!strcmp(name, "dense_gemv_kb")) { erh::dense_gemv_tune((int)value, 0); return ERH_OK; }       // process-wide tuning
     if (!strcmp(name, "dense_gemv_wgs")) { erh::dense_gemv_tune(0, (int)value); return ERH_OK; }

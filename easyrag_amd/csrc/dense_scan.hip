@@ -687,6 +687,11 @@ constexpr int TILE_BITS = 18;
 static_assert(LDS_BYTES == 160 * 1024, "pp LDS");
 }  // namespace pp
 
+// flush flags of the ping-pong kernels: plain LDS words (a generic volatile pointer would become flat accesses, which
+// count on vmcnt and drain the LDS-DMA queue at every use)
+#define ERH_PP_FLAG(IDX) \
+    (*reinterpret_cast<volatile __attribute__((address_space(3))) int *>(ERH_LDS_PTR(lds + pp::FLAG_OFF + 4 * (IDX))))
+
 #define ERH_PP_BARRIER()                                   \
     do {                                                   \
         asm volatile("s_barrier" ::: "memory");            \
@@ -705,7 +710,7 @@ static_assert(LDS_BYTES == 160 * 1024, "pp LDS");
             if (keep_ == 1.2345e-30f) *overflow = 7u;                                                 \
             break;                                                                                    \
         }                                                                                             \
-        if (threadIdx.x == 0) flag[(i + 1) & 1] = 0;                                                  \
+        if (threadIdx.x == 0) ERH_PP_FLAG((i + 1) & 1) = 0;                                           \
         const bool last_ = (i + 1 == n_tiles);                                                        \
         const int fill0_ = fill;                                                                      \
         for (int shift_ = 0;; shift_ += pp::CAPW) {                                                   \
@@ -785,13 +790,14 @@ static_assert(LDS_BYTES == 160 * 1024, "pp LDS");
             }                                                                                         \
             if (!over_) break;                                                                        \
         }                                                                                             \
-        if (fill > pp::CAPW / 2 && lane == 0) flag[i & 1] = 1;                                        \
+        if (fill > pp::CAPW / 2 && lane == 0) ERH_PP_FLAG(i & 1) = 1;                                 \
     } while (0)
 
 
 // PABL (measurement builds only, -DERH_MEASURE): bit mask -- 1 no epilogue, 2 thresholds forced to +inf, 4 no MFMA,
 // 8 no chunk-side DMA, 16 no query-side DMA, 32 no fragment reads, 64 phase clocks.  Anything but 0 and 64 gives
 // invalid results.  The option "dense_ablate" keeps its round-1 codes (pp_mask_of below maps them).
+constexpr int kPpVarProduct = 0;   // VAR of dense_scan_pp2_kernel the product build carries besides 0
 constexpr int kPpNoEpi = 1, kPpTauInf = 2, kPpNoMfma = 4, kPpNoDmaA = 8, kPpNoDmaB = 16, kPpNoFrag = 32, kPpClocks = 64;
 template <int PABL>
 __global__ __launch_bounds__(pp::NT) void dense_scan_pp_kernel(
@@ -842,8 +848,7 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp_kernel(
     const int a_lane_off = (grp * 128 + l31) * pp::RB;
     const int b_lane_off = pp::B_BASE + (wave_n * 64 + l31) * pp::RB;
     char *const rec = lds + pp::REC_BASE + wave * pp::REC_BYTES;
-    volatile int *const flag = reinterpret_cast<volatile int *>(lds + pp::FLAG_OFF);
-    if (threadIdx.x == 0) { flag[0] = 0; flag[1] = 0; }
+    if (threadIdx.x == 0) { ERH_PP_FLAG(0) = 0; ERH_PP_FLAG(1) = 0; }
 
     // issue state: next B stage pair (gb even, kb = gb % nk, sb = gb % BST), next A stage pair (ga, ka, sa, tile of ga);
     // m_odd = parity of the next memory phase M(h): even h issues the A pair (h+4, h+5), odd h the B pair (h+3, h+4)
@@ -970,7 +975,7 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp_kernel(
             ERH_PH(4);
             ERH_PP_BARRIER();
             ERH_PH(5);
-            if (!(PABL & kPpNoEpi)) flush_now = __builtin_amdgcn_readfirstlane(flag[i & 1]);
+            if (!(PABL & kPpNoEpi)) flush_now = __builtin_amdgcn_readfirstlane(ERH_PP_FLAG(i & 1));
         }
     } else {
         for (int i = 0; i < n_tiles; ++i) {
@@ -988,7 +993,7 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp_kernel(
             ERH_PH(4);
             ERH_PP_BARRIER();
             ERH_PH(5);
-            if (!(PABL & kPpNoEpi)) flush_now = __builtin_amdgcn_readfirstlane(flag[i & 1]);
+            if (!(PABL & kPpNoEpi)) flush_now = __builtin_amdgcn_readfirstlane(ERH_PP_FLAG(i & 1));
         }
     }
     if ((PABL & kPpClocks) && dbg && lane == 0 && (wave == 0 || wave == 4)) {
@@ -1017,13 +1022,20 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp_kernel(
 //   - ring positions are byte offsets that wrap by compare-and-subtract; the stage loop is unrolled by two, so the
 //     A-pair / B-pair alternation and the vmcnt(8) / vmcnt(4) alternation are compile-time;
 //   - fragment addresses are one VGPR add per operand and stage plus immediate offsets.
-template <int PABL>
+//   - VAR bit 0: a second barrier per stage between the two halves of an interval, so that the groups alternate strictly
+//     (one group in its matrix segment, the other in its memory segment, never both in the same kind);
+//     bit 1: static s_setprio 1 for the later-dispatched group (waves 4-7);
+//   - rot_stages: query tile qt walks K starting at stage qt * rot_stages (wrapping), so the workgroups that share a
+//     chunk-tile stream miss on DIFFERENT lines at any moment (scripts/ubench/stream: the shared stream runs 20-25 %
+//     faster); fp32 sums in another order are within the pruning margin by construction, the final scores are re-scored.
+template <int PABL, int VAR>
 __global__ __launch_bounds__(pp::NT) void dense_scan_pp2_kernel(
     const _Float16 *__restrict__ X, int64_t N, int d, int64_t c0, int64_t c1,
     const _Float16 *__restrict__ Q, int Bpad, int B,
     const float *__restrict__ tau, const int16_t *__restrict__ filter_dir, const int16_t *__restrict__ dir_id,
     ErhCand *__restrict__ cand, uint32_t *__restrict__ cand_cnt, int cap, uint32_t *__restrict__ overflow,
-    unsigned long long *__restrict__ dbg /* kPpClocks only */) {
+    unsigned long long *__restrict__ dbg /* kPpClocks only */, int rot_stages) {
+    constexpr bool SYNC2 = (VAR & 1) != 0, PRIO = (VAR & 2) != 0;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1047,6 +1059,7 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp2_kernel(
     const int64_t lim = (c1 < N) ? c1 : N;
 
     const int l31 = lane & 31, hh = lane >> 5;
+    const int k0 = ((qt * rot_stages) % nk) & ~1;                      // first K stage of every tile for this query tile
     float t_q[2];
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
@@ -1063,22 +1076,21 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp2_kernel(
         const int piece = (it * pp::NW + wave) * 64 + lane;
         const int r = piece >> 2, p4 = piece & 3;
         const int ls = p4 ^ row_swizzle<pp::PR>(r);                    // logical 16-byte slot stored at physical slot p4
-        pa[it] = X + (c0 + (int64_t)stream * pp::BM + r) * (int64_t)d + ls * 8;
-        pb[it] = Q + (q_row0 + r) * (int64_t)d + ls * 8;
+        pa[it] = X + (c0 + (int64_t)stream * pp::BM + r) * (int64_t)d + ls * 8 + k0 * pp::BK;
+        pb[it] = Q + (q_row0 + r) * (int64_t)d + ls * 8 + k0 * pp::BK;
     }
-    const int64_t a_jump = ((int64_t)n_streams * pp::BM - 1) * (int64_t)d;   // end of a tile row -> same row of the stream's next tile
+    const int64_t a_jump = (int64_t)n_streams * pp::BM * (int64_t)d;   // a row -> the same row of the stream's next tile
     const int sw = row_swizzle<pp::PR>(l31);
     const int a_rd0 = (grp * 128 + l31) * pp::RB + ((hh ^ sw) << 4);
     const int a_rd1 = (grp * 128 + l31) * pp::RB + (((2 + hh) ^ sw) << 4);
     const int b_rd0 = pp::B_BASE + (wave_n * 64 + l31) * pp::RB + ((hh ^ sw) << 4);
     const int b_rd1 = pp::B_BASE + (wave_n * 64 + l31) * pp::RB + (((2 + hh) ^ sw) << 4);
     char *const rec = lds + pp::REC_BASE + wave * pp::REC_BYTES;
-    volatile int *const flag = reinterpret_cast<volatile int *>(lds + pp::FLAG_OFF);
-    if (threadIdx.x == 0) { flag[0] = 0; flag[1] = 0; }
+    if (threadIdx.x == 0) { ERH_PP_FLAG(0) = 0; ERH_PP_FLAG(1) = 0; }
 
     // issue state: ring byte offsets of the next pair's first slot, stage-in-tile counters, pair issues left
     constexpr int kABytes = pp::AST * pp::A_BYTES, kBBytes = pp::BST * pp::B_BYTES;
-    int a_dst = 0, b_dst = 0, ka = 0, kb = 0;
+    int a_dst = 0, b_dst = 0, ka = k0, kb = k0;
     int a_left = total >> 1, b_left = total >> 1;                      // (nk is even: pairs never straddle a tile)
     // fragment-read state
     int fa_off = 0, fb_off = 0, f_left = total;
@@ -1099,7 +1111,8 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp2_kernel(
             }                                                                                         \
             ka += 2;                                                                                  \
             int64_t inc_ = 64;                                                                        \
-            if (ka == nk) { ka = 0; inc_ = 64 + a_jump; }                                             \
+            if (ka == nk) { ka = 0; inc_ = 64 - (int64_t)d; }       /* wrap to column 0 of the same rows */ \
+            if (ka == k0) inc_ += a_jump;                           /* tile complete: same column, next tile */ \
             pa[0] += inc_; pa[1] += inc_;                                                             \
             a_dst += 2 * pp::A_BYTES;                                                                 \
             if (a_dst >= kABytes) a_dst -= kABytes;                                                   \
@@ -1191,6 +1204,7 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp2_kernel(
     int flush_now = 0;                                                 // workgroup-uniform, decided one tile ahead
     int g = 0;
 
+    if (PRIO && grp == 1) __builtin_amdgcn_s_setprio(1);
     if (grp == 0) {
         ERH_PP2_READ();                                                // M(-1): fragments of stage 0, B(2,3)
         ERH_PP2_ISSUE_B();
@@ -1207,6 +1221,7 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp2_kernel(
                 ERH_PP2_ISSUE_A();
                 __builtin_amdgcn_sched_barrier(0);
                 ERH_PH(3);
+                if (SYNC2) ERH_PP_BARRIER();
                 ERH_PP2_COMPUTE(false);                                // C(g), g odd
                 ERH_PH(0);
                 ERH_PP2_WAIT(g + 1, true);
@@ -1217,12 +1232,13 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp2_kernel(
                 ERH_PP2_ISSUE_B();
                 __builtin_amdgcn_sched_barrier(0);
                 ERH_PH(3);
+                if (SYNC2) ERH_PP_BARRIER();
             }
             ERH_PP_EPILOGUE();
             ERH_PH(4);
             ERH_PP_BARRIER();
             ERH_PH(5);
-            if (!(PABL & kPpNoEpi)) flush_now = __builtin_amdgcn_readfirstlane(flag[i & 1]);
+            if (!(PABL & kPpNoEpi)) flush_now = __builtin_amdgcn_readfirstlane(ERH_PP_FLAG(i & 1));
         }
     } else {
         for (int i = 0; i < n_tiles; ++i) {
@@ -1237,6 +1253,7 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp2_kernel(
                 ERH_PH(2);
                 ERH_PP2_COMPUTE(kt == 0);
                 ERH_PH(0);
+                if (SYNC2) ERH_PP_BARRIER();
                 ERH_PP2_READ();                                        // M(g-1), g odd: fragments of g, A(g+3, g+4)
                 ERH_PP2_ISSUE_A();
                 __builtin_amdgcn_sched_barrier(0);
@@ -1247,12 +1264,13 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp2_kernel(
                 ERH_PH(2);
                 ERH_PP2_COMPUTE(false);
                 ERH_PH(0);
+                if (SYNC2) ERH_PP_BARRIER();
             }
             ERH_PP_EPILOGUE();
             ERH_PH(4);
             ERH_PP_BARRIER();
             ERH_PH(5);
-            if (!(PABL & kPpNoEpi)) flush_now = __builtin_amdgcn_readfirstlane(flag[i & 1]);
+            if (!(PABL & kPpNoEpi)) flush_now = __builtin_amdgcn_readfirstlane(ERH_PP_FLAG(i & 1));
         }
     }
     if ((PABL & kPpClocks) && dbg && lane == 0 && (wave == 0 || wave == 4)) {
@@ -1261,13 +1279,334 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp2_kernel(
         atomicAdd(&dbg[grp * 8 + 6], (unsigned long long)total);
     }
 #undef ERH_PH
-#undef ERH_PP2_GLDS
-#undef ERH_PP2_ISSUE_A
-#undef ERH_PP2_ISSUE_B
 #undef ERH_PP2_READ
 #undef ERH_PP2_COMPUTE
 #undef ERH_PP2_WAIT
 }
+
+// ---------------------------------------------------------------------------------------------
+// Ping-pong scan, strict alternation (option "dense_pp" = 3).  Same tiles, streams, rings, DMA order, epilogue and
+// results as dense_scan_pp2_kernel; what changes is what a segment contains.  Measured on the lean kernel
+// (profiles/r02c_kbench_mm.log): with matrix segments and barriers ONLY a stage takes ~1300 cycles against 1024 of MFMA
+// issue -- both groups' matrix segments fall between the same two barriers, the older group wins the pipe, and the
+// younger group's memory segment plus the barrier are exposed once per stage; with the LDS-DMA in, a memory segment
+// (12 fragment reads + 4 DMA instructions that block while the memory path is backed up) takes 720-940 cycles
+// against ~500 of a matrix segment, and the stage becomes the SUM of the two memory segments.  Here
+//   - there are two barriers per stage and the groups alternate strictly: between two barriers one group is in its
+//     matrix segment and the other in its memory segment, so the matrix pipe changes hands without draining;
+//   - the fragment reads move INTO the matrix segment: the two K sub-steps of a stage use separate fragment registers,
+//     and as soon as the MFMAs that read a fragment register of stage g have been issued, the same register is
+//     re-loaded with its stage g+1 contents (one ds_read_b128 behind every second MFMA), a whole segment before it
+//     is used -- the matrix segment stays MFMA-paced and nothing waits for LDS;
+//   - the memory segment is only the 4 DMA instructions and the counted wait, i.e. exactly the part that blocks on
+//     the memory path, and it runs beside the partner's matrix segment.
+// Order per group and stage g (M_h = DMA of A stages (h+4, h+5) for even h, of B stages (h+3, h+4) for odd h):
+//     group 0:  C(g)  |A|  M_g, wait  |B|        group 1:  M_g  |A|  C(g), wait  |B|
+// Reads of stage g+1 happen in C(g), i.e. after barrier |B| of stage g-1: before that barrier every wave has waited
+// for its pieces of stage g+1 (after M_h everything but the youngest 4 (h even) / 8 (h odd) instructions has landed),
+// and M_h overwrites the ring slots of stages h-1 and h, whose last reads (C(h-1)) retired before |B| of stage h-1
+// (lgkmcnt(0) ahead of every |B|).
+template <int PABL, int VAR>
+__global__ __launch_bounds__(pp::NT) void dense_scan_pp3_kernel(
+    const _Float16 *__restrict__ X, int64_t N, int d, int64_t c0, int64_t c1,
+    const _Float16 *__restrict__ Q, int Bpad, int B,
+    const float *__restrict__ tau, const int16_t *__restrict__ filter_dir, const int16_t *__restrict__ dir_id,
+    ErhCand *__restrict__ cand, uint32_t *__restrict__ cand_cnt, int cap, uint32_t *__restrict__ overflow,
+    unsigned long long *__restrict__ dbg /* kPpClocks only */, int rot_stages) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp = wave >> 2, wave_n = wave & 3;
+    long long tph[6] = {0, 0, 0, 0, 0, 0};
+    long long t_mark = (PABL & kPpClocks) ? clock64() : 0;
+#define ERH_PH(I) do { if (PABL & kPpClocks) { const long long n_ = clock64(); tph[I] += n_ - t_mark; t_mark = n_; } } while (0)
+    const int nk = d / pp::BK;
+
+    const int n_qt = Bpad / pp::BN;
+    const int64_t n_ct = (c1 - c0 + pp::BM - 1) / pp::BM;
+    const int xcd = blockIdx.x & 7;
+    const int jx = blockIdx.x >> 3;
+    const int qt = jx % n_qt;
+    const int stream = (jx / n_qt) * 8 + xcd;
+    const int n_streams = (gridDim.x / (8 * n_qt)) * 8;
+    if (stream >= n_ct) return;                                        // whole workgroup, before any barrier
+    const int n_tiles = (int)((n_ct - stream + n_streams - 1) / n_streams);
+    const int total = n_tiles * nk;                                    // flattened (tile, stage) sequence
+    const int64_t q_row0 = (int64_t)qt * pp::BN;
+    const int64_t lim = (c1 < N) ? c1 : N;
+
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int k0 = ((qt * rot_stages) % nk) & ~1;                      // first K stage of every tile for this query tile
+    float t_q[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int q = (int)q_row0 + wave_n * 64 + nt * 32 + l31;
+        t_q[nt] = (q < B && !(PABL & kPpTauInf)) ? tau[q] : INFINITY;
+    }
+    asm volatile("" ::"v"(t_q[0]), "v"(t_q[1]));                      // loaded before the DMA stream starts (keeps vmcnt countable)
+
+    const _Float16 *pa[2], *pb[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int piece = (it * pp::NW + wave) * 64 + lane;
+        const int r = piece >> 2, p4 = piece & 3;
+        const int ls = p4 ^ row_swizzle<pp::PR>(r);                    // logical 16-byte slot stored at physical slot p4
+        pa[it] = X + (c0 + (int64_t)stream * pp::BM + r) * (int64_t)d + ls * 8 + k0 * pp::BK;
+        pb[it] = Q + (q_row0 + r) * (int64_t)d + ls * 8 + k0 * pp::BK;
+    }
+    const int64_t a_jump = (int64_t)n_streams * pp::BM * (int64_t)d;   // a row -> the same row of the stream's next tile
+    const int sw = row_swizzle<pp::PR>(l31);
+    const int a_rd0 = (grp * 128 + l31) * pp::RB + ((hh ^ sw) << 4);
+    const int a_rd1 = (grp * 128 + l31) * pp::RB + (((2 + hh) ^ sw) << 4);
+    const int b_rd0 = pp::B_BASE + (wave_n * 64 + l31) * pp::RB + ((hh ^ sw) << 4);
+    const int b_rd1 = pp::B_BASE + (wave_n * 64 + l31) * pp::RB + (((2 + hh) ^ sw) << 4);
+    char *const rec = lds + pp::REC_BASE + wave * pp::REC_BYTES;
+    if (threadIdx.x == 0) { ERH_PP_FLAG(0) = 0; ERH_PP_FLAG(1) = 0; }
+
+    constexpr int kABytes = pp::AST * pp::A_BYTES, kBBytes = pp::BST * pp::B_BYTES;
+    int a_dst = 0, b_dst = 0, ka = k0, kb = k0;
+    int a_left = total >> 1, b_left = total >> 1;                      // (nk is even: pairs never straddle a tile)
+    int fa_off = 0, fb_off = 0;                                        // ring offsets of the next stage to read
+    half8 fa[4][2], fb[2][2];
+    char *const my_dst = lds + wave * 1024;                            // + it * 8192 + ring offset
+
+// one instruction (PART 0..3) of the A / B stage pair, then the pair's bookkeeping (VAR bit 0: issued from inside the
+// matrix segment)
+#define ERH_PP3_PART_A(PART)                                                                          \
+    do {                                                                                              \
+        if (a_left > 0) {                                                                             \
+            if (!(PABL & kPpNoDmaA)) {                                                                \
+                int d1_ = a_dst + pp::A_BYTES;                                                        \
+                if (d1_ == kABytes) d1_ = 0;                                                          \
+                if ((PART) == 0) ERH_PP2_GLDS(pa[0], my_dst + a_dst);                                 \
+                if ((PART) == 1) ERH_PP2_GLDS(pa[0] + 32, my_dst + d1_);                              \
+                if ((PART) == 2) ERH_PP2_GLDS(pa[1], my_dst + a_dst + 8192);                          \
+                if ((PART) == 3) ERH_PP2_GLDS(pa[1] + 32, my_dst + d1_ + 8192);                       \
+            }                                                                                         \
+            if ((PART) == 3) {                                                                        \
+                ka += 2;                                                                              \
+                int64_t inc_ = 64;                                                                    \
+                if (ka == nk) { ka = 0; inc_ = 64 - (int64_t)d; }                                     \
+                if (ka == k0) inc_ += a_jump;                                                         \
+                pa[0] += inc_; pa[1] += inc_;                                                         \
+                a_dst += 2 * pp::A_BYTES;                                                             \
+                if (a_dst >= kABytes) a_dst -= kABytes;                                               \
+                --a_left;                                                                             \
+            }                                                                                         \
+        }                                                                                             \
+    } while (0)
+#define ERH_PP3_PART_B(PART)                                                                          \
+    do {                                                                                              \
+        if (b_left > 0) {                                                                             \
+            if (!(PABL & kPpNoDmaB)) {                                                                \
+                const int d0_ = pp::B_BASE + b_dst, d1_ = pp::B_BASE + ((b_dst + pp::B_BYTES) & (kBBytes - 1)); \
+                if ((PART) == 0) ERH_PP2_GLDS(pb[0], my_dst + d0_);                                   \
+                if ((PART) == 1) ERH_PP2_GLDS(pb[0] + 32, my_dst + d1_);                              \
+                if ((PART) == 2) ERH_PP2_GLDS(pb[1], my_dst + d0_ + 8192);                            \
+                if ((PART) == 3) ERH_PP2_GLDS(pb[1] + 32, my_dst + d1_ + 8192);                       \
+            }                                                                                         \
+            if ((PART) == 3) {                                                                        \
+                kb += 2;                                                                              \
+                int64_t inc_ = 64;                                                                    \
+                if (kb == nk) { kb = 0; inc_ = 64 - (int64_t)d; }                                     \
+                pb[0] += inc_; pb[1] += inc_;                                                         \
+                b_dst = (b_dst + 2 * pp::B_BYTES) & (kBBytes - 1);                                    \
+                --b_left;                                                                             \
+            }                                                                                         \
+        }                                                                                             \
+    } while (0)
+// the twelve fragments of the stage at (fa_off, fb_off), all at once (prologue only)
+#define ERH_PP3_READ_ALL()                                                                            \
+    do {                                                                                              \
+        const char *pa0_ = lds + (a_rd0 + fa_off), *pa1_ = lds + (a_rd1 + fa_off);                    \
+        const char *pb0_ = lds + (b_rd0 + fb_off), *pb1_ = lds + (b_rd1 + fb_off);                    \
+        _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                            \
+            fa[mt][0] = *reinterpret_cast<const half8 *>(pa0_ + mt * 32 * pp::RB);                    \
+            fa[mt][1] = *reinterpret_cast<const half8 *>(pa1_ + mt * 32 * pp::RB);                    \
+        }                                                                                             \
+        _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                                            \
+            fb[nt][0] = *reinterpret_cast<const half8 *>(pb0_ + nt * 32 * pp::RB);                    \
+            fb[nt][1] = *reinterpret_cast<const half8 *>(pb1_ + nt * 32 * pp::RB);                    \
+        }                                                                                             \
+        fa_off += pp::A_BYTES;                                                                        \
+        if (fa_off == kABytes) fa_off = 0;                                                            \
+        fb_off = (fb_off + pp::B_BYTES) & (kBBytes - 1);                                              \
+    } while (0)
+// matrix segment of the current stage; each fragment register is re-loaded with the NEXT stage's contents right behind
+// the last MFMA that reads it (past the end of the stream the reads fetch stale ring bytes that nothing uses)
+#define ERH_PP3_HALF(J, PA_, PB_, FIRST, DMA)                                                            \
+    do {                                                                                              \
+        _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                            \
+            if (!(PABL & kPpNoMfma)) {                                                                \
+                if (FIRST) {                                                                          \
+                    const f32x16 z_ = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; \
+                    acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mt][J], fb[0][J], z_, 0, 0, 0);  \
+                    acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mt][J], fb[1][J], z_, 0, 0, 0);  \
+                } else {                                                                              \
+                    acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mt][J], fb[0][J], acc[mt][0], 0, 0, 0); \
+                    acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mt][J], fb[1][J], acc[mt][1], 0, 0, 0); \
+                }                                                                                     \
+            } else {                                                                                  \
+                asm volatile("" ::"v"(fa[mt][J]), "v"(fb[0][J]), "v"(fb[1][J]));                      \
+                if (FIRST) { _Pragma("unroll") for (int r = 0; r < 16; ++r) { acc[mt][0][r] = 0.f; acc[mt][1][r] = 0.f; } } \
+            }                                                                                         \
+            if (!(PABL & kPpNoFrag)) fa[mt][J] = *reinterpret_cast<const half8 *>(PA_ + mt * 32 * pp::RB); \
+            if (DMA == 1) ERH_PP3_PART_A(mt);                                                         \
+            if (DMA == 2) ERH_PP3_PART_B(mt);                                                         \
+            __builtin_amdgcn_sched_barrier(0);                                                        \
+        }                                                                                             \
+        if (!(PABL & kPpNoFrag)) {                                                                    \
+            fb[0][J] = *reinterpret_cast<const half8 *>(PB_);                                         \
+            fb[1][J] = *reinterpret_cast<const half8 *>(PB_ + 32 * pp::RB);                           \
+        }                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+    } while (0)
+// DMA0 / DMA1: which DMA pair (0 none, 1 the A pair, 2 the B pair) is issued, one instruction behind each MFMA pair,
+// inside the first / second K sub-step of the segment (VAR bit 0 only)
+#define ERH_PP3_COMPUTE(FIRST, DMA0, DMA1)                                                            \
+    do {                                                                                              \
+        const char *pa0_ = lds + (a_rd0 + fa_off), *pa1_ = lds + (a_rd1 + fa_off);                    \
+        const char *pb0_ = lds + (b_rd0 + fb_off), *pb1_ = lds + (b_rd1 + fb_off);                    \
+        ERH_PP3_HALF(0, pa0_, pb0_, FIRST, DMA0);                                                     \
+        ERH_PP3_HALF(1, pa1_, pb1_, false, DMA1);                                                     \
+        fa_off += pp::A_BYTES;                                                                        \
+        if (fa_off == kABytes) fa_off = 0;                                                            \
+        fb_off = (fb_off + pp::B_BYTES) & (kBBytes - 1);                                              \
+    } while (0)
+// after M_h: everything but the youngest 4 (h even: the A pair just issued) / 8 (h odd) instructions has landed; the
+// fragment reads of this wave's last matrix segment have retired (ring slots may be overwritten after the barrier)
+#define ERH_PP3_WAIT(H, ODD)                                                                          \
+    do {                                                                                              \
+        if ((H) + 6 >= total) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");             \
+        else if (ODD) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");                     \
+        else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");                              \
+    } while (0)
+
+    // prologue: A(0,1) B(0,1) A(2,3) B(2,3); stages 0 and 1 complete = the last 8 instructions may stay in flight
+    ERH_PP2_ISSUE_A();
+    ERH_PP2_ISSUE_B();
+    ERH_PP2_ISSUE_A();
+    ERH_PP2_ISSUE_B();
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    ERH_PP_BARRIER();
+    ERH_PP3_READ_ALL();                                                // stage 0
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    ERH_PP_BARRIER();                                                  // M_0 overwrites the slots of stage 0
+
+    f32x16 acc[4][2];
+    int fill = 0;                                                      // records buffered in this wave's area
+    int flush_now = 0;                                                 // workgroup-uniform, decided one tile ahead
+    int g = 0;
+
+    if (VAR & 1) {
+        // no memory segments at all: every wave issues the stage's DMA pair from inside its matrix segment (the older
+        // group behind the MFMA pairs of the first K sub-step, the younger group behind those of the second, so the two
+        // waves of a SIMD block on the memory path at different times) and there is one barrier per stage
+#define ERH_PP3_TILE_LOOP(D0A, D1A, D0B, D1B)                                                         \
+        for (int i = 0; i < n_tiles; ++i) {                                                           \
+            for (int kt = 0; kt < nk; kt += 2, g += 2) {                                              \
+                ERH_PP3_COMPUTE(kt == 0, D0A, D1A);                    /* C(g) with M_g inside */     \
+                ERH_PH(0);                                                                            \
+                ERH_PP3_WAIT(g, false);                                                               \
+                ERH_PH(1);                                                                            \
+                ERH_PP_BARRIER();                                                                     \
+                ERH_PH(2);                                                                            \
+                ERH_PP3_COMPUTE(false, D0B, D1B);                      /* C(g+1) with M_{g+1} inside */ \
+                ERH_PH(0);                                                                            \
+                ERH_PP3_WAIT(g + 1, true);                                                            \
+                ERH_PH(1);                                                                            \
+                ERH_PP_BARRIER();                                                                     \
+                ERH_PH(2);                                                                            \
+            }                                                                                         \
+            ERH_PP_EPILOGUE();                                                                        \
+            ERH_PH(4);                                                                                \
+            ERH_PP_BARRIER();                                                                         \
+            ERH_PH(5);                                                                                \
+            if (!(PABL & kPpNoEpi)) flush_now = __builtin_amdgcn_readfirstlane(ERH_PP_FLAG(i & 1));   \
+        }
+        if (grp == 0) { ERH_PP3_TILE_LOOP(1, 0, 2, 0) } else { ERH_PP3_TILE_LOOP(0, 1, 0, 2) }
+#undef ERH_PP3_TILE_LOOP
+    } else if (grp == 0) {
+        for (int i = 0; i < n_tiles; ++i) {
+            for (int kt = 0; kt < nk; kt += 2, g += 2) {
+                ERH_PP3_COMPUTE(kt == 0, 0, 0);                              // C(g)
+                ERH_PH(0);
+                ERH_PP_BARRIER();                                      // |A|
+                ERH_PH(2);
+                ERH_PP2_ISSUE_A();                                     // M_g
+                __builtin_amdgcn_sched_barrier(0);
+                ERH_PH(3);
+                ERH_PP3_WAIT(g, false);
+                ERH_PH(1);
+                ERH_PP_BARRIER();                                      // |B|
+                ERH_PH(2);
+                ERH_PP3_COMPUTE(false, 0, 0);                                // C(g+1)
+                ERH_PH(0);
+                ERH_PP_BARRIER();
+                ERH_PH(2);
+                ERH_PP2_ISSUE_B();                                     // M_{g+1}
+                __builtin_amdgcn_sched_barrier(0);
+                ERH_PH(3);
+                ERH_PP3_WAIT(g + 1, true);
+                ERH_PH(1);
+                ERH_PP_BARRIER();
+                ERH_PH(2);
+            }
+            ERH_PP_EPILOGUE();
+            ERH_PH(4);
+            ERH_PP_BARRIER();
+            ERH_PH(5);
+            if (!(PABL & kPpNoEpi)) flush_now = __builtin_amdgcn_readfirstlane(ERH_PP_FLAG(i & 1));
+        }
+    } else {
+        for (int i = 0; i < n_tiles; ++i) {
+            for (int kt = 0; kt < nk; kt += 2, g += 2) {
+                ERH_PP2_ISSUE_A();                                     // M_g
+                __builtin_amdgcn_sched_barrier(0);
+                ERH_PH(3);
+                ERH_PP_BARRIER();                                      // |A|
+                ERH_PH(2);
+                ERH_PP3_COMPUTE(kt == 0, 0, 0);                              // C(g)
+                ERH_PH(0);
+                ERH_PP3_WAIT(g, false);
+                ERH_PH(1);
+                ERH_PP_BARRIER();                                      // |B|
+                ERH_PH(2);
+                ERH_PP2_ISSUE_B();                                     // M_{g+1}
+                __builtin_amdgcn_sched_barrier(0);
+                ERH_PH(3);
+                ERH_PP_BARRIER();
+                ERH_PH(2);
+                ERH_PP3_COMPUTE(false, 0, 0);                                // C(g+1)
+                ERH_PH(0);
+                ERH_PP3_WAIT(g + 1, true);
+                ERH_PH(1);
+                ERH_PP_BARRIER();
+                ERH_PH(2);
+            }
+            ERH_PP_EPILOGUE();
+            ERH_PH(4);
+            ERH_PP_BARRIER();
+            ERH_PH(5);
+            if (!(PABL & kPpNoEpi)) flush_now = __builtin_amdgcn_readfirstlane(ERH_PP_FLAG(i & 1));
+        }
+    }
+    if ((PABL & kPpClocks) && dbg && lane == 0 && (wave == 0 || wave == 4)) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) atomicAdd(&dbg[grp * 8 + i], (unsigned long long)tph[i]);
+        atomicAdd(&dbg[grp * 8 + 6], (unsigned long long)total);
+    }
+#undef ERH_PH
+#undef ERH_PP3_READ_ALL
+#undef ERH_PP3_PART_A
+#undef ERH_PP3_PART_B
+#undef ERH_PP3_HALF
+#undef ERH_PP3_COMPUTE
+#undef ERH_PP3_WAIT
+}
+#undef ERH_PP2_GLDS
+#undef ERH_PP2_ISSUE_A
+#undef ERH_PP2_ISSUE_B
 
 using Cfg0 = ScanCfg<256, 256, 2, 4, 64, 3, 2>;   // one 8-wave workgroup per CU, 160 KiB LDS
 using Cfg1 = ScanCfg<128, 256, 1, 4, 32, 4, 3>;   // two 4-wave workgroups per CU, 80 KiB LDS each
@@ -1389,10 +1728,13 @@ constexpr int pp_mask_of(int code) {
         case 18: return kPpNoEpi | kPpNoMfma | kPpNoDmaA | kPpNoDmaB | kPpNoFrag; // barriers only
         case 20: return kPpNoEpi | kPpClocks;
         case 21: return kPpClocks;
+        case 22: return kPpNoEpi | kPpNoDmaA | kPpNoDmaB | kPpClocks;             // matrix + fragment reads, phase clocks
+        case 23: return kPpNoEpi | kPpNoDmaA | kPpNoDmaB | kPpNoFrag;             // matrix segments + barriers only
+        case 24: return kPpNoEpi | kPpNoDmaA | kPpNoDmaB | kPpNoFrag | kPpClocks;
         default: return 0;
     }
 }
-#define ERH_PP_MASKS(X) X(1) X(2) X(5) X(25) X(9) X(33) X(17) X(37) X(29) X(61) X(65) X(64)
+#define ERH_PP_MASKS(X) X(1) X(2) X(5) X(25) X(9) X(33) X(17) X(37) X(29) X(61) X(65) X(64) X(89) X(57) X(121)
 #endif
 
 hipError_t launch_pp(const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1, const _Float16 *Q, int Bpad, int B,
@@ -1405,17 +1747,51 @@ hipError_t launch_pp(const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1
     const int64_t n_ct = (c1 - c0 + pp::BM - 1) / pp::BM;
     if (n_ct / (grid_n / n_qt) + 1 >= (1ll << pp::TILE_BITS)) return hipErrorInvalidValue;   // tile index must fit the record
     dim3 grid((unsigned)grid_n), block(pp::NT);
+    // lean: bit 0 = lean-issue kernel, bits 1-2 = its VAR, bits 8.. = rot_stages (see dense_scan_pp2_kernel)
+    const int var = (lean >> 1) & 3, rot = lean >> 8;
+#define ERH_LAUNCH_PP2(A, V)                                                                               \
+    hipLaunchKernelGGL((dense_scan_pp2_kernel<A, V>), grid, block, pp::LDS_BYTES, st, X, N, d, c0, c1, Q, Bpad, B, \
+                       tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow, dbg, rot)
+#define ERH_LAUNCH_PP3(A)                                                                                  \
+    do {                                                                                                   \
+        if (var & 1)                                                                                       \
+            hipLaunchKernelGGL((dense_scan_pp3_kernel<A, 1>), grid, block, pp::LDS_BYTES, st, X, N, d, c0, c1, Q, Bpad, \
+                               B, tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow, dbg, rot);        \
+        else                                                                                               \
+            hipLaunchKernelGGL((dense_scan_pp3_kernel<A, 0>), grid, block, pp::LDS_BYTES, st, X, N, d, c0, c1, Q, Bpad, \
+                               B, tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow, dbg, rot);        \
+    } while (0)
 #define ERH_LAUNCH_PP(A)                                                                                   \
     do {                                                                                                   \
-        if (lean)                                                                                          \
-            hipLaunchKernelGGL((dense_scan_pp2_kernel<A>), grid, block, pp::LDS_BYTES, st, X, N, d, c0, c1, Q, Bpad, B, \
-                               tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow, dbg);                \
+        if (lean & 8)                                                                                      \
+            ERH_LAUNCH_PP3(A);                                                                             \
+        else if (lean & 1)                                                                                 \
+            ERH_LAUNCH_PP2(A, 0);                                                                          \
         else                                                                                               \
-            hipLaunchKernelGGL((dense_scan_pp_kernel<A>), grid, block, pp::LDS_BYTES, st, X, N, d, c0, c1, Q, Bpad, B, \
+            hipLaunchKernelGGL((dense_scan_pp_kernel<0>), grid, block, pp::LDS_BYTES, st, X, N, d, c0, c1, Q, Bpad, B, \
                                tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow, dbg);                \
     } while (0)
+#define ERH_LAUNCH_PP2V(A)                                                                                 \
+    do {                                                                                                   \
+        switch (var) {                                                                                     \
+            case 1: ERH_LAUNCH_PP2(A, 1); break;                                                           \
+            case 2: ERH_LAUNCH_PP2(A, 2); break;                                                           \
+            case 3: ERH_LAUNCH_PP2(A, 3); break;                                                           \
+            default: ERH_LAUNCH_PP2(A, 0); break;                                                          \
+        }                                                                                                  \
+    } while (0)
 #ifdef ERH_MEASURE
-    switch (pp_mask_of(pabl)) {
+    const int mask = pp_mask_of(pabl);
+    if ((lean & 1) && !(lean & 8) && var != 0 && (mask == 0 || mask == 1 || mask == 64 || mask == 65)) {
+        switch (mask) {
+            case 1: ERH_LAUNCH_PP2V(1); break;
+            case 64: ERH_LAUNCH_PP2V(64); break;
+            case 65: ERH_LAUNCH_PP2V(65); break;
+            default: ERH_LAUNCH_PP2V(0); break;
+        }
+        return hipGetLastError();
+    }
+    switch (mask) {
 #define ERH_PP_CASE(M) case M: ERH_LAUNCH_PP(M); break;
         ERH_PP_MASKS(ERH_PP_CASE)
 #undef ERH_PP_CASE
@@ -1423,8 +1799,20 @@ hipError_t launch_pp(const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1
     }
 #else
     (void)pabl;
-    ERH_LAUNCH_PP(0);
+    if (lean & 8) {
+        ERH_LAUNCH_PP3(0);
+    } else if (lean & 1) {
+        switch (var) {
+            case kPpVarProduct: ERH_LAUNCH_PP2(0, kPpVarProduct); break;
+            default: ERH_LAUNCH_PP2(0, 0); break;
+        }
+    } else {
+        ERH_LAUNCH_PP(0);
+    }
 #endif
+#undef ERH_LAUNCH_PP2V
+#undef ERH_LAUNCH_PP2
+#undef ERH_LAUNCH_PP3
 #undef ERH_LAUNCH_PP
     return hipGetLastError();
 }
@@ -1443,17 +1831,34 @@ hipError_t dense_scan_init() {
     if (e != hipSuccess) return e;
     e = set_attrs<Cfg2>();
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void *)dense_scan_pp_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            pp::LDS_BYTES);
+    if (e != hipSuccess) return e;
 #define ERH_SET_PP(A)                                                                                      \
-    e = hipFuncSetAttribute((const void *)dense_scan_pp_kernel<A>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+    e = hipFuncSetAttribute((const void *)dense_scan_pp2_kernel<A, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                             pp::LDS_BYTES);                                                                \
     if (e != hipSuccess) return e;                                                                         \
-    e = hipFuncSetAttribute((const void *)dense_scan_pp2_kernel<A>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+    e = hipFuncSetAttribute((const void *)dense_scan_pp3_kernel<A, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                            pp::LDS_BYTES);                                                                \
+    if (e != hipSuccess) return e;                                                                         \
+    e = hipFuncSetAttribute((const void *)dense_scan_pp3_kernel<A, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                            pp::LDS_BYTES);                                                                \
+    if (e != hipSuccess) return e;
+#define ERH_SET_PP2V(A, V)                                                                                 \
+    e = hipFuncSetAttribute((const void *)dense_scan_pp2_kernel<A, V>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                             pp::LDS_BYTES);                                                                \
     if (e != hipSuccess) return e;
     ERH_SET_PP(0)
 #ifdef ERH_MEASURE
     ERH_PP_MASKS(ERH_SET_PP)
+    ERH_SET_PP2V(0, 1) ERH_SET_PP2V(0, 2) ERH_SET_PP2V(0, 3)
+    ERH_SET_PP2V(1, 1) ERH_SET_PP2V(1, 2) ERH_SET_PP2V(1, 3)
+    ERH_SET_PP2V(64, 1) ERH_SET_PP2V(64, 2) ERH_SET_PP2V(64, 3)
+    ERH_SET_PP2V(65, 1) ERH_SET_PP2V(65, 2) ERH_SET_PP2V(65, 3)
+#else
+    if (kPpVarProduct != 0) { ERH_SET_PP2V(0, kPpVarProduct) }
 #endif
+#undef ERH_SET_PP2V
 #undef ERH_SET_PP
     return hipSuccess;
 }

@@ -60,7 +60,9 @@ hipError_t launch_permute_dir(const int16_t *dir_id, int64_t N, int64_t inv, int
 hipError_t launch_row_norm_max(const _Float16 *x, int64_t n, int d, float *out, hipStream_t st);
 // Seed stage: k-th best of S0[q][0..n0) (filter applied) -> tau[q] = kth - margin(q); candidates >= tau
 // are written to cand[q] and cand_cnt[q] is (re)initialised.
-hipError_t launch_seed_select(const float *S0, int ld_s0, int n0, int64_t c0, int B, int k,
+// rank <= k: position in the prefix that seeds the threshold (k: guaranteed bound, < k: speculative, verified by
+// launch_dense_finalize when it is given tau_verify)
+hipError_t launch_seed_select(const float *S0, int ld_s0, int n0, int64_t c0, int B, int k, int rank,
                               const float *qnorm, float xnorm_max, int d,
                               const int16_t *filter_dir, const int16_t *dir_id,
                               float *tau, ErhCand *cand, uint32_t *cand_cnt, int cap, uint32_t *bad, uint32_t *need_full,
@@ -74,7 +76,7 @@ hipError_t launch_dense_finalize(int B, int k, int mode, const float *qnorm, flo
                                  const ErhCand *cand, const uint32_t *cand_cnt, int cap,
                                  int32_t *out_ids, double *out_scores, int32_t *out_len,
                                  float *diag_maxerr, uint32_t *diag_uncert, uint32_t *bad, int64_t N, int64_t pos_mul,
-                                 int64_t pos_inv, hipStream_t st);
+                                 int64_t pos_inv, const float *tau_verify, hipStream_t st);
 // Exhaustive path for the queries flagged in bad[] (select.hip): exact fp64 scores of every chunk + streaming top-k.
 int dense_exhaustive_max();
 size_t dense_exhaustive_bytes(int64_t N);

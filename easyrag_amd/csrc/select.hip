@@ -174,8 +174,15 @@ __device__ __forceinline__ void seed_emit(const float *__restrict__ row, int n0,
     }
 }
 
+// `rank` <= k is the position in the prefix whose score seeds the threshold.  rank == k gives a guaranteed bound (the
+// k-th best of a subset never exceeds the k-th best of the whole).  rank < k is a SPECULATIVE bound: an estimate of
+// where the k-th best of the whole corpus lies, extrapolated from the prefix being an even sample of it (api.hip picks
+// the rank so that fewer than `rank` of the true top k land in the prefix except with probability ~1e-9 per query).
+// dense_finalize_kernel verifies it -- at least k candidates must score >= threshold + margin -- and hands the
+// query to the exhaustive path otherwise, so the result is exact either way; what the speculation buys is a
+// threshold ~3x tighter than any guaranteed one, from the first scanned tile on.
 __global__ __launch_bounds__(kSelThreads) void seed_select_kernel(
-    const float *__restrict__ S0, int ld_s0, int n0, int np2, int64_t c0, int k,
+    const float *__restrict__ S0, int ld_s0, int n0, int np2, int64_t c0, int k, int rank,
     const float *__restrict__ qnorm, float xnorm_max, int d,
     const int16_t *__restrict__ filter_dir, const int16_t *__restrict__ dir_id,
     float *__restrict__ tau, ErhCand *__restrict__ cand, uint32_t *__restrict__ cand_cnt, int cap,
@@ -202,7 +209,7 @@ __global__ __launch_bounds__(kSelThreads) void seed_select_kernel(
     const int nv = s_nvalid;
     float prune = -INFINITY;
     if (nv >= k) {                                   // uniform
-        const uint32_t p = (k <= kSelThreads) ? tmax[k - 1] : 0u;
+        const uint32_t p = (rank <= kSelThreads) ? tmax[rank - 1] : 0u;
         bool full_sort = (p == 0u);
         if (!full_sort) {
             for (int i = tid; i < n0; i += kSelThreads) {
@@ -220,7 +227,7 @@ __global__ __launch_bounds__(kSelThreads) void seed_select_kernel(
                 const int ns = erh_next_pow2(c2 < 2 ? 2 : c2);
                 for (int i = c2 + tid; i < ns; i += kSelThreads) buf[i] = 0u;
                 erh_bitonic_desc<uint32_t>(buf, ns);
-                prune = erh_ord2f(buf[k - 1]) - margin_of(qnorm[q], xnorm_max, d);
+                prune = erh_ord2f(buf[rank - 1]) - margin_of(qnorm[q], xnorm_max, d);
             }
         }
         if (full_sort) {                             // uniform: leave this query to seed_select_full_kernel
@@ -233,7 +240,7 @@ __global__ __launch_bounds__(kSelThreads) void seed_select_kernel(
 
 // Full-sort fallback for the queries flagged by seed_select_kernel.  dynamic LDS = 64 + np2*4 bytes.
 __global__ __launch_bounds__(kSelThreads) void seed_select_full_kernel(
-    const float *__restrict__ S0, int ld_s0, int n0, int np2, int64_t c0, int k,
+    const float *__restrict__ S0, int ld_s0, int n0, int np2, int64_t c0, int k, int rank,
     const float *__restrict__ qnorm, float xnorm_max, int d,
     const int16_t *__restrict__ filter_dir, const int16_t *__restrict__ dir_id,
     float *__restrict__ tau, ErhCand *__restrict__ cand, uint32_t *__restrict__ cand_cnt, int cap,
@@ -248,7 +255,7 @@ __global__ __launch_bounds__(kSelThreads) void seed_select_full_kernel(
     if (tid == 0) s_cnt = 0;
     for (int i = tid; i < np2; i += kSelThreads) keys[i] = seed_key(row, i, n0, fd, dir_id, c0);
     erh_bitonic_desc<uint32_t>(keys, np2);
-    const float prune = erh_ord2f(keys[k - 1]) - margin_of(qnorm[q], xnorm_max, d);
+    const float prune = erh_ord2f(keys[rank - 1]) - margin_of(qnorm[q], xnorm_max, d);
     __syncthreads();
     seed_emit(row, n0, c0, fd, dir_id, prune, q, tau, cand, cand_cnt, cap, bad, &s_cnt);
 }
@@ -322,14 +329,15 @@ __global__ __launch_bounds__(kFinThreads) void dense_finalize_kernel(
     const ErhCand *__restrict__ cand, const uint32_t *__restrict__ cand_cnt, int cap,
     int32_t *__restrict__ out_ids, double *__restrict__ out_scores, int32_t *__restrict__ out_len,
     float *__restrict__ diag_maxerr, uint32_t *__restrict__ diag_uncert, uint32_t *__restrict__ bad,
-    int64_t N, int64_t pos_mul, int64_t pos_inv /* candidates carry stored positions: orig = pos * pos_inv mod N */) {
+    int64_t N, int64_t pos_mul, int64_t pos_inv /* candidates carry stored positions: orig = pos * pos_inv mod N */,
+    const float *__restrict__ tau /* nullptr: thresholds were guaranteed bounds, nothing to verify */) {
     __shared__ __attribute__((aligned(16))) uint64_t buf[kFinBuf];
     __shared__ uint32_t tmax[kFinSlots];
     __shared__ double r_s64[erh::kDenseRescoreMax];
     __shared__ int32_t r_idx[erh::kDenseRescoreMax];
     __shared__ float r_s32[erh::kDenseRescoreMax];
     __shared__ int32_t r_pos[erh::kDenseRescoreMax];                    // stored position of the candidate (row of X)
-    __shared__ int s_cnt, s_m;
+    __shared__ int s_cnt, s_m, s_lvl;
     __shared__ unsigned int s_maxerr;
     const int q = blockIdx.x, tid = threadIdx.x;
     int c = (int)cand_cnt[q];
@@ -341,22 +349,39 @@ __global__ __launch_bounds__(kFinThreads) void dense_finalize_kernel(
     const int kk = k < c ? k : c;
     int32_t *o_ids = out_ids + (int64_t)q * k;
     double *o_sc = out_scores + (int64_t)q * k;
-    if (tid == 0) { out_len[q] = kk; s_cnt = 0; s_m = 0; s_maxerr = 0; }
+    if (tid == 0) { out_len[q] = kk; s_cnt = 0; s_m = 0; s_maxerr = 0; s_lvl = 0; }
     for (int i = kk + tid; i < k; i += kFinThreads) { o_ids[i] = -1; o_sc[i] = 0.0; }
     if (kk == 0) return;                                                // uniform
 
     const float delta = 0.5f * margin_of(qnorm[q], xnorm_max, d);
+    // A speculative threshold tau = T - 2*delta is valid iff k chunks reach T in fp32: then the k-th best exact score is
+    // >= T - delta and every member of the exact top k has an fp32 score >= T - 2*delta, i.e. is in the list.  (T is
+    // rebuilt from tau and nudged up a few ulps, which can only make the test stricter.)
+    float lvl = INFINITY;
+    if (tau) {
+        const float t = tau[q];
+        lvl = (t > -INFINITY) ? (t + 2.0f * delta) : -INFINITY;
+        if (lvl > -INFINITY) lvl += fabsf(lvl) * 1e-6f;
+    }
+    int n_lvl = 0;
     // pivot: k-th largest of the 1024 strided maxima (all of them candidates, so it bounds the k-th best from below)
 #pragma unroll
     for (int h = 0; h < kFinSlots / kFinThreads; ++h) {
         uint32_t mx = 0;
         for (int i = tid + h * kFinThreads; i < c; i += kFinSlots) {
-            const uint32_t o = erh_f2ord(mine[i].s);
+            const float sc = mine[i].s;
+            const uint32_t o = erh_f2ord(sc);
             mx = o > mx ? o : mx;
+            n_lvl += (sc >= lvl) ? 1 : 0;
         }
         tmax[tid + h * kFinThreads] = mx;
     }
-    erh_bitonic_desc<uint32_t>(tmax, kFinSlots);
+    if (tau) {
+        for (int o = 32; o >= 1; o >>= 1) n_lvl += __shfl_xor(n_lvl, o);
+        if ((tid & 63) == 0 && n_lvl) atomicAdd(&s_lvl, n_lvl);
+    }
+    erh_bitonic_desc<uint32_t>(tmax, kFinSlots);                        // begins and ends with a barrier
+    if (tau && tid == 0 && lvl > -INFINITY && s_lvl < k) bad[q] = 1u;   // the speculation failed: exhaustive path
     float gather_thr = -INFINITY;
     if (kk <= kFinSlots && tmax[kk - 1] != 0u) gather_thr = erh_ord2f(tmax[kk - 1]) - ((mode == 1) ? 0.f : 2.0f * delta);
     for (int i = tid; i < c; i += kFinThreads) {
@@ -728,17 +753,18 @@ hipError_t launch_row_norm_max(const _Float16 *x, int64_t n, int d, float *out, 
     return hipGetLastError();
 }
 
-hipError_t launch_seed_select(const float *S0, int ld_s0, int n0, int64_t c0, int B, int k,
+hipError_t launch_seed_select(const float *S0, int ld_s0, int n0, int64_t c0, int B, int k, int rank,
                               const float *qnorm, float xnorm_max, int d,
                               const int16_t *filter_dir, const int16_t *dir_id,
                               float *tau, ErhCand *cand, uint32_t *cand_cnt, int cap, uint32_t *bad,
                               uint32_t *need_full, hipStream_t st) {
     const int np2 = pow2_ge(n0 < 2 ? 2 : n0);
+    if (rank < 1 || rank > k) rank = k;
     hipLaunchKernelGGL(seed_select_kernel, dim3(B), dim3(kSelThreads), 0, st,
-                       S0, ld_s0, n0, np2, c0, k, qnorm, xnorm_max, d, filter_dir, dir_id, tau, cand, cand_cnt, cap,
+                       S0, ld_s0, n0, np2, c0, k, rank, qnorm, xnorm_max, d, filter_dir, dir_id, tau, cand, cand_cnt, cap,
                        bad, need_full);
     hipLaunchKernelGGL(seed_select_full_kernel, dim3(B), dim3(kSelThreads), (size_t)np2 * 4 + 64, st,
-                       S0, ld_s0, n0, np2, c0, k, qnorm, xnorm_max, d, filter_dir, dir_id, tau, cand, cand_cnt, cap,
+                       S0, ld_s0, n0, np2, c0, k, rank, qnorm, xnorm_max, d, filter_dir, dir_id, tau, cand, cand_cnt, cap,
                        bad, need_full);
     return hipGetLastError();
 }
@@ -760,10 +786,10 @@ hipError_t launch_dense_finalize(int B, int k, int mode, const float *qnorm, flo
                                  const ErhCand *cand, const uint32_t *cand_cnt, int cap,
                                  int32_t *out_ids, double *out_scores, int32_t *out_len,
                                  float *diag_maxerr, uint32_t *diag_uncert, uint32_t *bad, int64_t N,
-                                 int64_t pos_mul, int64_t pos_inv, hipStream_t st) {
+                                 int64_t pos_mul, int64_t pos_inv, const float *tau_verify, hipStream_t st) {
     hipLaunchKernelGGL(dense_finalize_kernel, dim3(B), dim3(kFinThreads), 0, st,
                        k, mode, qnorm, xnorm_max, d, X, Q16, cand, cand_cnt, cap,
-                       out_ids, out_scores, out_len, diag_maxerr, diag_uncert, bad, N, pos_mul, pos_inv);
+                       out_ids, out_scores, out_len, diag_maxerr, diag_uncert, bad, N, pos_mul, pos_inv, tau_verify);
     return hipGetLastError();
 }
 

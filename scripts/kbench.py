@@ -126,6 +126,97 @@ def main():
                 res[f"dense B={B} pp{lean} phase clocks per stage, group {g}"] = {
                     n_: round(v / stages, 1) for n_, v in zip(names, c[g * 8:g * 8 + 6])} if stages else {}
         del x
+    if what == "var":                                        # lean ping-pong scan: barrier / priority variants x K-rotation
+        x = synth.dense_corpus_torch(n, d, seed=2, device=dev)
+        eng.set_dense(x)
+        eng.set_option("dense_pp", 2)
+        for B, k in ((256, 100), (1024, 288)):
+            q = synth.dense_queries_torch(x, B, seed=7)
+            combos = [(v, 0) for v in (0, 1, 2, 3)] if B == 256 else [(v, r) for r in (0, 8) for v in (0, 1, 2, 3)] + [(0, 4), (0, 16), (1, 16)]
+            for rep in "ab":
+                for var, rot in combos:
+                    eng.set_option("dense_var", var)
+                    eng.set_option("dense_rot", rot)
+                    for abl in (0, 7):
+                        eng.set_option("dense_ablate", abl)
+                        res[f"dense B={B} var={var} rot={rot} pabl={abl} (run {rep})"] = timed(eng, lambda: eng.dense_topk(q, k, device_out=True))
+            eng.set_option("dense_ablate", 0)
+            for var, rot in ((0, 0), (1, 0)):
+                eng.set_option("dense_var", var)
+                eng.set_option("dense_rot", rot)
+                eng.set_option("debug_counters", 1)
+                eng.set_option("dense_ablate", 20)
+                eng.dense_topk(q, k, device_out=True)
+                torch.cuda.synchronize()
+                c = eng.debug_counters().astype(np.float64)
+                eng.set_option("dense_ablate", 0)
+                eng.set_option("debug_counters", 0)
+                names = ["matrix", "wait", "barrier", "memory", "epilogue", "epi_barrier"]
+                for g in (0, 1):
+                    stages = c[g * 8 + 6]
+                    res[f"dense B={B} var={var} phase clocks per stage, group {g}"] = {
+                        n_: round(v / stages, 1) for n_, v in zip(names, c[g * 8:g * 8 + 6])} if stages else {}
+            eng.set_option("dense_var", 0)
+            eng.set_option("dense_rot", 0)
+        del x
+    if what == "mm":                                         # matrix-side ablations of the lean ping-pong scan with phase clocks
+        x = synth.dense_corpus_torch(n, d, seed=2, device=dev)
+        eng.set_dense(x)
+        eng.set_option("dense_pp", 2)
+        names = ["matrix", "wait", "barrier", "memory", "epilogue", "epi_barrier"]
+        for B, k in ((256, 100), (1024, 288)):
+            q = synth.dense_queries_torch(x, B, seed=7)
+            for var in (0, 1):
+                eng.set_option("dense_var", var)
+                for rep in "ab":
+                    for abl in (7, 12, 23, 17, 18):
+                        eng.set_option("dense_ablate", abl)
+                        res[f"dense B={B} var={var} pabl={abl} (run {rep})"] = timed(eng, lambda: eng.dense_topk(q, k, device_out=True))
+                for abl in (21, 20, 22, 24):
+                    eng.set_option("debug_counters", 1)
+                    eng.set_option("dense_ablate", abl)
+                    eng.dense_topk(q, k, device_out=True)
+                    torch.cuda.synchronize()
+                    c = eng.debug_counters().astype(np.float64)
+                    eng.set_option("dense_ablate", 0)
+                    eng.set_option("debug_counters", 0)
+                    for g in (0, 1):
+                        stages = c[g * 8 + 6]
+                        res[f"dense B={B} var={var} pabl={abl} phase clocks per stage, group {g}"] = {
+                            n_: round(v / stages, 1) for n_, v in zip(names, c[g * 8:g * 8 + 6])} if stages else {}
+            eng.set_option("dense_var", 0)
+        del x
+    if what == "p3":                                         # strict-alternation ping-pong (dense_pp=3) vs the lean one (2)
+        x = synth.dense_corpus_torch(n, d, seed=2, device=dev)
+        eng.set_dense(x)
+        names = ["matrix", "wait", "barrier", "memory", "epilogue", "epi_barrier"]
+        for B, k in ((256, 100), (1024, 288)):
+            q = synth.dense_queries_torch(x, B, seed=7)
+            for rep in "ab":
+                for pp, var in ((2, 0), (3, 0), (3, 1)):
+                    eng.set_option("dense_pp", pp)
+                    eng.set_option("dense_var", var)
+                    for abl in (0, 7, 12, 23, 16):
+                        eng.set_option("dense_ablate", abl)
+                        res[f"dense B={B} pp={pp} var={var} pabl={abl} (run {rep})"] = timed(eng, lambda: eng.dense_topk(q, k, device_out=True))
+            eng.set_option("dense_pp", 3)
+            eng.set_option("dense_var", 1)
+            for abl in (21, 20):
+                eng.set_option("debug_counters", 1)
+                eng.set_option("dense_ablate", abl)
+                eng.dense_topk(q, k, device_out=True)
+                torch.cuda.synchronize()
+                c = eng.debug_counters().astype(np.float64)
+                eng.set_option("dense_ablate", 0)
+                eng.set_option("debug_counters", 0)
+                for g in (0, 1):
+                    stages = c[g * 8 + 6]
+                    res[f"dense B={B} pp=3 pabl={abl} phase clocks per stage, group {g}"] = {
+                        n_: round(v / stages, 1) for n_, v in zip(names, c[g * 8:g * 8 + 6])} if stages else {}
+            eng.set_option("dense_ablate", 0)
+            eng.set_option("dense_var", 0)
+        eng.set_option("dense_pp", 2)
+        del x
     if what == "bm25w":                                      # wave-owned scan vs block scan, section clocks
         indptr, doc, tf, lens, flat = synth.token_csr_torch(n, vocab, seed=3, device=dev)
         for variant, name in ((BM25S, "bm25s"), (OKAPI, "okapi")):

@@ -12,22 +12,28 @@ from oracle import dense_exact_scores, dense_exact_topk, qdrant_cosine_search, t
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[(0, 1, 2, 0), (0, 1, 1, 0), (0, 1, 0, 0), (0, 0, 0, 0), (1, 0, 0, 0), (2, 1, 0, 0), (0, 1, 2, 1)],
-                ids=["pingpong-lean-256x256x32", "pingpong-256x256x32", "cfg0-256x256x64-persistent", "cfg0-per-tile",
-                     "cfg1-128x256x32-per-tile", "cfg2-256x256x32-persistent", "gemv-16x16x32-small-batch"])
+# (dense_cfg, dense_persist, dense_pp, dense_gemv, dense_speculate)
+@pytest.fixture(params=[(0, 1, 3, 0, 1), (0, 1, 3, 0, 0), (0, 1, 2, 0, 1), (0, 1, 1, 0, 0), (0, 1, 0, 0, 1), (0, 0, 0, 0, 0),
+                        (1, 0, 0, 0, 1), (2, 1, 0, 0, 0), (0, 1, 3, 1, 1)],
+                ids=["pingpong-strict-256x256x32", "pingpong-strict-guaranteed-bounds", "pingpong-lean-256x256x32",
+                     "pingpong-256x256x32-guaranteed-bounds", "cfg0-256x256x64-persistent", "cfg0-per-tile-guaranteed-bounds",
+                     "cfg1-128x256x32-per-tile", "cfg2-256x256x32-persistent-guaranteed-bounds", "gemv-16x16x32-small-batch"])
 def scan_cfg(request, engine):
-    """Every dense-scan kernel / tile configuration / launch style must satisfy every parity test.  The last arm
-    lets batches of at most 16 queries take the skinny-GEMM stream (larger batches use the ping-pong scan); the
-    other arms pin the padded 256-query scans for every batch size."""
+    """Every dense-scan kernel / tile configuration / launch style must satisfy every parity test, with the speculative
+    (verified) first threshold and with guaranteed bounds refined in stages.  The last arm lets batches of at most 16
+    queries take the skinny-GEMM stream (larger batches use the ping-pong scan); the other arms pin the padded
+    256-query scans for every batch size."""
     engine.set_option("dense_cfg", request.param[0])
     engine.set_option("dense_persist", request.param[1])
     engine.set_option("dense_pp", request.param[2])
     engine.set_option("dense_gemv", request.param[3])
+    engine.set_option("dense_speculate", request.param[4])
     yield request.param
     engine.set_option("dense_cfg", 0)
     engine.set_option("dense_persist", 1)
-    engine.set_option("dense_pp", 2)
+    engine.set_option("dense_pp", 3)
     engine.set_option("dense_gemv", 1)
+    engine.set_option("dense_speculate", 1)
 
 
 def test_mfma_scores_match_plain_gpu_and_numpy(engine, scan_cfg):
@@ -224,6 +230,38 @@ def test_dense_corpus_sorted_by_topic(engine):
         engine.set_option("dense_shuffle", 1)
         engine.set_option("dense_n0", 32768)
         engine.set_option("dense_n1", 131072)
+
+
+def test_dense_speculation_failure_is_caught(engine):
+    """The first pruning threshold is speculative: the rank-r score of the stored prefix (r << k) estimates where the
+    corpus' k-th best lies, on the premise that the prefix is an even sample of the corpus.  Here the premise is
+    broken on purpose (dense_shuffle=0 and a caller order whose first rows are exactly what the queries ask for): the
+    threshold lands far above the true k-th best, fewer than k chunks reach it, dense_finalize_kernel notices, and the
+    exhaustive path answers every query -- same ids, same fp64 scores as the oracle.  With the row placement on, the
+    same data needs no fallback at all."""
+    rng = np.random.default_rng(77)
+    n, d, b, k = 40000, 256, 6, 60
+    topic = rng.standard_normal(d)
+    x32 = rng.standard_normal((n, d))
+    x32[:40] = topic + 0.2 * rng.standard_normal((40, d))          # 40 < k rows on topic, all inside the first n0 rows
+    x = to_f16_unit(x32)
+    q16 = to_f16_unit(topic + 0.2 * rng.standard_normal((b, d)))
+    engine.set_option("dense_n0", 512)
+    engine.set_option("dense_gemv", 0)
+    try:
+        for shuffle, want_exhaustive in ((0, b), (1, 0)):
+            engine.set_option("dense_shuffle", shuffle)
+            engine.set_dense(x)
+            ids, sc, ln = engine.dense_topk(q16, k)
+            assert engine.dense_diag()["exhaustive"] == want_exhaustive
+            for i in range(b):
+                oid, osc = dense_exact_topk(x, q16[i], k)
+                assert np.array_equal(ids[i], oid)
+                assert np.array_equal(sc[i].view(np.uint64), osc.view(np.uint64))
+    finally:
+        engine.set_option("dense_shuffle", 1)
+        engine.set_option("dense_n0", 32768)
+        engine.set_option("dense_gemv", 1)
 
 
 def test_dense_budgets_exhausted_still_answers(engine):
