@@ -45,6 +45,7 @@ struct Bm25State {
     std::vector<double> idf_host;         // idem (float32 values widened exactly for the bm25s variant)
     double avgdl = 0, average_idf = 0;
     bool built_on_device = false;
+    bool payload_positive = false;        // every payload > 0: the wave-owned scan may use threshold crossings instead of the sweep
     std::vector<int64_t> host_indptr;     // host copy: query validation + algorithmic-byte accounting
     int n_tiles = 0, tile_docs = 0;
     int n_fine = 0;                       // sub-ranges of the fine skip table (0 = not built: block scan only)
@@ -73,6 +74,7 @@ struct erh_handle {
     // reference pipeline, pipeline.py:187-210); erh_bm25_select picks the one the set / query calls act on
     Bm25State bm[ERH_BM25_SLOTS];
     int cur = 0;
+    int opt_bm25_crossing = 1;            // wave-owned scan: threshold crossings instead of the accumulator sweep (indices with positive payloads)
     int opt_bm25_wscan = 1;               // wave-owned scan when the batch qualifies (bm25.hip), else the block scan
     int64_t opt_bm25_fine_max_mb = 8192;  // largest fine skip table built for it
     // metadata
@@ -431,7 +433,8 @@ int bm25_topk_dev(erh_handle *h, const int32_t *qptr_dev, const int32_t *qtok_de
         if (wscan)
             return erh::launch_bm25_wscan(S.variant, S.indptr.as<int64_t>(), S.doc_ids.as<int32_t>(), S.payload.p,
                                           S.fine_off.as<int32_t>(), S.n_fine, S.n_tiles, S.Nb, qptr_dev, qtok_dev, B, k,
-                                          segs, filter_dev, dir, p_sc, p_ids, p_len, dbg, st);
+                                          segs, filter_dev, dir, p_sc, p_ids, p_len,
+                                          (h->opt_bm25_crossing && S.payload_positive) ? 1 : 0, dbg, st);
         return erh::launch_bm25_scan(S.variant, S.indptr.as<int64_t>(), S.doc_ids.as<int32_t>(), S.payload.p,
                                      S.tile_off.as<int32_t>(), S.n_tiles, S.Nb, qptr_dev, qtok_dev, B, k, segs,
                                      filter_dev, dir, p_sc, p_ids, p_len, h->opt_bm25_ablate, dbg, st);
@@ -574,6 +577,7 @@ int erh_set_option(erh_handle *h, const char *name, int64_t value) {
     if (!strcmp(name, "dense_ablate") || !strcmp(name, "bm25_ablate") || !strcmp(name, "debug_counters"))
         return value == 0 ? ERH_OK : h->fail(ERH_ERR_UNSUPPORTED, "measurement option: rebuild the library with ERH_MEASURE=1");
 #endif
+    if (!strcmp(name, "bm25_crossing")) { h->opt_bm25_crossing = value != 0; return ERH_OK; }
     if (!strcmp(name, "bm25_wscan")) { h->opt_bm25_wscan = value != 0; return ERH_OK; }   // the fine table is built at the next erh_set_bm25_*
     if (!strcmp(name, "bm25_fine_max_mb")) { if (value < 0) return h->fail(ERH_ERR_INVALID, "bm25_fine_max_mb < 0"); h->opt_bm25_fine_max_mb = value; return ERH_OK; }
     if (!strcmp(name, "debug_counters")) {
@@ -733,6 +737,22 @@ static int bm25_finish_tables(erh_handle *h, int variant, int64_t V, int64_t N, 
     return ERH_OK;
 }
 
+// After the payload of the selected slot is in place: does every posting carry a payload > 0?
+static int bm25_check_payload_sign(erh_handle *h, hipStream_t st) {
+    Bm25State &S = h->bm[h->cur];
+    S.payload_positive = false;
+    if (S.nnz <= 0) return ERH_OK;
+    HIPCHK(h, h->flags.ensure(64));
+    uint32_t *w = h->flags.as<uint32_t>() + 8;
+    HIPCHK(h, hipMemsetAsync(w, 0, 4, st));
+    HIPCHK(h, erh::launch_bm25_payload_sign(S.variant, S.payload.p, S.nnz, w, st));
+    uint32_t f = 1;
+    HIPCHK(h, hipMemcpyAsync(&f, w, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    S.payload_positive = (f == 0);
+    return ERH_OK;
+}
+
 static int bm25_common_upload(erh_handle *h, int variant, int64_t V, int64_t N, int64_t nnz,
                               const int64_t *indptr, const int32_t *doc_ids) {
     if (variant != ERH_BM25_OKAPI && variant != ERH_BM25_BM25S) return h->fail(ERH_ERR_INVALID, "bm25 variant");
@@ -775,7 +795,7 @@ int erh_set_bm25_csr(erh_handle *h, int variant, int64_t V, int64_t N, int64_t n
     HIPCHK(h, h->bm[h->cur].payload.ensure((size_t)std::max<int64_t>(nnz, 1) * es));
     if (nnz) HIPCHK(h, hipMemcpyAsync(h->bm[h->cur].payload.p, payload, (size_t)nnz * es, hipMemcpyHostToDevice, nullptr));
     HIPCHK(h, hipStreamSynchronize(nullptr));
-    return ERH_OK;
+    return bm25_check_payload_sign(h, nullptr);
 }
 
 int erh_set_bm25_tf(erh_handle *h, int variant, int64_t V, int64_t N, int64_t nnz,
@@ -803,7 +823,7 @@ int erh_set_bm25_tf(erh_handle *h, int variant, int64_t V, int64_t N, int64_t nn
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     cleanup();
     if (e != hipSuccess) { h->bm[h->cur].variant = -1; return h->fail(ERH_ERR_HIP, "erh_set_bm25_tf", e); }
-    return ERH_OK;
+    return bm25_check_payload_sign(h, st);
 }
 
 
@@ -949,7 +969,7 @@ int erh_build_bm25_index(erh_handle *h, int variant, int64_t V, int64_t N, int64
     S.nnz = nnz;
     S.built_on_device = true;
     if (out_nnz) *out_nnz = nnz;
-    return ERH_OK;
+    return bm25_check_payload_sign(h, st);
 }
 
 int erh_get_bm25_csr(erh_handle *h, int64_t *indptr, int32_t *doc_ids, int32_t *tf, double *idf, double *avgdl,

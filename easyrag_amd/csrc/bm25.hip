@@ -16,6 +16,7 @@
 //   - the tile is then swept once: entries that beat the running k-th best (score desc, index asc;
 //     score > 0 only, retrievers.py:195-196; optional dir filter, retrievers.py:198-202) are compacted
 //     into an LDS candidate list that is re-sorted and cut to k whenever it fills.
+#include <algorithm>
 #include "common.h"
 #include "kernels.h"
 
@@ -514,8 +515,45 @@ __device__ __forceinline__ void ws_apply(const WsSet<ST> &S, ST *acc, int64_t ba
     }
 }
 
-// grid = (segs, B), block = 1024; every query of the batch has at most kWsMaxTok tokens (the host checks).
+// Threshold crossings.  With strictly positive payloads a document's sum only grows while the tokens are applied, so
+// "the final sum reaches the running threshold th" happens exactly once per document: at the posting whose add takes
+// the sum from below th to >= th.  The wave notes the accumulator slot of every crossing in its own small LDS list
+// (ballot + mbcnt, no atomics; the common case costs two compares and one wave-uniform test per 64 postings).  After
+// the token loop the list IS the tile's survivor set of this sub-range: the wave reads the final sums of the noted
+// slots, moves the ones that pass the exact (score, index) test to the candidate list, and clears its sub-range with
+// plain 16-byte stores -- no sweep over 32768 accumulators of which a few dozen matter.  A wave whose list overflows
+// (kWsXCap crossings in one sub-range) sweeps its sub-range the old way, as does every wave after a full candidate
+// list; indices with non-positive payloads (possible with rank-bm25's epsilon floor on a degenerate corpus) and tiles
+// without a positive threshold never take this path.
+constexpr int kWsXCap = 64;         // crossings a wave notes per tile
+constexpr int kWsXBytes = (kBmThreads / 64) * kWsXCap * 4;   // the waves' crossing lists, behind the candidate list
+// (LDS floating-point atomics with return -- ds_add_rtn_f32 / _f64, all slots of a step in flight together -- give the
+// same sums bit for bit but run the scan 1.7x SLOWER than this read / add / write-back chain: profiles/r02c.)
 template <typename ST>
+__device__ __forceinline__ void ws_apply_x(const WsSet<ST> &S, ST *acc, int64_t base_doc, ST th, int32_t *xw, int &nx,
+                                           int lane) {
+#pragma unroll
+    for (int u = 0; u < WsSet<ST>::SLOTS; ++u) {
+        bool cross = false;
+        int slot = 0;
+        if (u < S.used && S.d[u] >= 0) {
+            slot = (int)((int64_t)S.d[u] - base_doc);
+            const ST old = acc[slot];
+            const ST nw = old + S.v[u];
+            acc[slot] = nw;
+            cross = (old < th) && !(nw < th);
+        }
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(cross);
+        if (m) {                                                          // wave-uniform, rare
+            const int pos = nx + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (cross && pos < kWsXCap) xw[pos] = slot;
+            nx += __builtin_popcountll(m);
+        }
+    }
+}
+
+// grid = (segs, B), block = 1024; every query of the batch has at most kWsMaxTok tokens (the host checks).
+template <typename ST, bool CROSSING /* every payload > 0 and normal: threshold crossings may replace the sweep */>
 __global__ __launch_bounds__(kBmThreads) void bm25_wscan_kernel(
     const int64_t *__restrict__ indptr, const int32_t *__restrict__ doc_ids, const ST *__restrict__ payload,
     const int32_t *__restrict__ fine_off, int n_fine, int n_tiles, int64_t N,
@@ -526,6 +564,7 @@ __global__ __launch_bounds__(kBmThreads) void bm25_wscan_kernel(
     using L = BmLds<ST>;
     constexpr int TILE = L::TILE, SUB = TILE / kWsWaves;
     static_assert(SUB % (64 * 16 / (int)sizeof(ST)) == 0, "a wave sweeps its sub-range in whole 16-byte rounds");
+    static_assert(L::OFF_LO + kWsXBytes <= 160 * 1024, "crossing lists must fit behind the candidate list");
     long long t_sec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long t_mark = dbg ? clock64() : 0;
 #define ERH_SEC(I) do { if (dbg) { const long long n_ = clock64(); t_sec[I] += n_ - t_mark; t_mark = n_; } } while (0)
@@ -538,6 +577,7 @@ __global__ __launch_bounds__(kBmThreads) void bm25_wscan_kernel(
     const int seg = blockIdx.x, q = blockIdx.y, tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int32_t *xw = reinterpret_cast<int32_t *>(smem + L::OFF_LO) + wave * kWsXCap;   // this wave's crossing list
     const int qs = q_indptr[q];
     int nq = q_indptr[q + 1] - qs;
     if (nq > kWsMaxTok) nq = kWsMaxTok;                                   // (never: the host routes longer queries to the block scan)
@@ -586,10 +626,23 @@ __global__ __launch_bounds__(kBmThreads) void bm25_wscan_kernel(
             if (more) bounds(tile + 1, lo_nxt, n_nxt);                    // lands while this tile is processed
             ERH_SEC(0);
             // ---- all tokens, in order, onto this wave's documents ------------------------------------------------
-            for (;;) {
-                ws_apply<ST>(S, acc, base_doc);
-                if (cur.j >= nq) break;                                   // the sub-range's postings are exhausted
-                ws_fill<ST>(S, cur, doc_ids, payload, lo_cur, n_cur, nq, lane);
+            const ST th = (ST)hdr->tau_s;                                 // fixed for the tile (it only moves in bm_shrink)
+            const int th_idx = hdr->tau_idx;
+            const bool use_x = CROSSING && tile != t_begin && th > (ST)0; // workgroup-uniform
+            int nx = 0;                                                   // wave-uniform: crossings noted in this tile
+            if (CROSSING) {
+                const ST thx = use_x ? th : (ST)-1;                       // (-1: nothing crosses, the adds are the same)
+                for (;;) {
+                    ws_apply_x<ST>(S, acc, base_doc, thx, xw, nx, lane);
+                    if (cur.j >= nq) break;
+                    ws_fill<ST>(S, cur, doc_ids, payload, lo_cur, n_cur, nq, lane);
+                }
+            } else {
+                for (;;) {
+                    ws_apply<ST>(S, acc, base_doc);
+                    if (cur.j >= nq) break;                               // the sub-range's postings are exhausted
+                    ws_fill<ST>(S, cur, doc_ids, payload, lo_cur, n_cur, nq, lane);
+                }
             }
             if (more) {                                                   // first step of the next tile: flies during the sweep
                 cur.j = -1; cur.off = 0; cur.nj = 0;
@@ -613,22 +666,57 @@ __global__ __launch_bounds__(kBmThreads) void bm25_wscan_kernel(
                 if (tid == 0 && p > (ST)0) { hdr->tau_s = (double)p; hdr->tau_idx = 0x7fffffff; }
                 __syncthreads();
             }
-            // ---- sweep the own sub-range; once per pass the workgroup decides about the candidate list -------------
+            // ---- survivors of the own sub-range -> candidate list; once per pass the workgroup decides about the list ---
+            bool swept = false;                                           // wave-uniform: the sub-range has been swept (= cleared)
+            bool from_list = use_x && nx <= kWsXCap;                      // wave-uniform: the crossing list is complete
+            if (dbg && tid == 0) { t_sec[6] += from_list ? 1 : 0; t_sec[7] += nx; }   // (measurement: tiles by list, crossings)
             for (;;) {
                 const int slot = ph % 3;
                 if (tid == 0) { hdr->full[(ph + 1) % 3] = 0; hdr->want[(ph + 1) % 3] = 0; }
-                const ST tau_s = (ST)hdr->tau_s;
-                const int tau_idx = hdr->tau_idx;
-                bm_sweep<ST>(hdr, acc, cs, ci, wave * SUB, (wave + 1) * SUB, 64, lane, base_doc, N, fd, dir_id, tau_s,
-                             tau_idx, &hdr->full[slot], &hdr->want[slot], k + kBmThreads / 2);
+                if (from_list) {
+                    // the noted slots hold final sums now; th / th_idx are still the workgroup's threshold (no shrink since)
+                    for (int i = lane; i < nx; i += 64) {
+                        const int sl = xw[i];
+                        const ST sv = acc[sl];
+                        const int64_t doc = base_doc + sl;
+                        bool pass = bm_pass<ST>(sv, doc, th, th_idx);
+                        if (pass && (doc >= N || (fd >= 0 && (int)dir_id[doc] != fd))) pass = false;
+                        if (pass) {
+                            const int pos = atomicAdd(&hdr->ncand, 1);
+                            if (pos < kBmCap) {
+                                cs[pos] = sv;
+                                ci[pos] = (int32_t)doc;
+                                acc[sl] = (ST)0;                          // moved: a later sweep must not see it again
+                                if (pos >= k + kBmThreads / 2) hdr->want[slot] = 1;
+                            } else {
+                                hdr->full[slot] = 1;                      // list full: it stays in its accumulator for the sweep below
+                            }
+                        }
+                    }
+                    from_list = false;                                    // a further pass (full list) sweeps
+                } else {
+                    const ST tau_s = (ST)hdr->tau_s;
+                    const int tau_idx = hdr->tau_idx;
+                    bm_sweep<ST>(hdr, acc, cs, ci, wave * SUB, (wave + 1) * SUB, 64, lane, base_doc, N, fd, dir_id, tau_s,
+                                 tau_idx, &hdr->full[slot], &hdr->want[slot], k + kBmThreads / 2);
+                    swept = true;
+                }
                 ERH_SEC(2);
-                __syncthreads();                                          // every sub-range swept
+                __syncthreads();                                          // every sub-range done
                 ERH_SEC(3);
                 const int full = hdr->full[slot], want = hdr->want[slot];
                 ++ph;
                 if (full || want) bm_shrink<ST>(hdr, cs, ci, k);          // uniform; cut to k, threshold becomes exact
                 ERH_SEC(4);
                 if (!full) break;                                         // (full: survivors were left behind -- sweep again)
+            }
+            if (!swept) {                                                 // nothing left here that matters: clear the sub-range
+                constexpr int VEC = 16 / (int)sizeof(ST);
+                typedef ST VT __attribute__((ext_vector_type(VEC)));
+                VT z;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) z[e] = (ST)0;
+                for (int i = wave * SUB + lane * VEC; i < (wave + 1) * SUB; i += 64 * VEC) *reinterpret_cast<VT *>(acc + i) = z;
             }
             lo_cur = lo_nxt;
             n_cur = n_nxt;
@@ -692,6 +780,16 @@ __global__ void bm25_add_term_kernel(const int64_t *__restrict__ indptr, const i
     }
 }
 
+// flag[0] = 1 if any payload is <= 0, subnormal or NaN: the crossing path of the wave-owned scan needs strictly growing
+// sums of normal numbers
+template <typename ST>
+__global__ void bm25_payload_sign_kernel(const ST *__restrict__ payload, int64_t nnz, uint32_t *__restrict__ flag) {
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += (int64_t)gridDim.x * blockDim.x)
+        bad |= !(payload[i] >= (sizeof(ST) == 4 ? (ST)1.17549435e-38f : (ST)2.2250738585072014e-308));   // positive and normal
+    if (__builtin_amdgcn_ballot_w64(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+}
+
 __global__ void widen_f32_kernel(const float *__restrict__ in, int64_t n, double *__restrict__ out) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         out[i] = (double)in[i];
@@ -711,11 +809,17 @@ hipError_t bm25_init() {
     e = hipFuncSetAttribute((const void *)bm25_scan_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)BmLds<double>::BYTES);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void *)bm25_wscan_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)BmLds<float>::OFF_LO);
+    e = hipFuncSetAttribute((const void *)bm25_wscan_kernel<float, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)BmLds<float>::OFF_LO + kWsXBytes);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void *)bm25_wscan_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)BmLds<double>::OFF_LO);
+    e = hipFuncSetAttribute((const void *)bm25_wscan_kernel<float, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)BmLds<float>::OFF_LO + kWsXBytes);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void *)bm25_wscan_kernel<double, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)BmLds<double>::OFF_LO + kWsXBytes);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void *)bm25_wscan_kernel<double, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)BmLds<double>::OFF_LO + kWsXBytes);
     if (e != hipSuccess) return e;
     return hipFuncSetAttribute((const void *)bm25_merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                8192 * 12 + 64);
@@ -770,18 +874,30 @@ hipError_t launch_bm25_wscan(int variant, const int64_t *indptr, const int32_t *
                              const int32_t *fine_off, int n_fine, int n_tiles, int64_t N,
                              const int32_t *q_indptr, const int32_t *q_tok, int B, int k, int segs,
                              const int16_t *filter_dir, const int16_t *dir_id,
-                             double *part_scores, int32_t *part_ids, int32_t *part_len,
+                             double *part_scores, int32_t *part_ids, int32_t *part_len, int crossing,
                              unsigned long long *dbg, hipStream_t st) {
     if (B <= 0) return hipSuccess;
     dim3 grid(segs, B), block(kBmThreads);
+#define ERH_WS_LAUNCH(ST, X)                                                                               \
+    hipLaunchKernelGGL((bm25_wscan_kernel<ST, X>), grid, block, BmLds<ST>::OFF_LO + kWsXBytes, st, indptr, doc_ids, \
+                       (const ST *)payload, fine_off, n_fine, n_tiles, N, q_indptr, q_tok, k, segs, filter_dir, dir_id, \
+                       part_scores, part_ids, part_len, dbg)
+    if (variant == 0) {
+        if (crossing) ERH_WS_LAUNCH(double, true); else ERH_WS_LAUNCH(double, false);
+    } else {
+        if (crossing) ERH_WS_LAUNCH(float, true); else ERH_WS_LAUNCH(float, false);
+    }
+#undef ERH_WS_LAUNCH
+    return hipGetLastError();
+}
+
+hipError_t launch_bm25_payload_sign(int variant, const void *payload, int64_t nnz, uint32_t *flag, hipStream_t st) {
+    if (nnz <= 0) return hipSuccess;
+    const unsigned g = (unsigned)std::min<int64_t>((nnz + 255) / 256, 8192);
     if (variant == 0)
-        hipLaunchKernelGGL(bm25_wscan_kernel<double>, grid, block, BmLds<double>::OFF_LO, st, indptr, doc_ids,
-                           (const double *)payload, fine_off, n_fine, n_tiles, N, q_indptr, q_tok, k, segs, filter_dir,
-                           dir_id, part_scores, part_ids, part_len, dbg);
+        hipLaunchKernelGGL(bm25_payload_sign_kernel<double>, dim3(g), dim3(256), 0, st, (const double *)payload, nnz, flag);
     else
-        hipLaunchKernelGGL(bm25_wscan_kernel<float>, grid, block, BmLds<float>::OFF_LO, st, indptr, doc_ids,
-                           (const float *)payload, fine_off, n_fine, n_tiles, N, q_indptr, q_tok, k, segs, filter_dir,
-                           dir_id, part_scores, part_ids, part_len, dbg);
+        hipLaunchKernelGGL(bm25_payload_sign_kernel<float>, dim3(g), dim3(256), 0, st, (const float *)payload, nnz, flag);
     return hipGetLastError();
 }
 

@@ -109,7 +109,10 @@ hipError_t launch_bm25_wscan(int variant, const int64_t *indptr, const int32_t *
                              const int32_t *q_indptr, const int32_t *q_tok, int B, int k, int segs,
                              const int16_t *filter_dir, const int16_t *dir_id,
                              double *part_scores, int32_t *part_ids, int32_t *part_len,
+                             int crossing /* every payload > 0: threshold crossings replace the sweep */,
                              unsigned long long *dbg, hipStream_t st);
+// *flag |= 1 if any payload is <= 0 (flag must be zeroed by the caller)
+hipError_t launch_bm25_payload_sign(int variant, const void *payload, int64_t nnz, uint32_t *flag, hipStream_t st);
 hipError_t launch_bm25_merge(int B, int k, int segs, const double *part_scores, const int32_t *part_ids,
                              const int32_t *part_len, int32_t *out_ids, double *out_scores, int32_t *out_len,
                              hipStream_t st);

@@ -13,12 +13,15 @@ from oracle.retrievers import Item
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[1, 0], ids=["wave-owned-scan", "block-scan"])
+@pytest.fixture(params=[(1, 1), (1, 0), (0, 0)], ids=["wave-owned-crossings", "wave-owned-sweep", "block-scan"])
 def bm25_kernel(request, engine):
-    """Both BM25 scan kernels must satisfy every parity test (the option takes effect at the next set_bm25)."""
-    engine.set_option("bm25_wscan", request.param)
+    """Every BM25 scan kernel / survivor-selection path must satisfy every parity test (bm25_wscan takes effect at the
+    next set_bm25)."""
+    engine.set_option("bm25_wscan", request.param[0])
+    engine.set_option("bm25_crossing", request.param[1])
     yield request.param
     engine.set_option("bm25_wscan", 1)
+    engine.set_option("bm25_crossing", 1)
 
 
 def _oracle_for(variant, docs):
@@ -82,6 +85,31 @@ def test_bm25_ties_and_filter(engine, bm25_kernel, variant):
         for b, q in enumerate(queries):
             mask = None if filt[b] < 0 else dir_id == filt[b]
             want = bm25_filter(_oracle_scores(ora, variant, q), k, mask)
+            assert list(ids[b, :ln[b]]) == [w[0] for w in want] and list(sc[b, :ln[b]]) == [w[1] for w in want]
+
+
+def test_bm25_okapi_negative_idf_floor(engine, bm25_kernel):
+    """rank-bm25 replaces negative idf values by epsilon * average_idf -- which is itself negative when most terms sit
+    in most documents.  Sums then do not grow monotonically, so the threshold-crossing path of the wave-owned scan
+    must stand down (the library checks the payload signs when an index is set); scores and the `score > 0` walk still
+    match the reference arithmetic."""
+    rng = np.random.default_rng(8)
+    docs = []
+    for _ in range(3000):                                    # six terms in ~80 % of the documents, two rare ones
+        doc = [t for t in range(6) if rng.random() < 0.8] or [0]
+        doc += [int(t) for t in rng.integers(0, 6, size=rng.integers(0, 4))]
+        doc += [6] * (rng.random() < 0.1) + [7] * (rng.random() < 0.1)
+        docs.append(doc)
+    ora = _oracle_for(OKAPI, docs)
+    idx = build_bm25_index(docs, OKAPI)
+    assert float(idx.payload.min()) < 0.0 < float(idx.payload.max())
+    engine.set_bm25(idx)
+    queries = [[0, 1, 7], [6, 7, 2, 2], [7], [3], [6, 0, 1, 2, 3, 4, 5]]
+    qi, qt = queries_to_csr([idx.tokens_to_ids(q) for q in queries])
+    for k in (5, 150):
+        ids, sc, ln = engine.bm25_topk(qi, qt, k)
+        for b, q in enumerate(queries):
+            want = bm25_filter(_oracle_scores(ora, OKAPI, q), k)
             assert list(ids[b, :ln[b]]) == [w[0] for w in want] and list(sc[b, :ln[b]]) == [w[1] for w in want]
 
 
