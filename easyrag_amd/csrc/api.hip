@@ -74,7 +74,8 @@ struct erh_handle {
     // reference pipeline, pipeline.py:187-210); erh_bm25_select picks the one the set / query calls act on
     Bm25State bm[ERH_BM25_SLOTS];
     int cur = 0;
-    int opt_bm25_crossing = 1;            // wave-owned scan: threshold crossings instead of the accumulator sweep (indices with positive payloads)
+    int opt_bm25_crossing = 1;            // wave-owned scan: threshold crossings instead of the accumulator sweep (indices with positive
+                                          // payloads); 1 = fp32 sums only (the fp64 kernel runs out of registers with it: +12 % time), 2 = both
     int opt_bm25_wscan = 1;               // wave-owned scan when the batch qualifies (bm25.hip), else the block scan
     int64_t opt_bm25_fine_max_mb = 8192;  // largest fine skip table built for it
     // metadata
@@ -298,7 +299,11 @@ int dense_topk_dev(erh_handle *h, const void *q_dev, int q_dtype, int normalize_
       if (small) e = erh::launch_dense_gemv_store(X, N, d, 0, (int)n0, Q16, B, h->S0.as<float>(), ld, h->n_cus, st);
       if (e == hipErrorInvalidValue) {
           (void)hipGetLastError();
-          e = erh::launch_dense_scan_store(h->opt_dense_cfg, Q16, Bpad, X, N, d, 0, (int)n0, h->S0.as<float>(), ld, st);
+          // one 256 x 256 tile per workgroup leaves CUs idle when the seed grid is small (B = 256: 128 tiles on 256 CUs);
+          // the 128 x 256 configuration (4 waves, two workgroups per CU) halves the tile and fills the chip
+          int store_cfg = h->opt_dense_cfg;
+          if (store_cfg == 0 && ((n0 + QT - 1) / QT) * (Bpad / QT) < h->n_cus) store_cfg = 1;
+          e = erh::launch_dense_scan_store(store_cfg, Q16, Bpad, X, N, d, 0, (int)n0, h->S0.as<float>(), ld, st);
       }
       HIPCHK(h, e); }
     // Rank of the prefix score that seeds the threshold.  Guaranteed: k.  Speculative: the prefix is an even sample of
@@ -434,7 +439,9 @@ int bm25_topk_dev(erh_handle *h, const int32_t *qptr_dev, const int32_t *qtok_de
             return erh::launch_bm25_wscan(S.variant, S.indptr.as<int64_t>(), S.doc_ids.as<int32_t>(), S.payload.p,
                                           S.fine_off.as<int32_t>(), S.n_fine, S.n_tiles, S.Nb, qptr_dev, qtok_dev, B, k,
                                           segs, filter_dev, dir, p_sc, p_ids, p_len,
-                                          (h->opt_bm25_crossing && S.payload_positive) ? 1 : 0, dbg, st);
+                                          (S.payload_positive && (h->opt_bm25_crossing >= 2 ||
+                                                                  (h->opt_bm25_crossing == 1 && S.variant != ERH_BM25_OKAPI))) ? 1 : 0,
+                                          dbg, st);
         return erh::launch_bm25_scan(S.variant, S.indptr.as<int64_t>(), S.doc_ids.as<int32_t>(), S.payload.p,
                                      S.tile_off.as<int32_t>(), S.n_tiles, S.Nb, qptr_dev, qtok_dev, B, k, segs,
                                      filter_dev, dir, p_sc, p_ids, p_len, h->opt_bm25_ablate, dbg, st);
@@ -577,7 +584,7 @@ int erh_set_option(erh_handle *h, const char *name, int64_t value) {
     if (!strcmp(name, "dense_ablate") || !strcmp(name, "bm25_ablate") || !strcmp(name, "debug_counters"))
         return value == 0 ? ERH_OK : h->fail(ERH_ERR_UNSUPPORTED, "measurement option: rebuild the library with ERH_MEASURE=1");
 #endif
-    if (!strcmp(name, "bm25_crossing")) { h->opt_bm25_crossing = value != 0; return ERH_OK; }
+    if (!strcmp(name, "bm25_crossing")) { if (value < 0 || value > 2) return h->fail(ERH_ERR_INVALID, "bm25_crossing"); h->opt_bm25_crossing = (int)value; return ERH_OK; }
     if (!strcmp(name, "bm25_wscan")) { h->opt_bm25_wscan = value != 0; return ERH_OK; }   // the fine table is built at the next erh_set_bm25_*
     if (!strcmp(name, "bm25_fine_max_mb")) { if (value < 0) return h->fail(ERH_ERR_INVALID, "bm25_fine_max_mb < 0"); h->opt_bm25_fine_max_mb = value; return ERH_OK; }
     if (!strcmp(name, "debug_counters")) {

@@ -692,6 +692,14 @@ static_assert(LDS_BYTES == 160 * 1024, "pp LDS");
 #define ERH_PP_FLAG(IDX) \
     (*reinterpret_cast<volatile __attribute__((address_space(3))) int *>(ERH_LDS_PTR(lds + pp::FLAG_OFF + 4 * (IDX))))
 
+// maximum of four accumulator values in two instructions (fmaxf would add a canonicalising v_max per operand: MFMA
+// results are never signalling NaNs, which the compiler cannot know)
+__device__ __forceinline__ float erh_max4(float a, float b, float c, float d) {
+    float m;
+    asm("v_max3_f32 %0, %1, %2, %3\n\tv_max_f32 %0, %0, %4" : "=&v"(m) : "v"(a), "v"(b), "v"(c), "v"(d));
+    return m;
+}
+
 #define ERH_PP_BARRIER()                                   \
     do {                                                   \
         asm volatile("s_barrier" ::: "memory");            \
@@ -723,12 +731,11 @@ static_assert(LDS_BYTES == 160 * 1024, "pp LDS");
                                  ((uint32_t)i << 14);                                                 \
                 asm volatile("" : "+v"(pk_l_));                                                       \
                 _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                    \
-                    /* four accumulator registers per wave-uniform test: two issue slots per register in the   \
-                       common no-survivor case (a compare and its share of the OR / branch) instead of a       \
-                       compare, a ballot test and a branch for every register */                               \
+                    /* four accumulator registers per wave-uniform test: their maximum (v_max3 + v_max), one    \
+                       compare and one branch in the common no-survivor case */                                 \
                     _Pragma("unroll") for (int r4 = 0; r4 < 16; r4 += 4) {                            \
-                        const bool any_ = (acc[mt][nt][r4] >= t_) | (acc[mt][nt][r4 + 1] >= t_) |     \
-                                          (acc[mt][nt][r4 + 2] >= t_) | (acc[mt][nt][r4 + 3] >= t_);  \
+                        const bool any_ = erh_max4(acc[mt][nt][r4], acc[mt][nt][r4 + 1], acc[mt][nt][r4 + 2],   \
+                                                   acc[mt][nt][r4 + 3]) >= t_;                                 \
                         if (__builtin_amdgcn_ballot_w64(any_)) {                                      \
                             _Pragma("unroll") for (int r = r4; r < r4 + 4; ++r) {                     \
                                 const float sc_ = acc[mt][nt][r];                                     \

@@ -115,7 +115,7 @@ def test_hybrid_configs3_exact(engine, dense_data, sparse_data, variant):
 
 @pytest.mark.parametrize("variant,k,n_sample", [(BM25S, 100, 32), (BM25S, 192, 32), (OKAPI, 100, 12), (OKAPI, 192, 12)],
                          ids=["bm25s-k100", "bm25s-k192", "okapi-k100", "okapi-k192"])
-@pytest.mark.parametrize("wscan,crossing", [(1, 1), (1, 0), (0, 0)], ids=["wave-owned-crossings", "wave-owned-sweep", "block-scan"])
+@pytest.mark.parametrize("wscan,crossing", [(1, 2), (1, 0), (0, 0)], ids=["wave-owned-crossings", "wave-owned-sweep", "block-scan"])
 def test_bm25_configs2_exact(engine, sparse_data, variant, k, n_sample, wscan, crossing):
     """B = 256: the document range of every query is split over two workgroups (segments) whose lists are merged."""
     queries = sparse_data[4]

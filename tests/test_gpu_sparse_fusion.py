@@ -13,7 +13,7 @@ from oracle.retrievers import Item
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[(1, 1), (1, 0), (0, 0)], ids=["wave-owned-crossings", "wave-owned-sweep", "block-scan"])
+@pytest.fixture(params=[(1, 2), (1, 0), (0, 0)], ids=["wave-owned-crossings", "wave-owned-sweep", "block-scan"])
 def bm25_kernel(request, engine):
     """Every BM25 scan kernel / survivor-selection path must satisfy every parity test (bm25_wscan takes effect at the
     next set_bm25)."""
