@@ -74,6 +74,7 @@ struct erh_handle {
     // reference pipeline, pipeline.py:187-210); erh_bm25_select picks the one the set / query calls act on
     Bm25State bm[ERH_BM25_SLOTS];
     int cur = 0;
+    int opt_bm25_segs = 0;                // document-range segments per query (0: enough to give the chip >= 512 workgroups)
     int opt_bm25_crossing = 1;            // wave-owned scan: threshold crossings instead of the accumulator sweep (indices with positive
                                           // payloads); 1 = fp32 sums only (the fp64 kernel runs out of registers with it: +12 % time), 2 = both
     int opt_bm25_wscan = 1;               // wave-owned scan when the batch qualifies (bm25.hip), else the block scan
@@ -103,6 +104,7 @@ struct erh_handle {
     int opt_dense_readahead = 1;           // cfg 2 only: fragments of the next K-step are read before its barrier
     int opt_small_single = 1;              // small batches: skip the refinement boundaries when the lists can take it
     int opt_dense_gemv = 1;                // batches of <= 16 queries: skinny-GEMM stream instead of the padded 256-query scan
+    int opt_n0_auto = 0;                   // seed prefix snapped down to a whole number of scan rounds (less seed work, more candidates: a wash at 1M chunks)
     int opt_dense_speculate = 1;           // speculative (verified) first threshold + a single scan stage; 0: guaranteed bounds, refined in stages
     int opt_dense_var = 0;                 // dense_scan_pp2_kernel VAR (bit 0: two barriers per stage, bit 1: static priority)
     int opt_dense_rot = 0;                 // K-rotation between the query tiles of a stream, in stages per query tile (-1: nk / n_qt)
@@ -263,6 +265,16 @@ int dense_topk_dev(erh_handle *h, const void *q_dev, int q_dtype, int normalize_
     uint32_t *bad = h->bad.as<uint32_t>();
     int64_t n0 = std::min<int64_t>(std::min<int64_t>(h->opt_n0, erh::kDenseN0Max), N);
     if (n0 < 1) n0 = 1;
+    // The persistent scan walks ceil(tiles / streams) rounds of 256-chunk tiles.  With dense_n0_auto the seed prefix shrinks
+    // (never below a quarter of the option, nor below 16 k) to where the rest of the corpus is a whole number of rounds:
+    // the same number of rounds as with the full prefix, and less seed work (1M chunks: 32768 -> 16960).
+    if (h->opt_n0_auto && h->opt_dense_speculate && N > n0 && B > erh::dense_gemv_max_queries()) {
+        const int64_t streams = std::max<int64_t>(8, (std::max(h->n_cus, 8) / (8 * (Bpad / QT))) * 8);
+        const int64_t step = streams * QT;
+        const int64_t rounds = (N - n0 + step - 1) / step;
+        const int64_t cand = N - rounds * step;
+        if (cand >= std::max<int64_t>(n0 / 4, 16 * (int64_t)k) && cand < n0) n0 = cand;
+    }
     const int ld = round_up((int)n0, 256);
     HIPCHK(h, h->S0.ensure((size_t)Bpad * ld * 4));
     uint32_t *flags = h->flags.as<uint32_t>();   // [0] overflow, [1] maxerr (float bits), [2] uncertified
@@ -426,7 +438,7 @@ int bm25_topk_dev(erh_handle *h, const int32_t *qptr_dev, const int32_t *qtok_de
                   int max_qlen, hipStream_t st) {
     Bm25State &S = h->bm[h->cur];
     const int16_t *dir = h->has_dir ? h->dir_id.as<int16_t>() : nullptr;
-    int segs = (512 + B - 1) / B;
+    int segs = h->opt_bm25_segs > 0 ? h->opt_bm25_segs : (512 + B - 1) / B;
     segs = std::max(1, std::min(segs, S.n_tiles));
     while (segs > 1 && (int64_t)segs * k > 8192) --segs;
     // wave-owned scan (no per-token workgroup barrier) when the index has its fine skip table and lane j can own
@@ -569,6 +581,7 @@ int erh_set_option(erh_handle *h, const char *name, int64_t value) {
     if (!strcmp(name, "dense_shuffle")) { h->opt_dense_shuffle = value != 0; return ERH_OK; }   // takes effect at the next erh_set_dense
     if (!strcmp(name, "dense_n1_auto")) { h->opt_n1_auto = value != 0; return ERH_OK; }
     if (!strcmp(name, "dense_pp")) { if (value < 0 || value > 3) return h->fail(ERH_ERR_INVALID, "dense_pp"); h->opt_dense_pp = (int)value; return ERH_OK; }
+    if (!strcmp(name, "dense_n0_auto")) { h->opt_n0_auto = value != 0; return ERH_OK; }
     if (!strcmp(name, "dense_speculate")) { h->opt_dense_speculate = value != 0; return ERH_OK; }
     if (!strcmp(name, "dense_var")) { if (value < 0 || value > 3) return h->fail(ERH_ERR_INVALID, "dense_var"); h->opt_dense_var = (int)value; return ERH_OK; }
     if (!strcmp(name, "dense_rot")) { if (value < -1 || value > 4096) return h->fail(ERH_ERR_INVALID, "dense_rot"); h->opt_dense_rot = (int)value; return ERH_OK; }
@@ -584,6 +597,7 @@ int erh_set_option(erh_handle *h, const char *name, int64_t value) {
     if (!strcmp(name, "dense_ablate") || !strcmp(name, "bm25_ablate") || !strcmp(name, "debug_counters"))
         return value == 0 ? ERH_OK : h->fail(ERH_ERR_UNSUPPORTED, "measurement option: rebuild the library with ERH_MEASURE=1");
 #endif
+    if (!strcmp(name, "bm25_segs")) { if (value < 0 || value > 64) return h->fail(ERH_ERR_INVALID, "bm25_segs"); h->opt_bm25_segs = (int)value; return ERH_OK; }
     if (!strcmp(name, "bm25_crossing")) { if (value < 0 || value > 2) return h->fail(ERH_ERR_INVALID, "bm25_crossing"); h->opt_bm25_crossing = (int)value; return ERH_OK; }
     if (!strcmp(name, "bm25_wscan")) { h->opt_bm25_wscan = value != 0; return ERH_OK; }   // the fine table is built at the next erh_set_bm25_*
     if (!strcmp(name, "bm25_fine_max_mb")) { if (value < 0) return h->fail(ERH_ERR_INVALID, "bm25_fine_max_mb < 0"); h->opt_bm25_fine_max_mb = value; return ERH_OK; }

@@ -323,7 +323,11 @@ constexpr int kFinBuf = 2048;
 constexpr int kFinThreads = 512;
 constexpr int kFinSlots = 1024;                      // pivot granularity: strided maxima of 1024 sub-sequences
 
-__global__ __launch_bounds__(kFinThreads) void dense_finalize_kernel(
+// QR = rounds of 512 row elements held in registers (d <= 512 * QR runs entirely from them); with QR <= 2 the kernel
+// fits 128 VGPRs, i.e. TWO workgroups per CU (at 144 registers only one fits, and the row gathers of one workgroup do
+// not keep a CU's memory queue busy).
+template <int QR>
+__global__ __launch_bounds__(kFinThreads, (QR <= 2) ? 4 : 2) void dense_finalize_kernel(
     int k, int mode, const float *__restrict__ qnorm, float xnorm_max, int d,
     const _Float16 *__restrict__ X, const _Float16 *__restrict__ Q16,
     const ErhCand *__restrict__ cand, const uint32_t *__restrict__ cand_cnt, int cap,
@@ -433,7 +437,6 @@ __global__ __launch_bounds__(kFinThreads) void dense_finalize_kernel(
     // registers (rounds of 512 elements, up to 4 = d <= 2048; longer rows reload them).
     const int lane = tid & 63, wave = tid >> 6;
     const _Float16 *qrow = Q16 + (int64_t)q * d;
-    constexpr int QR = 4;
     constexpr int RW = 2;                                               // rows per wave iteration
     constexpr int kWaves = kFinThreads / 64;
     half8 qreg[QR];
@@ -787,9 +790,14 @@ hipError_t launch_dense_finalize(int B, int k, int mode, const float *qnorm, flo
                                  int32_t *out_ids, double *out_scores, int32_t *out_len,
                                  float *diag_maxerr, uint32_t *diag_uncert, uint32_t *bad, int64_t N,
                                  int64_t pos_mul, int64_t pos_inv, const float *tau_verify, hipStream_t st) {
-    hipLaunchKernelGGL(dense_finalize_kernel, dim3(B), dim3(kFinThreads), 0, st,
-                       k, mode, qnorm, xnorm_max, d, X, Q16, cand, cand_cnt, cap,
-                       out_ids, out_scores, out_len, diag_maxerr, diag_uncert, bad, N, pos_mul, pos_inv, tau_verify);
+#define ERH_FIN_LAUNCH(QR)                                                                                  \
+    hipLaunchKernelGGL(dense_finalize_kernel<QR>, dim3(B), dim3(kFinThreads), 0, st, k, mode, qnorm, xnorm_max, d, X, Q16, \
+                       cand, cand_cnt, cap, out_ids, out_scores, out_len, diag_maxerr, diag_uncert, bad, N, pos_mul, \
+                       pos_inv, tau_verify)
+    if (d <= 512) ERH_FIN_LAUNCH(1);
+    else if (d <= 1024) ERH_FIN_LAUNCH(2);
+    else ERH_FIN_LAUNCH(4);
+#undef ERH_FIN_LAUNCH
     return hipGetLastError();
 }
 

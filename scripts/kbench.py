@@ -240,29 +240,31 @@ def main():
             tot = c[:6].sum()
             res[f"{name} wscan sections (% of thread-0 cycles, k=192)"] = {n_: round(100 * v / tot, 1) for n_, v in zip(names, c[:6])}
             res[f"{name} wscan cycles per query (thread 0)"] = {"total": round(tot / 1024)}
-    if what == "bm25x":                                      # wave-owned scan: threshold crossings vs accumulator sweep
+    if what == "bm25x":                                      # wave-owned scan: sweep / threshold crossings / free-running waves
         indptr, doc, tf, lens, flat = synth.token_csr_torch(n, vocab, seed=3, device=dev)
         for variant, name in ((BM25S, "bm25s"), (OKAPI, "okapi")):
             idx = build_bm25_index_from_postings(indptr, doc, tf, lens, variant, compute_payload=False)
             queries = synth.token_queries(flat, lens, vocab, 1024, seed=9)
             eng.set_bm25(idx, payload_on_device=True)
-            for cx in (1, 0, 1, 0):
-                eng.set_option("bm25_crossing", cx)
-                for Bq, k in ((1024, 192), (256, 100)):
-                    qi, qt = queries_to_csr(queries[:Bq])
-                    res[f"{name} crossing={cx} B={Bq} k={k} #{len(res)}"] = timed(eng, lambda: eng.bm25_topk(qi, qt, k, device_out=True), 3)
+            modes = ((0, 0), (2, 0))      # (bm25_crossing, reserved)
+            for rep in "ab":
+                for cx, fr in modes:
+                    eng.set_option("bm25_crossing", cx)
+                    for Bq, k in ((1024, 192), (256, 100)):
+                        qi, qt = queries_to_csr(queries[:Bq])
+                        res[f"{name} crossing={cx} free={fr} B={Bq} k={k} (run {rep})"] = timed(eng, lambda: eng.bm25_topk(qi, qt, k, device_out=True), 3)
             qi, qt = queries_to_csr(queries)
-            for cx in (1, 0):
+            for cx, fr in modes:
                 eng.set_option("bm25_crossing", cx)
                 eng.set_option("debug_counters", 1)
                 eng.bm25_topk(qi, qt, 192, device_out=True)
                 torch.cuda.synchronize()
                 c = eng.debug_counters().astype(np.float64)
                 eng.set_option("debug_counters", 0)
-                names = ["bounds+misc", "apply(+next fetch)", "survivors", "tile_barrier", "shrink", "final"]
+                names = ["bounds+misc", "apply(+next fetch)", "survivors", "barrier_wait", "shrink", "final"]
                 tot = c[:6].sum()
-                res[f"{name} crossing={cx} sections (% of thread-0 cycles, k=192)"] = {n_: round(100 * v / tot, 1) for n_, v in zip(names, c[:6])}
-                res[f"{name} crossing={cx} per query (thread 0)"] = {"cycles": round(tot / 1024), "tiles_by_list": round(c[6] / 1024, 1), "crossings_wave0": round(c[7] / 1024, 1)}
+                res[f"{name} crossing={cx} free={fr} sections (% of thread-0 cycles, k=192)"] = {n_: round(100 * v / tot, 1) for n_, v in zip(names, c[:6])}
+                res[f"{name} crossing={cx} free={fr} per query (thread 0)"] = {"cycles": round(tot / 1024), "tiles_by_list": round(c[6] / 1024, 1), "crossings_wave0": round(c[7] / 1024, 1)}
             eng.set_option("bm25_crossing", 1)
     if what in ("all", "dense"):
         x = synth.dense_corpus_torch(n, d, seed=2, device=dev)
