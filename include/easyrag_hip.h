@@ -215,14 +215,24 @@ int erh_reset_kernel_time(erh_handle *h);
 
 /* Tuning knobs: name/value pairs.  None of them changes a result (except the measurement-only ones, which say so).
  *   dense_n0 (32768)      rows of the stored prefix scored densely to seed the pruning thresholds (max 32768)
- *   dense_n1 (131072)     first refinement boundary; 0 = never refine.  Further boundaries follow x4 while 8x fits.
+ *   dense_speculate (1)   first threshold = the rank-r prefix score, r << k (an estimate of the corpus' k-th best from the
+ *                         prefix being an even sample; verified per query by the final kernel, exhaustive path if wrong),
+ *                         one scan stage; 0 = guaranteed bounds refined in stages (dense_n1 ...)
+ *   dense_n1 (131072)     dense_speculate 0: first refinement boundary; 0 = never refine.  Further boundaries follow x4 while 8x fits.
  *   dense_n1_auto (1)     snap the boundaries to whole rounds of the persistent scan
+ *   dense_n0_auto (0)     shrink the seed prefix to where the rest is a whole number of scan rounds
  *   dense_shuffle (1)     golden-ratio row placement of the chunk matrix (takes effect at the next erh_set_dense);
- *                         0 stores the rows in the caller's order
- *   dense_pp (2)          ping-pong persistent append scan: 2 = lean-issue kernel, 1 = the round-1 kernel; 0 = lock-step kernels (dense_persist 1 / 0 = persistent /
+ *                         keep it on for corpora sorted by document or topic
+ *   dense_pp (3)          ping-pong persistent append scan: 3 = strict alternation (fragment reads inside the matrix segment),
+ *                         2 = lean-issue kernel, 1 = the round-1 kernel; 0 = lock-step kernels (dense_persist 1 / 0 = persistent /
  *                         one workgroup per tile, dense_cfg 0..2 = their tile configuration, dense_readahead)
+ *   dense_var, dense_rot  schedule variants of the ping-pong kernels (measurement: see DESIGN.md, dead ends)
  *   dense_gemv (1)        batches of at most 16 queries stream the chunk matrix through a 16x16x32 skinny-GEMM kernel
  *                         (the reference's one-query-at-a-time call pattern) instead of the padded 256-query scan
+ *   bm25_crossing (1)     wave-owned scan: survivors from threshold crossings noted in the token loop instead of a sweep
+ *                         over the accumulators (1 = fp32 sums only, 2 = fp64 too, 0 = always sweep); indices with a
+ *                         non-positive payload always sweep
+ *   bm25_segs (0)         document-range segments per query (0 = enough for >= 512 workgroups)
  *   bm25_wscan (1)        wave-owned BM25 scan (no per-token workgroup barrier) for batches whose queries have at most
  *                         64 tokens; 0 = block scan for everything.  Needs a fine skip table (4 bytes per term and per
  *                         2048 / 1024 documents), built by erh_set_bm25_* unless it would exceed bm25_fine_max_mb (8192)
