@@ -59,6 +59,8 @@ struct erh_handle {
     std::string err;
     // dense state
     DevBuf X;
+    DevBuf Xt;                               // tiled copy of X for the ping-pong scan (option dense_tiled), valid iff xt_valid
+    bool xt_valid = false;
     int64_t N = 0;
     int d = 0;
     float xnorm_max = 0.f;
@@ -105,6 +107,7 @@ struct erh_handle {
     int opt_small_single = 1;              // small batches: skip the refinement boundaries when the lists can take it
     int opt_dense_gemv = 1;                // batches of <= 16 queries: skinny-GEMM stream instead of the padded 256-query scan
     int opt_n0_auto = 0;                   // seed prefix snapped down to a whole number of scan rounds (less seed work, more candidates: a wash at 1M chunks)
+    int opt_dense_tiled = 1;               // keep a tiled, pre-swizzled copy of the chunk matrix for the ping-pong scan (+ N * d * 2 bytes)
     int opt_dense_speculate = 1;           // speculative (verified) first threshold + a single scan stage; 0: guaranteed bounds, refined in stages
     int opt_dense_var = 0;                 // dense_scan_pp2_kernel VAR (bit 0: two barriers per stage, bit 1: static priority)
     int opt_dense_rot = 0;                 // K-rotation between the query tiles of a stream, in stages per query tile (-1: nk / n_qt)
@@ -225,11 +228,17 @@ hipError_t scan_append(erh_handle *h, const _Float16 *X, int64_t N, int d, int64
     const int abl = h->opt_dense_ablate;
     const bool pp_code = abl == 0 || abl == 7 || abl == 8 || (abl >= 11 && abl <= 18) || (abl >= 20 && abl <= 24);
     if (h->opt_dense_pp && pp_code) {
-        hipError_t e = erh::launch_dense_scan_pp(X, N, d, c0, c1, Q16, Bpad, B, tau, filt, dir, cand, cnt, cap, flags,
-                                                 h->n_cus, h->opt_dense_ablate,
+        const bool own = X == h->X.as<_Float16>();
+        const int QT = erh::dense_scan_q_tile();
+        // the strict ping-pong kernel streams the tiled copy when there is one and the stage starts on a tile boundary
+        const bool tiled = own && h->opt_dense_pp >= 3 && h->opt_dense_tiled && h->xt_valid && h->opt_dense_var == 0 &&
+                           c0 % QT == 0;
+        const int var = tiled ? 2 : h->opt_dense_var;
+        hipError_t e = erh::launch_dense_scan_pp(tiled ? h->Xt.as<_Float16>() : X, N, d, c0, c1, Q16, Bpad, B, tau, filt, dir,
+                                                 cand, cnt, cap, flags, h->n_cus, h->opt_dense_ablate,
                                                  h->opt_debug_counters ? h->dbg.as<unsigned long long>() : nullptr,
-                                                 (h->opt_dense_pp >= 2 && X == h->X.as<_Float16>())
-                                                     ? (1 | (h->opt_dense_var << 1) | (h->opt_dense_pp >= 3 ? 8 : 0) | (dense_rot_stages(h, d, Bpad) << 8)) : 0, st);
+                                                 (h->opt_dense_pp >= 2 && own)
+                                                     ? (1 | (var << 1) | (h->opt_dense_pp >= 3 ? 8 : 0) | (dense_rot_stages(h, d, Bpad) << 8)) : 0, st);
         if (e != hipErrorInvalidValue) return e;
         (void)hipGetLastError();
     }
@@ -548,7 +557,7 @@ int erh_destroy(erh_handle *h) {
     (void)hipDeviceSynchronize();
     drain_events(h);
     for (auto &ev : h->pool) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
-    DevBuf *bufs[] = {&h->X, &h->content_id, &h->dir_id,
+    DevBuf *bufs[] = {&h->X, &h->Xt, &h->content_id, &h->dir_id,
                       &h->qin, &h->Q16, &h->qnorm, &h->tau, &h->S0, &h->cand, &h->cand_cnt, &h->flags, &h->filt, &h->filt2,
                       &h->o_ids, &h->o_sc, &h->o_len, &h->qptr, &h->qtok, &h->part_sc, &h->part_ids, &h->part_len,
                       &h->hy_sids, &h->hy_ssc, &h->hy_slen, &h->hy_dids, &h->hy_dsc, &h->hy_dlen,
@@ -582,6 +591,7 @@ int erh_set_option(erh_handle *h, const char *name, int64_t value) {
     if (!strcmp(name, "dense_n1_auto")) { h->opt_n1_auto = value != 0; return ERH_OK; }
     if (!strcmp(name, "dense_pp")) { if (value < 0 || value > 3) return h->fail(ERH_ERR_INVALID, "dense_pp"); h->opt_dense_pp = (int)value; return ERH_OK; }
     if (!strcmp(name, "dense_n0_auto")) { h->opt_n0_auto = value != 0; return ERH_OK; }
+    if (!strcmp(name, "dense_tiled")) { h->opt_dense_tiled = value != 0; return ERH_OK; }   // building the copy: at the next erh_set_dense
     if (!strcmp(name, "dense_speculate")) { h->opt_dense_speculate = value != 0; return ERH_OK; }
     if (!strcmp(name, "dense_var")) { if (value < 0 || value > 3) return h->fail(ERH_ERR_INVALID, "dense_var"); h->opt_dense_var = (int)value; return ERH_OK; }
     if (!strcmp(name, "dense_rot")) { if (value < -1 || value > 4096) return h->fail(ERH_ERR_INVALID, "dense_rot"); h->opt_dense_rot = (int)value; return ERH_OK; }
@@ -730,6 +740,17 @@ int erh_set_dense(erh_handle *h, const void *x, int64_t n, int d, int dtype, int
     h->xnorm_max = xn;
     h->N = n;
     h->d = d;
+    // tiled copy for the ping-pong scan (dense_scan.hip: dense_tile_rows_kernel); d / 32 >= 8 stages as the kernel wants
+    h->xt_valid = false;
+    if (h->opt_dense_tiled && d % 64 == 0 && d >= 256) {
+        const int64_t n_tiles = (n + 255) / 256;
+        HIPCHK(h, h->Xt.ensure((size_t)n_tiles * 256 * (size_t)d * 2));
+        HIPCHK(h, erh::launch_dense_tile_rows(h->X.as<_Float16>(), n, d, h->Xt.p, st));
+        HIPCHK(h, hipStreamSynchronize(st));
+        h->xt_valid = true;
+    } else {
+        h->Xt.release();
+    }
     return ERH_OK;
 }
 

@@ -1292,6 +1292,27 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp2_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// Tiled copy of the chunk matrix for the ping-pong scan (option "dense_tiled").  For the 256-row tile T and the
+// stage pair kp the 32 KiB block at ((T * pairs + kp) * 32 KiB) holds the two 16 KiB LDS stage images back to back,
+// already swizzled: piece p (16 bytes) of the image of stage 2 kp + s is row p >> 2 of the tile, logical 16-byte slot
+// (p & 3) ^ ((p >> 4) & 3) of that row's 64 bytes of the stage.  Every LDS-DMA instruction of the scan then moves 1 KiB
+// of consecutive bytes (eight full 128-byte lines instead of sixteen half lines with a 2 KiB stride) and a workgroup
+// streams a tile as 512 KiB of consecutive addresses.  Rows past N come from the zero padding behind the matrix.
+__global__ __launch_bounds__(256) void dense_tile_rows_kernel(const _Float16 *__restrict__ X, int d, int64_t n_tiles,
+                                                              int4 *__restrict__ Xt) {
+    const int pairs = d / 64;
+    const int64_t total = n_tiles * pairs * 2048;                      // 16-byte pieces
+    for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
+        const int p = (int)(o & 1023), sidx = (int)((o >> 10) & 1);
+        const int64_t blk = o >> 11;
+        const int kp = (int)(blk % pairs);
+        const int64_t T = blk / pairs;
+        const int r = p >> 2, ls = (p & 3) ^ row_swizzle<pp::PR>(r);
+        Xt[o] = *reinterpret_cast<const int4 *>(X + (T * 256 + r) * (int64_t)d + (2 * kp + sidx) * 32 + ls * 8);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Ping-pong scan, strict alternation (option "dense_pp" = 3).  Same tiles, streams, rings, DMA order, epilogue and
 // results as dense_scan_pp2_kernel; what changes is what a segment contains.  Measured on the lean kernel
 // (profiles/r02c_kbench_mm.log): with matrix segments and barriers ONLY a stage takes ~1300 cycles against 1024 of MFMA
@@ -1352,6 +1373,7 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp3_kernel(
     }
     asm volatile("" ::"v"(t_q[0]), "v"(t_q[1]));                      // loaded before the DMA stream starts (keeps vmcnt countable)
 
+    constexpr bool TILED = (VAR & 2) != 0;                             // X is the tiled copy (dense_tile_rows_kernel), c0 % 256 == 0
     const _Float16 *pa[2], *pb[2];
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
@@ -1361,7 +1383,10 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp3_kernel(
         pa[it] = X + (c0 + (int64_t)stream * pp::BM + r) * (int64_t)d + ls * 8 + k0 * pp::BK;
         pb[it] = Q + (q_row0 + r) * (int64_t)d + ls * 8 + k0 * pp::BK;
     }
-    const int64_t a_jump = (int64_t)n_streams * pp::BM * (int64_t)d;   // a row -> the same row of the stream's next tile
+    if (TILED)                                                         // one pointer: this wave's 1 KiB of the pair's first stage image
+        pa[0] = X + ((c0 / pp::BM + stream) * (int64_t)(d / 64) + k0 / 2) * 16384 + wave * 512 + lane * 8;
+    // a row -> the same row of the stream's next tile (tiled: a stage pair -> the same pair of the next tile), in halves
+    const int64_t a_jump = (int64_t)n_streams * pp::BM * (int64_t)d;
     const int sw = row_swizzle<pp::PR>(l31);
     const int a_rd0 = (grp * 128 + l31) * pp::RB + ((hh ^ sw) << 4);
     const int a_rd1 = (grp * 128 + l31) * pp::RB + (((2 + hh) ^ sw) << 4);
@@ -1377,6 +1402,29 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp3_kernel(
     half8 fa[4][2], fb[2][2];
     char *const my_dst = lds + wave * 1024;                            // + it * 8192 + ring offset
 
+// the chunk-side stage pair from the tiled copy: four instructions of 1 KiB of consecutive bytes each
+#define ERH_PP3_ISSUE_AT()                                                                            \
+    do {                                                                                              \
+        if (a_left > 0) {                                                                             \
+            if (!(PABL & kPpNoDmaA)) {                                                                \
+                int d1_ = a_dst + pp::A_BYTES;                                                        \
+                if (d1_ == kABytes) d1_ = 0;                                                          \
+                ERH_PP2_GLDS(pa[0], my_dst + a_dst);                                                  \
+                ERH_PP2_GLDS(pa[0] + 4096, my_dst + a_dst + 8192);                                    \
+                ERH_PP2_GLDS(pa[0] + 8192, my_dst + d1_);                                             \
+                ERH_PP2_GLDS(pa[0] + 12288, my_dst + d1_ + 8192);                                     \
+            }                                                                                         \
+            ka += 2;                                                                                  \
+            int64_t inc_ = 16384;                                          /* halves: the next pair's block */ \
+            if (ka == nk) { ka = 0; inc_ = 16384 - (int64_t)pp::BM * d; }  /* wrap to pair 0 of the same tile */ \
+            if (ka == k0) inc_ += a_jump;                                                             \
+            pa[0] += inc_;                                                                            \
+            a_dst += 2 * pp::A_BYTES;                                                                 \
+            if (a_dst >= kABytes) a_dst -= kABytes;                                                   \
+            --a_left;                                                                                 \
+        }                                                                                             \
+    } while (0)
+#define ERH_PP3_ISSUE_A() do { if (TILED) ERH_PP3_ISSUE_AT(); else ERH_PP2_ISSUE_A(); } while (0)
 // one instruction (PART 0..3) of the A / B stage pair, then the pair's bookkeeping (VAR bit 0: issued from inside the
 // matrix segment)
 #define ERH_PP3_PART_A(PART)                                                                          \
@@ -1490,9 +1538,9 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp3_kernel(
     } while (0)
 
     // prologue: A(0,1) B(0,1) A(2,3) B(2,3); stages 0 and 1 complete = the last 8 instructions may stay in flight
-    ERH_PP2_ISSUE_A();
+    ERH_PP3_ISSUE_A();
     ERH_PP2_ISSUE_B();
-    ERH_PP2_ISSUE_A();
+    ERH_PP3_ISSUE_A();
     ERH_PP2_ISSUE_B();
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     ERH_PP_BARRIER();
@@ -1540,7 +1588,7 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp3_kernel(
                 ERH_PH(0);
                 ERH_PP_BARRIER();                                      // |A|
                 ERH_PH(2);
-                ERH_PP2_ISSUE_A();                                     // M_g
+                ERH_PP3_ISSUE_A();                                     // M_g
                 __builtin_amdgcn_sched_barrier(0);
                 ERH_PH(3);
                 ERH_PP3_WAIT(g, false);
@@ -1568,7 +1616,7 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp3_kernel(
     } else {
         for (int i = 0; i < n_tiles; ++i) {
             for (int kt = 0; kt < nk; kt += 2, g += 2) {
-                ERH_PP2_ISSUE_A();                                     // M_g
+                ERH_PP3_ISSUE_A();                                     // M_g
                 __builtin_amdgcn_sched_barrier(0);
                 ERH_PH(3);
                 ERH_PP_BARRIER();                                      // |A|
@@ -1605,6 +1653,8 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp3_kernel(
     }
 #undef ERH_PH
 #undef ERH_PP3_READ_ALL
+#undef ERH_PP3_ISSUE_A
+#undef ERH_PP3_ISSUE_AT
 #undef ERH_PP3_PART_A
 #undef ERH_PP3_PART_B
 #undef ERH_PP3_HALF
@@ -1761,7 +1811,10 @@ hipError_t launch_pp(const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1
                        tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow, dbg, rot)
 #define ERH_LAUNCH_PP3(A)                                                                                  \
     do {                                                                                                   \
-        if (var & 1)                                                                                       \
+        if (var & 2)                                                                                       \
+            hipLaunchKernelGGL((dense_scan_pp3_kernel<A, 2>), grid, block, pp::LDS_BYTES, st, X, N, d, c0, c1, Q, Bpad, \
+                               B, tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow, dbg, rot);        \
+        else if (var & 1)                                                                                  \
             hipLaunchKernelGGL((dense_scan_pp3_kernel<A, 1>), grid, block, pp::LDS_BYTES, st, X, N, d, c0, c1, Q, Bpad, \
                                B, tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow, dbg, rot);        \
         else                                                                                               \
@@ -1850,6 +1903,9 @@ hipError_t dense_scan_init() {
     if (e != hipSuccess) return e;                                                                         \
     e = hipFuncSetAttribute((const void *)dense_scan_pp3_kernel<A, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                             pp::LDS_BYTES);                                                                \
+    if (e != hipSuccess) return e;                                                                         \
+    e = hipFuncSetAttribute((const void *)dense_scan_pp3_kernel<A, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                            pp::LDS_BYTES);                                                                \
     if (e != hipSuccess) return e;
 #define ERH_SET_PP2V(A, V)                                                                                 \
     e = hipFuncSetAttribute((const void *)dense_scan_pp2_kernel<A, V>, hipFuncAttributeMaxDynamicSharedMemorySize, \
@@ -1880,6 +1936,13 @@ hipError_t launch_dense_scan_pp(const _Float16 *X, int64_t N, int d, int64_t c0,
     if (d % (2 * pp::BK) != 0 || d / pp::BK < 8) return hipErrorInvalidValue;   // stage pairs never straddle a tile
     return launch_pp(X, N, d, c0, c1, Q, Bpad, B, tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow, n_cus, pabl,
                      dbg, lean, st);
+}
+
+hipError_t launch_dense_tile_rows(const _Float16 *X, int64_t N, int d, void *Xt, hipStream_t st) {
+    if (d % 64 != 0) return hipErrorInvalidValue;
+    const int64_t n_tiles = (N + pp::BM - 1) / pp::BM;
+    hipLaunchKernelGGL(dense_tile_rows_kernel, dim3(8192), dim3(256), 0, st, X, d, n_tiles, reinterpret_cast<int4 *>(Xt));
+    return hipGetLastError();
 }
 
 hipError_t launch_dense_scan_store(int cfg, const _Float16 *Q, int Bpad, const _Float16 *X, int64_t N, int d,

@@ -21,6 +21,8 @@ hipError_t launch_dense_scan_pp(const _Float16 *X, int64_t N, int d, int64_t c0,
                                 ErhCand *cand, uint32_t *cand_cnt, int cap, uint32_t *overflow, int n_cus, int pabl,
                                 unsigned long long *dbg, int lean /* the lean-issue kernel: X must be padded by kDensePadRows zero rows */,
                                 hipStream_t st);
+// tiled copy of the chunk matrix for the ping-pong scan: ceil(N / 256) * 256 * d halves (see dense_tile_rows_kernel)
+hipError_t launch_dense_tile_rows(const _Float16 *X, int64_t N, int d, void *Xt, hipStream_t st);
 constexpr int kDensePadRows = 256;   // zero rows erh_set_dense keeps behind the matrix (tiles past N read them)
 hipError_t launch_dense_scan_persist(int cfg, const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1,
                                      const _Float16 *Q, int Bpad, int B, const float *tau,

@@ -12,28 +12,30 @@ from oracle import dense_exact_scores, dense_exact_topk, qdrant_cosine_search, t
 pytestmark = pytest.mark.gpu
 
 
-# (dense_cfg, dense_persist, dense_pp, dense_gemv, dense_speculate)
-@pytest.fixture(params=[(0, 1, 3, 0, 1), (0, 1, 3, 0, 0), (0, 1, 2, 0, 1), (0, 1, 1, 0, 0), (0, 1, 0, 0, 1), (0, 0, 0, 0, 0),
-                        (1, 0, 0, 0, 1), (2, 1, 0, 0, 0), (0, 1, 3, 1, 1)],
-                ids=["pingpong-strict-256x256x32", "pingpong-strict-guaranteed-bounds", "pingpong-lean-256x256x32",
+# (dense_cfg, dense_persist, dense_pp, dense_gemv, dense_speculate, dense_tiled)
+@pytest.fixture(params=[(0, 1, 3, 0, 1, 1), (0, 1, 3, 0, 0, 0), (0, 1, 2, 0, 1, 0), (0, 1, 1, 0, 0, 0), (0, 1, 0, 0, 1, 0),
+                        (0, 0, 0, 0, 0, 0), (1, 0, 0, 0, 1, 0), (2, 1, 0, 0, 0, 0), (0, 1, 3, 1, 1, 1)],
+                ids=["pingpong-strict-tiled-256x256x32", "pingpong-strict-rowmajor-guaranteed-bounds", "pingpong-lean-256x256x32",
                      "pingpong-256x256x32-guaranteed-bounds", "cfg0-256x256x64-persistent", "cfg0-per-tile-guaranteed-bounds",
                      "cfg1-128x256x32-per-tile", "cfg2-256x256x32-persistent-guaranteed-bounds", "gemv-16x16x32-small-batch"])
 def scan_cfg(request, engine):
-    """Every dense-scan kernel / tile configuration / launch style must satisfy every parity test, with the speculative
-    (verified) first threshold and with guaranteed bounds refined in stages.  The last arm lets batches of at most 16
-    queries take the skinny-GEMM stream (larger batches use the ping-pong scan); the other arms pin the padded
-    256-query scans for every batch size."""
+    """Every dense-scan kernel / tile configuration / launch style / chunk layout must satisfy every parity test, with
+    the speculative (verified) first threshold and with guaranteed bounds refined in stages.  The last arm lets batches of
+    at most 16 queries take the skinny-GEMM stream (larger batches use the ping-pong scan); the other arms pin the padded
+    256-query scans for every batch size.  (dense_tiled takes effect at the next set_dense: every test sets its own.)"""
     engine.set_option("dense_cfg", request.param[0])
     engine.set_option("dense_persist", request.param[1])
     engine.set_option("dense_pp", request.param[2])
     engine.set_option("dense_gemv", request.param[3])
     engine.set_option("dense_speculate", request.param[4])
+    engine.set_option("dense_tiled", request.param[5])
     yield request.param
     engine.set_option("dense_cfg", 0)
     engine.set_option("dense_persist", 1)
     engine.set_option("dense_pp", 3)
     engine.set_option("dense_gemv", 1)
     engine.set_option("dense_speculate", 1)
+    engine.set_option("dense_tiled", 1)
 
 
 def test_mfma_scores_match_plain_gpu_and_numpy(engine, scan_cfg):
