@@ -216,13 +216,13 @@ __global__ __launch_bounds__(kSelThreads) void seed_select_kernel(
     const int16_t *__restrict__ filter_dir, const int16_t *__restrict__ dir_id,
     float *__restrict__ tau, ErhCand *__restrict__ cand, uint32_t *__restrict__ cand_cnt, int cap,
     uint32_t *__restrict__ bad, uint32_t *__restrict__ need_full) {
-    __shared__ int s_nvalid, s_cnt, s_cnt2;
+    __shared__ int s_nvalid, s_cnt, s_cnt2, s_keep;
     __shared__ uint32_t tmax[kSelThreads];
-    __shared__ uint32_t buf[kSeedBuf];
+    __shared__ uint64_t buf[kSeedBuf];
     const int q = blockIdx.x, tid = threadIdx.x;
     const float *row = S0 + (int64_t)q * ld_s0;
     const int fd = filter_dir ? (int)filter_dir[q] : -1;
-    if (tid == 0) { s_nvalid = 0; s_cnt = 0; s_cnt2 = 0; need_full[q] = 0u; }
+    if (tid == 0) { s_nvalid = 0; s_cnt = 0; s_cnt2 = 0; s_keep = 0; need_full[q] = 0u; }
     __syncthreads();
     int myvalid = 0;
     uint32_t mx = 0;
@@ -235,15 +235,19 @@ __global__ __launch_bounds__(kSelThreads) void seed_select_kernel(
     if ((tid & 63) == 0 && myvalid) atomicAdd(&s_nvalid, myvalid);
     erh_bitonic_desc<uint32_t>(tmax, kSelThreads);   // begins and ends with a barrier
     const int nv = s_nvalid;
-    float prune = -INFINITY;
     if (nv >= k) {                                   // uniform
         const uint32_t p = (rank <= kSelThreads) ? tmax[rank - 1] : 0u;
         bool full_sort = (p == 0u);
         if (!full_sort) {
-            seed_visit(row, n0, fd, dir_id, c0, [&](uint32_t key, float, int) {
-                if (key >= p) {
+            // p bounds the rank-th score from below, so the final threshold (rank-th score - margin) is >= p - margin:
+            // one pass gathers everything that can become a candidate, with its index, and the candidates are then
+            // emitted from LDS -- the row (128 KiB per query out of L2 / Infinity Cache) is read twice, not three times
+            const float margin = margin_of(qnorm[q], xnorm_max, d);
+            const float g_thr = erh_ord2f(p) - margin;
+            seed_visit(row, n0, fd, dir_id, c0, [&](uint32_t key, float sc, int i) {
+                if (key != 0u && sc >= g_thr) {
                     const int pos = atomicAdd(&s_cnt2, 1);
-                    if (pos < kSeedBuf) buf[pos] = key;
+                    if (pos < kSeedBuf) buf[pos] = erh_key32(sc, (int32_t)(c0 + i));
                 }
             });
             __syncthreads();
@@ -252,9 +256,28 @@ __global__ __launch_bounds__(kSelThreads) void seed_select_kernel(
                 full_sort = true;
             } else {
                 const int ns = erh_next_pow2(c2 < 2 ? 2 : c2);
-                for (int i = c2 + tid; i < ns; i += kSelThreads) buf[i] = 0u;
-                erh_bitonic_desc<uint32_t>(buf, ns);
-                prune = erh_ord2f(buf[rank - 1]) - margin_of(qnorm[q], xnorm_max, d);
+                for (int i = c2 + tid; i < ns; i += kSelThreads) buf[i] = 0ull;
+                erh_bitonic_desc<uint64_t>(buf, ns);
+                const float prune = erh_key32_score(buf[rank - 1]) - margin;
+                for (int i = tid; i < c2; i += kSelThreads) {             // survivors are a prefix of the sorted keys
+                    const bool keep_i = erh_key32_score(buf[i]) >= prune;
+                    const bool keep_n = (i + 1 < c2) ? (erh_key32_score(buf[i + 1]) >= prune) : false;
+                    if (keep_i && !keep_n) s_keep = i + 1;
+                }
+                __syncthreads();
+                const int m = s_keep;
+                for (int i = tid; i < m && i < cap; i += kSelThreads) {
+                    ErhCand c;
+                    c.s = erh_key32_score(buf[i]);
+                    c.idx = erh_key32_idx(buf[i]);
+                    cand[(int64_t)q * cap + i] = c;
+                }
+                if (tid == 0) {
+                    tau[q] = prune;
+                    cand_cnt[q] = (uint32_t)(m < cap ? m : cap);
+                    if (m > cap) bad[q] = 1u;
+                }
+                return;
             }
         }
         if (full_sort) {                             // uniform: leave this query to seed_select_full_kernel
@@ -262,7 +285,7 @@ __global__ __launch_bounds__(kSelThreads) void seed_select_kernel(
             return;
         }
     }
-    seed_emit(row, n0, c0, fd, dir_id, prune, q, tau, cand, cand_cnt, cap, bad, &s_cnt);
+    seed_emit(row, n0, c0, fd, dir_id, -INFINITY, q, tau, cand, cand_cnt, cap, bad, &s_cnt);   // fewer than k valid rows: all of them
 }
 
 // Full-sort fallback for the queries flagged by seed_select_kernel.  dynamic LDS = 64 + np2*4 bytes.
