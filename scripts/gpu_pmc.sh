@@ -38,7 +38,7 @@ pat = re.compile(r"bm25_w?scan" if wl == "bm25" else r"dense_(scan|gemv)")
 def klass(name):
     if wl == "bm25":
         return "wscan" if "wscan" in name else "scan"
-    for key in ("pp2", "_pp_", "persist", "append", "store", "gemv"):
+    for key in ("pp3", "pp2", "_pp_", "persist", "append", "store", "gemv"):
         if key in name:
             return key.strip("_")
     return "other"
