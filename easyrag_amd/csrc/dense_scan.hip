@@ -1340,7 +1340,8 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp3_kernel(
     const _Float16 *__restrict__ Q, int Bpad, int B,
     const float *__restrict__ tau, const int16_t *__restrict__ filter_dir, const int16_t *__restrict__ dir_id,
     ErhCand *__restrict__ cand, uint32_t *__restrict__ cand_cnt, int cap, uint32_t *__restrict__ overflow,
-    unsigned long long *__restrict__ dbg /* kPpClocks only */, int rot_stages) {
+    unsigned long long *__restrict__ dbg /* kPpClocks only */, int rot_stages,
+    uint32_t *__restrict__ stream_sync /* one zeroed word per stream, or null: see ERH_PP3_STREAM_SYNC */) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1537,6 +1538,28 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp3_kernel(
         else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");                              \
     } while (0)
 
+// The query-tile workgroups of a stream read the same chunk tiles; left alone they drift apart (different survivor
+// counts), lines leave the XCD's 4 MiB L2 between the first and the last reader, and HBM delivers 1.5x the matrix at
+// B = 1024.  Every kSyncTiles tiles the workgroups of a stream meet at a counter (thread 0: one relaxed agent-scope
+// add, then a bounded poll; no data changes hands, so no fences) -- pacing them to the slowest costs nothing, the
+// launch ends with the slowest anyway.  Together with the K-rotation (each query tile starts a chunk tile at another
+// K offset) the workgroups then miss on DIFFERENT lines of the SAME tile.
+#define ERH_PP3_STREAM_SYNC()                                                                         \
+    do {                                                                                              \
+        if (stream_sync && n_qt > 1 && (i + 1) % kSyncTiles == 0 && i + 1 < n_tiles) {                \
+            if (threadIdx.x == 0) {                                                                   \
+                __hip_atomic_fetch_add(stream_sync + stream, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+                const uint32_t want_ = (uint32_t)n_qt * (uint32_t)((i + 1) / kSyncTiles);             \
+                for (int spin_ = 0; spin_ < 8192; ++spin_) {                                          \
+                    if (__hip_atomic_load(stream_sync + stream, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want_) break; \
+                    __builtin_amdgcn_s_sleep(8);                                                      \
+                }                                                                                     \
+            }                                                                                         \
+            ERH_PP_BARRIER();                                                                         \
+        }                                                                                             \
+    } while (0)
+    constexpr int kSyncTiles = 4;
+
     // prologue: A(0,1) B(0,1) A(2,3) B(2,3); stages 0 and 1 complete = the last 8 instructions may stay in flight
     ERH_PP3_ISSUE_A();
     ERH_PP2_ISSUE_B();
@@ -1578,6 +1601,7 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp3_kernel(
             ERH_PP_BARRIER();                                                                         \
             ERH_PH(5);                                                                                \
             if (!(PABL & kPpNoEpi)) flush_now = __builtin_amdgcn_readfirstlane(ERH_PP_FLAG(i & 1));   \
+            ERH_PP3_STREAM_SYNC();                                                                    \
         }
         if (grp == 0) { ERH_PP3_TILE_LOOP(1, 0, 2, 0) } else { ERH_PP3_TILE_LOOP(0, 1, 0, 2) }
 #undef ERH_PP3_TILE_LOOP
@@ -1612,6 +1636,7 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp3_kernel(
             ERH_PP_BARRIER();
             ERH_PH(5);
             if (!(PABL & kPpNoEpi)) flush_now = __builtin_amdgcn_readfirstlane(ERH_PP_FLAG(i & 1));
+            ERH_PP3_STREAM_SYNC();
         }
     } else {
         for (int i = 0; i < n_tiles; ++i) {
@@ -1644,6 +1669,7 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp3_kernel(
             ERH_PP_BARRIER();
             ERH_PH(5);
             if (!(PABL & kPpNoEpi)) flush_now = __builtin_amdgcn_readfirstlane(ERH_PP_FLAG(i & 1));
+            ERH_PP3_STREAM_SYNC();
         }
     }
     if ((PABL & kPpClocks) && dbg && lane == 0 && (wave == 0 || wave == 4)) {
@@ -1653,6 +1679,7 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp3_kernel(
     }
 #undef ERH_PH
 #undef ERH_PP3_READ_ALL
+#undef ERH_PP3_STREAM_SYNC
 #undef ERH_PP3_ISSUE_A
 #undef ERH_PP3_ISSUE_AT
 #undef ERH_PP3_PART_A
@@ -1797,7 +1824,7 @@ constexpr int pp_mask_of(int code) {
 hipError_t launch_pp(const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1, const _Float16 *Q, int Bpad, int B,
                      const float *tau, const int16_t *filter_dir, const int16_t *dir_id, ErhCand *cand,
                      uint32_t *cand_cnt, int cap, uint32_t *overflow, int ctas, int pabl, unsigned long long *dbg,
-                     int lean, hipStream_t st) {
+                     int lean, uint32_t *stream_sync, hipStream_t st) {
     const int n_qt = Bpad / pp::BN;
     const int grid_n = ctas / (8 * n_qt) * (8 * n_qt);
     if (grid_n <= 0) return hipErrorInvalidValue;
@@ -1813,13 +1840,13 @@ hipError_t launch_pp(const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1
     do {                                                                                                   \
         if (var & 2)                                                                                       \
             hipLaunchKernelGGL((dense_scan_pp3_kernel<A, 2>), grid, block, pp::LDS_BYTES, st, X, N, d, c0, c1, Q, Bpad, \
-                               B, tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow, dbg, rot);        \
+                               B, tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow, dbg, rot, stream_sync); \
         else if (var & 1)                                                                                  \
             hipLaunchKernelGGL((dense_scan_pp3_kernel<A, 1>), grid, block, pp::LDS_BYTES, st, X, N, d, c0, c1, Q, Bpad, \
-                               B, tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow, dbg, rot);        \
+                               B, tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow, dbg, rot, stream_sync); \
         else                                                                                               \
             hipLaunchKernelGGL((dense_scan_pp3_kernel<A, 0>), grid, block, pp::LDS_BYTES, st, X, N, d, c0, c1, Q, Bpad, \
-                               B, tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow, dbg, rot);        \
+                               B, tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow, dbg, rot, stream_sync); \
     } while (0)
 #define ERH_LAUNCH_PP(A)                                                                                   \
     do {                                                                                                   \
@@ -1931,11 +1958,11 @@ hipError_t dense_scan_init() {
 hipError_t launch_dense_scan_pp(const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1, const _Float16 *Q,
                                 int Bpad, int B, const float *tau, const int16_t *filter_dir, const int16_t *dir_id,
                                 ErhCand *cand, uint32_t *cand_cnt, int cap, uint32_t *overflow, int n_cus, int pabl,
-                                unsigned long long *dbg, int lean, hipStream_t st) {
+                                unsigned long long *dbg, int lean, uint32_t *stream_sync, hipStream_t st) {
     if (c1 <= c0) return hipSuccess;
     if (d % (2 * pp::BK) != 0 || d / pp::BK < 8) return hipErrorInvalidValue;   // stage pairs never straddle a tile
     return launch_pp(X, N, d, c0, c1, Q, Bpad, B, tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow, n_cus, pabl,
-                     dbg, lean, st);
+                     dbg, lean, stream_sync, st);
 }
 
 hipError_t launch_dense_tile_rows(const _Float16 *X, int64_t N, int d, void *Xt, hipStream_t st) {

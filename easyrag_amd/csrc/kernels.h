@@ -20,6 +20,7 @@ hipError_t launch_dense_scan_pp(const _Float16 *X, int64_t N, int d, int64_t c0,
                                 int Bpad, int B, const float *tau, const int16_t *filter_dir, const int16_t *dir_id,
                                 ErhCand *cand, uint32_t *cand_cnt, int cap, uint32_t *overflow, int n_cus, int pabl,
                                 unsigned long long *dbg, int lean /* the lean-issue kernel: X must be padded by kDensePadRows zero rows */,
+                                uint32_t *stream_sync /* dense_pp 3: 256 zeroed words (one per stream) or null */,
                                 hipStream_t st);
 // tiled copy of the chunk matrix for the ping-pong scan: ceil(N / 256) * 256 * d halves (see dense_tile_rows_kernel)
 hipError_t launch_dense_tile_rows(const _Float16 *X, int64_t N, int d, void *Xt, hipStream_t st);

@@ -226,7 +226,9 @@ int erh_reset_kernel_time(erh_handle *h);
  *   dense_pp (3)          ping-pong persistent append scan: 3 = strict alternation (fragment reads inside the matrix segment),
  *                         2 = lean-issue kernel, 1 = the round-1 kernel; 0 = lock-step kernels (dense_persist 1 / 0 = persistent /
  *                         one workgroup per tile, dense_cfg 0..2 = their tile configuration, dense_readahead)
- *   dense_var, dense_rot  schedule variants of the ping-pong kernels (measurement: see DESIGN.md, dead ends)
+ *   dense_tiled (1)       keep a tiled, pre-swizzled copy of the chunk matrix for the ping-pong scan (+ N * d * 2 bytes; takes
+ *                         effect at the next erh_set_dense)
+ *   dense_var, dense_rot, dense_sync   schedule variants of the ping-pong kernels (measured, off: see DESIGN.md, dead ends)
  *   dense_gemv (1)        batches of at most 16 queries stream the chunk matrix through a 16x16x32 skinny-GEMM kernel
  *                         (the reference's one-query-at-a-time call pattern) instead of the padded 256-query scan
  *   bm25_crossing (1)     wave-owned scan: survivors from threshold crossings noted in the token loop instead of a sweep
