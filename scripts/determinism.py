@@ -46,10 +46,15 @@ def main():
             elif not all(np.array_equal(a.view(np.uint8), b.view(np.uint8)) for a, b in zip(ref, cur)):
                 bad += 1
                 print(f"{name}: repeat {r} differs from repeat 0")
-        if name != "bm25":                                    # the lock-step scan kernels must give the same exact result
-            for pp, persist in ((0, 1), (0, 0)):
-                eng.set_option("dense_pp", pp)
-                eng.set_option("dense_persist", persist)
+        if name != "bm25":                                    # every other scan kernel / pruning scheme must give the same exact result
+            variants = (("lean ping-pong", {"dense_pp": 2}), ("round-1 ping-pong", {"dense_pp": 1}),
+                        ("lock-step persistent", {"dense_pp": 0, "dense_persist": 1}),
+                        ("lock-step per tile", {"dense_pp": 0, "dense_persist": 0}),
+                        ("strict ping-pong, guaranteed bounds", {"dense_speculate": 0}),
+                        ("strict ping-pong, stream sync + K rotation", {"dense_sync": 1, "dense_rot": -1}))
+            for label, opts in variants:
+                for o, v in opts.items():
+                    eng.set_option(o, v)
                 if name == "hybrid":
                     out = eng.hybrid_topk(q16, qi, qt, k_dense=288, k_sparse=192, K=60, topk=10, device_out=True)
                 else:
@@ -59,10 +64,10 @@ def main():
                 cur = [np.asarray(t.cpu()) for t in out]
                 if not all(np.array_equal(a.view(np.uint8), b.view(np.uint8)) for a, b in zip(ref, cur)):
                     bad += 1
-                    print(f"{name}: dense_pp={pp} dense_persist={persist} differs from the ping-pong kernel")
-            eng.set_option("dense_pp", 1)
-            eng.set_option("dense_persist", 1)
-        extra = "" if name == "bm25" else " (+ both lock-step kernels)"
+                    print(f"{name}: {label} differs from the default kernel")
+                for o, v in (("dense_pp", 3), ("dense_persist", 1), ("dense_speculate", 1), ("dense_sync", 0), ("dense_rot", 0)):
+                    eng.set_option(o, v)
+        extra = "" if name == "bm25" else " (+ six other scan kernels / pruning schemes)"
         print(f"{name}: {reps} repeats{extra}, B={B}: {'identical' if not bad else 'DIFFERENCES'}")
     eng.close()
     sys.exit(1 if bad else 0)
