@@ -34,8 +34,8 @@ RIDGE = MFMA_F16_PEAK_TF * 1e12 / (HBM_PEAK_GBS * 1e9)   # FLOP per byte
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="hybrid", choices=["hybrid", "dense", "bm25"])
     ap.add_argument("--chunks", type=int, default=1_000_000)
     ap.add_argument("--dim", type=int, default=1024)
