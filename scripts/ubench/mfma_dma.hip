@@ -19,6 +19,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kTileBytes = 256 * 1024 * 2;        // 512 KiB: 256 rows x 1024 halves
 constexpr int kStages = 32;                       // stages of 32 halves per tile
 
+// DIST 4: the chunk side does not go through LDS at all -- every wave loads its 2 KiB of the stage straight into
+// registers (4-deep ring, the data is the MFMA A operand), the query side stays LDS-DMA.
 // DIST: who issues the 32 DMA instructions of a stage -- 0 every wave its share, 1 the second half of the waves only
 // (one MFMA-only and one MFMA+DMA wave per SIMD), 2 four extra loader waves that issue no MFMA at all (NW + 4 waves)
 template <int NW, int MODE, int SHARE, int DIST>
@@ -26,14 +28,14 @@ __global__ __launch_bounds__((NW + (DIST == 2 ? 4 : 0)) * 64) void k(const char 
                                              float *__restrict__ sink) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int NT = 64 / NW;                   // accumulator tiles of 32 x 32; 2 * NT MFMAs per wave and stage
-    constexpr int NL = (DIST == 0 || DIST == 3) ? NW : DIST == 1 ? NW / 2 : 4;   // waves that issue DMA
+    constexpr int NL = (DIST == 0 || DIST == 3 || DIST == 4) ? NW : DIST == 1 ? NW / 2 : 4;   // waves that issue DMA
     constexpr int DPW = 32 / NL;                  // DMA instructions per issuing wave and stage (half chunk side, half query side)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const bool loader = (DIST == 0 || DIST == 3) ? true : DIST == 1 ? (wave >= NW / 2) : (wave >= NW);
+    const bool loader = (DIST == 0 || DIST == 3 || DIST == 4) ? true : DIST == 1 ? (wave >= NW / 2) : (wave >= NW);
     const bool mfma_first = DIST == 3 && wave < NW / 2;         // 3: ping-pong order (one wave of each kind per SIMD)
     const bool computer = DIST == 2 ? (wave < NW) : true;
-    const int lw = (DIST == 0 || DIST == 3) ? wave : DIST == 1 ? wave - NW / 2 : wave - NW;   // rank among the issuing waves
+    const int lw = (DIST == 0 || DIST == 3 || DIST == 4) ? wave : DIST == 1 ? wave - NW / 2 : wave - NW;   // rank among the issuing waves
     const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
     const int qt = jx % SHARE;
     const int stream = (jx / SHARE) * 8 + xcd;
@@ -72,7 +74,44 @@ __global__ __launch_bounds__((NW + (DIST == 2 ? 4 : 0)) * 64) void k(const char 
 #define STAGE_END()                                                                           \
             if ((MODE & 2) && loader) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DPW) : "memory"); \
             asm volatile("s_barrier" ::: "memory");
-    if (mfma_first) {
+    if (DIST == 4) {
+        // flattened (tile, stage) sequence; register ring of 4 stages x 2 fragments
+        half8 ra[4][2];
+        const int64_t tiles_mine = (n_tiles - stream + n_streams - 1) / n_streams;
+        const int64_t total = tiles_mine * kStages;
+        auto src = [&](int64_t g) -> const char * {
+            const int64_t t = stream + (g / kStages) * n_streams;
+            return X + t * (int64_t)kTileBytes + (g % kStages) * 16384 + wave * 2048 + lane * 16;
+        };
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            ra[g][0] = *reinterpret_cast<const half8 *>(src(g));
+            ra[g][1] = *reinterpret_cast<const half8 *>(src(g) + 1024);
+        }
+        for (int64_t g0 = 0; g0 < total; g0 += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t g = g0 + u;
+                const int s = (int)(g % kStages);
+                if ((MODE & 2) && g + 3 < total) {
+                    ra[(u + 3) & 3][0] = *reinterpret_cast<const half8 *>(src(g + 3));
+                    ra[(u + 3) & 3][1] = *reinterpret_cast<const half8 *>(src(g + 3) + 1024);
+                }
+                if (MODE & 2) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) GLDS(Q + s * 16384 + (i * NW + wave) * 1024 + lane * 16, lds + kA + b_dst + (i * NW + wave) * 1024);
+                    b_dst = (b_dst + 16384) & (kB - 1);
+                }
+                if (MODE & 1) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int w = 0; w < NT; ++w) acc[w] = __builtin_amdgcn_mfma_f32_32x32x16_f16((MODE & 2) ? ra[u][j] : a, b, acc[w], 0, 0, 0);
+                }
+                asm volatile("s_barrier" ::: "memory");
+            }
+        }
+    } else if (mfma_first) {
         for (int64_t t = stream; t < n_tiles; t += n_streams) {
             const char *xt = X + t * (int64_t)kTileBytes;
             for (int s = 0; s < kStages; ++s) { DO_MFMA() DO_DMA() STAGE_END() }
@@ -127,8 +166,8 @@ int main() {
     hipMemset(Q, 1, 4 * kTileBytes);
     hipMalloc(&sink, 64);
 #define ALL(NW, SH, D) run<NW, 1, SH, D>(X, n_tiles, Q, sink); run<NW, 2, SH, D>(X, n_tiles, Q, sink); run<NW, 3, SH, D>(X, n_tiles, Q, sink);
-    ALL(8, 4, 0) ALL(8, 4, 3)
-    ALL(8, 1, 0) ALL(8, 1, 3)
-    ALL(8, 4, 0) ALL(8, 4, 3)
+    ALL(8, 4, 3) ALL(8, 4, 4)
+    ALL(8, 1, 3) ALL(8, 1, 4)
+    ALL(8, 4, 3) ALL(8, 4, 4)
     return 0;
 }
