@@ -70,6 +70,7 @@ SIGNATURES = {
     "erh_debug_counters": (_i32, [_vp, _vp]),
     "erh_dense_diag": (_i32, [_vp, C.POINTER(_dbl), C.POINTER(_dbl), C.POINTER(_i32)]),
     "erh_dense_exhaustive_count": (_i32, [_vp, C.POINTER(_i32)]),
+    "erh_dense_seed_rank": (_i32, [_i32, _i64, _i64]),
     "erh_debug_dense_scores": (_i32, [_vp, _vp, _i32, _i64, _i32, _i32, _vp]),
 }
 

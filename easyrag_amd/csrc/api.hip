@@ -337,14 +337,13 @@ int dense_topk_dev(erh_handle *h, const void *q_dev, int q_dtype, int normalize_
       HIPCHK(h, e); }
     // Rank of the prefix score that seeds the threshold.  Guaranteed: k.  Speculative: the prefix is an even sample of
     // the corpus (erh_set_dense's row placement), so the number of true top-k members inside it is ~Poisson(mu),
-    // mu = k * n0 / N; the rank mu + 6.5 sqrt(mu) + 3 is exceeded with probability ~1e-9, i.e. the rank-th prefix score
+    // mu = k * n0 / N; the rank mu + 6.5 sqrt(mu) + 3 is reached with probability < 1e-7, i.e. the rank-th prefix score
     // is below the corpus' k-th best -- which dense_finalize_kernel verifies for every query (exhaustive path if not).
     int rank = k;
     bool speculate = false;
     if (h->opt_dense_speculate && N > n0) {
-        const double mu = (double)k * (double)n0 / (double)N;
-        const double r = std::ceil(mu + 6.5 * std::sqrt(mu) + 3.0);
-        if (r < (double)k) { rank = (int)r; speculate = true; }
+        rank = erh_dense_seed_rank(k, n0, N);
+        speculate = rank < k;
     }
     { ProfScope ps(h, st, ERH_K_DENSE_SELECT, 0, 0);
       HIPCHK(h, erh::launch_seed_select(h->S0.as<float>(), ld, (int)n0, 0, B, k, rank, h->qnorm.as<float>(), h->xnorm_max, d,
@@ -685,6 +684,14 @@ int erh_dense_diag(erh_handle *h, double *max_abs_err, double *margin, int32_t *
     if (margin) *margin = h->diag_margin;
     if (uncertified) *uncertified = h->diag_uncert;
     return ERH_OK;
+}
+
+int erh_dense_seed_rank(int k, int64_t n0, int64_t n) {
+    if (k < 1) return k;
+    if (n0 < 1 || n <= n0) return k;
+    const double mu = (double)k * (double)n0 / (double)n;
+    const double r = std::ceil(mu + 6.5 * std::sqrt(mu) + 3.0);
+    return r < (double)k ? (int)r : k;
 }
 
 int erh_dense_exhaustive_count(erh_handle *h, int32_t *count) {

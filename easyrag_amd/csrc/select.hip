@@ -206,7 +206,7 @@ __device__ __forceinline__ void seed_emit(const float *__restrict__ row, int n0,
 // `rank` <= k is the position in the prefix whose score seeds the threshold.  rank == k gives a guaranteed bound (the
 // k-th best of a subset never exceeds the k-th best of the whole).  rank < k is a SPECULATIVE bound: an estimate of
 // where the k-th best of the whole corpus lies, extrapolated from the prefix being an even sample of it (api.hip picks
-// the rank so that fewer than `rank` of the true top k land in the prefix except with probability ~1e-9 per query).
+// the rank so that fewer than `rank` of the true top k land in the prefix except with probability < 1e-7 per query).
 // dense_finalize_kernel verifies it -- at least k candidates must score >= threshold + margin -- and hands the
 // query to the exhaustive path otherwise, so the result is exact either way; what the speculation buys is a
 // threshold ~3x tighter than any guaranteed one, from the first scanned tile on.

@@ -264,6 +264,13 @@ int erh_dense_diag(erh_handle *h, double *max_abs_err, double *margin, int32_t *
  * score of every chunk, streaming top-k; same results contract).  Normally 0. */
 int erh_dense_exhaustive_count(erh_handle *h, int32_t *count);
 
+/* Pure function (no handle, no device): the rank of the seed-prefix score that erh_dense_topk takes as its first pruning
+ * threshold for top-k over n chunks with a prefix of n0 -- k itself (a guaranteed bound) or, with option dense_speculate,
+ * ceil(mu + 6.5 sqrt(mu) + 3) < k with mu = k * n0 / n: the prefix is an even sample of the corpus, the number of true
+ * top-k members inside it is ~Binomial(k, n0 / n), and `rank` or more of them land there with probability < 1e-7
+ * (tests/test_speculation_rank.py); every query's threshold is verified on the device anyway. */
+int erh_dense_seed_rank(int k, int64_t n0, int64_t n);
+
 /* Debug: plain (non-MFMA) fp32 scores of B fp16 queries against rows [row0, row0+rows) of the stored
  * matrix, out float32[B*rows] on the host; and the MFMA scores of the same block. */
 int erh_debug_dense_scores(erh_handle *h, const void *q_f16_host, int B, int64_t row0, int rows,
