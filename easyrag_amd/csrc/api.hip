@@ -59,6 +59,9 @@ struct erh_handle {
     std::string err;
     // dense state
     DevBuf X;
+    DevBuf qorder;                           // BM25: workgroup -> query, heaviest posting volume first (bm25_lpt)
+    std::vector<int32_t> qorder_host;
+    bool qorder_valid = false;
     DevBuf scan_sync;                        // one counter per chunk-tile stream of the ping-pong scan (dense_sync)
     DevBuf Xt;                               // tiled copy of X for the ping-pong scan (option dense_tiled), valid iff xt_valid
     bool xt_valid = false;
@@ -77,6 +80,7 @@ struct erh_handle {
     // reference pipeline, pipeline.py:187-210); erh_bm25_select picks the one the set / query calls act on
     Bm25State bm[ERH_BM25_SLOTS];
     int cur = 0;
+    int opt_bm25_lpt = 1;                 // launch the queries with the most postings first (shorter tail of the scan)
     int opt_bm25_segs = 0;                // document-range segments per query (0: enough to give the chip >= 512 workgroups)
     int opt_bm25_crossing = 1;            // wave-owned scan: threshold crossings instead of the accumulator sweep (indices with positive
                                           // payloads); 1 = fp32 sums only (the fp64 kernel runs out of registers with it: +12 % time), 2 = both
@@ -462,16 +466,17 @@ int bm25_topk_dev(erh_handle *h, const int32_t *qptr_dev, const int32_t *qtok_de
     const bool wscan = h->opt_bm25_wscan && S.n_fine > 0 && max_qlen <= erh::bm25_wscan_max_tokens() &&
                        h->opt_bm25_ablate == 0;
     unsigned long long *dbg = h->opt_debug_counters ? h->dbg.as<unsigned long long>() : nullptr;
+    const int32_t *q_order = (h->qorder_valid && qptr_dev == h->qptr.as<int32_t>()) ? h->qorder.as<int32_t>() : nullptr;
     auto scan = [&](double *p_sc, int32_t *p_ids, int32_t *p_len) -> hipError_t {
         if (wscan)
             return erh::launch_bm25_wscan(S.variant, S.indptr.as<int64_t>(), S.doc_ids.as<int32_t>(), S.payload.p,
-                                          S.fine_off.as<int32_t>(), S.n_fine, S.n_tiles, S.Nb, qptr_dev, qtok_dev, B, k,
+                                          S.fine_off.as<int32_t>(), S.n_fine, S.n_tiles, S.Nb, qptr_dev, qtok_dev, q_order, B, k,
                                           segs, filter_dev, dir, p_sc, p_ids, p_len,
                                           (S.payload_positive && (h->opt_bm25_crossing >= 2 ||
                                                                   (h->opt_bm25_crossing == 1 && S.variant != ERH_BM25_OKAPI))) ? 1 : 0,
                                           dbg, st);
         return erh::launch_bm25_scan(S.variant, S.indptr.as<int64_t>(), S.doc_ids.as<int32_t>(), S.payload.p,
-                                     S.tile_off.as<int32_t>(), S.n_tiles, S.Nb, qptr_dev, qtok_dev, B, k, segs,
+                                     S.tile_off.as<int32_t>(), S.n_tiles, S.Nb, qptr_dev, qtok_dev, q_order, B, k, segs,
                                      filter_dev, dir, p_sc, p_ids, p_len, h->opt_bm25_ablate, dbg, st);
     };
     if (segs == 1) {
@@ -509,6 +514,20 @@ int upload_bm25_queries(erh_handle *h, const int32_t *q_indptr, const int32_t *q
         total += (double)(host_indptr[t + 1] - host_indptr[t]) * per;
     }
     *bytes = total;
+    // longest-processing-time-first order: a query's scan time follows its posting volume (60 k ... 300 k postings), the
+    // dispatcher hands out workgroups in index order, and with four workgroups per CU the makespan is set by what starts last
+    h->qorder_valid = false;
+    if (h->opt_bm25_lpt && B > 1) {
+        std::vector<int64_t> cost((size_t)B, 0);
+        for (int b = 0; b < B; ++b)
+            for (int i = q_indptr[b]; i < q_indptr[b + 1]; ++i) cost[b] += host_indptr[q_tok[i] + 1] - host_indptr[q_tok[i]];
+        h->qorder_host.resize((size_t)B);
+        for (int b = 0; b < B; ++b) h->qorder_host[b] = b;
+        std::stable_sort(h->qorder_host.begin(), h->qorder_host.end(), [&](int32_t x, int32_t y) { return cost[x] > cost[y]; });
+        HIPCHK(h, h->qorder.ensure((size_t)B * 4));
+        HIPCHK(h, hipMemcpyAsync(h->qorder.p, h->qorder_host.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
+        h->qorder_valid = true;
+    }
     HIPCHK(h, h->qptr.ensure((size_t)(B + 1) * 4));
     HIPCHK(h, h->qtok.ensure((size_t)std::max(nt, 1) * 4));
     HIPCHK(h, hipMemcpyAsync(h->qptr.p, q_indptr, (size_t)(B + 1) * 4, hipMemcpyHostToDevice, st));
@@ -564,7 +583,7 @@ int erh_destroy(erh_handle *h) {
     (void)hipDeviceSynchronize();
     drain_events(h);
     for (auto &ev : h->pool) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
-    DevBuf *bufs[] = {&h->X, &h->Xt, &h->scan_sync, &h->content_id, &h->dir_id,
+    DevBuf *bufs[] = {&h->X, &h->Xt, &h->scan_sync, &h->qorder, &h->content_id, &h->dir_id,
                       &h->qin, &h->Q16, &h->qnorm, &h->tau, &h->S0, &h->cand, &h->cand_cnt, &h->flags, &h->filt, &h->filt2,
                       &h->o_ids, &h->o_sc, &h->o_len, &h->qptr, &h->qtok, &h->part_sc, &h->part_ids, &h->part_len,
                       &h->hy_sids, &h->hy_ssc, &h->hy_slen, &h->hy_dids, &h->hy_dsc, &h->hy_dlen,
@@ -615,6 +634,7 @@ int erh_set_option(erh_handle *h, const char *name, int64_t value) {
     if (!strcmp(name, "dense_ablate") || !strcmp(name, "bm25_ablate") || !strcmp(name, "debug_counters"))
         return value == 0 ? ERH_OK : h->fail(ERH_ERR_UNSUPPORTED, "measurement option: rebuild the library with ERH_MEASURE=1");
 #endif
+    if (!strcmp(name, "bm25_lpt")) { h->opt_bm25_lpt = value != 0; return ERH_OK; }
     if (!strcmp(name, "bm25_segs")) { if (value < 0 || value > 64) return h->fail(ERH_ERR_INVALID, "bm25_segs"); h->opt_bm25_segs = (int)value; return ERH_OK; }
     if (!strcmp(name, "bm25_crossing")) { if (value < 0 || value > 2) return h->fail(ERH_ERR_INVALID, "bm25_crossing"); h->opt_bm25_crossing = (int)value; return ERH_OK; }
     if (!strcmp(name, "bm25_wscan")) { h->opt_bm25_wscan = value != 0; return ERH_OK; }   // the fine table is built at the next erh_set_bm25_*

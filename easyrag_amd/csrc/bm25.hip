@@ -266,7 +266,8 @@ template <typename ST>
 __global__ __launch_bounds__(kBmThreads) void bm25_scan_kernel(
     const int64_t *__restrict__ indptr, const int32_t *__restrict__ doc_ids, const ST *__restrict__ payload,
     const int32_t *__restrict__ tile_off, int n_tiles, int64_t N,
-    const int32_t *__restrict__ q_indptr, const int32_t *__restrict__ q_tok, int k, int segs,
+    const int32_t *__restrict__ q_indptr, const int32_t *__restrict__ q_tok,
+    const int32_t *__restrict__ q_order /* workgroup y -> query: heaviest queries first, or null */, int k, int segs,
     const int16_t *__restrict__ filter_dir, const int16_t *__restrict__ dir_id,
     double *__restrict__ part_scores, int32_t *__restrict__ part_ids, int32_t *__restrict__ part_len,
     int ablate /* measurement only: 1 no add, 2 no sweep, 4 no token barrier, 8 no posting loads */,
@@ -284,7 +285,7 @@ __global__ __launch_bounds__(kBmThreads) void bm25_scan_kernel(
     int64_t *s_lo = reinterpret_cast<int64_t *>(smem + L::OFF_LO);
     int64_t *s_hi = reinterpret_cast<int64_t *>(smem + L::OFF_HI);
 
-    const int seg = blockIdx.x, q = blockIdx.y, tid = threadIdx.x;
+    const int seg = blockIdx.x, q = q_order ? q_order[blockIdx.y] : (int)blockIdx.y, tid = threadIdx.x;
     const int qs = q_indptr[q], nq = q_indptr[q + 1] - qs;
     const int fd = filter_dir ? (int)filter_dir[q] : -1;
     const int t_begin = (int)((int64_t)n_tiles * seg / segs);
@@ -557,7 +558,8 @@ template <typename ST, bool CROSSING /* every payload > 0 and normal: threshold 
 __global__ __launch_bounds__(kBmThreads) void bm25_wscan_kernel(
     const int64_t *__restrict__ indptr, const int32_t *__restrict__ doc_ids, const ST *__restrict__ payload,
     const int32_t *__restrict__ fine_off, int n_fine, int n_tiles, int64_t N,
-    const int32_t *__restrict__ q_indptr, const int32_t *__restrict__ q_tok, int k, int segs,
+    const int32_t *__restrict__ q_indptr, const int32_t *__restrict__ q_tok,
+    const int32_t *__restrict__ q_order /* workgroup y -> query: heaviest queries first, or null */, int k, int segs,
     const int16_t *__restrict__ filter_dir, const int16_t *__restrict__ dir_id,
     double *__restrict__ part_scores, int32_t *__restrict__ part_ids, int32_t *__restrict__ part_len,
     unsigned long long *__restrict__ dbg /* measurement only: section clock sums of thread 0, or null */) {
@@ -574,7 +576,7 @@ __global__ __launch_bounds__(kBmThreads) void bm25_wscan_kernel(
     ST *cs = reinterpret_cast<ST *>(smem + L::OFF_CS);
     int32_t *ci = reinterpret_cast<int32_t *>(smem + L::OFF_CI);
 
-    const int seg = blockIdx.x, q = blockIdx.y, tid = threadIdx.x;
+    const int seg = blockIdx.x, q = q_order ? q_order[blockIdx.y] : (int)blockIdx.y, tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int32_t *xw = reinterpret_cast<int32_t *>(smem + L::OFF_LO) + wave * kWsXCap;   // this wave's crossing list
@@ -850,7 +852,7 @@ hipError_t launch_bm25_payload(int variant, int64_t V, int64_t nnz, const int64_
 
 hipError_t launch_bm25_scan(int variant, const int64_t *indptr, const int32_t *doc_ids, const void *payload,
                             const int32_t *tile_off, int n_tiles, int64_t N,
-                            const int32_t *q_indptr, const int32_t *q_tok, int B, int k, int segs,
+                            const int32_t *q_indptr, const int32_t *q_tok, const int32_t *q_order, int B, int k, int segs,
                             const int16_t *filter_dir, const int16_t *dir_id,
                             double *part_scores, int32_t *part_ids, int32_t *part_len, int ablate,
                             unsigned long long *dbg, hipStream_t st) {
@@ -858,11 +860,11 @@ hipError_t launch_bm25_scan(int variant, const int64_t *indptr, const int32_t *d
     dim3 grid(segs, B), block(kBmThreads);
     if (variant == 0)
         hipLaunchKernelGGL(bm25_scan_kernel<double>, grid, block, BmLds<double>::BYTES, st, indptr, doc_ids,
-                           (const double *)payload, tile_off, n_tiles, N, q_indptr, q_tok, k, segs, filter_dir, dir_id,
+                           (const double *)payload, tile_off, n_tiles, N, q_indptr, q_tok, q_order, k, segs, filter_dir, dir_id,
                            part_scores, part_ids, part_len, ablate, dbg);
     else
         hipLaunchKernelGGL(bm25_scan_kernel<float>, grid, block, BmLds<float>::BYTES, st, indptr, doc_ids,
-                           (const float *)payload, tile_off, n_tiles, N, q_indptr, q_tok, k, segs, filter_dir, dir_id,
+                           (const float *)payload, tile_off, n_tiles, N, q_indptr, q_tok, q_order, k, segs, filter_dir, dir_id,
                            part_scores, part_ids, part_len, ablate, dbg);
     return hipGetLastError();
 }
@@ -872,7 +874,7 @@ int bm25_wscan_sub_docs(int variant) { return (variant == 0 ? kBm25TileF64 : kBm
 
 hipError_t launch_bm25_wscan(int variant, const int64_t *indptr, const int32_t *doc_ids, const void *payload,
                              const int32_t *fine_off, int n_fine, int n_tiles, int64_t N,
-                             const int32_t *q_indptr, const int32_t *q_tok, int B, int k, int segs,
+                             const int32_t *q_indptr, const int32_t *q_tok, const int32_t *q_order, int B, int k, int segs,
                              const int16_t *filter_dir, const int16_t *dir_id,
                              double *part_scores, int32_t *part_ids, int32_t *part_len, int crossing,
                              unsigned long long *dbg, hipStream_t st) {
@@ -880,7 +882,7 @@ hipError_t launch_bm25_wscan(int variant, const int64_t *indptr, const int32_t *
     dim3 grid(segs, B), block(kBmThreads);
 #define ERH_WS_LAUNCH(ST, X)                                                                               \
     hipLaunchKernelGGL((bm25_wscan_kernel<ST, X>), grid, block, BmLds<ST>::OFF_LO + kWsXBytes, st, indptr, doc_ids, \
-                       (const ST *)payload, fine_off, n_fine, n_tiles, N, q_indptr, q_tok, k, segs, filter_dir, dir_id, \
+                       (const ST *)payload, fine_off, n_fine, n_tiles, N, q_indptr, q_tok, q_order, k, segs, filter_dir, dir_id, \
                        part_scores, part_ids, part_len, dbg)
     if (variant == 0) {
         if (crossing) ERH_WS_LAUNCH(double, true); else ERH_WS_LAUNCH(double, false);

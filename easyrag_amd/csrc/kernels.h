@@ -100,7 +100,8 @@ hipError_t launch_bm25_payload(int variant, int64_t V, int64_t nnz, const int64_
 // segs partial lists per query; partial_* are [B][segs][k]
 hipError_t launch_bm25_scan(int variant, const int64_t *indptr, const int32_t *doc_ids, const void *payload,
                             const int32_t *tile_off, int n_tiles, int64_t N,
-                            const int32_t *q_indptr, const int32_t *q_tok, int B, int k, int segs,
+                            const int32_t *q_indptr, const int32_t *q_tok,
+                            const int32_t *q_order /* workgroup -> query (heaviest first) or null */, int B, int k, int segs,
                             const int16_t *filter_dir, const int16_t *dir_id,
                             double *part_scores, int32_t *part_ids, int32_t *part_len, int ablate,
                             unsigned long long *dbg, hipStream_t st);
@@ -109,7 +110,7 @@ int bm25_wscan_max_tokens();
 int bm25_wscan_sub_docs(int variant);
 hipError_t launch_bm25_wscan(int variant, const int64_t *indptr, const int32_t *doc_ids, const void *payload,
                              const int32_t *fine_off, int n_fine, int n_tiles, int64_t N,
-                             const int32_t *q_indptr, const int32_t *q_tok, int B, int k, int segs,
+                             const int32_t *q_indptr, const int32_t *q_tok, const int32_t *q_order, int B, int k, int segs,
                              const int16_t *filter_dir, const int16_t *dir_id,
                              double *part_scores, int32_t *part_ids, int32_t *part_len,
                              int crossing /* every payload > 0: threshold crossings replace the sweep */,

@@ -234,6 +234,7 @@ int erh_reset_kernel_time(erh_handle *h);
  *   bm25_crossing (1)     wave-owned scan: survivors from threshold crossings noted in the token loop instead of a sweep
  *                         over the accumulators (1 = fp32 sums only, 2 = fp64 too, 0 = always sweep); indices with a
  *                         non-positive payload always sweep
+ *   bm25_lpt (1)          launch the queries of a batch in order of decreasing posting volume (shorter tail of the scan)
  *   bm25_segs (0)         document-range segments per query (0 = enough for >= 512 workgroups)
  *   bm25_wscan (1)        wave-owned BM25 scan (no per-token workgroup barrier) for batches whose queries have at most
  *                         64 tokens; 0 = block scan for everything.  Needs a fine skip table (4 bytes per term and per
