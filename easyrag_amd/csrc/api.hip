@@ -41,15 +41,18 @@ struct Bm25State {
     int variant = -1;
     int64_t V = 0, Nb = 0, nnz = 0;
     DevBuf indptr, doc_ids, payload, tile_off, fine_off;
+    DevBuf post;                          // fixed-point scan: interleaved {document, fixed-point payload} postings + one sentinel
+    double qmax = 0;                      // largest fixed-point payload
     DevBuf tf;                            // kept by erh_build_bm25_index (what erh_get_bm25_csr returns)
     std::vector<double> idf_host;         // idem (float32 values widened exactly for the bm25s variant)
     double avgdl = 0, average_idf = 0;
     bool built_on_device = false;
     bool payload_positive = false;        // every payload > 0: the wave-owned scan may use threshold crossings instead of the sweep
+    bool ascan_ok = false;                // ... and also as fp32: the fixed-point scan applies (bm25.hip: bm25_ascan_kernel)
     std::vector<int64_t> host_indptr;     // host copy: query validation + algorithmic-byte accounting
     int n_tiles = 0, tile_docs = 0;
     int n_fine = 0;                       // sub-ranges of the fine skip table (0 = not built: block scan only)
-    void release() { indptr.release(); doc_ids.release(); payload.release(); tile_off.release(); fine_off.release(); tf.release(); }
+    void release() { indptr.release(); doc_ids.release(); payload.release(); tile_off.release(); fine_off.release(); tf.release(); post.release(); }
 };
 
 }  // namespace
@@ -84,7 +87,9 @@ struct erh_handle {
     int opt_bm25_segs = 0;                // document-range segments per query (0: enough to give the chip >= 512 workgroups)
     int opt_bm25_crossing = 1;            // wave-owned scan: threshold crossings instead of the accumulator sweep (indices with positive
                                           // payloads); 1 = fp32 sums only (the fp64 kernel runs out of registers with it: +12 % time), 2 = both
-    int opt_bm25_wscan = 1;               // wave-owned scan when the batch qualifies (bm25.hip), else the block scan
+    int opt_bm25_ascan = 1;               // approximate-order scan + exact re-score when the index qualifies (positive payloads)
+    int opt_bm25_wscan = 0;               // otherwise: wave-owned scan when the batch qualifies (needs the fine skip table, built at the
+                                          // next erh_set_bm25_*), else the block scan
     int64_t opt_bm25_fine_max_mb = 8192;  // largest fine skip table built for it
     // metadata
     int64_t Nmeta = 0;
@@ -94,6 +99,7 @@ struct erh_handle {
     DevBuf qin, Q16, qnorm, tau, S0, cand, cand_cnt, flags, filt, filt2, seed_need;
     DevBuf o_ids, o_sc, o_len;              // staging for host outputs
     DevBuf qptr, qtok, part_sc, part_ids, part_len;
+    DevBuf bm_redo;                          // approximate-order scan: (query, segment) pairs that go to the exact block scan
     DevBuf hy_sids, hy_ssc, hy_slen, hy_dids, hy_dsc, hy_dlen;
     DevBuf fa_ids, fa_sc, fa_len, fb_ids, fb_sc, fb_len;
     DevBuf scores_tmp, scores_wide;
@@ -458,16 +464,38 @@ int bm25_topk_dev(erh_handle *h, const int32_t *qptr_dev, const int32_t *qtok_de
                   int max_qlen, hipStream_t st) {
     Bm25State &S = h->bm[h->cur];
     const int16_t *dir = h->has_dir ? h->dir_id.as<int16_t>() : nullptr;
-    int segs = h->opt_bm25_segs > 0 ? h->opt_bm25_segs : (512 + B - 1) / B;
-    segs = std::max(1, std::min(segs, S.n_tiles));
-    while (segs > 1 && (int64_t)segs * k > 8192) --segs;
-    // wave-owned scan (no per-token workgroup barrier) when the index has its fine skip table and lane j can own
-    // token j of every query; otherwise the block scan.  Both produce the same lists.
-    const bool wscan = h->opt_bm25_wscan && S.n_fine > 0 && max_qlen <= erh::bm25_wscan_max_tokens() &&
+    // approximate-order scan + exact re-score (default) when every payload is a positive normal number; otherwise the
+    // wave-owned scan (no per-token workgroup barrier) when the index has its fine skip table and lane j can own token j
+    // of every query; otherwise the block scan.  All three produce the same lists.
+    const bool ascan = h->opt_bm25_ascan && S.ascan_ok && h->opt_bm25_ablate == 0;
+    const bool wscan = !ascan && h->opt_bm25_wscan && S.n_fine > 0 && max_qlen <= erh::bm25_wscan_max_tokens() &&
                        h->opt_bm25_ablate == 0;
+    const int tiles = ascan ? erh::bm25_ascan_tiles(S.Nb) : S.n_tiles;
+    int segs = h->opt_bm25_segs > 0 ? h->opt_bm25_segs : (512 + B - 1) / B;
+    segs = std::max(1, std::min(segs, tiles));
+    while (segs > 1 && (int64_t)segs * k > 8192) --segs;
     unsigned long long *dbg = h->opt_debug_counters ? h->dbg.as<unsigned long long>() : nullptr;
     const int32_t *q_order = (h->qorder_valid && qptr_dev == h->qptr.as<int32_t>()) ? h->qorder.as<int32_t>() : nullptr;
+    if (ascan) {
+        HIPCHK(h, h->bm_redo.ensure((size_t)B * segs * 4));
+        HIPCHK(h, hipMemsetAsync(h->bm_redo.p, 0, (size_t)B * segs * 4, st));
+    }
     auto scan = [&](double *p_sc, int32_t *p_ids, int32_t *p_len) -> hipError_t {
+        if (ascan) {
+            const int tshift = S.tile_docs == erh::kBm25TileF32 ? 0 : 1;
+            hipError_t e = erh::launch_bm25_ascan(S.variant, S.indptr.as<int64_t>(), S.doc_ids.as<int32_t>(), S.payload.p,
+                                                  S.post.p, (uint32_t)S.nnz, S.qmax,
+                                                  S.tile_off.as<int32_t>(), S.n_tiles, tshift, S.Nb, qptr_dev, qtok_dev, q_order,
+                                                  B, k, segs, filter_dev, dir, p_sc, p_ids, p_len, h->bm_redo.as<uint32_t>(),
+                                                  dbg, st);
+            if (e != hipSuccess) return e;
+            // near-tie floods (rare): those workgroups are scanned again by the exact block scan (same document ranges per
+            // segment), the others exit at once
+            return erh::launch_bm25_scan(S.variant, S.indptr.as<int64_t>(), S.doc_ids.as<int32_t>(), S.payload.p,
+                                         S.tile_off.as<int32_t>(), S.n_tiles, S.Nb, qptr_dev, qtok_dev, q_order, B, k, segs,
+                                         filter_dev, dir, p_sc, p_ids, p_len, h->bm_redo.as<uint32_t>(), tiles, tshift, 0,
+                                         nullptr, st);
+        }
         if (wscan)
             return erh::launch_bm25_wscan(S.variant, S.indptr.as<int64_t>(), S.doc_ids.as<int32_t>(), S.payload.p,
                                           S.fine_off.as<int32_t>(), S.n_fine, S.n_tiles, S.Nb, qptr_dev, qtok_dev, q_order, B, k,
@@ -477,7 +505,7 @@ int bm25_topk_dev(erh_handle *h, const int32_t *qptr_dev, const int32_t *qtok_de
                                           dbg, st);
         return erh::launch_bm25_scan(S.variant, S.indptr.as<int64_t>(), S.doc_ids.as<int32_t>(), S.payload.p,
                                      S.tile_off.as<int32_t>(), S.n_tiles, S.Nb, qptr_dev, qtok_dev, q_order, B, k, segs,
-                                     filter_dev, dir, p_sc, p_ids, p_len, h->opt_bm25_ablate, dbg, st);
+                                     filter_dev, dir, p_sc, p_ids, p_len, nullptr, 0, 0, h->opt_bm25_ablate, dbg, st);
     };
     if (segs == 1) {
         ProfScope ps(h, st, ERH_K_BM25_SCAN, postings_bytes, 0);
@@ -588,7 +616,7 @@ int erh_destroy(erh_handle *h) {
                       &h->o_ids, &h->o_sc, &h->o_len, &h->qptr, &h->qtok, &h->part_sc, &h->part_ids, &h->part_len,
                       &h->hy_sids, &h->hy_ssc, &h->hy_slen, &h->hy_dids, &h->hy_dsc, &h->hy_dlen,
                       &h->fa_ids, &h->fa_sc, &h->fa_len, &h->fb_ids, &h->fb_sc, &h->fb_len,
-                      &h->scores_tmp, &h->scores_wide, &h->dbg, &h->dir_pos, &h->seed_need, &h->bad, &h->ex_ws};
+                      &h->scores_tmp, &h->scores_wide, &h->dbg, &h->dir_pos, &h->seed_need, &h->bad, &h->ex_ws, &h->bm_redo};
     for (DevBuf *b : bufs) b->release();
     for (auto &b : h->bm) b.release();
     if (h->comm) (void)erh_comm_destroy(h);
@@ -637,6 +665,7 @@ int erh_set_option(erh_handle *h, const char *name, int64_t value) {
     if (!strcmp(name, "bm25_lpt")) { h->opt_bm25_lpt = value != 0; return ERH_OK; }
     if (!strcmp(name, "bm25_segs")) { if (value < 0 || value > 64) return h->fail(ERH_ERR_INVALID, "bm25_segs"); h->opt_bm25_segs = (int)value; return ERH_OK; }
     if (!strcmp(name, "bm25_crossing")) { if (value < 0 || value > 2) return h->fail(ERH_ERR_INVALID, "bm25_crossing"); h->opt_bm25_crossing = (int)value; return ERH_OK; }
+    if (!strcmp(name, "bm25_ascan")) { h->opt_bm25_ascan = value != 0; return ERH_OK; }
     if (!strcmp(name, "bm25_wscan")) { h->opt_bm25_wscan = value != 0; return ERH_OK; }   // the fine table is built at the next erh_set_bm25_*
     if (!strcmp(name, "bm25_fine_max_mb")) { if (value < 0) return h->fail(ERH_ERR_INVALID, "bm25_fine_max_mb < 0"); h->opt_bm25_fine_max_mb = value; return ERH_OK; }
     if (!strcmp(name, "debug_counters")) {
@@ -828,6 +857,52 @@ static int bm25_check_payload_sign(erh_handle *h, hipStream_t st) {
     HIPCHK(h, hipMemcpyAsync(&f, w, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(h, hipStreamSynchronize(st));
     S.payload_positive = (f == 0);
+    // fixed-point scan: an interleaved copy of the postings with the payload as trunc(p32 * 2^S) + 1.  bm25s payloads are
+    // fp32 already; Okapi goes through an fp32 copy, which must be positive and normal as well (an fp64 payload below
+    // 1.2e-38 would round to a subnormal or to zero).  8 bytes per posting on top of the index.
+    S.ascan_ok = false;
+    S.post.release();
+    if (S.payload_positive && h->opt_bm25_ascan && S.nnz < (1LL << 28)) {         // (32-bit byte offsets into post[])
+        DevBuf p32buf;
+        const float *p32 = S.payload.as<float>();
+        bool ok = true;
+        hipError_t e = hipSuccess;
+        if (S.variant == ERH_BM25_OKAPI) {
+            e = p32buf.ensure((size_t)S.nnz * 4);
+            if (e == hipSuccess) e = erh::launch_narrow_f64(S.payload.as<double>(), S.nnz, p32buf.as<float>(), st);
+            if (e == hipSuccess) e = hipMemsetAsync(w, 0, 4, st);
+            if (e == hipSuccess) e = erh::launch_bm25_payload_sign(ERH_BM25_BM25S, p32buf.p, S.nnz, w, st);
+            f = 1;
+            if (e == hipSuccess) e = hipMemcpyAsync(&f, w, 4, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            ok = (e == hipSuccess && f == 0);
+            p32 = p32buf.as<float>();
+        }
+        float pmax = 0.f;
+        if (ok) {
+            e = hipMemsetAsync(w, 0, 4, st);
+            if (e == hipSuccess) e = erh::launch_bm25_payload_max(p32, S.nnz, w, st);
+            if (e == hipSuccess) e = hipMemcpyAsync(&f, w, 4, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            memcpy(&pmax, &f, 4);
+            ok = e == hipSuccess && pmax > 0.f && std::isfinite(pmax);
+        }
+        if (ok) {
+            const float scale = erh::bm25_post_scale(pmax);
+            ok = scale >= 4096.f;                                                // a coarser grid than 2^-12 is not worth scanning
+            if (ok) {
+                e = S.post.ensure((size_t)(S.nnz + 1) * 8);
+                if (e == hipSuccess) e = erh::launch_bm25_post(S.doc_ids.as<int32_t>(), p32, S.nnz, scale, S.post.p, st);
+                if (e == hipSuccess) e = hipStreamSynchronize(st);
+                S.qmax = std::floor((double)pmax * (double)scale) + 1.0;
+                ok = e == hipSuccess;
+            }
+        }
+        p32buf.release();
+        if (e != hipSuccess) { S.post.release(); return h->fail(e == hipErrorOutOfMemory ? ERH_ERR_NOMEM : ERH_ERR_HIP, "bm25 fixed-point postings", e); }
+        S.ascan_ok = ok;
+        if (!ok) S.post.release();
+    }
     return ERH_OK;
 }
 
@@ -849,7 +924,7 @@ static int bm25_common_upload(erh_handle *h, int variant, int64_t V, int64_t N, 
     HIPCHK(h, hipSetDevice(h->device));
     hipStream_t st = nullptr;
     HIPCHK(h, h->bm[h->cur].indptr.ensure((size_t)(V + 1) * 8));
-    HIPCHK(h, h->bm[h->cur].doc_ids.ensure((size_t)std::max<int64_t>(nnz, 1) * 4));
+    HIPCHK(h, h->bm[h->cur].doc_ids.ensure((size_t)(nnz + 1) * 4));          // + the sentinel posting of the fixed-point scan
     HIPCHK(h, hipMemcpyAsync(h->bm[h->cur].indptr.p, indptr, (size_t)(V + 1) * 8, hipMemcpyHostToDevice, st));
     if (nnz) HIPCHK(h, hipMemcpyAsync(h->bm[h->cur].doc_ids.p, doc_ids, (size_t)nnz * 4, hipMemcpyHostToDevice, st));
     int rc_t = bm25_finish_tables(h, variant, V, N, st);
@@ -870,7 +945,7 @@ int erh_set_bm25_csr(erh_handle *h, int variant, int64_t V, int64_t N, int64_t n
     int rc = bm25_common_upload(h, variant, V, N, nnz, indptr, doc_ids);
     if (rc != ERH_OK) { h->bm[h->cur].variant = -1; return rc; }
     const size_t es = (variant == ERH_BM25_OKAPI) ? 8 : 4;
-    HIPCHK(h, h->bm[h->cur].payload.ensure((size_t)std::max<int64_t>(nnz, 1) * es));
+    HIPCHK(h, h->bm[h->cur].payload.ensure((size_t)(nnz + 1) * es));
     if (nnz) HIPCHK(h, hipMemcpyAsync(h->bm[h->cur].payload.p, payload, (size_t)nnz * es, hipMemcpyHostToDevice, nullptr));
     HIPCHK(h, hipStreamSynchronize(nullptr));
     return bm25_check_payload_sign(h, nullptr);
@@ -886,7 +961,7 @@ int erh_set_bm25_tf(erh_handle *h, int variant, int64_t V, int64_t N, int64_t nn
     if (rc != ERH_OK) { h->bm[h->cur].variant = -1; return rc; }
     const size_t es = (variant == ERH_BM25_OKAPI) ? 8 : 4;
     hipStream_t st = nullptr;
-    HIPCHK(h, h->bm[h->cur].payload.ensure((size_t)std::max<int64_t>(nnz, 1) * es));
+    HIPCHK(h, h->bm[h->cur].payload.ensure((size_t)(nnz + 1) * es));
     DevBuf d_tf, d_dl, d_idf;
     auto cleanup = [&]() { d_tf.release(); d_dl.release(); d_idf.release(); };
     hipError_t e = d_tf.ensure((size_t)std::max<int64_t>(nnz, 1) * 4);
@@ -982,7 +1057,7 @@ int erh_build_bm25_index(erh_handle *h, int variant, int64_t V, int64_t N, int64
     d_keys.release();
     d_sorted.release();
     d_temp.release();
-    BUILD_CHK(S.doc_ids.ensure((size_t)std::max<int64_t>(nnz, 1) * 4));
+    BUILD_CHK(S.doc_ids.ensure((size_t)(nnz + 1) * 4));
     BUILD_CHK(S.tf.ensure((size_t)std::max<int64_t>(nnz, 1) * 4));
     BUILD_CHK(d_df.ensure((size_t)V * 8));
     BUILD_CHK(erh::launch_csr_split(d_uniq.as<uint64_t>(), d_cnt.as<int32_t>(), nnz, V, S.doc_ids.as<int32_t>(),
@@ -1021,7 +1096,7 @@ int erh_build_bm25_index(erh_handle *h, int variant, int64_t V, int64_t N, int64
     BUILD_CHK(S.indptr.ensure((size_t)(V + 1) * 8));
     BUILD_CHK(hipMemcpyAsync(S.indptr.p, indptr.data(), (size_t)(V + 1) * 8, hipMemcpyHostToDevice, st));
     const size_t es = (variant == ERH_BM25_OKAPI) ? 8 : 4;
-    BUILD_CHK(S.payload.ensure((size_t)std::max<int64_t>(nnz, 1) * es));
+    BUILD_CHK(S.payload.ensure((size_t)(nnz + 1) * es));
     BUILD_CHK(d_dl.ensure((size_t)N * 4));
     BUILD_CHK(hipMemcpyAsync(d_dl.p, dl.data(), (size_t)N * 4, hipMemcpyHostToDevice, st));
     BUILD_CHK(d_idf.ensure((size_t)V * es));

@@ -106,6 +106,8 @@ struct BmHdr {
     double tau_s;   // running k-th best: score part (0 => "score > 0" is the only condition)
     int full[3];    // wave-owned scan: "list was full during sweep pass p" (p mod 3), see bm25_wscan_kernel
     int want[3];    // wave-owned scan: "list grew past k + 512 during sweep pass p"
+    float theta;    // approximate-order scan: k-th best approximate sum seen so far (tau_s holds theta * (1 - margin))
+    int redo;       // approximate-order scan: near-tie flood, the query goes to the exact block scan
 };
 static_assert(sizeof(BmHdr) <= 64, "BmHdr must fit the 64-byte LDS header");
 
@@ -270,9 +272,12 @@ __global__ __launch_bounds__(kBmThreads) void bm25_scan_kernel(
     const int32_t *__restrict__ q_order /* workgroup y -> query: heaviest queries first, or null */, int k, int segs,
     const int16_t *__restrict__ filter_dir, const int16_t *__restrict__ dir_id,
     double *__restrict__ part_scores, int32_t *__restrict__ part_ids, int32_t *__restrict__ part_len,
+    const uint32_t *__restrict__ only /* null, or one word per (query, segment): scan it only if non-zero */,
+    int cut_tiles, int cut_shift /* segment boundaries: (cut_tiles * seg / segs) << cut_shift (the approximate-order scan's cuts) */,
     int ablate /* measurement only: 1 no add, 2 no sweep, 4 no token barrier, 8 no posting loads */,
     unsigned long long *__restrict__ dbg /* measurement only: per-section shader-clock sums of thread 0, or null */) {
     using L = BmLds<ST>;
+    if (only && !only[(int64_t)(q_order ? q_order[blockIdx.y] : (int)blockIdx.y) * segs + blockIdx.x]) return;   // workgroup-uniform
     long long t_sec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long t_mark = dbg ? clock64() : 0;
 #define ERH_SEC(I) do { if (dbg) { const long long n_ = clock64(); t_sec[I] += n_ - t_mark; t_mark = n_; } } while (0)
@@ -288,8 +293,9 @@ __global__ __launch_bounds__(kBmThreads) void bm25_scan_kernel(
     const int seg = blockIdx.x, q = q_order ? q_order[blockIdx.y] : (int)blockIdx.y, tid = threadIdx.x;
     const int qs = q_indptr[q], nq = q_indptr[q + 1] - qs;
     const int fd = filter_dir ? (int)filter_dir[q] : -1;
-    const int t_begin = (int)((int64_t)n_tiles * seg / segs);
-    const int t_end = (int)((int64_t)n_tiles * (seg + 1) / segs);
+    const int t_begin = (int)((int64_t)cut_tiles * seg / segs) << cut_shift;
+    int t_end = (int)((int64_t)cut_tiles * (seg + 1) / segs) << cut_shift;
+    t_end = t_end < n_tiles ? t_end : n_tiles;
     const int64_t out_base = ((int64_t)q * segs + seg) * k;
 
     if (tid == 0) { hdr->ncand = 0; hdr->total = 0; hdr->tau_idx = -1; hdr->tau_s = 0.0; }
@@ -739,6 +745,639 @@ __global__ __launch_bounds__(kBmThreads) void bm25_wscan_kernel(
 #undef ERH_SEC
 }
 
+// ---- fixed-point scan + exact re-score (default when every payload of the index is a positive normal number) --------
+// The block scan and the wave-owned scan above keep the library's summation order DURING the scan, which makes every
+// document a serial read-add-write chain.  This kernel separates the two jobs:
+//   scan     the postings of a tile are scattered with LDS INTEGER atomics (ds_add_rtn_u32: 7-8 cycles per 64 postings
+//            on a busy CU; ds_add_f32 serialises at 192 -- scripts/ubench/lds_scatter.hip).  The index keeps an
+//            interleaved copy of the postings for it, {document, q} with the payload in fixed point,
+//            q = trunc(p32 * 2^S) + 1, 2^S chosen per index so that 64 payloads cannot overflow 32 bits (8 bytes per
+//            posting for both variants, one 8-byte load per lane).  Integer sums do not depend on the order, so every
+//            lane of every wave carries a posting: the (token, 64-posting piece) sequence of a tile is dealt
+//            round-robin to the 16 waves, and the postings of tile t+1 are already in registers (requested one tile
+//            ahead with a static number of loads: lanes and register slots past the end read a sentinel posting) while
+//            tile t is applied and cleared.  Wave 0 prepares the posting ranges two tiles ahead (DPP prefix sum over
+//            the tokens) and publishes them in LDS.  The kernel is bound by instruction issue (one wave-instruction
+//            per cycle and CU), so the loop is written for few instructions per posting, not for few bytes;
+//   select   sums only grow, so "the final sum reaches the threshold" happens at exactly one add per document: the
+//            returned old value tells (thq - 1 - old < q, unsigned: exact) and the accumulator slot is noted in the
+//            list of the wave that OWNS that part of the accumulators.  After the tile's barrier every wave moves its
+//            own noted slots to the candidate list and clears its own 2048 accumulators -- program order inside the
+//            wave, no barrier in between, no sweep over 32768 sums.  Tiles without a threshold yet (the first one,
+//            seeded by a radix select over the per-thread maxima) and overflowing lists use the sweep of the block scan
+//            on the integer sums;
+//   bound    for a document with n <= nq matched tokens, real-arithmetic score S, library value f (fp32 / fp64 sum in
+//            query-token order) and fixed-point sum a = aq / 2^S:  S~ < a <= S~ + n 2^-S  (S~: sum of the fp32 payloads,
+//            within S (1 +- 2^-24)), f within S (1 +- n 2^-24).  With eps = 1.01 (nq + 2) 2^-24:
+//            f < a (1 + eps) and f >= (a - n 2^-S)(1 - eps).  If k listed documents have aq >= thetaq, a document with
+//            aq < thq = floor(thetaq (1 - 3 eps)) - nq - 1 has f strictly below all k of them: it can never be in the
+//            top k.  Everything else stays on the list (k entries plus the near ties of the k-th); thetaq is the exact
+//            k-th largest listed sum (LDS radix select, no sort);
+//   re-score the final list is scored EXACTLY: one binary search per (document, query token) inside the tile range of the
+//            skip table (four searches in flight per thread), the payloads summed in query-token order in the library's
+//            type (adding 0.0 for an absent token changes nothing), then ranked by (score desc, index asc) by counting.
+//            ids and scores are the library's, bit for bit.
+// A list that does not shrink below its capacity (thousands of documents within the margin of the k-th score -- e.g. a
+// corpus of near-identical short documents) or a query whose sums could overflow sets redo[query, segment]: the host
+// launches the exact block scan for those workgroups only.  Indices with non-positive payloads never come here
+// (api.hip checks when an index is set).
+constexpr int kAsTile = erh::kBm25TileF32;
+constexpr int kAsU = 12;                                 // 64-posting pieces per wave and tile held in registers
+constexpr int kAsReserve = 256;                          // free list slots a shrink must leave
+constexpr int kAsTokChunk = 64;                          // lane j <-> query token j
+constexpr int kAsRegion = kAsTile / kWsWaves;            // accumulators a wave owns (notes, clears)
+constexpr int kAsXW = 96;                                // threshold crossings noted per region and tile
+constexpr size_t kAsOffHdr2 = 64;
+constexpr size_t kAsOffXcnt = 128;                       // int xz[2][17]: crossings per region, then the largest position handed out
+constexpr size_t kAsOffTok = 320;                        // int32 tok[64]   (re-score stage)
+constexpr size_t kAsOffIp = 576;                         // uint32 ip[64]
+constexpr size_t kAsOffRng = 1024;                       // int4 rng[3][64]
+constexpr size_t kAsOffAcc = 4096;
+constexpr size_t kAsOffCa = kAsOffAcc + (size_t)kAsTile * 4;
+constexpr size_t kAsOffCi = kAsOffCa + (size_t)kBmCap * 4;
+constexpr size_t kAsOffXl = kAsOffCi + (size_t)kBmCap * 4;
+constexpr size_t kAsOffHist = kAsOffXl + (size_t)kWsWaves * kAsXW * 4;
+constexpr size_t kAsBytes = kAsOffHist + 256 * 4;
+static_assert(kAsOffXcnt + 2 * 17 * 4 <= kAsOffTok && kAsOffIp + 64 * 4 <= kAsOffRng, "header tables overlap");
+static_assert(kAsOffRng + 3 * 64 * 16 <= kAsOffAcc, "range tables overlap the accumulators");
+static_assert(kAsBytes <= 160 * 1024, "fixed-point scan LDS layout exceeds one CU");
+static_assert(kWsWaves == 16, "region bookkeeping assumes 16 waves");
+
+struct AsHdr {
+    uint32_t thetaq;                // k-th best fixed-point sum seen so far (0: fewer than k candidates yet)
+    uint32_t thq;                   // drop threshold (>= 1): a document below it can never reach the top k
+    int redo;                       // near-tie flood / possible overflow: the query goes to the exact block scan
+    int sel_bin, sel_need;          // radix select scratch
+    int keep;                       // compaction counter
+};
+static_assert(sizeof(AsHdr) <= 64, "AsHdr must fit its 64-byte slot");
+
+typedef int as_int4 __attribute__((ext_vector_type(4)));
+typedef uint32_t as_uint2 __attribute__((ext_vector_type(2)));
+struct AsRng {                      // posting ranges of one tile: lane j = query token j
+    int pex;                        // 64-posting pieces of the tokens before this one (0x7fffffff: no such token)
+    int n;                          // postings
+    uint32_t start;                 // index of the first one
+    int pt;                         // wave-uniform: pieces of the tile
+};
+struct AsSet { as_uint2 p[kAsU]; };  // .x document, .y fixed-point payload
+
+// inclusive prefix sum over the 64 lanes (DPP: four shifts inside the rows of 16, two row broadcasts)
+__device__ __forceinline__ int as_wave_scan(int x) {
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);       // row_shr:1, lanes shifted in read 0
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);      // row_bcast:15 into rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);      // row_bcast:31 into rows 2 and 3
+    return x;
+}
+
+// lane j: raw skip-table entries a, b of token j (0, 0 for lanes without a token) -> ranges
+__device__ __forceinline__ as_int4 as_make_ranges(uint32_t ip, int a, int b, int nq, int lane) {
+    const int n = b - a;
+    const int c = (n + 63) >> 6;
+    const int incl = as_wave_scan(c);
+    as_int4 r;
+    r[0] = lane < nq ? incl - c : 0x7fffffff;
+    r[1] = n;
+    r[2] = (int)(ip + (uint32_t)a);
+    r[3] = __builtin_amdgcn_readlane(incl, 63);
+    return r;
+}
+__device__ __forceinline__ AsRng as_unpack(as_int4 r) {
+    AsRng R;
+    R.pex = r[0]; R.n = r[1]; R.start = (uint32_t)r[2]; R.pt = __builtin_amdgcn_readfirstlane(r[3]);
+    return R;
+}
+
+// piece p (wave-uniform, 0 <= p < R.pt) -> index of this lane's posting, or `sentinel` past the end of the token's range
+__device__ __forceinline__ uint32_t as_decode(const AsRng &R, int p, int lane, uint32_t sentinel) {
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(R.pex <= p);
+    const int j = __builtin_popcountll(m) - 1;                            // last token whose pieces start at or before p
+    const int pj = __builtin_amdgcn_readlane(R.pex, j);
+    const int nj = __builtin_amdgcn_readlane(R.n, j);
+    const uint32_t sj = (uint32_t)__builtin_amdgcn_readlane((int)R.start, j);
+    const int o = (p - pj) << 6;                                          // scalar
+    return lane < nj - o ? sj + (uint32_t)o + (uint32_t)lane : sentinel;
+}
+
+// kAsU loads whatever the tile holds (their number is static: the compiler can count them); slots past the wave's last
+// piece read the sentinel posting without decoding anything
+__device__ __forceinline__ void as_fill(AsSet &S, const AsRng &R, const as_uint2 *__restrict__ post, int lane, int wave,
+                                        uint32_t sentinel) {
+#pragma unroll
+    for (int u = 0; u < kAsU; ++u) {
+        const int p = wave + u * kWsWaves;
+        uint32_t idx = sentinel;
+        if (p < R.pt) idx = as_decode(R, p, lane, sentinel);              // wave-uniform branch around ALU work only
+        S.p[u] = post[idx];
+    }
+}
+
+// rare: slot `sl` crossed the threshold -> list of the wave that owns the slot; xz[16] keeps the largest position
+__device__ __forceinline__ void as_note(bool cross, int sl, int32_t *xl, int *xz) {
+    if (__builtin_amdgcn_ballot_w64(cross)) {                             // wave-uniform
+        if (cross) {
+            const int r = sl / kAsRegion;
+            const int pos = atomicAdd(&xz[r], 1);
+            if (pos < kAsXW) xl[r * kAsXW + pos] = sl;
+            atomicMax(&xz[16], pos + 1);
+        }
+    }
+}
+
+// `np` pieces of the set (wave-uniform) onto the integer sums
+__device__ __forceinline__ void as_apply(const AsSet &S, int np, uint32_t *accu, int base_doc, uint32_t thx, int32_t *xl,
+                                         int *xz) {
+    uint32_t old[kAsU];
+#pragma unroll
+    for (int u = 0; u < kAsU; ++u) {                                      // all adds of the set in flight together
+        old[u] = thx;                                                     // (lanes without a posting: never a crossing)
+        if (u < np && (int)S.p[u].x >= 0) old[u] = atomicAdd(&accu[(int)S.p[u].x - base_doc], S.p[u].y);
+    }
+    if (thx) {                                                            // (no threshold yet: nothing to note, the tile is swept)
+#pragma unroll
+        for (int u = 0; u < kAsU; ++u)
+            if (u < np) as_note(thx - 1u - old[u] < S.p[u].y, (int)S.p[u].x - base_doc, xl, xz);   // old < thx <= old + q
+    }
+}
+
+// pieces from `p0` on, straight from memory (tiles with more than kAsU * 16 pieces; queries of more than 64 tokens)
+__device__ __forceinline__ void as_direct(const AsRng &R, int p0, uint32_t *accu, int base_doc,
+                                          const as_uint2 *__restrict__ post, int lane, uint32_t sentinel, uint32_t thx,
+                                          int32_t *xl, int *xz) {
+    for (int p = p0; p < R.pt; p += 2 * kWsWaves) {
+        const uint32_t i0 = as_decode(R, p, lane, sentinel);
+        const uint32_t i1 = p + kWsWaves < R.pt ? as_decode(R, p + kWsWaves, lane, sentinel) : sentinel;
+        const as_uint2 x0 = post[i0], x1 = post[i1];
+        uint32_t o0 = thx, o1 = thx;
+        if ((int)x0.x >= 0) o0 = atomicAdd(&accu[(int)x0.x - base_doc], x0.y);
+        if ((int)x1.x >= 0) o1 = atomicAdd(&accu[(int)x1.x - base_doc], x1.y);
+        if (thx) {
+            as_note(thx - 1u - o0 < x0.y, (int)x0.x - base_doc, xl, xz);
+            as_note(thx - 1u - o1 < x1.y, (int)x1.x - base_doc, xl, xz);
+        }
+    }
+}
+
+// k-th largest of v[0..n) (1 <= k <= n): radix select, four passes of eight bits over an LDS histogram.  Uniform call.
+__device__ __forceinline__ uint32_t as_kth_largest(const uint32_t *v, int n, int k, uint32_t *hist, AsHdr *h2) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    uint32_t prefix = 0u, mask = 0u;
+    int need = k;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        if (tid < 256) hist[tid] = 0u;
+        __syncthreads();
+        for (int i = tid; i < n; i += kBmThreads) {
+            const uint32_t x = v[i];
+            if ((x & mask) == prefix) atomicAdd(&hist[(x >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid < 64) {                                                   // wave 0: bins 4 lane .. 4 lane + 3, from the top
+            const uint32_t h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2_ = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+            const int s = (int)(h0 + h1 + h2_ + h3);
+            const int incl = as_wave_scan(s);
+            const int total = __builtin_amdgcn_readlane(incl, 63);
+            const int above = total - incl;                               // members of the bins of higher lanes
+            if (above < need && need <= above + s) {                      // exactly one lane
+                int a = above, bin = 4 * lane;
+                const int hh[4] = {(int)h3, (int)h2_, (int)h1, (int)h0};
+                bool done = false;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    if (!done) {
+                        if (need <= a + hh[b]) { bin = 4 * lane + 3 - b; done = true; }
+                        else a += hh[b];
+                    }
+                }
+                h2->sel_bin = bin;
+                h2->sel_need = need - a;
+            }
+        }
+        __syncthreads();
+        prefix |= (uint32_t)h2->sel_bin << shift;
+        mask |= 255u << shift;
+        need = h2->sel_need;
+    }
+    __syncthreads();                                                      // (everyone has read sel_* before a later call writes them)
+    return prefix;
+}
+
+__device__ __forceinline__ uint32_t as_drop_threshold(uint32_t thetaq, double keep_frac, int nq) {
+    const long long t = (long long)((double)thetaq * keep_frac) - nq - 1;
+    return t > 1 ? (uint32_t)t : 1u;
+}
+
+// Refresh thetaq / the drop threshold from the list and keep what is not provably out (list order is arbitrary).
+__device__ __forceinline__ void as_shrink(BmHdr *hdr, AsHdr *h2, uint32_t *ca, int32_t *ci, uint32_t *hist, int k,
+                                          double keep_frac, int nq, int reserve) {
+    __syncthreads();
+    const int n = hdr->ncand < kBmCap ? hdr->ncand : kBmCap;
+    if (n >= k) {                                                         // uniform
+        const uint32_t th = as_kth_largest(ca, n, k, hist, h2);
+        if (threadIdx.x == 0 && th > h2->thetaq) { h2->thetaq = th; h2->thq = as_drop_threshold(th, keep_frac, nq); }
+    }
+    if (threadIdx.x == 0) h2->keep = 0;
+    __syncthreads();
+    const uint32_t thq = h2->thq;
+    // compaction in place: every thread holds its (at most two) entries in registers across the barrier
+    const int i0 = threadIdx.x, i1 = threadIdx.x + kBmThreads;
+    uint32_t v0 = 0u, v1 = 0u;
+    int32_t d0 = 0, d1 = 0;
+    if (i0 < n) { v0 = ca[i0]; d0 = ci[i0]; }
+    if (i1 < n) { v1 = ca[i1]; d1 = ci[i1]; }
+    __syncthreads();
+    const bool k0 = i0 < n && v0 >= thq, k1 = i1 < n && v1 >= thq;
+    if (k0) { const int pos = atomicAdd(&h2->keep, 1); ca[pos] = v0; ci[pos] = d0; }
+    if (k1) { const int pos = atomicAdd(&h2->keep, 1); ca[pos] = v1; ci[pos] = d1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        hdr->ncand = h2->keep;
+        if (h2->keep > kBmCap - reserve) h2->redo = 1;                    // near-tie flood: no room for the next tile
+    }
+    __syncthreads();
+}
+
+// grid = (segs, B), block = 1024.  tile_off has n_tab + 1 entries per term at a granularity of kAsTile >> tshift documents;
+// post = the interleaved fixed-point postings with one sentinel {document -1, q 0} at index nnz.
+template <typename ST>
+__global__ __launch_bounds__(kBmThreads) void bm25_ascan_kernel(
+    const int64_t *__restrict__ indptr, const int32_t *__restrict__ doc_ids, const ST *__restrict__ payload,
+    const as_uint2 *__restrict__ post, uint32_t nnz, double qmax /* largest fixed-point payload of the index */,
+    const int32_t *__restrict__ tile_off, int n_tab, int tshift, int n_tiles, int64_t N,
+    const int32_t *__restrict__ q_indptr, const int32_t *__restrict__ q_tok, const int32_t *__restrict__ q_order, int k,
+    int segs, const int16_t *__restrict__ filter_dir, const int16_t *__restrict__ dir_id,
+    double *__restrict__ part_scores, int32_t *__restrict__ part_ids, int32_t *__restrict__ part_len,
+    uint32_t *__restrict__ redo, unsigned long long *__restrict__ dbg) {
+#ifdef ERH_MEASURE
+    long long t_sec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long t_mark = dbg ? clock64() : 0;
+#define ERH_SEC(I) do { if (dbg) { const long long n_ = clock64(); t_sec[I] += n_ - t_mark; t_mark = n_; } } while (0)
+#else
+#define ERH_SEC(I) do { } while (0)
+#endif
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    BmHdr *hdr = reinterpret_cast<BmHdr *>(smem);
+    AsHdr *h2 = reinterpret_cast<AsHdr *>(smem + kAsOffHdr2);
+    int *xzb = reinterpret_cast<int *>(smem + kAsOffXcnt);
+    int32_t *s_tok = reinterpret_cast<int32_t *>(smem + kAsOffTok);
+    uint32_t *s_ip = reinterpret_cast<uint32_t *>(smem + kAsOffIp);
+    as_int4 *rng = reinterpret_cast<as_int4 *>(smem + kAsOffRng);
+    uint32_t *accu = reinterpret_cast<uint32_t *>(smem + kAsOffAcc);
+    uint32_t *ca = reinterpret_cast<uint32_t *>(smem + kAsOffCa);
+    int32_t *ci = reinterpret_cast<int32_t *>(smem + kAsOffCi);
+    int32_t *xl = reinterpret_cast<int32_t *>(smem + kAsOffXl);
+    uint32_t *hist = reinterpret_cast<uint32_t *>(smem + kAsOffHist);
+
+    const int seg = blockIdx.x, q = q_order ? q_order[blockIdx.y] : (int)blockIdx.y, tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qs = q_indptr[q];
+    const int nq = q_indptr[q + 1] - qs;
+    const int fd = filter_dir ? (int)filter_dir[q] : -1;
+    const int t_begin = (int)((int64_t)n_tiles * seg / segs);
+    const int t_end = (int)((int64_t)n_tiles * (seg + 1) / segs);
+    const int64_t out_base = ((int64_t)q * segs + seg) * k;
+    const double keep_frac = 1.0 - 3.0 * 1.01 * (double)(nq + 2) * 5.9604644775390625e-08;   // 1 - 3 eps
+
+    if (tid == 0) {
+        hdr->ncand = 0; hdr->total = 0; hdr->tau_idx = 0x7fffffff; hdr->tau_s = 0.0;
+        hdr->full[0] = hdr->full[1] = hdr->full[2] = 0;
+        hdr->want[0] = hdr->want[1] = hdr->want[2] = 0;
+        h2->thetaq = 0u; h2->thq = 1u; h2->keep = 0;
+        h2->redo = ((double)nq * qmax >= 4294967296.0) ? 1 : 0;           // the sums could overflow: leave it to the exact scan
+    }
+    if (tid < 2 * 17) xzb[tid] = 0;
+    for (int i = tid; i < kAsTile; i += kBmThreads) accu[i] = 0u;
+    __syncthreads();
+
+    int ph = 0;                                                           // sweep pass counter (workgroup-uniform)
+    // The tile's sums are complete (barrier behind the adds): survivors -> list, accumulators cleared.
+    // nc0 = hdr->ncand as it was before the tile (nobody changes it during the adds).  true: give up (redo).
+    auto finish_tile = [&](int tile, int base_doc, uint32_t thq, int nc0) __attribute__((always_inline)) -> bool {
+        const int par = tile & 1;
+        const int *xz = xzb + par * 17;
+        const int xmax = xz[16];                                          // most crossings noted for one region
+        const int cnt = xz[wave];                                         // ... for this wave's region
+        if (tid < 17) xzb[(par ^ 1) * 17 + tid] = 0;                      // the next tile's counters (idle until the next barrier)
+        bool by_list = thq > 1u && xmax <= kAsXW;                         // workgroup-uniform
+        if (by_list && nc0 + kWsWaves * xmax > kBmCap) {                  // make room first (rare)
+            as_shrink(hdr, h2, ca, ci, hist, k, keep_frac, nq, kAsReserve);
+            if (h2->redo) return true;
+            by_list = hdr->ncand + kWsWaves * xmax <= kBmCap;             // (stable: read behind as_shrink's last barrier)
+        }
+        if (by_list) {
+            // this wave's own region: the noted slots hold final sums (>= the thq of the adds; the threshold may have moved
+            // up in a shrink just now), then the clear -- program order inside the wave, no barrier in between
+            if (cnt > 0) {
+                const uint32_t thn = h2->thq;
+                for (int i = lane; i < cnt; i += 64) {
+                    const int sl = xl[wave * kAsXW + i];
+                    const uint32_t av = accu[sl];
+                    const int64_t doc = (int64_t)base_doc + sl;
+                    bool pass = av >= thn;
+                    if (pass && (doc >= N || (fd >= 0 && (int)dir_id[doc] != fd))) pass = false;
+                    if (pass) {
+                        const int pos = atomicAdd(&hdr->ncand, 1);        // fits: ncand + 16 xmax <= kBmCap
+                        ca[pos] = av;
+                        ci[pos] = (int32_t)doc;
+                    }
+                }
+            }
+            typedef uint32_t UT __attribute__((ext_vector_type(4)));
+            const UT z = {0u, 0u, 0u, 0u};
+            uint32_t *mine = accu + wave * kAsRegion + lane * 4;
+#pragma unroll
+            for (int i = 0; i < kAsRegion / 256; ++i) *reinterpret_cast<UT *>(mine + i * 256) = z;
+            ERH_SEC(3);
+            __syncthreads();
+            ERH_SEC(4);
+            if (hdr->ncand > k + kBmThreads / 2) {                        // uniform: keep the list short, the threshold current
+                as_shrink(hdr, h2, ca, ci, hist, k, keep_frac, nq, kAsReserve);
+                ERH_SEC(5);
+                if (h2->redo) return true;
+            }
+            return false;
+        }
+        if (tile == t_begin && k <= kBmThreads && fd < 0) {
+            // k-th largest of the per-thread maxima: k distinct documents reach it, so it is a valid first thetaq
+            typedef uint32_t UT __attribute__((ext_vector_type(4)));
+            uint32_t mx = 0u;
+            for (int i = tid * 4; i < kAsTile; i += kBmThreads * 4) {
+                const UT v = *reinterpret_cast<const UT *>(accu + i);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) mx = v[e] > mx ? v[e] : mx;
+            }
+            ca[tid] = mx;                                                 // the list is still empty
+            const uint32_t p = as_kth_largest(ca, kBmThreads, k, hist, h2);   // begins and ends with barriers
+            if (tid == 0 && p > 0u) { h2->thetaq = p; h2->thq = as_drop_threshold(p, keep_frac, nq); }
+            __syncthreads();
+        }
+        for (;;) {
+            const int slot = ph % 3;
+            if (tid == 0) { hdr->full[(ph + 1) % 3] = 0; hdr->want[(ph + 1) % 3] = 0; }
+            bm_sweep<uint32_t>(hdr, accu, ca, ci, 0, kAsTile, kBmThreads, tid, (int64_t)base_doc, N, fd, dir_id, h2->thq,
+                               0x7fffffff, &hdr->full[slot], &hdr->want[slot], k + kBmThreads / 2);
+            ERH_SEC(3);
+            __syncthreads();
+            ERH_SEC(4);
+            const int full = hdr->full[slot], want = hdr->want[slot];
+            ++ph;
+            if (full || want) {
+                as_shrink(hdr, h2, ca, ci, hist, k, keep_frac, nq, kAsReserve);
+                ERH_SEC(5);
+                if (h2->redo) return true;                                // (written before as_shrink's last barrier)
+            }
+            if (!full) return false;                                      // (full: survivors were left behind -- sweep again)
+        }
+    };
+
+    bool stop = h2->redo != 0;
+    if (nq > 0 && t_begin < t_end && !stop) {
+        if (nq <= kAsTokChunk) {
+            // wave 0, lane j: token j's posting base and its row of the skip table; ranges are published two tiles ahead
+            uint32_t ip = 0u;
+            const int32_t *fo = tile_off;
+            const bool tokl = wave == 0 && lane < nq;
+            if (tokl) {
+                const int64_t tok = q_tok[qs + lane];
+                ip = (uint32_t)indptr[tok];
+                fo = tile_off + tok * (int64_t)(n_tab + 1);
+            }
+            auto raw = [&](int t, int &a, int &b) __attribute__((always_inline)) {   // wave 0 only; t is clamped
+                t = t < t_end ? t : t_end - 1;
+                int i0 = t << tshift, i1 = (t + 1) << tshift;
+                i0 = i0 < n_tab ? i0 : n_tab;
+                i1 = i1 < n_tab ? i1 : n_tab;
+                a = tokl ? fo[i0] : 0;
+                b = tokl ? fo[i1] : 0;
+            };
+            int ra = 0, rb = 0;
+            if (wave == 0) {
+                raw(t_begin, ra, rb);
+                rng[0 * 64 + lane] = as_make_ranges(ip, ra, rb, nq, lane);
+                raw(t_begin + 1, ra, rb);
+                rng[1 * 64 + lane] = as_make_ranges(ip, ra, rb, nq, lane);
+                raw(t_begin + 2, ra, rb);                                 // consumed in the first tile body
+            }
+            __syncthreads();
+            AsRng Rc = as_unpack(rng[lane]), Rn = Rc;
+            AsSet A, B;
+            as_fill(A, Rc, post, lane, wave, nnz);
+            int r3 = 0;                                                   // (tile - t_begin) % 3: slot of the current tile's ranges
+            auto body = [&](AsSet &cur, AsSet &nxt, int tile) __attribute__((always_inline)) -> bool {
+                const int base_doc = tile * kAsTile;
+                const uint32_t thq = h2->thq;                             // fixed for the tile (it only moves in as_shrink)
+                const int nc0 = hdr->ncand;
+                int *xz = xzb + (tile & 1) * 17;
+                const int r_n = r3 == 2 ? 0 : r3 + 1, r_nn = r_n == 2 ? 0 : r_n + 1;
+                Rn = as_unpack(rng[r_n * 64 + lane]);                     // next tile (clamped past the end): postings requested now
+                as_fill(nxt, Rn, post, lane, wave, nnz);
+                if (wave == 0) {                                          // ranges of tile + 2 -> LDS, skip-table entries of tile + 3
+                    rng[r_nn * 64 + lane] = as_make_ranges(ip, ra, rb, nq, lane);
+                    raw(tile + 3, ra, rb);
+                }
+                ERH_SEC(0);
+                const uint32_t thx = thq > 1u ? thq : 0u;
+                int np = (Rc.pt - wave + kWsWaves - 1) / kWsWaves;        // this wave's pieces of the tile
+                np = np < kAsU ? np : kAsU;
+                as_apply(cur, np, accu, base_doc, thx, xl, xz);
+                as_direct(Rc, wave + kAsU * kWsWaves, accu, base_doc, post, lane, nnz, thx, xl, xz);
+                ERH_SEC(1);
+                __syncthreads();                                          // every posting of the tile is in its sum
+                ERH_SEC(2);
+                const bool st = finish_tile(tile, base_doc, thq, nc0);
+                Rc = Rn;
+                r3 = r_n;
+                return st;
+            };
+            for (int tile = t_begin; tile < t_end && !stop; tile += 2) {
+                stop = body(A, B, tile);
+                if (!stop && tile + 1 < t_end) stop = body(B, A, tile + 1);
+            }
+        } else {
+            // long queries: chunks of 64 tokens, ranges and postings fetched on the spot by every wave
+            for (int tile = t_begin; tile < t_end && !stop; ++tile) {
+                const int base_doc = tile * kAsTile;
+                const uint32_t thq = h2->thq;
+                const int nc0 = hdr->ncand;
+                int *xz = xzb + (tile & 1) * 17;
+                for (int c0 = 0; c0 < nq; c0 += kAsTokChunk) {
+                    const int nqc = nq - c0 < kAsTokChunk ? nq - c0 : kAsTokChunk;
+                    int a = 0, b = 0;
+                    uint32_t ipc = 0u;
+                    if (lane < nqc) {
+                        const int64_t tok = q_tok[qs + c0 + lane];
+                        ipc = (uint32_t)indptr[tok];
+                        const int32_t *foc = tile_off + tok * (int64_t)(n_tab + 1);
+                        int i0 = tile << tshift, i1 = (tile + 1) << tshift;
+                        i0 = i0 < n_tab ? i0 : n_tab;
+                        i1 = i1 < n_tab ? i1 : n_tab;
+                        a = foc[i0];
+                        b = foc[i1];
+                    }
+                    const AsRng R = as_unpack(as_make_ranges(ipc, a, b, nqc, lane));
+                    as_direct(R, wave, accu, base_doc, post, lane, nnz, thq > 1u ? thq : 0u, xl, xz);
+                }
+                ERH_SEC(1);
+                __syncthreads();
+                ERH_SEC(2);
+                stop = finish_tile(tile, base_doc, thq, nc0);
+            }
+        }
+    }
+    if (!stop) as_shrink(hdr, h2, ca, ci, hist, k, keep_frac, nq, 0);     // final list: k entries + the near ties of the k-th
+    if (h2->redo) {                                                       // workgroup-uniform
+        if (tid == 0) { redo[(int64_t)q * segs + seg] = 1u; part_len[(int64_t)q * segs + seg] = 0; }
+        return;
+    }
+    ERH_SEC(5);
+    // ---- exact re-score of the list, in query-token order, in the library's type ------------------------------------------
+    const int n_keep = hdr->ncand;
+    ST *fs = reinterpret_cast<ST *>(smem + kAsOffAcc);                    // the accumulators are dead: exact sums ...
+    ST *M = fs + kBmCap;                                                  // ... and the (entry, token) payload matrix
+    constexpr int kMCap = (int)(((size_t)kAsTile * 4 - (size_t)kBmCap * sizeof(ST)) / sizeof(ST));
+    const int tab_shift = 15 - tshift;                                    // log2 of the skip table's granularity
+    static_assert(kAsTile == 32768, "tab_shift assumes 32768-document tiles");
+    for (int i = tid; i < kBmCap; i += kBmThreads) fs[i] = (ST)0;
+    for (int c0 = 0; c0 < nq; c0 += kAsTokChunk) {
+        const int nqc = nq - c0 < kAsTokChunk ? nq - c0 : kAsTokChunk;
+        const int ld = nqc | 1;                                           // odd row length: conflict-free column walk
+        __syncthreads();
+        if (tid < nqc) {
+            const int32_t tok = q_tok[qs + c0 + tid];
+            s_tok[tid] = tok;
+            s_ip[tid] = (uint32_t)indptr[tok];
+        }
+        __syncthreads();
+        const int ec_max = kMCap / ld;
+        for (int e0 = 0; e0 < n_keep; e0 += ec_max) {
+            const int ec = n_keep - e0 < ec_max ? n_keep - e0 : ec_max;
+            const int items = ec * nqc;
+            constexpr int R = 4;                                          // searches in flight per thread
+            for (int w0 = tid; w0 < items; w0 += R * kBmThreads) {
+                uint32_t lo[R], hi[R], hi0[R];
+                int32_t doc[R];
+                int mpos[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int w = w0 + r * kBmThreads;
+                    lo[r] = hi[r] = hi0[r] = 0u;
+                    doc[r] = 0;
+                    mpos[r] = -1;
+                    if (w < items) {
+                        const int e = w / nqc, j = w - e * nqc;
+                        doc[r] = ci[e0 + e];
+                        const int32_t *to = tile_off + (int64_t)s_tok[j] * (n_tab + 1) + (doc[r] >> tab_shift);
+                        lo[r] = s_ip[j] + (uint32_t)to[0];
+                        hi[r] = hi0[r] = s_ip[j] + (uint32_t)to[1];
+                        mpos[r] = e * ld + j;
+                    }
+                }
+                for (;;) {                                                // first posting with document >= doc, R at a time
+                    bool act[R];
+                    uint32_t mid[R];
+                    int32_t dv[R];
+                    bool any = false;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        act[r] = lo[r] < hi[r];
+                        mid[r] = (lo[r] + hi[r]) >> 1;
+                        dv[r] = act[r] ? doc_ids[mid[r]] : 0;
+                        any |= act[r];
+                    }
+                    if (!any) break;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        if (act[r]) { if (dv[r] < doc[r]) lo[r] = mid[r] + 1u; else hi[r] = mid[r]; }
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    if (mpos[r] >= 0) {
+                        ST val = (ST)0;
+                        if (lo[r] < hi0[r] && doc_ids[lo[r]] == doc[r]) val = payload[lo[r]];
+                        M[mpos[r]] = val;
+                    }
+                }
+            }
+            __syncthreads();
+            for (int e = tid; e < ec; e += kBmThreads) {
+                ST s = fs[e0 + e];
+                for (int j = 0; j < nqc; ++j) s = s + M[e * ld + j];      // token order; + 0.0 for an absent token
+                fs[e0 + e] = s;
+            }
+            __syncthreads();
+        }
+    }
+    ERH_SEC(6);
+    // ---- rank by counting: entry e goes to position #{entries that beat it} (keys (score, index) are distinct) -----------
+    int *rank = reinterpret_cast<int *>(ca);                              // the approximate sums are dead
+    __syncthreads();
+    for (int i = tid; i < n_keep; i += kBmThreads) rank[i] = 0;
+    __syncthreads();
+    if (n_keep > 0) {
+        const int parts = n_keep < kBmThreads ? kBmThreads / n_keep : 1;
+        const int chunk = (n_keep + parts - 1) / parts;
+        for (int w = tid; w < n_keep * parts; w += kBmThreads) {
+            const int part = w / n_keep, e = w - part * n_keep;           // consecutive lanes: consecutive entries, same part
+            const ST se = fs[e];
+            const int32_t ie = ci[e];
+            const int j1 = (part + 1) * chunk < n_keep ? (part + 1) * chunk : n_keep;
+            int cnt = 0;
+            for (int j = part * chunk; j < j1; ++j) {
+                const ST sj = fs[j];
+                const int32_t ij = ci[j];
+                cnt += (sj > se || (sj == se && ij < ie)) ? 1 : 0;
+            }
+            if (cnt) atomicAdd(&rank[e], cnt);
+        }
+    }
+    __syncthreads();
+    const int n = n_keep < k ? n_keep : k;
+    for (int e = tid; e < n_keep; e += kBmThreads) {
+        const int r = rank[e];
+        if (r < k) { part_scores[out_base + r] = (double)fs[e]; part_ids[out_base + r] = ci[e]; }
+    }
+    for (int i = n + tid; i < k; i += kBmThreads) { part_scores[out_base + i] = 0.0; part_ids[out_base + i] = -1; }
+    if (tid == 0) part_len[(int64_t)q * segs + seg] = n;
+    ERH_SEC(7);
+#ifdef ERH_MEASURE
+    if (dbg && tid == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) atomicAdd(&dbg[i], (unsigned long long)t_sec[i]);
+    }
+#endif
+#undef ERH_SEC
+}
+
+// interleaved fixed-point postings of the scan above: post[i] = {document, trunc(p32 * scale) + 1}, post[nnz] = {-1, 0}
+__global__ void bm25_post_kernel(const int32_t *__restrict__ doc_ids, const float *__restrict__ pay32, int64_t nnz, float scale,
+                                 as_uint2 *__restrict__ post) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= nnz; i += (int64_t)gridDim.x * blockDim.x) {
+        as_uint2 v;
+        if (i < nnz) { v.x = (uint32_t)doc_ids[i]; v.y = (uint32_t)(pay32[i] * scale) + 1u; }
+        else { v.x = 0xffffffffu; v.y = 0u; }
+        post[i] = v;
+    }
+}
+
+// bits[0] = max over the fp32 payloads (positive floats order like their bit patterns)
+__global__ void bm25_payload_max_kernel(const float *__restrict__ p, int64_t n, uint32_t *__restrict__ bits) {
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        m = p[i] > m ? p[i] : m;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const float t = __shfl_xor(m, o); m = t > m ? t : m; }
+    if ((threadIdx.x & 63) == 0) atomicMax(bits, __float_as_uint(m));
+}
+
+__global__ void narrow_f64_kernel(const double *__restrict__ in, int64_t n, float *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = (float)in[i];
+}
+
 // Merge `segs` sorted partial lists of one query: grid = B, block = 1024, LDS = P*(8+4) (+64), P = pow2 >= segs*k.
 __global__ __launch_bounds__(kBmThreads) void bm25_merge_kernel(
     int k, int segs, int P, const double *__restrict__ part_scores, const int32_t *__restrict__ part_ids,
@@ -823,6 +1462,10 @@ hipError_t bm25_init() {
     e = hipFuncSetAttribute((const void *)bm25_wscan_kernel<double, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)BmLds<double>::OFF_LO + kWsXBytes);
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void *)bm25_ascan_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAsBytes);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void *)bm25_ascan_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAsBytes);
+    if (e != hipSuccess) return e;
     return hipFuncSetAttribute((const void *)bm25_merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                8192 * 12 + 64);
 }
@@ -854,18 +1497,68 @@ hipError_t launch_bm25_scan(int variant, const int64_t *indptr, const int32_t *d
                             const int32_t *tile_off, int n_tiles, int64_t N,
                             const int32_t *q_indptr, const int32_t *q_tok, const int32_t *q_order, int B, int k, int segs,
                             const int16_t *filter_dir, const int16_t *dir_id,
-                            double *part_scores, int32_t *part_ids, int32_t *part_len, int ablate,
-                            unsigned long long *dbg, hipStream_t st) {
+                            double *part_scores, int32_t *part_ids, int32_t *part_len, const uint32_t *only, int cut_tiles,
+                            int cut_shift, int ablate, unsigned long long *dbg, hipStream_t st) {
     if (B <= 0) return hipSuccess;
+    if (cut_tiles <= 0) { cut_tiles = n_tiles; cut_shift = 0; }
     dim3 grid(segs, B), block(kBmThreads);
     if (variant == 0)
         hipLaunchKernelGGL(bm25_scan_kernel<double>, grid, block, BmLds<double>::BYTES, st, indptr, doc_ids,
                            (const double *)payload, tile_off, n_tiles, N, q_indptr, q_tok, q_order, k, segs, filter_dir, dir_id,
-                           part_scores, part_ids, part_len, ablate, dbg);
+                           part_scores, part_ids, part_len, only, cut_tiles, cut_shift, ablate, dbg);
     else
         hipLaunchKernelGGL(bm25_scan_kernel<float>, grid, block, BmLds<float>::BYTES, st, indptr, doc_ids,
                            (const float *)payload, tile_off, n_tiles, N, q_indptr, q_tok, q_order, k, segs, filter_dir, dir_id,
-                           part_scores, part_ids, part_len, ablate, dbg);
+                           part_scores, part_ids, part_len, only, cut_tiles, cut_shift, ablate, dbg);
+    return hipGetLastError();
+}
+
+hipError_t launch_bm25_ascan(int variant, const int64_t *indptr, const int32_t *doc_ids, const void *payload,
+                             const void *post, uint32_t nnz, double qmax, const int32_t *tile_off, int n_tab, int tshift,
+                             int64_t N, const int32_t *q_indptr, const int32_t *q_tok, const int32_t *q_order, int B, int k,
+                             int segs, const int16_t *filter_dir, const int16_t *dir_id,
+                             double *part_scores, int32_t *part_ids, int32_t *part_len, uint32_t *redo,
+                             unsigned long long *dbg, hipStream_t st) {
+    if (B <= 0) return hipSuccess;
+    const int n_tiles = (int)((N + kAsTile - 1) / kAsTile);
+    dim3 grid(segs, B), block(kBmThreads);
+    if (variant == 0)
+        hipLaunchKernelGGL(bm25_ascan_kernel<double>, grid, block, kAsBytes, st, indptr, doc_ids, (const double *)payload,
+                           (const as_uint2 *)post, nnz, qmax, tile_off, n_tab, tshift, n_tiles, N, q_indptr, q_tok, q_order, k,
+                           segs, filter_dir, dir_id, part_scores, part_ids, part_len, redo, dbg);
+    else
+        hipLaunchKernelGGL(bm25_ascan_kernel<float>, grid, block, kAsBytes, st, indptr, doc_ids, (const float *)payload,
+                           (const as_uint2 *)post, nnz, qmax, tile_off, n_tab, tshift, n_tiles, N, q_indptr, q_tok, q_order, k,
+                           segs, filter_dir, dir_id, part_scores, part_ids, part_len, redo, dbg);
+    return hipGetLastError();
+}
+
+// scale of the fixed-point copy: the largest power of two with 64 * (pmax * scale + 1) < 2^32 (at most 2^30)
+float bm25_post_scale(float pmax) {
+    const float bound = 64.0f * pmax * 1.001f + 66.0f;
+    int S = 0;
+    if (bound < 2147483648.0f) { uint32_t b = (uint32_t)bound; S = 0; while (S < 30 && ((uint64_t)(b + 1) << (S + 1)) <= (1ull << 32)) ++S; }
+    return ldexpf(1.0f, S);
+}
+
+hipError_t launch_bm25_post(const int32_t *doc_ids, const float *pay32, int64_t nnz, float scale, void *post, hipStream_t st) {
+    const unsigned g = (unsigned)std::min<int64_t>((nnz + 1 + 255) / 256, 8192);
+    hipLaunchKernelGGL(bm25_post_kernel, dim3(g), dim3(256), 0, st, doc_ids, pay32, nnz, scale, (as_uint2 *)post);
+    return hipGetLastError();
+}
+
+int bm25_ascan_tiles(int64_t N) { return (int)((N + kAsTile - 1) / kAsTile); }
+
+hipError_t launch_bm25_payload_max(const float *pay32, int64_t nnz, uint32_t *bits, hipStream_t st) {
+    if (nnz <= 0) return hipSuccess;
+    const unsigned g = (unsigned)std::min<int64_t>((nnz + 255) / 256, 4096);
+    hipLaunchKernelGGL(bm25_payload_max_kernel, dim3(g), dim3(256), 0, st, pay32, nnz, bits);
+    return hipGetLastError();
+}
+
+hipError_t launch_narrow_f64(const double *in, int64_t n, float *out, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(narrow_f64_kernel, dim3(2048), dim3(256), 0, st, in, n, out);
     return hipGetLastError();
 }
 

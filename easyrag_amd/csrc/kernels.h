@@ -103,8 +103,26 @@ hipError_t launch_bm25_scan(int variant, const int64_t *indptr, const int32_t *d
                             const int32_t *q_indptr, const int32_t *q_tok,
                             const int32_t *q_order /* workgroup -> query (heaviest first) or null */, int B, int k, int segs,
                             const int16_t *filter_dir, const int16_t *dir_id,
-                            double *part_scores, int32_t *part_ids, int32_t *part_len, int ablate,
+                            double *part_scores, int32_t *part_ids, int32_t *part_len,
+                            const uint32_t *only /* null, or [B][segs]: scan only the flagged (query, segment) pairs */,
+                            int cut_tiles, int cut_shift /* segment cuts at (cut_tiles * seg / segs) << cut_shift tiles; 0: n_tiles */, int ablate,
                             unsigned long long *dbg, hipStream_t st);
+// fixed-point scan + exact re-score (bm25.hip: bm25_ascan_kernel): integer LDS atomics in any order, exact scores of the
+// final list by binary search.  tile_off: n_tab + 1 entries per term at 32768 >> tshift documents; post: interleaved
+// {document, fixed-point payload} postings built by launch_bm25_post (nnz + 1 entries, the last one a sentinel), qmax the
+// largest fixed-point payload; redo: zeroed [B][segs] words, set where the list overflowed with near ties or the sums
+// could overflow (those workgroups are then scanned by launch_bm25_scan(..., only = redo)).
+int bm25_ascan_tiles(int64_t N);
+float bm25_post_scale(float pmax);
+hipError_t launch_bm25_post(const int32_t *doc_ids, const float *pay32, int64_t nnz, float scale, void *post, hipStream_t st);
+hipError_t launch_bm25_ascan(int variant, const int64_t *indptr, const int32_t *doc_ids, const void *payload,
+                             const void *post, uint32_t nnz, double qmax, const int32_t *tile_off, int n_tab, int tshift,
+                             int64_t N, const int32_t *q_indptr, const int32_t *q_tok, const int32_t *q_order, int B, int k,
+                             int segs, const int16_t *filter_dir, const int16_t *dir_id,
+                             double *part_scores, int32_t *part_ids, int32_t *part_len, uint32_t *redo,
+                             unsigned long long *dbg, hipStream_t st);
+hipError_t launch_narrow_f64(const double *in, int64_t n, float *out, hipStream_t st);
+hipError_t launch_bm25_payload_max(const float *pay32, int64_t nnz, uint32_t *bits, hipStream_t st);
 // wave-owned scan (bm25.hip: bm25_wscan_kernel): fine_off = skip table at bm25_wscan_sub_docs() granularity
 int bm25_wscan_max_tokens();
 int bm25_wscan_sub_docs(int variant);

@@ -34,10 +34,10 @@ cd $GRAFT_REPO_ROOT
 python - "$WL" "$TAG" "$OUT" <<'PY'
 import collections, csv, glob, re, sys
 wl, tag, out = sys.argv[1:4]
-pat = re.compile(r"bm25_w?scan" if wl == "bm25" else r"dense_(scan|gemv)")
+pat = re.compile(r"bm25_[wa]?scan" if wl == "bm25" else r"dense_(scan|gemv)")
 def klass(name):
     if wl == "bm25":
-        return "wscan" if "wscan" in name else "scan"
+        return "ascan" if "ascan" in name else ("wscan" if "wscan" in name else "scan")
     for key in ("pp3", "pp2", "_pp_", "persist", "append", "store", "gemv"):
         if key in name:
             return key.strip("_")

@@ -240,6 +240,26 @@ def main():
             tot = c[:6].sum()
             res[f"{name} wscan sections (% of thread-0 cycles, k=192)"] = {n_: round(100 * v / tot, 1) for n_, v in zip(names, c[:6])}
             res[f"{name} wscan cycles per query (thread 0)"] = {"total": round(tot / 1024)}
+    if what == "bm25a":                                      # approximate-order scan + exact re-score: times and section clocks
+        indptr, doc, tf, lens, flat = synth.token_csr_torch(n, vocab, seed=3, device=dev)
+        for variant, name in ((BM25S, "bm25s"), (OKAPI, "okapi")):
+            idx = build_bm25_index_from_postings(indptr, doc, tf, lens, variant, compute_payload=False)
+            queries = synth.token_queries(flat, lens, vocab, 1024, seed=9)
+            eng.set_bm25(idx, payload_on_device=True)
+            for rep in "ab":
+                for Bq, k in ((1024, 192), (256, 100), (16, 192), (1, 192)):
+                    qi, qt = queries_to_csr(queries[:Bq])
+                    res[f"{name} ascan B={Bq} k={k} (run {rep})"] = timed(eng, lambda: eng.bm25_topk(qi, qt, k, device_out=True), 3)
+            qi, qt = queries_to_csr(queries)
+            eng.set_option("debug_counters", 1)
+            eng.bm25_topk(qi, qt, 192, device_out=True)
+            torch.cuda.synchronize()
+            c = eng.debug_counters().astype(np.float64)
+            eng.set_option("debug_counters", 0)
+            names = ["ranges+fill_issue", "apply", "apply_barrier", "sweep", "sweep_barrier", "shrink", "rescore", "final"]
+            tot = c[:8].sum()
+            res[f"{name} ascan sections (% of thread-0 cycles, k=192)"] = {n_: round(100 * v / tot, 1) for n_, v in zip(names, c[:8])}
+            res[f"{name} ascan cycles per query (thread 0)"] = {"total": round(tot / 1024)}
     if what == "bm25x":                                      # wave-owned scan: sweep / threshold crossings / free-running waves
         indptr, doc, tf, lens, flat = synth.token_csr_torch(n, vocab, seed=3, device=dev)
         for variant, name in ((BM25S, "bm25s"), (OKAPI, "okapi")):

@@ -115,11 +115,13 @@ def test_hybrid_configs3_exact(engine, dense_data, sparse_data, variant):
 
 @pytest.mark.parametrize("variant,k,n_sample", [(BM25S, 100, 32), (BM25S, 192, 32), (OKAPI, 100, 12), (OKAPI, 192, 12)],
                          ids=["bm25s-k100", "bm25s-k192", "okapi-k100", "okapi-k192"])
-@pytest.mark.parametrize("wscan,crossing", [(1, 2), (1, 0), (0, 0)], ids=["wave-owned-crossings", "wave-owned-sweep", "block-scan"])
-def test_bm25_configs2_exact(engine, sparse_data, variant, k, n_sample, wscan, crossing):
+@pytest.mark.parametrize("ascan,wscan,crossing", [(1, 0, 1), (0, 1, 2), (0, 1, 0), (0, 0, 0)],
+                         ids=["approx-scan-rescore", "wave-owned-crossings", "wave-owned-sweep", "block-scan"])
+def test_bm25_configs2_exact(engine, sparse_data, variant, k, n_sample, ascan, wscan, crossing):
     """B = 256: the document range of every query is split over two workgroups (segments) whose lists are merged."""
     queries = sparse_data[4]
     idx = host_index(sparse_data, variant)
+    engine.set_option("bm25_ascan", ascan)
     engine.set_option("bm25_wscan", wscan)
     engine.set_option("bm25_crossing", crossing)
     try:
@@ -127,7 +129,8 @@ def test_bm25_configs2_exact(engine, sparse_data, variant, k, n_sample, wscan, c
         qi, qt = queries_to_csr(queries[:256])
         ids, sc, ln = engine.bm25_topk(qi, qt, k)
     finally:
-        engine.set_option("bm25_wscan", 1)
+        engine.set_option("bm25_ascan", 1)
+        engine.set_option("bm25_wscan", 0)
         engine.set_option("bm25_crossing", 1)
     assert np.all(ln == k)
     for b in list(range(0, 256, 256 // n_sample))[:n_sample]:

@@ -13,14 +13,17 @@ from oracle.retrievers import Item
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[(1, 2), (1, 0), (0, 0)], ids=["wave-owned-crossings", "wave-owned-sweep", "block-scan"])
+@pytest.fixture(params=[(1, 0, 1), (0, 1, 2), (0, 1, 0), (0, 0, 0)],
+                ids=["approx-scan-rescore", "wave-owned-crossings", "wave-owned-sweep", "block-scan"])
 def bm25_kernel(request, engine):
-    """Every BM25 scan kernel / survivor-selection path must satisfy every parity test (bm25_wscan takes effect at the
-    next set_bm25)."""
-    engine.set_option("bm25_wscan", request.param[0])
-    engine.set_option("bm25_crossing", request.param[1])
+    """Every BM25 scan kernel / survivor-selection path must satisfy every parity test (bm25_ascan / bm25_wscan take
+    effect at the next set_bm25)."""
+    engine.set_option("bm25_ascan", request.param[0])
+    engine.set_option("bm25_wscan", request.param[1])
+    engine.set_option("bm25_crossing", request.param[2])
     yield request.param
-    engine.set_option("bm25_wscan", 1)
+    engine.set_option("bm25_ascan", 1)
+    engine.set_option("bm25_wscan", 0)
     engine.set_option("bm25_crossing", 1)
 
 
@@ -86,6 +89,34 @@ def test_bm25_ties_and_filter(engine, bm25_kernel, variant):
             mask = None if filt[b] < 0 else dir_id == filt[b]
             want = bm25_filter(_oracle_scores(ora, variant, q), k, mask)
             assert list(ids[b, :ln[b]]) == [w[0] for w in want] and list(sc[b, :ln[b]]) == [w[1] for w in want]
+
+
+@pytest.mark.parametrize("variant", [OKAPI, BM25S])
+def test_bm25_near_tie_flood(engine, bm25_kernel, variant):
+    """Five distinct documents, 1800 copies each: thousands of exact ties around any k-th score.  The approximate-order
+    scan cannot shrink its list below capacity (every tied document lies within the margin) and must hand the query to
+    the exact block scan; one- and two-token queries (order-independent sums) and longer ones, with and without filter."""
+    rng = np.random.default_rng(12)
+    base = [list(map(int, rng.integers(0, 9, size=rng.integers(3, 8)))) for _ in range(5)]
+    n = 9000
+    docs = [base[i % 5] for i in range(n)]
+    ora = _oracle_for(variant, docs)
+    idx = build_bm25_index(docs, variant)
+    engine.set_bm25(idx)
+    dir_id = (np.arange(n) % 3).astype(np.int16)
+    engine.set_doc_meta(n, None, dir_id)
+    present = sorted({t for d in base for t in d})
+    queries = [[present[0]], present[:2], present[:4] + [present[1]], list(present), [present[-1]] * 3 + present[:3]]
+    qi, qt = queries_to_csr([idx.tokens_to_ids(q) for q in queries])
+    for filt in (None, np.array([0, -1, 2, 1, 0], np.int16)):
+        for k in (3, 192, 1000):
+            ids, sc, ln = engine.bm25_topk(qi, qt, k, filter_dir=filt)
+            for b, q in enumerate(queries):
+                mask = None if (filt is None or filt[b] < 0) else dir_id == filt[b]
+                want = bm25_filter(_oracle_scores(ora, variant, q), k, mask)
+                assert ln[b] == len(want)
+                assert list(ids[b, :ln[b]]) == [w[0] for w in want], f"k={k} query {b}: ids differ"
+                assert list(sc[b, :ln[b]]) == [w[1] for w in want], f"k={k} query {b}: scores differ"
 
 
 def test_bm25_okapi_negative_idf_floor(engine, bm25_kernel):
