@@ -467,7 +467,7 @@ int bm25_topk_dev(erh_handle *h, const int32_t *qptr_dev, const int32_t *qtok_de
     // approximate-order scan + exact re-score (default) when every payload is a positive normal number; otherwise the
     // wave-owned scan (no per-token workgroup barrier) when the index has its fine skip table and lane j can own token j
     // of every query; otherwise the block scan.  All three produce the same lists.
-    const bool ascan = h->opt_bm25_ascan && S.ascan_ok && h->opt_bm25_ablate == 0;
+    const bool ascan = h->opt_bm25_ascan && S.ascan_ok;
     const bool wscan = !ascan && h->opt_bm25_wscan && S.n_fine > 0 && max_qlen <= erh::bm25_wscan_max_tokens() &&
                        h->opt_bm25_ablate == 0;
     const int tiles = ascan ? erh::bm25_ascan_tiles(S.Nb) : S.n_tiles;
@@ -487,7 +487,7 @@ int bm25_topk_dev(erh_handle *h, const int32_t *qptr_dev, const int32_t *qtok_de
                                                   S.post.p, (uint32_t)S.nnz, S.qmax,
                                                   S.tile_off.as<int32_t>(), S.n_tiles, tshift, S.Nb, qptr_dev, qtok_dev, q_order,
                                                   B, k, segs, filter_dev, dir, p_sc, p_ids, p_len, h->bm_redo.as<uint32_t>(),
-                                                  dbg, st);
+                                                  h->opt_bm25_ablate, dbg, st);
             if (e != hipSuccess) return e;
             // near-tie floods (rare): those workgroups are scanned again by the exact block scan (same document ranges per
             // segment), the others exit at once
@@ -891,7 +891,7 @@ static int bm25_check_payload_sign(erh_handle *h, hipStream_t st) {
             const float scale = erh::bm25_post_scale(pmax);
             ok = scale >= 4096.f;                                                // a coarser grid than 2^-12 is not worth scanning
             if (ok) {
-                e = S.post.ensure((size_t)(S.nnz + 1) * 8);
+                e = S.post.ensure((size_t)(S.nnz + 2) * 8);            // + two sentinel postings (one 16-byte load)
                 if (e == hipSuccess) e = erh::launch_bm25_post(S.doc_ids.as<int32_t>(), p32, S.nnz, scale, S.post.p, st);
                 if (e == hipSuccess) e = hipStreamSynchronize(st);
                 S.qmax = std::floor((double)pmax * (double)scale) + 1.0;

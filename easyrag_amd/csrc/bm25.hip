@@ -782,7 +782,7 @@ __global__ __launch_bounds__(kBmThreads) void bm25_wscan_kernel(
 // launches the exact block scan for those workgroups only.  Indices with non-positive payloads never come here
 // (api.hip checks when an index is set).
 constexpr int kAsTile = erh::kBm25TileF32;
-constexpr int kAsU = 12;                                 // 64-posting pieces per wave and tile held in registers
+constexpr int kAsU = 6;                                  // 128-posting pieces per wave and tile held in registers
 constexpr int kAsReserve = 256;                          // free list slots a shrink must leave
 constexpr int kAsTokChunk = 64;                          // lane j <-> query token j
 constexpr int kAsRegion = kAsTile / kWsWaves;            // accumulators a wave owns (notes, clears)
@@ -814,13 +814,9 @@ static_assert(sizeof(AsHdr) <= 64, "AsHdr must fit its 64-byte slot");
 
 typedef int as_int4 __attribute__((ext_vector_type(4)));
 typedef uint32_t as_uint2 __attribute__((ext_vector_type(2)));
-struct AsRng {                      // posting ranges of one tile: lane j = query token j
-    int pex;                        // 64-posting pieces of the tokens before this one (0x7fffffff: no such token)
-    int n;                          // postings
-    uint32_t start;                 // index of the first one
-    int pt;                         // wave-uniform: pieces of the tile
-};
-struct AsSet { as_uint2 p[kAsU]; };  // .x document, .y fixed-point payload
+typedef uint32_t as_uint4 __attribute__((ext_vector_type(4)));
+constexpr int kAsPiece = 128;                            // postings per piece: two consecutive ones per lane, one 16-byte load
+struct AsSet { as_uint4 p[kAsU]; };  // two postings per lane: .x/.z document, .y/.w fixed-point payload
 
 // inclusive prefix sum over the 64 lanes (DPP: four shifts inside the rows of 16, two row broadcasts)
 __device__ __forceinline__ int as_wave_scan(int x) {
@@ -833,10 +829,11 @@ __device__ __forceinline__ int as_wave_scan(int x) {
     return x;
 }
 
-// lane j: raw skip-table entries a, b of token j (0, 0 for lanes without a token) -> ranges
+// lane j: raw skip-table entries a, b of token j (0, 0 for lanes without a token) -> ranges of one tile:
+// {pieces of the tokens before this one (0x7fffffff: no such token), postings, index of the first one, pieces of the tile}
 __device__ __forceinline__ as_int4 as_make_ranges(uint32_t ip, int a, int b, int nq, int lane) {
     const int n = b - a;
-    const int c = (n + 63) >> 6;
+    const int c = (n + kAsPiece - 1) / kAsPiece;
     const int incl = as_wave_scan(c);
     as_int4 r;
     r[0] = lane < nq ? incl - c : 0x7fffffff;
@@ -845,78 +842,79 @@ __device__ __forceinline__ as_int4 as_make_ranges(uint32_t ip, int a, int b, int
     r[3] = __builtin_amdgcn_readlane(incl, 63);
     return r;
 }
-__device__ __forceinline__ AsRng as_unpack(as_int4 r) {
-    AsRng R;
-    R.pex = r[0]; R.n = r[1]; R.start = (uint32_t)r[2]; R.pt = __builtin_amdgcn_readfirstlane(r[3]);
-    return R;
+
+// Piece descriptors of one tile, one per lane: lane u of wave w describes piece p = w + 16 u of the tile whose ranges
+// lie in LDS at `rt` (64 x the vector above): first posting index and how many postings the piece holds (<= 0: none --
+// past the token's range or past the tile's last piece; > 128: the token goes on in its next piece).  Every lane scans
+// the tokens' piece offsets with broadcast reads; no wave-uniform control flow, no scalar work.
+__device__ __forceinline__ void as_describe(const as_int4 *rt, int nq, int lane, int wave, uint32_t &dstart, int &dcnt) {
+    const int p = wave + lane * kWsWaves;
+    int j = -1;
+    if (nq <= 16) {                                                       // all reads in flight together (lanes past nq hold 0x7fffffff)
+        int px[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) px[i] = rt[i][0];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) j += (px[i] <= p) ? 1 : 0;
+    } else {
+        for (int i = 0; i < nq; ++i) j += (rt[i][0] <= p) ? 1 : 0;        // non-decreasing: last token with offset <= p
+    }
+    const as_int4 r = rt[j < 0 ? 0 : j];
+    const int o = (p - r[0]) * kAsPiece;
+    dstart = (uint32_t)r[2] + (uint32_t)o;
+    dcnt = r[1] - o;
 }
 
-// piece p (wave-uniform, 0 <= p < R.pt) -> index of this lane's posting, or `sentinel` past the end of the token's range
-__device__ __forceinline__ uint32_t as_decode(const AsRng &R, int p, int lane, uint32_t sentinel) {
-    const unsigned long long m = __builtin_amdgcn_ballot_w64(R.pex <= p);
-    const int j = __builtin_popcountll(m) - 1;                            // last token whose pieces start at or before p
-    const int pj = __builtin_amdgcn_readlane(R.pex, j);
-    const int nj = __builtin_amdgcn_readlane(R.n, j);
-    const uint32_t sj = (uint32_t)__builtin_amdgcn_readlane((int)R.start, j);
-    const int o = (p - pj) << 6;                                          // scalar
-    return lane < nj - o ? sj + (uint32_t)o + (uint32_t)lane : sentinel;
-}
-
-// kAsU loads whatever the tile holds (their number is static: the compiler can count them); slots past the wave's last
-// piece read the sentinel posting without decoding anything
-__device__ __forceinline__ void as_fill(AsSet &S, const AsRng &R, const as_uint2 *__restrict__ post, int lane, int wave,
-                                        uint32_t sentinel) {
+// pieces [r0, r0 + kAsU) of this wave (np of them exist) -> registers; lanes without a posting read the sentinel pair
+__device__ __forceinline__ void as_fill(AsSet &S, uint32_t dstart, int dcnt, int r0, int np, const as_uint2 *__restrict__ post,
+                                        int lane, uint32_t sentinel) {
 #pragma unroll
     for (int u = 0; u < kAsU; ++u) {
-        const int p = wave + u * kWsWaves;
-        uint32_t idx = sentinel;
-        if (p < R.pt) idx = as_decode(R, p, lane, sentinel);              // wave-uniform branch around ALU work only
-        S.p[u] = post[idx];
+        if (r0 + u < np) {                                                // wave-uniform
+            const uint32_t st = (uint32_t)__builtin_amdgcn_readlane((int)dstart, r0 + u);
+            const int cn = __builtin_amdgcn_readlane(dcnt, r0 + u);
+            const uint32_t idx = 2 * lane < cn ? st + 2u * (uint32_t)lane : sentinel;
+            S.p[u] = *reinterpret_cast<const as_uint4 *>(post + idx);
+        }
     }
 }
 
 // rare: slot `sl` crossed the threshold -> list of the wave that owns the slot; xz[16] keeps the largest position
 __device__ __forceinline__ void as_note(bool cross, int sl, int32_t *xl, int *xz) {
-    if (__builtin_amdgcn_ballot_w64(cross)) {                             // wave-uniform
-        if (cross) {
-            const int r = sl / kAsRegion;
-            const int pos = atomicAdd(&xz[r], 1);
-            if (pos < kAsXW) xl[r * kAsXW + pos] = sl;
-            atomicMax(&xz[16], pos + 1);
-        }
+    if (cross) {
+        const int r = sl / kAsRegion;
+        const int pos = atomicAdd(&xz[r], 1);
+        if (pos < kAsXW) xl[r * kAsXW + pos] = sl;
+        atomicMax(&xz[16], pos + 1);
     }
 }
 
-// `np` pieces of the set (wave-uniform) onto the integer sums
-__device__ __forceinline__ void as_apply(const AsSet &S, int np, uint32_t *accu, int base_doc, uint32_t thx, int32_t *xl,
-                                         int *xz) {
-    uint32_t old[kAsU];
+// the same pieces onto the integer sums
+__device__ __forceinline__ void as_apply(const AsSet &S, int dcnt, int r0, int np, int lane, uint32_t *accu, int base_doc,
+                                         uint32_t thx, int32_t *xl, int *xz) {
+    uint32_t o0[kAsU], o1[kAsU];
+    bool any = false;
 #pragma unroll
-    for (int u = 0; u < kAsU; ++u) {                                      // all adds of the set in flight together
-        old[u] = thx;                                                     // (lanes without a posting: never a crossing)
-        if (u < np && (int)S.p[u].x >= 0) old[u] = atomicAdd(&accu[(int)S.p[u].x - base_doc], S.p[u].y);
+    for (int u = 0; u < kAsU; ++u) {                                      // all adds of the round in flight together
+        o0[u] = o1[u] = thx;                                              // (lanes without a posting: never a crossing)
+        if (r0 + u < np) {                                                // wave-uniform
+            const int cn = __builtin_amdgcn_readlane(dcnt, r0 + u);
+            if ((int)S.p[u].x >= 0) o0[u] = atomicAdd(&accu[(int)S.p[u].x - base_doc], S.p[u].y);
+            if (2 * lane + 1 < cn) o1[u] = atomicAdd(&accu[(int)S.p[u].z - base_doc], S.p[u].w);
+        }
     }
     if (thx) {                                                            // (no threshold yet: nothing to note, the tile is swept)
 #pragma unroll
         for (int u = 0; u < kAsU; ++u)
-            if (u < np) as_note(thx - 1u - old[u] < S.p[u].y, (int)S.p[u].x - base_doc, xl, xz);   // old < thx <= old + q
-    }
-}
-
-// pieces from `p0` on, straight from memory (tiles with more than kAsU * 16 pieces; queries of more than 64 tokens)
-__device__ __forceinline__ void as_direct(const AsRng &R, int p0, uint32_t *accu, int base_doc,
-                                          const as_uint2 *__restrict__ post, int lane, uint32_t sentinel, uint32_t thx,
-                                          int32_t *xl, int *xz) {
-    for (int p = p0; p < R.pt; p += 2 * kWsWaves) {
-        const uint32_t i0 = as_decode(R, p, lane, sentinel);
-        const uint32_t i1 = p + kWsWaves < R.pt ? as_decode(R, p + kWsWaves, lane, sentinel) : sentinel;
-        const as_uint2 x0 = post[i0], x1 = post[i1];
-        uint32_t o0 = thx, o1 = thx;
-        if ((int)x0.x >= 0) o0 = atomicAdd(&accu[(int)x0.x - base_doc], x0.y);
-        if ((int)x1.x >= 0) o1 = atomicAdd(&accu[(int)x1.x - base_doc], x1.y);
-        if (thx) {
-            as_note(thx - 1u - o0 < x0.y, (int)x0.x - base_doc, xl, xz);
-            as_note(thx - 1u - o1 < x1.y, (int)x1.x - base_doc, xl, xz);
+            if (r0 + u < np) any |= (thx - 1u - o0[u] < S.p[u].y) | (thx - 1u - o1[u] < S.p[u].w);   // old < thx <= old + q
+        if (__builtin_amdgcn_ballot_w64(any)) {                           // wave-uniform, rare once the threshold has settled
+#pragma unroll
+            for (int u = 0; u < kAsU; ++u) {
+                if (r0 + u < np) {
+                    as_note(thx - 1u - o0[u] < S.p[u].y, (int)S.p[u].x - base_doc, xl, xz);
+                    as_note(thx - 1u - o1[u] < S.p[u].w, (int)S.p[u].z - base_doc, xl, xz);
+                }
+            }
         }
     }
 }
@@ -1009,12 +1007,15 @@ __global__ __launch_bounds__(kBmThreads) void bm25_ascan_kernel(
     const int32_t *__restrict__ q_indptr, const int32_t *__restrict__ q_tok, const int32_t *__restrict__ q_order, int k,
     int segs, const int16_t *__restrict__ filter_dir, const int16_t *__restrict__ dir_id,
     double *__restrict__ part_scores, int32_t *__restrict__ part_ids, int32_t *__restrict__ part_len,
-    uint32_t *__restrict__ redo, unsigned long long *__restrict__ dbg) {
+    uint32_t *__restrict__ redo, int abl /* measurement builds: 1 no adds, 2 no posting loads, 4 no clear, 8 one descriptor set */,
+    unsigned long long *__restrict__ dbg) {
 #ifdef ERH_MEASURE
+#define ERH_ABL(B) (abl & (B))
     long long t_sec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long t_mark = dbg ? clock64() : 0;
 #define ERH_SEC(I) do { if (dbg) { const long long n_ = clock64(); t_sec[I] += n_ - t_mark; t_mark = n_; } } while (0)
 #else
+#define ERH_ABL(B) 0
 #define ERH_SEC(I) do { } while (0)
 #endif
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1056,6 +1057,7 @@ __global__ __launch_bounds__(kBmThreads) void bm25_ascan_kernel(
     // The tile's sums are complete (barrier behind the adds): survivors -> list, accumulators cleared.
     // nc0 = hdr->ncand as it was before the tile (nobody changes it during the adds).  true: give up (redo).
     auto finish_tile = [&](int tile, int base_doc, uint32_t thq, int nc0) __attribute__((always_inline)) -> bool {
+        if (h2->redo) return true;                                        // (wave 0 saw a tile it cannot describe)
         const int par = tile & 1;
         const int *xz = xzb + par * 17;
         const int xmax = xz[16];                                          // most crossings noted for one region
@@ -1088,8 +1090,10 @@ __global__ __launch_bounds__(kBmThreads) void bm25_ascan_kernel(
             typedef uint32_t UT __attribute__((ext_vector_type(4)));
             const UT z = {0u, 0u, 0u, 0u};
             uint32_t *mine = accu + wave * kAsRegion + lane * 4;
+            if (!ERH_ABL(4)) {
 #pragma unroll
-            for (int i = 0; i < kAsRegion / 256; ++i) *reinterpret_cast<UT *>(mine + i * 256) = z;
+                for (int i = 0; i < kAsRegion / 256; ++i) *reinterpret_cast<UT *>(mine + i * 256) = z;
+            }
             ERH_SEC(3);
             __syncthreads();
             ERH_SEC(4);
@@ -1135,6 +1139,10 @@ __global__ __launch_bounds__(kBmThreads) void bm25_ascan_kernel(
 
     bool stop = h2->redo != 0;
     if (nq > 0 && t_begin < t_end && !stop) {
+        AsSet S;
+        auto pieces_of = [&](int pt) __attribute__((always_inline)) -> int {   // this wave's share of a tile's pt pieces
+            return pt > wave ? (pt - wave + kWsWaves - 1) / kWsWaves : 0;
+        };
         if (nq <= kAsTokChunk) {
             // wave 0, lane j: token j's posting base and its row of the skip table; ranges are published two tiles ahead
             uint32_t ip = 0u;
@@ -1153,75 +1161,93 @@ __global__ __launch_bounds__(kBmThreads) void bm25_ascan_kernel(
                 a = tokl ? fo[i0] : 0;
                 b = tokl ? fo[i1] : 0;
             };
+            auto publish = [&](int slot, int a, int b) __attribute__((always_inline)) {   // wave 0 only
+                const as_int4 r = as_make_ranges(ip, a, b, nq, lane);
+                rng[slot * 64 + lane] = r;
+                if (lane == 0 && r[3] > 64 * kWsWaves) h2->redo = 1;      // more pieces than a wave's lanes can describe
+            };
             int ra = 0, rb = 0;
             if (wave == 0) {
                 raw(t_begin, ra, rb);
-                rng[0 * 64 + lane] = as_make_ranges(ip, ra, rb, nq, lane);
+                publish(0, ra, rb);
                 raw(t_begin + 1, ra, rb);
-                rng[1 * 64 + lane] = as_make_ranges(ip, ra, rb, nq, lane);
+                publish(1, ra, rb);
                 raw(t_begin + 2, ra, rb);                                 // consumed in the first tile body
             }
             __syncthreads();
-            AsRng Rc = as_unpack(rng[lane]), Rn = Rc;
-            AsSet A, B;
-            as_fill(A, Rc, post, lane, wave, nnz);
+            uint32_t ds_c, ds_n = 0u;                                     // this tile's / the next tile's piece descriptors
+            int dc_c, dc_n = 0;
+            as_describe(rng, nq, lane, wave, ds_c, dc_c);
+            int np_c = pieces_of(__builtin_amdgcn_readfirstlane(rng[0][3])), np_n = 0;
+            as_fill(S, ds_c, dc_c, 0, np_c, post, lane, nnz);
             int r3 = 0;                                                   // (tile - t_begin) % 3: slot of the current tile's ranges
-            auto body = [&](AsSet &cur, AsSet &nxt, int tile) __attribute__((always_inline)) -> bool {
+            for (int tile = t_begin; tile < t_end && !stop; ++tile) {
                 const int base_doc = tile * kAsTile;
                 const uint32_t thq = h2->thq;                             // fixed for the tile (it only moves in as_shrink)
                 const int nc0 = hdr->ncand;
                 int *xz = xzb + (tile & 1) * 17;
                 const int r_n = r3 == 2 ? 0 : r3 + 1, r_nn = r_n == 2 ? 0 : r_n + 1;
-                Rn = as_unpack(rng[r_n * 64 + lane]);                     // next tile (clamped past the end): postings requested now
-                as_fill(nxt, Rn, post, lane, wave, nnz);
-                if (wave == 0) {                                          // ranges of tile + 2 -> LDS, skip-table entries of tile + 3
-                    rng[r_nn * 64 + lane] = as_make_ranges(ip, ra, rb, nq, lane);
-                    raw(tile + 3, ra, rb);
+                if (!ERH_ABL(8)) {                                        // next tile (clamped past the end)
+                    as_describe(rng + r_n * 64, nq, lane, wave, ds_n, dc_n);
+                    np_n = pieces_of(__builtin_amdgcn_readfirstlane(rng[r_n * 64][3]));
                 }
                 ERH_SEC(0);
                 const uint32_t thx = thq > 1u ? thq : 0u;
-                int np = (Rc.pt - wave + kWsWaves - 1) / kWsWaves;        // this wave's pieces of the tile
-                np = np < kAsU ? np : kAsU;
-                as_apply(cur, np, accu, base_doc, thx, xl, xz);
-                as_direct(Rc, wave + kAsU * kWsWaves, accu, base_doc, post, lane, nnz, thx, xl, xz);
+                if (!ERH_ABL(1)) as_apply(S, dc_c, 0, np_c, lane, accu, base_doc, thx, xl, xz);   // (requested a tile ago)
+                for (int r0 = kAsU; r0 < np_c; r0 += kAsU) {              // more pieces than the register slots hold (rare)
+                    as_fill(S, ds_c, dc_c, r0, np_c, post, lane, nnz);
+                    as_apply(S, dc_c, r0, np_c, lane, accu, base_doc, thx, xl, xz);
+                }
+                if (!ERH_ABL(2)) as_fill(S, ds_n, dc_n, 0, np_n, post, lane, nnz);   // lands during the bookkeeping below
+                if (wave == 0) {                                          // ranges of tile + 2 -> LDS, skip-table entries of tile + 3
+                    publish(r_nn, ra, rb);
+                    raw(tile + 3, ra, rb);
+                }
                 ERH_SEC(1);
                 __syncthreads();                                          // every posting of the tile is in its sum
                 ERH_SEC(2);
-                const bool st = finish_tile(tile, base_doc, thq, nc0);
-                Rc = Rn;
+                stop = finish_tile(tile, base_doc, thq, nc0);
+                ds_c = ds_n; dc_c = dc_n; np_c = np_n;
                 r3 = r_n;
-                return st;
-            };
-            for (int tile = t_begin; tile < t_end && !stop; tile += 2) {
-                stop = body(A, B, tile);
-                if (!stop && tile + 1 < t_end) stop = body(B, A, tile + 1);
             }
         } else {
-            // long queries: chunks of 64 tokens, ranges and postings fetched on the spot by every wave
+            // long queries: chunks of 64 tokens; wave 0 publishes the chunk's ranges, everybody fetches and applies on the spot
             for (int tile = t_begin; tile < t_end && !stop; ++tile) {
                 const int base_doc = tile * kAsTile;
                 const uint32_t thq = h2->thq;
                 const int nc0 = hdr->ncand;
+                const uint32_t thx = thq > 1u ? thq : 0u;
                 int *xz = xzb + (tile & 1) * 17;
                 for (int c0 = 0; c0 < nq; c0 += kAsTokChunk) {
                     const int nqc = nq - c0 < kAsTokChunk ? nq - c0 : kAsTokChunk;
-                    int a = 0, b = 0;
-                    uint32_t ipc = 0u;
-                    if (lane < nqc) {
-                        const int64_t tok = q_tok[qs + c0 + lane];
-                        ipc = (uint32_t)indptr[tok];
-                        const int32_t *foc = tile_off + tok * (int64_t)(n_tab + 1);
-                        int i0 = tile << tshift, i1 = (tile + 1) << tshift;
-                        i0 = i0 < n_tab ? i0 : n_tab;
-                        i1 = i1 < n_tab ? i1 : n_tab;
-                        a = foc[i0];
-                        b = foc[i1];
+                    if (wave == 0) {
+                        int a = 0, b = 0;
+                        uint32_t ipc = 0u;
+                        if (lane < nqc) {
+                            const int64_t tok = q_tok[qs + c0 + lane];
+                            ipc = (uint32_t)indptr[tok];
+                            const int32_t *foc = tile_off + tok * (int64_t)(n_tab + 1);
+                            int i0 = tile << tshift, i1 = (tile + 1) << tshift;
+                            i0 = i0 < n_tab ? i0 : n_tab;
+                            i1 = i1 < n_tab ? i1 : n_tab;
+                            a = foc[i0];
+                            b = foc[i1];
+                        }
+                        const as_int4 r = as_make_ranges(ipc, a, b, nqc, lane);
+                        rng[lane] = r;
+                        if (lane == 0 && r[3] > 64 * kWsWaves) h2->redo = 1;
                     }
-                    const AsRng R = as_unpack(as_make_ranges(ipc, a, b, nqc, lane));
-                    as_direct(R, wave, accu, base_doc, post, lane, nnz, thq > 1u ? thq : 0u, xl, xz);
+                    __syncthreads();
+                    uint32_t ds;
+                    int dc;
+                    as_describe(rng, nqc, lane, wave, ds, dc);
+                    const int np = pieces_of(__builtin_amdgcn_readfirstlane(rng[0][3]));
+                    for (int r0 = 0; r0 < np; r0 += kAsU) {
+                        as_fill(S, ds, dc, r0, np, post, lane, nnz);
+                        as_apply(S, dc, r0, np, lane, accu, base_doc, thx, xl, xz);
+                    }
+                    __syncthreads();                                      // (the ranges are overwritten by the next chunk)
                 }
-                ERH_SEC(1);
-                __syncthreads();
                 ERH_SEC(2);
                 stop = finish_tile(tile, base_doc, thq, nc0);
             }
@@ -1232,6 +1258,7 @@ __global__ __launch_bounds__(kBmThreads) void bm25_ascan_kernel(
         if (tid == 0) { redo[(int64_t)q * segs + seg] = 1u; part_len[(int64_t)q * segs + seg] = 0; }
         return;
     }
+    if (ERH_ABL(0xff)) { if (tid == 0) part_len[(int64_t)q * segs + seg] = 0; return; }   // (ablations: the list is garbage)
     ERH_SEC(5);
     // ---- exact re-score of the list, in query-token order, in the library's type ------------------------------------------
     const int n_keep = hdr->ncand;
@@ -1350,12 +1377,13 @@ __global__ __launch_bounds__(kBmThreads) void bm25_ascan_kernel(
     }
 #endif
 #undef ERH_SEC
+#undef ERH_ABL
 }
 
-// interleaved fixed-point postings of the scan above: post[i] = {document, trunc(p32 * scale) + 1}, post[nnz] = {-1, 0}
+// interleaved fixed-point postings of the scan above: post[i] = {document, trunc(p32 * scale) + 1}, post[nnz] = post[nnz + 1] = {-1, 0}
 __global__ void bm25_post_kernel(const int32_t *__restrict__ doc_ids, const float *__restrict__ pay32, int64_t nnz, float scale,
                                  as_uint2 *__restrict__ post) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= nnz; i += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= nnz + 1; i += (int64_t)gridDim.x * blockDim.x) {
         as_uint2 v;
         if (i < nnz) { v.x = (uint32_t)doc_ids[i]; v.y = (uint32_t)(pay32[i] * scale) + 1u; }
         else { v.x = 0xffffffffu; v.y = 0u; }
@@ -1517,7 +1545,7 @@ hipError_t launch_bm25_ascan(int variant, const int64_t *indptr, const int32_t *
                              const void *post, uint32_t nnz, double qmax, const int32_t *tile_off, int n_tab, int tshift,
                              int64_t N, const int32_t *q_indptr, const int32_t *q_tok, const int32_t *q_order, int B, int k,
                              int segs, const int16_t *filter_dir, const int16_t *dir_id,
-                             double *part_scores, int32_t *part_ids, int32_t *part_len, uint32_t *redo,
+                             double *part_scores, int32_t *part_ids, int32_t *part_len, uint32_t *redo, int ablate,
                              unsigned long long *dbg, hipStream_t st) {
     if (B <= 0) return hipSuccess;
     const int n_tiles = (int)((N + kAsTile - 1) / kAsTile);
@@ -1525,11 +1553,11 @@ hipError_t launch_bm25_ascan(int variant, const int64_t *indptr, const int32_t *
     if (variant == 0)
         hipLaunchKernelGGL(bm25_ascan_kernel<double>, grid, block, kAsBytes, st, indptr, doc_ids, (const double *)payload,
                            (const as_uint2 *)post, nnz, qmax, tile_off, n_tab, tshift, n_tiles, N, q_indptr, q_tok, q_order, k,
-                           segs, filter_dir, dir_id, part_scores, part_ids, part_len, redo, dbg);
+                           segs, filter_dir, dir_id, part_scores, part_ids, part_len, redo, ablate, dbg);
     else
         hipLaunchKernelGGL(bm25_ascan_kernel<float>, grid, block, kAsBytes, st, indptr, doc_ids, (const float *)payload,
                            (const as_uint2 *)post, nnz, qmax, tile_off, n_tab, tshift, n_tiles, N, q_indptr, q_tok, q_order, k,
-                           segs, filter_dir, dir_id, part_scores, part_ids, part_len, redo, dbg);
+                           segs, filter_dir, dir_id, part_scores, part_ids, part_len, redo, ablate, dbg);
     return hipGetLastError();
 }
 
@@ -1542,7 +1570,7 @@ float bm25_post_scale(float pmax) {
 }
 
 hipError_t launch_bm25_post(const int32_t *doc_ids, const float *pay32, int64_t nnz, float scale, void *post, hipStream_t st) {
-    const unsigned g = (unsigned)std::min<int64_t>((nnz + 1 + 255) / 256, 8192);
+    const unsigned g = (unsigned)std::min<int64_t>((nnz + 2 + 255) / 256, 8192);
     hipLaunchKernelGGL(bm25_post_kernel, dim3(g), dim3(256), 0, st, doc_ids, pay32, nnz, scale, (as_uint2 *)post);
     return hipGetLastError();
 }

@@ -120,7 +120,7 @@ hipError_t launch_bm25_ascan(int variant, const int64_t *indptr, const int32_t *
                              int64_t N, const int32_t *q_indptr, const int32_t *q_tok, const int32_t *q_order, int B, int k,
                              int segs, const int16_t *filter_dir, const int16_t *dir_id,
                              double *part_scores, int32_t *part_ids, int32_t *part_len, uint32_t *redo,
-                             unsigned long long *dbg, hipStream_t st);
+                             int ablate /* measurement builds only */, unsigned long long *dbg, hipStream_t st);
 hipError_t launch_narrow_f64(const double *in, int64_t n, float *out, hipStream_t st);
 hipError_t launch_bm25_payload_max(const float *pay32, int64_t nnz, uint32_t *bits, hipStream_t st);
 // wave-owned scan (bm25.hip: bm25_wscan_kernel): fine_off = skip table at bm25_wscan_sub_docs() granularity

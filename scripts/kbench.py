@@ -240,7 +240,12 @@ def main():
             tot = c[:6].sum()
             res[f"{name} wscan sections (% of thread-0 cycles, k=192)"] = {n_: round(100 * v / tot, 1) for n_, v in zip(names, c[:6])}
             res[f"{name} wscan cycles per query (thread 0)"] = {"total": round(tot / 1024)}
-    if what == "bm25a":                                      # approximate-order scan + exact re-score: times and section clocks
+    if what == "bm25a":                                      # fixed-point scan + exact re-score: times, ablations, section clocks
+        class _Live(dict):
+            def __setitem__(self, k_, v_):
+                print(f"{k_:44s} {json.dumps(v_)}", flush=True)
+                super().__setitem__(k_, v_)
+        res = _Live()
         indptr, doc, tf, lens, flat = synth.token_csr_torch(n, vocab, seed=3, device=dev)
         for variant, name in ((BM25S, "bm25s"), (OKAPI, "okapi")):
             idx = build_bm25_index_from_postings(indptr, doc, tf, lens, variant, compute_payload=False)
@@ -251,6 +256,11 @@ def main():
                     qi, qt = queries_to_csr(queries[:Bq])
                     res[f"{name} ascan B={Bq} k={k} (run {rep})"] = timed(eng, lambda: eng.bm25_topk(qi, qt, k, device_out=True), 3)
             qi, qt = queries_to_csr(queries)
+            if name == "bm25s":
+                for abl in (0, 1):                # 1 no adds, 4 no clear, 8 one descriptor set (cached loads, adds out of range)
+                    eng.set_option("bm25_ablate", abl)
+                    res[f"{name} ascan B=1024 k=192 ablate={abl}"] = timed(eng, lambda: eng.bm25_topk(qi, qt, 192, device_out=True), 3)
+                eng.set_option("bm25_ablate", 0)
             eng.set_option("debug_counters", 1)
             eng.bm25_topk(qi, qt, 192, device_out=True)
             torch.cuda.synchronize()
