@@ -46,6 +46,9 @@ def parse_args():
     ap.add_argument("--variant", default="bm25s", choices=["bm25s", "okapi"])
     ap.add_argument("--cpu-queries", type=int, default=96, help="queries in the bounded CPU-baseline sample, ~15 s of host work (0 = skip)")
     ap.add_argument("--option", action="append", default=[], help="library option name=value (e.g. dense_n1=131072)")
+    ap.add_argument("--sub", type=int, default=1, help="1 (default): after the headline run, time the other BASELINE.json configs and the "
+                                                       "single-query latencies on the same corpus (sub_benchmarks in the JSON line; "
+                                                       "hybrid workload, one GPU, default sizes only)")
     return ap.parse_args()
 
 
@@ -115,7 +118,40 @@ def cpu_baseline(x_dev, q16_dev, idx, payload, queries, k_dense, k_sparse, topk,
         out["batched_dense"] = {"value": n_sample / (dt - t_dense + t_batched), "unit": "queries/s",
                                 "what": f"dense route as ONE fp32 GEMM [{n_sample} x {x32.shape[0]}] + partition/sort per row "
                                         f"({t_batched:.1f} s instead of {t_dense:.1f} s); sparse route and fusion unchanged"}
+    if ora is not None:
+        out["okapi_literal"] = okapi_literal_loop(idx, queries)
     return out, top_ids
+
+
+def okapi_literal_loop(idx, queries, n_docs=50_000, n_queries=8):
+    """rank_bm25.BM25Okapi.get_scores as the library runs it -- `[(doc.get(q) or 0) for doc in doc_freqs]` per query
+    token over one dict per document (the reference's default bm25_type 0) -- timed on the first `n_docs`
+    documents of the corpus (building 1M Python dicts would take minutes; the loop is linear in the number of documents,
+    and the figure for 1M documents is given as an explicit extrapolation, not as a measurement)."""
+    from oracle import BM25Okapi
+    n_docs = min(n_docs, idx.n_docs)
+    t0 = time.perf_counter()
+    docs = [[] for _ in range(n_docs)]
+    for t in range(idx.n_vocab):                               # postings -> token lists (tf repeats) of the first n_docs documents
+        s, e = int(idx.indptr[t]), int(idx.indptr[t + 1])
+        if s == e:
+            continue
+        d = idx.doc_ids[s:e]
+        cut = int(np.searchsorted(d, n_docs))
+        for di, f in zip(d[:cut].tolist(), idx.tf[s:s + cut].tolist()):
+            docs[di].extend([t] * f)
+    ora = BM25Okapi(docs, k1=1.5, b=0.75, epsilon=0.25)
+    t_build = time.perf_counter() - t0
+    nq = min(n_queries, len(queries))
+    t0 = time.perf_counter()
+    for b in range(nq):
+        ora.get_scores([int(t) for t in queries[b]])
+    dt = time.perf_counter() - t0
+    per_q = dt / max(nq, 1)
+    return {"n_queries": nq, "n_docs": n_docs, "seconds": dt, "s_per_query": per_q, "index_build_s": t_build,
+            "extrapolated_s_per_query_at_corpus_size": per_q * idx.n_docs / n_docs,
+            "what": "rank_bm25 dict loop (one dict lookup per document and query token), get_scores only; "
+                    "linear extrapolation in the number of documents, stated not measured"}
 
 
 def pmc_traffic(args, kernel_class, algorithmic_bytes):
@@ -139,6 +175,104 @@ def pmc_traffic(args, kernel_class, algorithmic_bytes):
     t = float(rec["hbm_bytes_per_launch"])
     return {"traffic": t, "traffic_unit": "bytes/launch", "traffic_over_algorithmic": t / algorithmic_bytes,
             "traffic_source": "profiles/pmc_traffic.json (" + rec["command"] + "; " + rec["correction"] + ")"}
+
+
+def roofline_of(kd, dom):
+    """Roofline block of one kernel class from the library's HIP-event time and the algorithmic work it booked."""
+    if not kd["launches"]:
+        return None
+    sec = kd["ms"] * 1e-3
+    ai = kd["flops"] / kd["bytes"] if kd["bytes"] else 0.0
+    if dom == "dense_scan" and ai > RIDGE:
+        ach = kd["flops"] / sec / 1e12
+        roof = {"bound": "mfma", "achieved": ach, "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s", "frac": ach / MFMA_F16_PEAK_TF,
+                "traffic": None}
+    else:
+        ach = kd["bytes"] / sec / 1e9
+        roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None}
+    roof.update({"kernel": dom, "launches": int(kd["launches"]), "avg_launch_ms": kd["ms"] / kd["launches"],
+                 "algorithmic_bytes_per_launch": kd["bytes"] / kd["launches"],
+                 "flops_per_launch": kd["flops"] / kd["launches"], "arithmetic_intensity": ai,
+                 "hbm_equiv_gbs": kd["bytes"] / sec / 1e9 if kd["bytes"] else None})
+    return roof
+
+
+def run_sub(eng, classes, fn, n_queries, dom, min_seconds=0.3, sync_each=False, what=""):
+    """One sub-benchmark on the resident corpus: enough steps for >= min_seconds of timed work, kernel classes from the
+    library's event timers, roofline of `dom`.  sync_each: host-visible latency of single calls (B = 1)."""
+    import torch
+    for i in range(2):
+        fn(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(3):
+        fn(i)
+    torch.cuda.synchronize()
+    est = max((time.perf_counter() - t0) / 3, 1e-5)
+    steps = int(min(4000, max(10, np.ceil(min_seconds / est))))
+    eng.set_profiling(True)
+    eng.reset_kernel_time()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        fn(i)
+        if sync_each:
+            torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    eng.set_profiling(False)
+    kt = {name: eng.kernel_time(cls) for name, cls in classes}
+    rec = {"what": what, "queries_per_step": n_queries, "steps": steps, "ms_per_step": dt / steps * 1e3,
+           "value": n_queries * steps / dt, "unit": "queries/s", "timed_seconds": dt,
+           "kernel_ms_per_step": {k_: v["ms"] / steps for k_, v in kt.items()}}
+    if dom is not None:
+        rec["roofline"] = roofline_of(kt[dom], dom)
+    return rec
+
+
+def sub_benchmarks(eng, synth, queries_to_csr, build_index, OKAPI, q16_pool, tok_pool, csr_pool, postings, pool):
+    """The BASELINE.json configurations the headline is NOT quoted on, and the reference's own call pattern (one query at
+    a time), timed on the corpus that is already resident: each with its own step count (>= 0.3 s of timed work),
+    kernel-class times from the library's HIP events and a roofline block.  Roughly 10 s of wall time in all."""
+    from easyrag_amd._lib import ERH_K_BM25_MERGE, ERH_K_BM25_SCAN, ERH_K_DENSE_SCAN, ERH_K_DENSE_SELECT, ERH_K_FUSE
+    classes = (("dense_scan", ERH_K_DENSE_SCAN), ("dense_select", ERH_K_DENSE_SELECT), ("bm25_scan", ERH_K_BM25_SCAN),
+               ("bm25_merge", ERH_K_BM25_MERGE), ("fuse", ERH_K_FUSE))
+    out = {}
+    q256 = [q[:256].contiguous() for q in q16_pool]
+    csr256 = [queries_to_csr(t[:256]) for t in tok_pool]
+    out["dense_b256_top100"] = run_sub(
+        eng, classes, lambda i: eng.dense_topk(q256[i % pool], 100, device_out=True), 256, "dense_scan",
+        what="configs[1]: 1M x 1024 fp16, dense cosine top-100 only, batch 256")
+    out["bm25_b256_top100"] = run_sub(
+        eng, classes, lambda i: eng.bm25_topk(*csr256[i % pool], 100, device_out=True), 256, "bm25_scan",
+        what="configs[2]: 1M chunks, BM25 (bm25s, fp32) only top-100, batch 256")
+    q1 = [q[:1].contiguous() for q in q16_pool]
+    csr1 = [queries_to_csr(t[:1]) for t in tok_pool]
+    out["dense_b1_top288_latency"] = run_sub(
+        eng, classes, lambda i: eng.dense_topk(q1[i % pool], 288, device_out=True), 1, "dense_scan", sync_each=True,
+        what="one query per call (the reference's call pattern), dense top-288, host-visible latency per call")
+    out["hybrid_b1_latency"] = run_sub(
+        eng, classes, lambda i: eng.hybrid_topk(q1[i % pool], *csr1[i % pool], k_dense=288, k_sparse=192, K=60, topk=10,
+                                                device_out=True), 1, "dense_scan", sync_each=True,
+        what="one query per call, dense(288)+BM25(192)+RRF top-10, host-visible latency per call")
+    # the reference's default BM25 (bm25_type 0 = rank-bm25 Okapi, float64): a second index slot over the same postings
+    indptr, doc, tf, lens = postings
+    idx_ok = build_index(indptr, doc, tf, lens, OKAPI, compute_payload=False)
+    eng.set_bm25(idx_ok, payload_on_device=True, slot=1)
+    try:
+        out["hybrid_okapi_b1024"] = run_sub(
+            eng, classes, lambda i: eng.hybrid_topk(q16_pool[i % pool], *csr_pool[i % pool], k_dense=288, k_sparse=192, K=60,
+                                                    topk=10, device_out=True, slot=1), int(q16_pool[0].shape[0]), "dense_scan",
+            what="configs[3] with the reference's default bm25_type 0 (Okapi, float64 scores)")
+        kt = out["hybrid_okapi_b1024"]
+        out["bm25_okapi_b256_top100"] = run_sub(
+            eng, classes, lambda i: eng.bm25_topk(*csr256[i % pool], 100, device_out=True, slot=1), 256, "bm25_scan",
+            what="configs[2] with Okapi (float64) scores, batch 256")
+        del kt
+    finally:
+        eng.free_bm25_slot(1)
+        eng._select(0)
+    return out
 
 
 def spawn_ranks(args) -> int:
@@ -226,12 +360,18 @@ def main():
 
     counter = [0]
 
+    gather_events = []
+
     def step():
         p = counter[0] % pool
         counter[0] += 1
         out = local_step(p)
         if world > 1:
-            out = shards.gather(*out)
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+            out = shards.gather(*out)                         # erh_dense_check, pack -> ONE all-gather -> unpack
+            ev[1].record()
+            gather_events.append(ev)
         return out
 
     for _ in range(args.warmup):
@@ -241,6 +381,7 @@ def main():
         eng.dense_check()                                     # raises on candidate overflow
     eng.set_profiling(True)
     eng.reset_kernel_time()
+    gather_events.clear()
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
@@ -266,24 +407,7 @@ def main():
         per_step = {k_: (v["ms"] / args.steps) for k_, v in kt.items()}
         dom = "bm25_scan" if args.workload == "bm25" else "dense_scan"
         kd = kt[dom]
-        roof = None
-        if kd["launches"]:
-            sec = kd["ms"] * 1e-3
-            ai = kd["flops"] / kd["bytes"] if kd["bytes"] else 0.0
-            if dom == "dense_scan" and ai > RIDGE:
-                ach = kd["flops"] / sec / 1e12
-                roof = {"bound": "mfma", "achieved": ach, "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s",
-                        "frac": ach / MFMA_F16_PEAK_TF, "traffic": None}
-            else:
-                ach = kd["bytes"] / sec / 1e9
-                roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": ach / HBM_PEAK_GBS, "traffic": None}
-            roof.update({"kernel": dom, "launches": int(kd["launches"]),
-                         "avg_launch_ms": kd["ms"] / kd["launches"],
-                         "algorithmic_bytes_per_launch": kd["bytes"] / kd["launches"],
-                         "flops_per_launch": kd["flops"] / kd["launches"],
-                         "arithmetic_intensity": ai,
-                         "hbm_equiv_gbs": kd["bytes"] / sec / 1e9 if kd["bytes"] else None})
+        roof = roofline_of(kd, dom)
         if roof is not None:
             roof.update(pmc_traffic(args, dom, roof["algorithmic_bytes_per_launch"]))
         cpu = None
@@ -320,10 +444,20 @@ def main():
                        "query_batches_rotated": pool,
                        "parallelism": f"query-sharded x{world}, corpus replicated, all-gather of fused top-k"
                                       + (f" ({shards.mode})" if world > 1 else "")},
+            "multi_gpu": None if world == 1 else {
+                "rccl_ranks": int(torch.distributed.get_world_size()), "backend": torch.distributed.get_backend(),
+                "gather_mode": shards.mode, "gather_fallback_reason": shards.fallback_reason,
+                "allgather_ms_per_step": (sum(a.elapsed_time(b) for a, b in gather_events) / max(len(gather_events), 1)),
+                "allgather_what": "rank 0: dense_check + pack kernel + all_gather_into_tensor + unpack kernel (CUDA events)"},
             "roofline": roof,
             "cpu_baseline": cpu,
             "kernel_ms_per_step": per_step,
         }
+        default_shape = (args.chunks == 1_000_000 and args.dim == 1024 and args.vocab == 262_144 and args.batch == 0
+                         and not args.option and args.variant == "bm25s")
+        if args.sub and world == 1 and args.workload == "hybrid" and default_shape:
+            rec["sub_benchmarks"] = sub_benchmarks(eng, synth, queries_to_csr, build_bm25_index_from_postings, OKAPI,
+                                                   q16_pool, tok_pool, csr_pool, (indptr, doc, tf, lens), pool)
         print(json.dumps(rec), flush=True)
     if world > 1:
         torch.distributed.barrier()

@@ -54,10 +54,32 @@ def _digest() -> str:
 
 
 def build(force: bool = False, verbose: bool = False) -> Path:
-    """Compile every HIP translation unit for gfx950 and link the shared library. Idempotent."""
+    """Compile every HIP translation unit for gfx950 and link the shared library. Idempotent; concurrent callers (the
+    ranks of a multi-GPU launch) serialise on a lock file, and a box without hipcc keeps using a library that exists."""
     dig = _digest()
     if not force and LIB_PATH.exists() and STAMP.exists() and STAMP.read_text().strip() == dig:
         return LIB_PATH
+    import fcntl
+    with open(str(LIB_PATH) + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and LIB_PATH.exists() and STAMP.exists() and STAMP.read_text().strip() == dig:
+                return LIB_PATH                      # another process built it while this one waited
+            try:
+                _hipcc()
+            except RuntimeError:
+                if LIB_PATH.exists():
+                    import warnings
+                    warnings.warn(f"hipcc not found: using the existing {LIB_PATH.name} although its source digest "
+                                  f"stamp is missing or stale")
+                    return LIB_PATH
+                raise
+            return _build_locked(dig, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(dig: str, verbose: bool) -> Path:
     hipcc = _hipcc()
     obj_dir = PKG_DIR / ("build_measure" if MEASURE else "build")
     obj_dir.mkdir(exist_ok=True)

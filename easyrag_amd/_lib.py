@@ -45,6 +45,7 @@ SIGNATURES = {
     "erh_build_bm25_index": (_i32, [_vp, _i32, _i64, _i64, _i64, _vp, _vp, _i32, _dbl, _dbl, _dbl, C.POINTER(_i64)]),
     "erh_get_bm25_csr": (_i32, [_vp, _vp, _vp, _vp, _vp, C.POINTER(_dbl), C.POINTER(_dbl)]),
     "erh_bm25_select": (_i32, [_vp, _i32]),
+    "erh_bm25_release": (_i32, [_vp, _i32]),
     "erh_get_bm25_payload": (_i32, [_vp, _vp]),
     "erh_set_doc_meta": (_i32, [_vp, _i64, _vp, _vp]),
     "erh_dense_topk": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _vp]),

@@ -6,7 +6,11 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <future>
+#include <memory>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -108,6 +112,7 @@ struct erh_handle {
     // multi-GPU exchange (erh_comm_* / erh_allgather_topk): RCCL communicator + packed send / receive rows
     void *comm = nullptr;
     int comm_rank = 0, comm_world = 1;
+    int opt_comm_timeout_s = 120;            // bounded wait of erh_comm_init
     DevBuf gather_send, gather_recv;
     // options
     int64_t opt_n0 = 32768, opt_n1 = 131072;
@@ -597,7 +602,7 @@ int erh_create(int device, erh_handle **out) {
     h->device = device;
     h->n_cus = prop.multiProcessorCount;
     if (erh::dense_scan_init() != hipSuccess || erh::select_init() != hipSuccess || erh::bm25_init() != hipSuccess ||
-        erh::fuse_init() != hipSuccess) {
+        erh::fuse_init() != hipSuccess || erh::dense_gemv_init() != hipSuccess) {   // (function attributes are per device)
         delete h;
         return ERH_ERR_HIP;
     }
@@ -662,6 +667,7 @@ int erh_set_option(erh_handle *h, const char *name, int64_t value) {
     if (!strcmp(name, "dense_ablate") || !strcmp(name, "bm25_ablate") || !strcmp(name, "debug_counters"))
         return value == 0 ? ERH_OK : h->fail(ERH_ERR_UNSUPPORTED, "measurement option: rebuild the library with ERH_MEASURE=1");
 #endif
+    if (!strcmp(name, "comm_timeout_s")) { if (value < 1 || value > 86400) return h->fail(ERH_ERR_INVALID, "comm_timeout_s"); h->opt_comm_timeout_s = (int)value; return ERH_OK; }
     if (!strcmp(name, "bm25_lpt")) { h->opt_bm25_lpt = value != 0; return ERH_OK; }
     if (!strcmp(name, "bm25_segs")) { if (value < 0 || value > 64) return h->fail(ERH_ERR_INVALID, "bm25_segs"); h->opt_bm25_segs = (int)value; return ERH_OK; }
     if (!strcmp(name, "bm25_crossing")) { if (value < 0 || value > 2) return h->fail(ERH_ERR_INVALID, "bm25_crossing"); h->opt_bm25_crossing = (int)value; return ERH_OK; }
@@ -712,7 +718,7 @@ int erh_reset_kernel_time(erh_handle *h) {
 
 int erh_dense_check(erh_handle *h, void *stream) {
     if (!h) return ERH_ERR_INVALID;
-    if (!h->flags.p) return ERH_OK;
+    if (!h->flags.p || !h->last.valid) return ERH_OK;           // no dense route has run on this handle
     HIPCHK(h, hipSetDevice(h->device));
     return dense_check_flags(h, (hipStream_t)stream);
 }
@@ -1147,6 +1153,17 @@ int erh_bm25_select(erh_handle *h, int slot) {
     return ERH_OK;
 }
 
+int erh_bm25_release(erh_handle *h, int slot) {
+    if (!h) return ERH_ERR_INVALID;
+    if (slot < 0 || slot >= ERH_BM25_SLOTS) return h->fail(ERH_ERR_INVALID, "erh_bm25_release: slot out of range");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipDeviceSynchronize());                            // nothing in flight may still read the slot
+    Bm25State &S = h->bm[slot];
+    S.release();
+    S = Bm25State();
+    return ERH_OK;
+}
+
 int erh_get_bm25_payload(erh_handle *h, void *out_payload) {
     if (!h || !out_payload) return ERH_ERR_INVALID;
     if (h->bm[h->cur].variant < 0) return h->fail(ERH_ERR_STATE, "bm25 index not set");
@@ -1530,8 +1547,25 @@ int erh_comm_init(erh_handle *h, int rank, int world, const void *id128) {
     HIPCHK(h, hipSetDevice(h->device));
     rccl_unique_id id;
     memcpy(&id, id128, sizeof id);
-    void *c = nullptr;
-    const int rc = r.CommInitRank(&c, world, id, rank);
+    // ncclCommInitRank blocks until every rank has joined.  A rank that never arrives (crashed, wrong id) must not hang
+    // the others for ever: the call runs on a helper thread and this one waits at most comm_timeout_s seconds (option,
+    // default 120).  After a timeout the helper is abandoned (it may still be blocked inside RCCL) and the handle stays
+    // without a communicator -- callers fall back to the torch.distributed gather (easyrag_amd.dist.QueryShards).
+    struct InitState { void *comm = nullptr; int rc = -1; };
+    auto state = std::make_shared<InitState>();
+    auto done = std::make_shared<std::promise<void>>();
+    std::future<void> fut = done->get_future();
+    const int dev = h->device;
+    auto init_fn = r.CommInitRank;
+    std::thread([state, done, init_fn, id, world, rank, dev]() {
+        (void)hipSetDevice(dev);
+        state->rc = init_fn(&state->comm, world, id, rank);
+        done->set_value();
+    }).detach();
+    if (fut.wait_for(std::chrono::seconds(h->opt_comm_timeout_s)) != std::future_status::ready)
+        return h->fail(ERH_ERR_HIP, "erh_comm_init: ncclCommInitRank did not return within comm_timeout_s (a rank is missing?)");
+    const int rc = state->rc;
+    void *c = state->comm;
     if (rc != 0) return rccl_fail(h, "ncclCommInitRank", rc);
     h->comm = c;
     h->comm_rank = rank;

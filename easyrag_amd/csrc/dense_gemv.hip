@@ -120,16 +120,6 @@ static hipError_t gemv_launch(bool store, const _Float16 *X, int64_t N, int d, i
     if (c1 <= c0) return hipSuccess;
     const size_t lds = (size_t)d * 32;                                   // d/32 steps x 1 KiB
     if (B > 16 || d % 32 != 0 || lds > 128 * 1024) return hipErrorInvalidValue;
-    static bool attr_set = false;
-    if (!attr_set) {
-        const void *fns[] = {(const void *)dense_gemv_kernel<false, 32>, (const void *)dense_gemv_kernel<true, 32>,
-                             (const void *)dense_gemv_kernel<false, 16>, (const void *)dense_gemv_kernel<true, 16>};
-        for (const void *f : fns) {
-            hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-            if (e != hipSuccess) return e;
-        }
-        attr_set = true;
-    }
     // resident grid: LDS allows 160 KiB / lds workgroups per CU; registers 2-3 (KB 32) or 4-5 (KB 16) waves per SIMD
     int per_cu = (int)((160 * 1024) / (lds + 256));
     if (per_cu > g_gemv_wgs) per_cu = g_gemv_wgs;
@@ -144,6 +134,17 @@ static hipError_t gemv_launch(bool store, const _Float16 *X, int64_t N, int d, i
     else { if (store) ERH_GV_LAUNCH(true, 32); else ERH_GV_LAUNCH(false, 32); }
 #undef ERH_GV_LAUNCH
     return hipGetLastError();
+}
+
+// dynamic-LDS limit of the kernels on the CURRENT device (erh_create calls it for every handle: attributes are per device)
+hipError_t dense_gemv_init() {
+    const void *fns[] = {(const void *)dense_gemv_kernel<false, 32>, (const void *)dense_gemv_kernel<true, 32>,
+                         (const void *)dense_gemv_kernel<false, 16>, (const void *)dense_gemv_kernel<true, 16>};
+    for (const void *f : fns) {
+        hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 void dense_gemv_tune(int kb, int wgs) {

@@ -35,6 +35,7 @@ hipError_t launch_dense_naive(const _Float16 *Q, int B, const _Float16 *X, int64
 
 // ---- dense_gemv.hip: append scan for batches of at most dense_gemv_max_queries() queries ----------------------------
 int dense_gemv_max_queries();
+hipError_t dense_gemv_init();
 void dense_gemv_tune(int kb, int wgs);   // loads in flight per wave (16 / 32 steps), workgroups per CU
 hipError_t launch_dense_gemv_append(const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1, const _Float16 *Q, int B,
                                     const float *tau, const int16_t *filter_dir, const int16_t *dir_id, ErhCand *cand,

@@ -18,6 +18,7 @@ The reference has no counterpart (single process, one query at a time: src/main.
 from __future__ import annotations
 
 import os
+import sys
 from typing import Callable, Optional, Tuple
 
 import torch
@@ -114,10 +115,47 @@ class QueryShards:
         self.mode = mode
         self._k = None
         self._send = self._recv = self._out = None
+        self.fallback_reason = None
         if mode == "native" and world > 1:
-            uid = [engine.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(uid, src=0, group=group)
-            engine.comm_init(rank, world, uid[0])
+            self._init_native()
+
+    def _init_native(self):
+        """Join the library's own RCCL communicator -- or, if any rank cannot (librccl not loadable, ncclCommInitRank
+        failed or timed out), fall back to the "torch" gather on EVERY rank (the decision is an all-reduce, so no rank
+        is left waiting inside a collective the others never enter)."""
+        eng, rank, world, group = self.engine, self.rank, self.world, self.group
+        dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+
+        def all_ok(ok: bool) -> bool:
+            t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+            return bool(int(t.item()))
+
+        reason = None
+        uid = None
+        try:                                              # every rank probes its own librccl (cheap) before anyone blocks
+            uid = eng.comm_unique_id()
+        except Exception as exc:                          # noqa: BLE001 -- any failure means "not available here"
+            reason = f"librccl not usable on rank {rank}: {exc}"
+        if all_ok(reason is None):
+            box = [uid if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0, group=group)
+            try:
+                eng.comm_init(rank, world, box[0])
+            except Exception as exc:                      # noqa: BLE001
+                reason = f"erh_comm_init failed on rank {rank}: {exc}"
+            if not all_ok(reason is None):
+                reason = reason or "erh_comm_init failed on another rank"
+                try:
+                    eng.comm_destroy()
+                except Exception:                         # noqa: BLE001
+                    pass
+        else:
+            reason = reason or "librccl not usable on another rank"
+        if reason is not None:
+            self.mode, self.fallback_reason = "torch", reason
+            print(f"[easyrag_amd.dist] rank {rank}: native gather unavailable, using torch.distributed ({reason})",
+                  file=sys.stderr, flush=True)
 
     def _buffers(self, k: int, device):
         if self._k != k:
@@ -130,12 +168,17 @@ class QueryShards:
             self._k = k
         return self._send, self._recv, self._out
 
-    def gather(self, ids, sc, ln):
+    def gather(self, ids, sc, ln, check: bool = True):
+        """All-gather this rank's [B_local x k] result.  `check` (default): erh_dense_check first -- a dense / fused call
+        with device outputs leaves queries that need more than one round of the exhaustive path (and the re-run of the
+        fusion over their corrected lists) to that call, so rows must not leave the rank before it has run."""
         lo, hi = self.bounds
         if ids.shape[0] != hi - lo:
             raise ValueError(f"rank {self.rank} must contribute its shard of {hi - lo} queries, got {ids.shape[0]}")
         if self.mode == "host":
             return allgather_topk(ids, sc, ln, self.n, self.group)
+        if check:
+            self.engine.dense_check()                      # (returns at once when the last call had no dense route)
         k = int(ids.shape[1])
         send, recv, out = self._buffers(k, ids.device)
         if self.mode == "native":

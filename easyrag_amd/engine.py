@@ -120,10 +120,13 @@ class RetrievalEngine:
         raise RuntimeError(f"all {_lib.ERH_BM25_SLOTS} BM25 index slots of this engine are in use")
 
     def free_bm25_slot(self, slot: int):
+        """Empty a slot: the device copies of its index are freed as well (erh_bm25_release)."""
+        if self._bm25_slots[slot] is not None and getattr(self, "_h", None):
+            self._check(self._lib.erh_bm25_release(self._h, int(slot)))
         self._bm25_slots[slot] = None
 
     def _select(self, slot: Optional[int]) -> int:
-        slot = self._bm25_cur if slot is None else int(slot)
+        slot = 0 if slot is None else int(slot)              # every BM25 call names its slot; None = slot 0, as documented
         if not 0 <= slot < _lib.ERH_BM25_SLOTS:
             raise ValueError("BM25 slot out of range")
         if slot != self._bm25_cur:

@@ -13,8 +13,10 @@
  * with id = -1, score = 0.  A handle is thread-compatible (one handle per host thread).
  * All device work of a call is enqueued on `stream` (a hipStream_t passed as void*, NULL = the
  * default stream).  With host output buffers the call returns after the results have landed;
- * with device output buffers (out_is_device = 1) it returns after enqueueing and erh_sync()
- * (or any stream synchronisation) completes it.
+ * with device output buffers (out_is_device = 1) it returns after enqueueing; BM25 / fusion results are
+ * complete after erh_sync() (or any stream synchronisation), dense and fused results after erh_dense_check()
+ * -- a plain stream synchronisation is NOT enough there: queries that need more than one round of the
+ * exhaustive path are finished by that call.
  *
  * Tie rule everywhere: score descending, then document index ascending ("canonical" order; the
  * reference's numpy argsort()[::-1] order among equal scores is implementation-defined).
@@ -119,6 +121,9 @@ int erh_get_bm25_csr(erh_handle *h, int64_t *indptr, int32_t *doc_ids, int32_t *
  * erh_hybrid_topk act on (default 0).  Document metadata (erh_set_doc_meta) is shared by all slots. */
 #define ERH_BM25_SLOTS 4
 int erh_bm25_select(erh_handle *h, int slot);
+/* Free the device copies (postings, skip tables, fixed-point copy) of one slot; the slot is empty afterwards.
+ * (BM25Retriever's throw-away index of get_scores(query, docs), retrievers.py:131-147, lives in such a slot.) */
+int erh_bm25_release(erh_handle *h, int slot);
 
 /* Copy the payload the handle holds back to the host (float32 or float64 [nnz]); parity/debug. */
 int erh_get_bm25_payload(erh_handle *h, void *out_payload);
@@ -231,22 +236,30 @@ int erh_reset_kernel_time(erh_handle *h);
  *   dense_var, dense_rot, dense_sync   schedule variants of the ping-pong kernels (measured, off: see DESIGN.md, dead ends)
  *   dense_gemv (1)        batches of at most 16 queries stream the chunk matrix through a 16x16x32 skinny-GEMM kernel
  *                         (the reference's one-query-at-a-time call pattern) instead of the padded 256-query scan
+ *   bm25_ascan (1)        fixed-point BM25 scan + exact re-score: the postings are scattered into integer LDS sums in any order
+ *                         (one 16-byte load and two integer atomics per lane), documents whose sum can still reach the
+ *                         running k-th best stay on a list, and the final list is scored exactly (binary search per
+ *                         document and token, library summation order).  Needs an index whose payloads are all positive
+ *                         normal numbers, else the kernels below run; keeps an interleaved copy of the postings (8
+ *                         bytes each), built at the next erh_set_bm25_* / erh_build_bm25_index.  0 = off
  *   bm25_crossing (1)     wave-owned scan: survivors from threshold crossings noted in the token loop instead of a sweep
  *                         over the accumulators (1 = fp32 sums only, 2 = fp64 too, 0 = always sweep); indices with a
  *                         non-positive payload always sweep
  *   bm25_lpt (1)          launch the queries of a batch in order of decreasing posting volume (shorter tail of the scan)
  *   bm25_segs (0)         document-range segments per query (0 = enough for >= 512 workgroups)
- *   bm25_wscan (1)        wave-owned BM25 scan (no per-token workgroup barrier) for batches whose queries have at most
- *                         64 tokens; 0 = block scan for everything.  Needs a fine skip table (4 bytes per term and per
- *                         2048 / 1024 documents), built by erh_set_bm25_* unless it would exceed bm25_fine_max_mb (8192)
+ *   bm25_wscan (0)        when bm25_ascan does not apply: wave-owned BM25 scan (no per-token workgroup barrier) for batches
+ *                         whose queries have at most 64 tokens; 0 = block scan.  Needs a fine skip table (4 bytes per term
+ *                         and per 2048 / 1024 documents: 0.5 GB at 1M documents x 262144 terms, growing with V * N), built
+ *                         by the next erh_set_bm25_* unless it would exceed bm25_fine_max_mb (8192)
+ *   comm_timeout_s (120)  bounded wait of erh_comm_init for the other ranks
  *   dense_ablate, bm25_ablate, debug_counters   MEASUREMENT BUILDS ONLY (library compiled with -DERH_MEASURE, i.e.
  *                         ERH_MEASURE=1 python -m easyrag_amd._build): variants with parts of a kernel removed /
  *                         section clocks; results are invalid while an ablate value is non-zero.  The product
  *                         build contains none of these variants and rejects non-zero values (ERH_ERR_UNSUPPORTED). */
 int erh_set_option(erh_handle *h, const char *name, int64_t value);
 
-/* After a dense / hybrid call with DEVICE outputs: synchronise `stream` and read the call's flag words (host-output
- * calls do this themselves).  Queries whose candidate budgets overflowed are answered by the exhaustive path on the
+/* REQUIRED after a dense / hybrid call with DEVICE outputs, before the rows are read or sent anywhere (erh_sync is not
+ * a substitute): synchronise `stream` and read the call's flag words (host-output calls do this themselves).  Queries whose candidate budgets overflowed are answered by the exhaustive path on the
  * device, up to 16 per call without any host involvement; if a call flagged more, the remaining rounds (and, for a
  * fused call, the RRF over the corrected lists) are run here, so that the results are complete when this returns. */
 int erh_dense_check(erh_handle *h, void *stream);

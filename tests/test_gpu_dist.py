@@ -80,3 +80,38 @@ def test_query_shards_world1_torch_and_native(engine, workload):
             assert torch.equal(a, b)
     finally:
         engine.comm_destroy()
+
+
+def test_gather_completes_the_exhaustive_rounds_first(engine):
+    """with device outputs only the first 16 uncertified queries of a batch are answered by the exhaustive path
+    on the stream; the remaining rounds run inside erh_dense_check.  QueryShards.gather must therefore check before it
+    packs: 40 queries whose speculative threshold fails (the sampling premise is broken on purpose, as in
+    test_dense_speculation_failure_is_caught) go through a device-output call and the gather, and must equal the
+    host-output call (which checks itself)."""
+    import torch
+    from oracle import to_f16_unit
+    rng = np.random.default_rng(5)
+    n, d, b, k = 40000, 256, 40, 60
+    topic = rng.standard_normal(d)
+    x32 = rng.standard_normal((n, d))
+    x32[:40] = topic + 0.2 * rng.standard_normal((40, d))
+    x = to_f16_unit(x32)
+    q16 = to_f16_unit(topic + 0.2 * rng.standard_normal((b, d)))
+    engine.set_option("dense_n0", 512)
+    engine.set_option("dense_gemv", 0)
+    engine.set_option("dense_shuffle", 0)
+    try:
+        engine.set_dense(x)
+        want = engine.dense_topk(q16, k)                                  # host outputs: complete on return
+        assert engine.dense_diag()["exhaustive"] == b
+        qd = torch.from_numpy(q16).cuda()
+        sh = erd.QueryShards(b, 0, 1, engine=engine, mode="torch")
+        got = sh.step(lambda lo, hi: engine.dense_topk(qd[lo:hi], k, device_out=True))
+        torch.cuda.synchronize()
+        assert np.array_equal(got[0].cpu().numpy(), want[0])
+        assert np.array_equal(got[1].cpu().numpy().view(np.uint64), want[1].view(np.uint64))
+        assert np.array_equal(got[2].cpu().numpy(), want[2])
+    finally:
+        engine.set_option("dense_shuffle", 1)
+        engine.set_option("dense_n0", 32768)
+        engine.set_option("dense_gemv", 1)

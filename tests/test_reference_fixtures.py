@@ -47,7 +47,9 @@ def test_fixture_matches_reference_data_when_present():
     data = mod.build()
     assert data == _fixture()
     # the stop-word file is loaded as pipeline.py:28-31 does: a set of stripped lines (767 lines, duplicates collapse)
-    assert data["stop_size"] == 749 and "" in mod.load_stopwords("/root/reference/src/data/hit_stopwords.txt") or True
+    stop_set = mod.load_stopwords("/root/reference/src/data/hit_stopwords.txt")
+    assert data["stop_size"] == len(stop_set) == 749  # 767 lines in the file; duplicates and stripped variants collapse
+    assert "" not in stop_set                        # (no blank line survives the strip: ' ' is dropped by the tokenizer rule)
     # and the oracle's tokenize_and_remove_stopwords agrees with the generator's restatement on every query
     stop = mod.load_stopwords("/root/reference/src/data/hit_stopwords.txt")
     cutter = mod.CharCutter()
