@@ -16,7 +16,7 @@ MEASURE = os.environ.get("ERH_MEASURE", "0") not in ("", "0")
 LIB_PATH = PKG_DIR / ("libeasyrag_hip_measure.so" if MEASURE else "libeasyrag_hip.so")
 STAMP = PKG_DIR / (".libeasyrag_hip_measure.stamp" if MEASURE else ".libeasyrag_hip.stamp")
 
-SOURCES = ["api.hip", "dense_scan.hip", "dense_gemv.hip", "select.hip", "bm25.hip", "fuse.hip", "index_build.hip"]
+SOURCES = ["api.hip", "dense_scan.hip", "dense_gemv.hip", "select.hip", "bm25.hip", "fuse.hip", "index_build.hip", "text.hip"]
 HEADERS = ["common.h", "kernels.h"]
 
 HIPCC_FLAGS = [

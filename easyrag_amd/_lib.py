@@ -73,6 +73,15 @@ SIGNATURES = {
     "erh_dense_exhaustive_count": (_i32, [_vp, C.POINTER(_i32)]),
     "erh_dense_seed_rank": (_i32, [_i32, _i64, _i64]),
     "erh_debug_dense_scores": (_i32, [_vp, _vp, _i32, _i64, _i32, _i32, _vp]),
+    "erh_vocab_create": (_i32, [C.POINTER(_vp)]),
+    "erh_vocab_destroy": (_i32, [_vp]),
+    "erh_vocab_size": (_i64, [_vp]),
+    "erh_vocab_encode": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _i64, _vp, C.POINTER(_i64)]),
+    "erh_vocab_token": (_i32, [_vp, _i32, C.POINTER(_vp), C.POINTER(_i32)]),
+    "erh_cutter_create": (_i32, [_vp, _i64, C.POINTER(_vp)]),
+    "erh_cutter_destroy": (_i32, [_vp]),
+    "erh_cutter_cut": (_i32, [_vp, _vp, _i64, _vp, _i64, C.POINTER(_i64)]),
+    "erh_text_encode": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _i64, _vp, C.POINTER(_i64)]),
 }
 
 

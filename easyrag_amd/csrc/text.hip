@@ -1,0 +1,386 @@
+// Text side of the BM25 index build, host only (second half): the reference tokenises every
+// node with jieba and feeds Python token lists to rank_bm25 / bm25s
+// (/root/reference/src/easyrag/custom/retrievers.py:72-76, 94-118; src/easyrag/pipeline/pipeline.py:176-178).  Here:
+//   erh_vocab_*    token bytes -> term ids through an open-addressing hash table; ids follow first appearance, exactly
+//                  like the Python dict loop they replace (easyrag_amd/index.py: vocab_ids), so the CSR built from them
+//                  is bit-identical;
+//   erh_cutter_*   a dictionary cutter with jieba's sentence-splitting rules and its DAG / maximum-log-probability route
+//                  (jieba 0.42.1, Tokenizer.cut(sentence, cut_all=False, HMM=False)) over a caller-supplied dictionary in
+//                  jieba's "word freq [tag]" text format.  jieba's default call also runs an HMM over runs of
+//                  out-of-dictionary characters; its model tables ship with jieba and are not reproduced here, so this
+//                  cutter is the HMM=False algorithm.
+// No device code in this file; it is part of libeasyrag_hip.so so that one library serves the whole retriever shim.
+#include "../../include/easyrag_hip.h"
+
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+namespace {
+
+// FNV-1a, 64 bit, byte by byte (so a fragment's hash extends to the next character in O(1)), then a finaliser
+constexpr uint64_t kFnvBasis = 1469598103934665603ull;
+inline uint64_t fnv_extend(uint64_t h, const char *p, size_t n) {
+    for (size_t i = 0; i < n; ++i) { h ^= (unsigned char)p[i]; h *= 1099511628211ull; }
+    return h;
+}
+inline uint64_t fnv_final(uint64_t h) {
+    h ^= h >> 32;
+    h *= 0x9e3779b97f4a7c15ull;
+    h ^= h >> 29;
+    return h;
+}
+inline uint64_t hash_bytes(const char *p, size_t n) { return fnv_final(fnv_extend(kFnvBasis, p, n)); }
+
+}  // namespace
+
+struct erh_vocab {
+    std::vector<char> arena;                 // token bytes, back to back
+    std::vector<int64_t> tok_off;            // token id -> [tok_off[id], tok_off[id + 1])
+    std::vector<int32_t> slots;              // open addressing: -1 empty, else token id
+    std::vector<uint64_t> hashes;            // per token id
+    size_t mask = 0;
+
+    erh_vocab() { tok_off.push_back(0); slots.assign(1024, -1); mask = 1023; }
+
+    void grow() {
+        const size_t n = slots.size() * 2;
+        std::vector<int32_t> s(n, -1);
+        const size_t m = n - 1;
+        for (size_t id = 0; id < hashes.size(); ++id) {
+            size_t i = hashes[id] & m;
+            while (s[i] >= 0) i = (i + 1) & m;
+            s[i] = (int32_t)id;
+        }
+        slots.swap(s);
+        mask = m;
+    }
+
+    int32_t find_or_add(const char *p, size_t n, bool add) { return find_or_add(hash_bytes(p, n), p, n, add); }
+
+    int32_t find_or_add(uint64_t h, const char *p, size_t n, bool add) {
+        size_t i = h & mask;
+        for (;;) {
+            const int32_t id = slots[i];
+            if (id < 0) break;
+            if (hashes[id] == h) {
+                const int64_t b = tok_off[id], e = tok_off[id + 1];
+                if ((size_t)(e - b) == n && memcmp(arena.data() + b, p, n) == 0) return id;
+            }
+            i = (i + 1) & mask;
+        }
+        if (!add) return -1;
+        if (hashes.size() >= 0x7ffffffeull) return -2;
+        const int32_t id = (int32_t)hashes.size();
+        arena.insert(arena.end(), p, p + n);
+        tok_off.push_back((int64_t)arena.size());
+        hashes.push_back(h);
+        slots[i] = id;
+        if (hashes.size() * 10 > slots.size() * 6) grow();       // load factor <= 0.6
+        return id;
+    }
+};
+
+struct erh_cutter {
+    erh_vocab words;                         // jieba's FREQ keys: every word and every prefix of a word ...
+    std::vector<int64_t> freq;               // ... and their frequencies by id (prefixes that are not words: 0)
+    double total = 0.0;
+
+    void set(const char *p, size_t n, int64_t f, bool overwrite) {
+        const int32_t id = words.find_or_add(p, n, true);
+        if ((size_t)id >= freq.size()) { freq.resize((size_t)id + 1, 0); freq[id] = f; }
+        else if (overwrite) freq[id] = f;
+    }
+};
+
+namespace {
+
+// UTF-8 -> code points + byte offset of each (offsets has one more entry: the end).  Malformed bytes decode as
+// themselves (one "character" per byte, value 0xDC80 + byte, Python's surrogateescape convention), so cutting never fails.
+void decode_utf8(const char *s, int64_t n, std::vector<uint32_t> &cp, std::vector<int64_t> &off) {
+    cp.clear();
+    off.clear();
+    int64_t i = 0;
+    while (i < n) {
+        const unsigned char c = (unsigned char)s[i];
+        uint32_t v = 0xDC80u + c;
+        int len = 1;
+        if (c < 0x80) { v = c; }
+        else if ((c & 0xE0) == 0xC0 && i + 1 < n && ((unsigned char)s[i + 1] & 0xC0) == 0x80) {
+            const uint32_t w = ((uint32_t)(c & 0x1F) << 6) | ((unsigned char)s[i + 1] & 0x3F);
+            if (w >= 0x80) { v = w; len = 2; }
+        } else if ((c & 0xF0) == 0xE0 && i + 2 < n && ((unsigned char)s[i + 1] & 0xC0) == 0x80 &&
+                   ((unsigned char)s[i + 2] & 0xC0) == 0x80) {
+            const uint32_t w = ((uint32_t)(c & 0x0F) << 12) | (((uint32_t)(unsigned char)s[i + 1] & 0x3F) << 6) |
+                               ((unsigned char)s[i + 2] & 0x3F);
+            if (w >= 0x800 && !(w >= 0xD800 && w <= 0xDFFF)) { v = w; len = 3; }
+        } else if ((c & 0xF8) == 0xF0 && i + 3 < n && ((unsigned char)s[i + 1] & 0xC0) == 0x80 &&
+                   ((unsigned char)s[i + 2] & 0xC0) == 0x80 && ((unsigned char)s[i + 3] & 0xC0) == 0x80) {
+            const uint32_t w = ((uint32_t)(c & 0x07) << 18) | (((uint32_t)(unsigned char)s[i + 1] & 0x3F) << 12) |
+                               (((uint32_t)(unsigned char)s[i + 2] & 0x3F) << 6) | ((unsigned char)s[i + 3] & 0x3F);
+            if (w >= 0x10000 && w <= 0x10FFFF) { v = w; len = 4; }
+        }
+        cp.push_back(v);
+        off.push_back(i);
+        i += len;
+    }
+    off.push_back(n);
+}
+
+// jieba.re_han_default: [一-鿕a-zA-Z0-9+#&\._%\-]
+inline bool is_han_class(uint32_t c) {
+    if (c >= 0x4E00 && c <= 0x9FD5) return true;
+    if ((c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z') || (c >= '0' && c <= '9')) return true;
+    return c == '+' || c == '#' || c == '&' || c == '.' || c == '_' || c == '%' || c == '-';
+}
+// Python's \s on str patterns (= str.isspace)
+inline bool is_space(uint32_t c) {
+    if ((c >= 0x09 && c <= 0x0D) || (c >= 0x1C && c <= 0x20)) return true;
+    switch (c) {
+        case 0x85: case 0xA0: case 0x1680: case 0x2028: case 0x2029: case 0x202F: case 0x205F: case 0x3000: return true;
+        default: return c >= 0x2000 && c <= 0x200A;
+    }
+}
+inline bool is_eng(uint32_t c) { return (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z') || (c >= '0' && c <= '9'); }
+
+// one block of han-class characters [b, e): jieba's get_DAG + calc + __cut_DAG_NO_HMM; appends token END positions
+// (character indices) to `ends`
+void cut_block(const erh_cutter *c, const char *s, const std::vector<int64_t> &off, const std::vector<uint32_t> &cp, int64_t b,
+               int64_t e, std::vector<int64_t> &ends) {
+    const int64_t N = e - b;
+    // DAG edges k -> i (sentence[k : i + 1] is a word) with the word's frequency, found by extending the fragment's
+    // hash one character at a time; dag_off[k] .. dag_off[k + 1] index the edge arrays
+    std::vector<int32_t> dag_off((size_t)N + 1, 0), dag_to;
+    std::vector<int64_t> dag_f;
+    for (int64_t k = 0; k < N; ++k) {
+        uint64_t h = kFnvBasis;
+        const char *p0 = s + off[b + k];
+        bool any = false;
+        for (int64_t i = k; i < N; ++i) {                                // frag = sentence[k : i + 1]
+            h = fnv_extend(h, s + off[b + i], (size_t)(off[b + i + 1] - off[b + i]));
+            const int32_t id = const_cast<erh_vocab &>(c->words).find_or_add(fnv_final(h), p0, (size_t)(off[b + i + 1] - off[b + k]), false);
+            if (id < 0) break;                                           // `while i < N and frag in self.FREQ`
+            if (c->freq[id]) { dag_to.push_back((int32_t)i); dag_f.push_back(c->freq[id]); any = true; }
+        }
+        if (!any) { dag_to.push_back((int32_t)k); dag_f.push_back(1); }   // a character on its own: `FREQ.get(...) or 1`
+        dag_off[k + 1] = (int32_t)dag_to.size();
+    }
+    const double logtotal = std::log(c->total);
+    std::vector<double> rp((size_t)N + 1, 0.0);
+    std::vector<int32_t> rx((size_t)N + 1, 0);
+    for (int64_t idx = N - 1; idx >= 0; --idx) {
+        bool first = true;
+        double best = 0.0;
+        int32_t bx = 0;
+        for (int32_t ed = dag_off[idx]; ed < dag_off[idx + 1]; ++ed) {   // max over tuples (log-probability, x)
+            const int32_t x = dag_to[ed];
+            const double v = std::log((double)dag_f[ed]) - logtotal + rp[x + 1];
+            if (first || v > best || (v == best && x > bx)) { best = v; bx = x; first = false; }
+        }
+        rp[idx] = best;
+        rx[idx] = bx;
+    }
+    int64_t x = 0;
+    bool buf = false;                                                    // a run of single ASCII letters / digits is open
+    while (x < N) {
+        const int64_t y = rx[x] + 1;
+        if (y - x == 1 && is_eng(cp[b + x])) {
+            buf = true;
+        } else {
+            if (buf) { ends.push_back(b + x); buf = false; }
+            ends.push_back(b + y);
+        }
+        x = y;
+    }
+    if (buf) ends.push_back(b + N);
+}
+
+// whole sentence: jieba's cut() block splitting around cut_block; token END positions in characters
+void cut_text(const erh_cutter *c, const char *text, int64_t n_bytes, std::vector<uint32_t> &cp, std::vector<int64_t> &off,
+              std::vector<int64_t> &ends) {
+    ends.clear();
+    decode_utf8(text, n_bytes, cp, off);
+    const int64_t n = (int64_t)cp.size();
+    int64_t i = 0;
+    while (i < n) {
+        if (is_han_class(cp[i])) {                                       // re_han.split: maximal runs of the han class
+            int64_t e = i;
+            while (e < n && is_han_class(cp[e])) ++e;
+            cut_block(c, text, off, cp, i, e, ends);
+            i = e;
+        } else if (cp[i] == '\r' && i + 1 < n && cp[i + 1] == '\n') {   // re_skip: (\r\n|\s), the pair first
+            ends.push_back(i + 2);
+            i += 2;
+        } else {                                                         // a white-space character, or any other one, alone
+            ends.push_back(i + 1);
+            ++i;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int erh_vocab_create(erh_vocab **out) {
+    if (!out) return ERH_ERR_INVALID;
+    *out = new (std::nothrow) erh_vocab();
+    return *out ? ERH_OK : ERH_ERR_NOMEM;
+}
+
+int erh_vocab_destroy(erh_vocab *v) {
+    if (!v) return ERH_ERR_INVALID;
+    delete v;
+    return ERH_OK;
+}
+
+int64_t erh_vocab_size(const erh_vocab *v) { return v ? (int64_t)v->hashes.size() : -1; }
+
+int erh_vocab_encode(erh_vocab *v, const char *bytes, const int64_t *doc_off, int64_t n_docs, int sep, int add,
+                     int32_t *out_ids, int64_t cap, int32_t *out_lens, int64_t *n_out) {
+    if (!v || !doc_off || n_docs < 0 || !n_out || (n_docs > 0 && !out_lens) || sep < 0 || sep > 255) return ERH_ERR_INVALID;
+    int64_t w = 0;
+    try {
+        for (int64_t d = 0; d < n_docs; ++d) {
+            const int64_t b = doc_off[d], e = doc_off[d + 1];
+            if (e < b || (e > b && !bytes)) return ERH_ERR_INVALID;
+            int32_t cnt = 0;
+            if (e > b) {                                                 // an empty document has no tokens
+                int64_t t0 = b;
+                for (int64_t i = b; i <= e; ++i) {
+                    if (i == e || (unsigned char)bytes[i] == (unsigned char)sep) {
+                        const int32_t id = v->find_or_add(bytes + t0, (size_t)(i - t0), add != 0);
+                        if (id == -2) return ERH_ERR_UNSUPPORTED;        // more than 2^31 - 2 distinct tokens
+                        if (w < cap && out_ids) out_ids[w] = id;
+                        ++w;
+                        ++cnt;
+                        t0 = i + 1;
+                    }
+                }
+            }
+            out_lens[d] = cnt;
+        }
+    } catch (const std::bad_alloc &) {
+        return ERH_ERR_NOMEM;
+    }
+    *n_out = w;
+    return (out_ids && w > cap) ? ERH_ERR_OVERFLOW : ERH_OK;             // (the caller re-runs with a larger buffer; ids are stable)
+}
+
+int erh_vocab_token(const erh_vocab *v, int32_t id, const char **bytes, int32_t *len) {
+    if (!v || !bytes || !len || id < 0 || (size_t)id >= v->hashes.size()) return ERH_ERR_INVALID;
+    *bytes = v->arena.data() + v->tok_off[id];
+    *len = (int32_t)(v->tok_off[id + 1] - v->tok_off[id]);
+    return ERH_OK;
+}
+
+int erh_cutter_create(const char *dict_text, int64_t n_bytes, erh_cutter **out) {
+    if (!out || (n_bytes > 0 && !dict_text) || n_bytes < 0) return ERH_ERR_INVALID;
+    *out = nullptr;
+    erh_cutter *c = new (std::nothrow) erh_cutter();
+    if (!c) return ERH_ERR_NOMEM;
+    try {
+        // jieba.Tokenizer.gen_pfdict: `word, freq = line.split(' ')[:2]`; every prefix of a word enters with frequency 0
+        int64_t i = 0;
+        std::vector<uint32_t> cp;
+        std::vector<int64_t> off;
+        while (i < n_bytes) {
+            int64_t e = i;
+            while (e < n_bytes && dict_text[e] != '\n') ++e;
+            int64_t le = e;
+            while (le > i && (dict_text[le - 1] == '\r' || dict_text[le - 1] == ' ' || dict_text[le - 1] == '\t')) --le;
+            int64_t ls = i;
+            while (ls < le && (dict_text[ls] == ' ' || dict_text[ls] == '\t')) ++ls;   // (jieba strips the line)
+            if (ls < le) {
+                int64_t sp = ls;
+                while (sp < le && dict_text[sp] != ' ') ++sp;
+                if (sp == le) { delete c; return ERH_ERR_INVALID; }      // "word freq" needs the frequency
+                int64_t fe = sp + 1;
+                while (fe < le && dict_text[fe] != ' ') ++fe;
+                char *endp = nullptr;
+                const std::string num(dict_text + sp + 1, (size_t)(fe - sp - 1));
+                const long long f = strtoll(num.c_str(), &endp, 10);
+                if (num.empty() || *endp != '\0' || f < 0) { delete c; return ERH_ERR_INVALID; }
+                const char *wp = dict_text + ls;
+                const size_t wn = (size_t)(sp - ls);
+                c->set(wp, wn, f, true);                                 // lfreq[word] = freq (a repeated word: the last one)
+                c->total += (double)f;
+                decode_utf8(wp, (int64_t)wn, cp, off);
+                for (size_t ch = 0; ch + 1 < cp.size(); ++ch)            // proper prefixes enter with 0 unless present
+                    c->set(wp, (size_t)off[ch + 1], 0, false);
+            }
+            i = e + 1;
+        }
+    } catch (const std::bad_alloc &) {
+        delete c;
+        return ERH_ERR_NOMEM;
+    }
+    if (!(c->total > 0.0)) { delete c; return ERH_ERR_INVALID; }         // log(total) must exist
+    *out = c;
+    return ERH_OK;
+}
+
+int erh_cutter_destroy(erh_cutter *c) {
+    if (!c) return ERH_ERR_INVALID;
+    delete c;
+    return ERH_OK;
+}
+
+int erh_cutter_cut(const erh_cutter *c, const char *text, int64_t n_bytes, int64_t *out_ends, int64_t cap, int64_t *n_tokens) {
+    if (!c || !n_tokens || n_bytes < 0 || (n_bytes > 0 && !text)) return ERH_ERR_INVALID;
+    try {
+        std::vector<uint32_t> cp;
+        std::vector<int64_t> off, ends;
+        cut_text(c, text, n_bytes, cp, off, ends);
+        *n_tokens = (int64_t)ends.size();
+        if (out_ends) {
+            if ((int64_t)ends.size() > cap) return ERH_ERR_OVERFLOW;
+            for (size_t t = 0; t < ends.size(); ++t) out_ends[t] = off[(size_t)ends[t]];   // byte offsets of the token ends
+        }
+    } catch (const std::bad_alloc &) {
+        return ERH_ERR_NOMEM;
+    }
+    return ERH_OK;
+}
+
+int erh_text_encode(const erh_cutter *c, erh_vocab *v, const erh_vocab *stop, const char *bytes, const int64_t *text_off,
+                    int64_t n_texts, int add, int32_t *out_ids, int64_t cap, int32_t *out_lens, int64_t *n_out) {
+    if (!c || !v || !text_off || n_texts < 0 || !n_out || (n_texts > 0 && !out_lens)) return ERH_ERR_INVALID;
+    int64_t w = 0;
+    try {
+        std::vector<uint32_t> cp;
+        std::vector<int64_t> off, ends;
+        for (int64_t d = 0; d < n_texts; ++d) {
+            const int64_t b = text_off[d], e = text_off[d + 1];
+            if (e < b || (e > b && !bytes)) return ERH_ERR_INVALID;
+            cut_text(c, bytes + b, e - b, cp, off, ends);
+            int32_t cnt = 0;
+            int64_t t0 = 0;
+            for (int64_t end_ch : ends) {
+                const int64_t t1 = off[(size_t)end_ch];
+                const char *tp = bytes + b + t0;
+                const size_t tn = (size_t)(t1 - t0);
+                t0 = t1;
+                if (tn == 1 && tp[0] == ' ') continue;                   // `word != ' '` (retrievers.py:75)
+                if (stop && const_cast<erh_vocab *>(stop)->find_or_add(tp, tn, false) >= 0) continue;   // `word not in stopwords`
+                const int32_t id = v->find_or_add(tp, tn, add != 0);
+                if (id == -2) return ERH_ERR_UNSUPPORTED;
+                if (id < 0) continue;                                    // add == 0: out-of-vocabulary query token
+                if (w < cap && out_ids) out_ids[w] = id;
+                ++w;
+                ++cnt;
+            }
+            out_lens[d] = cnt;
+        }
+    } catch (const std::bad_alloc &) {
+        return ERH_ERR_NOMEM;
+    }
+    *n_out = w;
+    return (out_ids && w > cap) ? ERH_ERR_OVERFLOW : ERH_OK;
+}
+
+}  // extern "C"

@@ -251,8 +251,11 @@ class BM25Retriever(_RetrieverBase):
         self._similarity_top_k = similarity_top_k
         self.embed_type = embed_type
         self.stopwords = stopwords
-        self._corpus = [tokenize_and_remove_stopwords(tokenizer, get_node_content(n, embed_type), stopwords)
-                        for n in self._nodes]
+        # a NativeCutter tokenises, drops stop words and numbers the tokens inside the library (erh_text_encode): no Python
+        # object per token.  Any other tokenizer (jieba.Tokenizer(), as the pipeline passes) goes through its own cut().
+        native_text = device_build and hasattr(tokenizer, "encode_texts") and "" not in self._str_stopwords(stopwords)[1]
+        self._corpus = None if native_text else [
+            tokenize_and_remove_stopwords(tokenizer, get_node_content(n, embed_type), stopwords) for n in self._nodes]
         self.bm25_type = bm25_type
         self.k1, self.b, self.epsilon = 1.5, 0.75, 0.25          # ref retrievers.py:103-105
         self._corpus_state = _corpus_for(self._nodes, engine)
@@ -264,7 +267,13 @@ class BM25Retriever(_RetrieverBase):
         if device_build:
             # tokens -> ids on the host (dictionary lookups), everything else of the index build on the GPU
             # (erh_build_bm25_index: sort, run lengths, df, idf, payload); nothing but the vocabulary stays here
-            vocab, flat, lens = vocab_ids(self._corpus)
+            if native_text:
+                from .text import NativeVocab
+                vocab = NativeVocab()
+                flat, lens = tokenizer.encode_texts([get_node_content(n, embed_type) for n in self._nodes], vocab,
+                                                    self._str_stopwords(stopwords)[0])
+            else:
+                vocab, flat, lens = vocab_ids(self._corpus)
             self.bm25: BM25Index = self.engine.build_bm25(flat, lens, max(len(vocab), 1), variant=variant, k1=self.k1,
                                                           b=self.b, epsilon=self.epsilon, slot=self._slot, fetch=False)
             self.bm25.vocab = vocab
@@ -273,6 +282,13 @@ class BM25Retriever(_RetrieverBase):
                                          compute_payload=not payload_on_device)
             self.engine.set_bm25(self.bm25, payload_on_device=payload_on_device, slot=self._slot)
         self.filter_dict = None
+
+    @staticmethod
+    def _str_stopwords(stopwords):
+        """(usable stop words, the ones the native path cannot express): membership of '' never matters (no cutter emits an
+        empty token); anything that is not a str can never equal a token."""
+        sw = [w for w in stopwords if isinstance(w, str) and w != ""]
+        return sw, [w for w in sw if "\x00" in w]
 
     def close(self):
         """Give the BM25 slot back to the engine."""

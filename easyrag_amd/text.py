@@ -1,0 +1,169 @@
+"""Native text side of the BM25 index build (libeasyrag_hip.so: csrc/text.hip; include/easyrag_hip.h, erh_vocab_* /
+erh_cutter_*).  Host code, no GPU involved.
+
+  NativeVocab    token -> term id, ids by first appearance: replaces the per-token Python dict loop of the shim's index
+                 build (``easyrag_amd.index.vocab_ids``) -- the reference's libraries do the same walk inside
+                 ``rank_bm25.BM25Okapi.__init__`` / ``bm25s.BM25.index`` (retrievers.py:94-118).
+  NativeCutter   a tokenizer object with jieba's ``cut`` interface (what ``tokenize_and_remove_stopwords`` calls,
+                 retrievers.py:72-76; the pipeline passes ``jieba.Tokenizer()``, pipeline.py:176-178) running jieba
+                 0.42.1's dictionary-DAG algorithm for ``cut(sentence, cut_all=False, HMM=False)`` over a caller-supplied
+                 dictionary in jieba's text format.  jieba's default (HMM=True) also re-cuts runs of out-of-dictionary
+                 characters with an HMM whose tables ship with jieba; that step is not reproduced here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Hashable, Iterable, List, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+
+_SEP = "\x00"
+
+
+class NativeVocab:
+    def __init__(self):
+        self._lib = _lib.load()
+        h = C.c_void_p()
+        rc = self._lib.erh_vocab_create(C.byref(h))
+        if rc != 0:
+            raise _lib.ErhError(rc, "erh_vocab_create failed")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.erh_vocab_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self) -> int:
+        return int(self._lib.erh_vocab_size(self._h))
+
+    @staticmethod
+    def representable(doc: Sequence[Hashable]) -> bool:
+        """Token lists go through the library as NUL-separated UTF-8; that covers lists of str without NUL / empty tokens."""
+        return all(isinstance(t, str) for t in doc) and "" not in doc and _SEP not in "".join(doc)
+
+    def encode(self, corpus: Sequence[Sequence[str]], add: bool = True) -> Tuple[np.ndarray, np.ndarray]:
+        """Token lists -> (flat int32 ids of all documents back to back, int32 tokens per document).  One C call; the
+        Python work is one join + one encode per DOCUMENT."""
+        blobs = [_SEP.join(d).encode("utf-8", "surrogatepass") for d in corpus]
+        off = np.zeros(len(blobs) + 1, np.int64)
+        if blobs:
+            np.cumsum(np.fromiter((len(b) for b in blobs), dtype=np.int64, count=len(blobs)), out=off[1:])
+        blob = b"".join(blobs)
+        lens = np.zeros(max(len(blobs), 1), np.int32)
+        cap = int(off[-1]) // 2 + len(blobs) + 1                         # >= the token count unless tokens are single bytes
+        need = C.c_int64(0)
+        for _ in range(2):
+            ids = np.empty(max(cap, 1), np.int32)
+            rc = self._lib.erh_vocab_encode(self._h, blob, off.ctypes.data, len(blobs), 0, 1 if add else 0,
+                                            ids.ctypes.data, cap, lens.ctypes.data, C.byref(need))
+            if rc == _lib.ERH_ERR_OVERFLOW:
+                cap = int(need.value)
+                continue
+            if rc != 0:
+                raise _lib.ErhError(rc, "erh_vocab_encode failed")
+            return ids[: int(need.value)].copy(), lens[: len(blobs)].copy()
+        raise RuntimeError("erh_vocab_encode: token count changed between two passes")
+
+    def ids_of(self, tokens: Sequence[str]) -> np.ndarray:
+        """Query side: known tokens -> ids in order, repeats kept, out-of-vocabulary tokens dropped."""
+        toks = [t for t in tokens if isinstance(t, str) and t != "" and _SEP not in t]
+        if not toks:
+            return np.zeros(0, np.int32)
+        ids, _ = self.encode([toks], add=False)
+        return ids[ids >= 0]
+
+    def token(self, i: int) -> str:
+        p, n = C.c_void_p(), C.c_int32()
+        rc = self._lib.erh_vocab_token(self._h, int(i), C.byref(p), C.byref(n))
+        if rc != 0:
+            raise IndexError(i)
+        return C.string_at(p, n.value).decode("utf-8", "surrogatepass")
+
+    def __contains__(self, tok) -> bool:
+        return isinstance(tok, str) and self.ids_of([tok]).size == 1
+
+    def __getitem__(self, tok) -> int:
+        ids = self.ids_of([tok]) if isinstance(tok, str) else np.zeros(0, np.int32)
+        if ids.size != 1:
+            raise KeyError(tok)
+        return int(ids[0])
+
+
+class NativeCutter:
+    """``cut(text)`` like ``jieba.Tokenizer().cut(text, HMM=False)`` over the given dictionary (jieba text format: one
+    ``word freq [tag]`` per line)."""
+
+    def __init__(self, dict_text: str):
+        self._lib = _lib.load()
+        raw = dict_text.encode("utf-8")
+        h = C.c_void_p()
+        rc = self._lib.erh_cutter_create(raw, len(raw), C.byref(h))
+        if rc != 0:
+            raise _lib.ErhError(rc, "erh_cutter_create failed (dictionary lines must read 'word freq [tag]')")
+        self._h = h
+
+    @classmethod
+    def from_file(cls, path: str) -> "NativeCutter":
+        with open(path, encoding="utf-8") as f:
+            return cls(f.read())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.erh_cutter_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def cut(self, text: str, cut_all: bool = False, HMM: bool = False) -> List[str]:
+        if cut_all or HMM:
+            raise NotImplementedError("NativeCutter implements jieba's cut(sentence, cut_all=False, HMM=False)")
+        raw = text.encode("utf-8", "surrogatepass")
+        cap = len(text) + 1
+        ends = np.empty(cap, np.int64)
+        n = C.c_int64(0)
+        rc = self._lib.erh_cutter_cut(self._h, raw, len(raw), ends.ctypes.data, cap, C.byref(n))
+        if rc != 0:
+            raise _lib.ErhError(rc, "erh_cutter_cut failed")
+        out, b = [], 0
+        for e in ends[: n.value].tolist():
+            out.append(raw[b:e].decode("utf-8", "surrogatepass"))
+            b = e
+        return out
+
+    lcut = cut
+
+    def encode_texts(self, texts: Sequence[str], vocab: NativeVocab, stopwords: Iterable[str] = (), add: bool = True
+                     ) -> Tuple[np.ndarray, np.ndarray]:
+        """``[tokenize_and_remove_stopwords(self, t, stopwords) for t in texts]`` -> term ids, without a Python object per
+        token (erh_text_encode): returns (flat int32 ids, int32 tokens per text)."""
+        stop = NativeVocab()
+        sw = [w for w in stopwords if isinstance(w, str) and w != "" and _SEP not in w]
+        if sw:
+            stop.encode([sw], add=True)
+        blobs = [t.encode("utf-8", "surrogatepass") for t in texts]
+        off = np.zeros(len(blobs) + 1, np.int64)
+        if blobs:
+            np.cumsum(np.fromiter((len(b) for b in blobs), dtype=np.int64, count=len(blobs)), out=off[1:])
+        blob = b"".join(blobs)
+        lens = np.zeros(max(len(blobs), 1), np.int32)
+        cap = int(off[-1]) + 1
+        need = C.c_int64(0)
+        ids = np.empty(cap, np.int32)
+        rc = self._lib.erh_text_encode(self._h, vocab._h, stop._h if sw else None, blob, off.ctypes.data, len(blobs),
+                                       1 if add else 0, ids.ctypes.data, cap, lens.ctypes.data, C.byref(need))
+        if rc != 0:
+            raise _lib.ErhError(rc, "erh_text_encode failed")
+        return ids[: int(need.value)].copy(), lens[: len(blobs)].copy()

@@ -133,6 +133,47 @@ int erh_get_bm25_payload(erh_handle *h, void *out_payload);
  *   dir_id     int16[N]: class id for the equality filter; NULL = no filtering possible. */
 int erh_set_doc_meta(erh_handle *h, int64_t N, const int32_t *content_id, const int16_t *dir_id);
 
+/* ---- text side of the index build (host only; no device, no handle) --------------------------------------------
+ * Replaces the Python side of BM25Retriever.__init__ / tokenize_and_remove_stopwords (retrievers.py:72-76, 94-118) and
+ * the jieba.Tokenizer() the pipeline creates (pipeline.py:176-178).
+ *
+ * erh_vocab: token bytes -> term ids, ids in order of first appearance (what the Python dict loop of the shim gave:
+ * the CSR built from the ids is bit-identical).
+ *   erh_vocab_encode  n_docs documents; document i = bytes[doc_off[i], doc_off[i+1]), its tokens separated by the byte
+ *                     `sep` (an empty range = no tokens).  add != 0: unseen tokens get the next id; add == 0: they
+ *                     encode as -1 (query side: out-of-vocabulary).  Writes the ids of all documents back to back
+ *                     (at most `cap`; ERH_ERR_OVERFLOW with *n_out = the number needed if it does not fit -- ids stay
+ *                     assigned, call again) and the token count of each document.  out_ids may be NULL to count only.
+ *   erh_vocab_token   bytes of token `id` (valid until the next erh_vocab_encode with add != 0).
+ *
+ * erh_cutter: sentence -> tokens with jieba 0.42.1's rules for Tokenizer.cut(sentence, cut_all=False, HMM=False): blocks
+ * of [CJK 4E00-9FD5, ASCII letters / digits, + # & . _ % -] are cut along the maximum-log-probability route through the
+ * dictionary DAG (runs of single ASCII letters / digits are glued back together), "\r\n" and single white-space
+ * characters are tokens of their own (the reference drops ' ' afterwards, retrievers.py:74-75), every other character is
+ * a token.  The dictionary is the caller's, in jieba's text format ("word freq [tag]" per line).  jieba's DEFAULT call
+ * (HMM=True) additionally re-cuts runs of out-of-dictionary characters with an HMM whose tables ship with jieba; that
+ * step is not reproduced.
+ *   erh_cutter_cut    byte offsets of the token ENDS (token t = text[end[t-1], end[t]), end[-1] = 0), at most `cap`;
+ *                     *n_tokens = how many there are (ERH_ERR_OVERFLOW if more than cap); out_ends may be NULL. */
+typedef struct erh_vocab erh_vocab;
+int     erh_vocab_create(erh_vocab **out);
+int     erh_vocab_destroy(erh_vocab *v);
+int64_t erh_vocab_size(const erh_vocab *v);
+int     erh_vocab_encode(erh_vocab *v, const char *bytes, const int64_t *doc_off, int64_t n_docs, int sep, int add,
+                         int32_t *out_ids, int64_t cap, int32_t *out_lens, int64_t *n_out);
+int     erh_vocab_token(const erh_vocab *v, int32_t id, const char **bytes, int32_t *len);
+typedef struct erh_cutter erh_cutter;
+int     erh_cutter_create(const char *dict_text, int64_t n_bytes, erh_cutter **out);
+int     erh_cutter_destroy(erh_cutter *c);
+int     erh_cutter_cut(const erh_cutter *c, const char *text, int64_t n_bytes, int64_t *out_ends, int64_t cap,
+                       int64_t *n_tokens);
+/* tokenize_and_remove_stopwords + the id walk in one pass, nothing per token on the caller's side: text i =
+ * bytes[text_off[i], text_off[i+1]) is cut, tokens equal to ' ' or present in `stop` (a vocabulary used as a set, may be
+ * NULL) are dropped (retrievers.py:72-76), the rest is encoded through `v` as erh_vocab_encode does (add == 0: unknown
+ * tokens are dropped -- the query side).  Same output convention as erh_vocab_encode. */
+int     erh_text_encode(const erh_cutter *c, erh_vocab *v, const erh_vocab *stop, const char *bytes, const int64_t *text_off,
+                        int64_t n_texts, int add, int32_t *out_ids, int64_t cap, int32_t *out_lens, int64_t *n_out);
+
 /* ---- queries ------------------------------------------------------------------------- */
 
 /* Dense top-k for B queries.  q is [B x d] (ERH_F16 or ERH_F32, host or device); normalize_q != 0

@@ -213,3 +213,38 @@ def test_engine_sharing_rules(corpus, tokenizer):
         e.close()
     assert r.retrieve("w5 w9")
     r.close()
+
+
+@pytest.mark.parametrize("bm25_type", [0, 1])
+def test_bm25_retriever_with_the_native_cutter(bm25_type):
+    """f3: a Chinese corpus tokenised, stop-word filtered and numbered inside the library (NativeCutter: erh_text_encode)
+    gives the same index and the same results as the same retriever fed by a Python tokenizer object with the same
+    cutting rules (the restatement of jieba's HMM=False algorithm) -- and both match the oracle."""
+    from easyrag_amd.text import NativeCutter
+    from oracle.jieba_cut import DictCutter
+    rng = np.random.default_rng(21)
+    chars = [chr(c) for c in range(0x4E00, 0x4E00 + 50)]
+    words = sorted({"".join(chars[int(i)] for i in rng.integers(0, len(chars), size=int(rng.integers(1, 4)))) for _ in range(300)})
+    dict_text = "\n".join(f"{w} {int(rng.integers(1, 900))}" for w in words)
+    texts = ["".join(words[int(i)] for i in rng.integers(0, len(words), size=int(rng.integers(5, 40)))) + "。 ok"
+             for _ in range(800)]
+    nodes = [TextNode(text=t, metadata={"dir": "umac" if i % 2 else "rcp"}, id_=f"c{i}") for i, t in enumerate(texts)]
+    stop = {words[0], words[5], "。", ""}
+    native, python = NativeCutter(dict_text), DictCutter(dict_text)
+    r_nat = BM25Retriever.from_defaults(nodes=nodes, tokenizer=native, similarity_top_k=15, stopwords=stop, bm25_type=bm25_type)
+    r_py = BM25Retriever.from_defaults(nodes=nodes, tokenizer=python, similarity_top_k=15, stopwords=stop, bm25_type=bm25_type,
+                                       engine=r_nat.engine)
+    assert r_nat._corpus is None and r_py._corpus is not None          # the native path kept no Python token lists
+    toks = [tokenize_and_remove_stopwords(python, t, stop) for t in texts]
+    ora = BM25Okapi(toks, 1.5, 0.75, 0.25) if bm25_type == 0 else BM25SLucene(1.5, 0.75).index(toks)
+    for query in (texts[3][:9], words[7] + words[7] + words[20], words[0] + "未登录"):
+        qt = tokenize_and_remove_stopwords(python, query, stop)
+        if not qt and bm25_type == 1:
+            continue
+        want = bm25_filter(ora.get_scores(qt) if qt else np.zeros(len(nodes)), 15)
+        for r in (r_nat, r_py):
+            got = r.retrieve(query)
+            assert [g.node.node_id for g in got] == [nodes[i].node_id for i, _ in want]
+            assert [g.score for g in got] == [s for _, s in want]
+    r_py.close()
+    r_nat.close()
