@@ -405,14 +405,46 @@ class HybridRetriever(_RetrieverBase):
         self.topk = topk
 
     # -- classmethods over already-retrieved lists (ref retrievers.py:239-274) ----------------------------
+    # The pipeline calls them once per query on a few hundred NodeWithScore objects it already holds on the host
+    # (pipeline.py:362, 408: 192 + 6 or 192 + 288 items).  A kernel launch plus six PCIe stagings for that is slower than
+    # the reference's own loop, so lists of up to `fusion_device_min` items are merged right here on the objects (any
+    # number of lists, as the reference accepts); the library's fusion kernels (erh_rrf / erh_fusion, and the fused
+    # erh_hybrid_topk that `aretrieve` runs) take over for larger inputs and for everything that is already on the device.
+    fusion_device_min = 512          # (and at most 2048 items: the kernels' LDS budget)
+
+    @staticmethod
+    def _fuse_host(lists, rrf: bool, K: int, topk: int):
+        if not rrf:                                  # first occurrence of a content wins, raw scores, stable sort
+            seen, merged = set(), []
+            for lst in lists:
+                for node in lst:
+                    c = node.get_content()
+                    if c not in seen:
+                        merged.append(node)
+                        seen.add(c)
+            merged.sort(key=lambda node: node.score, reverse=True)
+            return merged[:min(len(merged), topk)]
+        score, last = {}, {}                         # dict order = first appearance; the LAST node of a content is returned
+        for lst in lists:
+            for rank, item in enumerate(lst, 1):
+                c = item.get_content()
+                last[c] = item
+                score[c] = score.get(c, 0.0) + 1 / (rank + K)
+        out = []
+        for c, sc in sorted(score.items(), key=lambda kv: kv[1], reverse=True):
+            node = last[c]
+            node.score = sc                          # the reference overwrites the node's score with the RRF score
+            out.append(node)
+        return out[:min(topk, len(out))]
+
     @classmethod
     def _fuse(cls, lists, rrf: bool, K: int, topk: int):
         lists = [list(x) for x in lists]
+        n_items = sum(len(x) for x in lists)
+        if n_items <= cls.fusion_device_min or n_items > 2048 or len(lists) > 2:
+            return cls._fuse_host(lists, rrf, K, topk)
         if len(lists) == 1:
             lists.append([])
-        if len(lists) != 2:
-            # fold left: fusing more than two lists is not used by the reference pipeline
-            raise ValueError("exactly two rank lists are supported")
         items, cid, per_list = _lists_to_device_form(lists)
         if not items:
             return []

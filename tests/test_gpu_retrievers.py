@@ -120,15 +120,29 @@ def test_dense_and_hybrid_retrievers(corpus, tokenizer):
                 seen.add(nodes[i].node_id)
                 exp_sync.append(nodes[i].node_id)
         assert [g.node.node_id for g in sync] == exp_sync
-        # classmethods over already-retrieved lists (pipeline.py:362, 408)
+        # classmethods over already-retrieved lists (pipeline.py:362, 408): on the host objects for inputs of this size
+        # (the default), through the library's fusion kernels when forced (fusion_device_min = 0) -- same answer
+        for dev_min in (HybridRetriever.fusion_device_min, 0):
+            HybridRetriever.fusion_device_min, keep = dev_min, HybridRetriever.fusion_device_min
+            try:
+                s_nodes, d_nodes = sparse.retrieve(query), dense.retrieve(query)
+                rr = HybridRetriever.reciprocal_rank_fusion([s_nodes, d_nodes], topk=10)
+                assert [g.node.node_id for g in rr] == [nodes[w.idx].node_id for w in want[:10]]
+                assert [g.score for g in rr] == [w.score for w in want[:10]]
+                s_nodes, d_nodes = sparse.retrieve(query), dense.retrieve(query)
+                wantf = fusion([[Item(i, cid[i], s) for i, s in sp], Bl], topk=256)
+                fu = HybridRetriever.fusion([s_nodes, d_nodes], topk=256)
+                assert [g.node.node_id for g in fu] == [nodes[w.idx].node_id for w in wantf]
+            finally:
+                HybridRetriever.fusion_device_min = keep
+        # any number of lists, as the reference's loops accept (retrievers.py:245, 261)
         s_nodes, d_nodes = sparse.retrieve(query), dense.retrieve(query)
-        rr = HybridRetriever.reciprocal_rank_fusion([s_nodes, d_nodes], topk=10)
-        assert [g.node.node_id for g in rr] == [nodes[w.idx].node_id for w in want[:10]]
-        assert [g.score for g in rr] == [w.score for w in want[:10]]
-        s_nodes, d_nodes = sparse.retrieve(query), dense.retrieve(query)
-        wantf = fusion([[Item(i, cid[i], s) for i, s in sp], Bl], topk=256)
-        fu = HybridRetriever.fusion([s_nodes, d_nodes], topk=256)
-        assert [g.node.node_id for g in fu] == [nodes[w.idx].node_id for w in wantf]
+        three = [s_nodes, d_nodes, s_nodes[:5]]
+        want3 = reciprocal_rank_fusion([[Item(i, cid[i], s) for i, s in sp], Bl, [Item(i, cid[i], s) for i, s in sp][:5]], topk=20)
+        rr3 = HybridRetriever.reciprocal_rank_fusion(three, topk=20)
+        assert [g.node.node_id for g in rr3] == [nodes[w.idx].node_id for w in want3]
+        assert [g.score for g in rr3] == [w.score for w in want3]
+        assert HybridRetriever.fusion([], topk=5) == [] and HybridRetriever.reciprocal_rank_fusion([[]], topk=5) == []
     # filters pushed down through the hybrid retriever (retrievers.py:278, 283): filter_dict -> sparse route only,
     # filters -> dense route only; every combination against the oracle composition
     query = "w5 w9 w3"
