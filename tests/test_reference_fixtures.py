@@ -141,3 +141,37 @@ def test_gpu_retriever_on_reference_queries(bm25_type):
     finally:
         r.close()
         r.engine.close()
+
+
+def test_bm25s_readme_example_two_decimals():
+    """bm25s' README quick-start prints, for the query "does the fish purr like a cat?" over its four-sentence corpus,
+    `Rank 1 (score: 1.06): a cat is a feline and likes to purr` and `Rank 2 (score: 0.48): a fish is a creature that lives
+    in water and swims` -- RECALLED from the 0.1.x README, two decimals, not fetched (no network).  The token lists are an
+    assumption stated here: its default English stop words removed, words of >= 2 letters, no stemming effect on the
+    matching terms ("likes" in the corpus does not meet "like" in the query), i.e. document lengths 4, 6, 5, 5.  With
+    method="lucene", k1=1.5, b=0.75 (the constructor defaults the reference uses, retrievers.py:107-110) the restated
+    arithmetic gives 2 x 0.52924 = 1.0585 and 0.4816; a different idf (robertson, atire), a different length
+    normalisation or a `+1` in the numerator would not round to these two values."""
+    from oracle import BM25SLucene
+    corpus = [["cat", "feline", "likes", "purr"], ["dog", "human", "best", "friend", "loves", "play"],
+              ["bird", "beautiful", "animal", "can", "fly"], ["fish", "creature", "lives", "water", "swims"]]
+    ora = BM25SLucene(k1=1.5, b=0.75).index(corpus)
+    scores = ora.get_scores(["does", "fish", "purr", "like", "cat"])
+    assert scores.dtype == np.float32
+    assert [round(float(s), 2) for s in scores] == [1.06, 0.0, 0.0, 0.48]
+    assert abs(float(scores[0]) - 2 * np.log(1 + 3.5 / 1.5) / 2.275) < 1e-6
+    assert abs(float(scores[3]) - np.log(1 + 3.5 / 1.5) / 2.5) < 1e-6
+
+
+def test_qdrant_cosine_definition_on_non_unit_vectors():
+    """Qdrant's documented COSINE distance = dot(a, b) / (|a| |b|); its local mode normalises stored vectors and the
+    query (a zero vector divides by a tiny guard instead of by 0 and scores 0).  Three stored vectors that are not unit
+    length, a query that is not either: 1.0, 0.6, 0.0 -- and the order of the search walk."""
+    from oracle import qdrant_cosine_search
+    vecs = np.array([[1.0, 0.0], [3.0, 4.0], [0.0, 0.0]], np.float32)
+    ids, sc = qdrant_cosine_search(vecs, [6.0, 8.0], 3)
+    assert list(ids) == [1, 0, 2]
+    assert np.allclose(sc, [1.0, 0.6, 0.0], atol=1e-6)              # fp32 arithmetic, returned as Python floats (0.60000002...)
+    assert float(sc[1]) == float(np.float32(0.6))
+    ids, sc = qdrant_cosine_search(vecs, [6.0, 8.0], 2, mask=np.array([True, False, True]))
+    assert list(ids) == [0, 2] and abs(float(sc[0]) - 0.6) < 1e-6
