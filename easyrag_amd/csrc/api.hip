@@ -45,6 +45,8 @@ struct Bm25State {
     int variant = -1;
     int64_t V = 0, Nb = 0, nnz = 0;
     DevBuf indptr, doc_ids, payload, tile_off, fine_off;
+    DevBuf tile_off16;                    // bm25s: skip table at 16384 documents for the two-workgroups-per-CU scan (Okapi: tile_off is that)
+    int n_tiles16 = 0;
     DevBuf post;                          // fixed-point scan: interleaved {document, fixed-point payload} postings + one sentinel
     double qmax = 0;                      // largest fixed-point payload
     DevBuf tf;                            // kept by erh_build_bm25_index (what erh_get_bm25_csr returns)
@@ -56,7 +58,7 @@ struct Bm25State {
     std::vector<int64_t> host_indptr;     // host copy: query validation + algorithmic-byte accounting
     int n_tiles = 0, tile_docs = 0;
     int n_fine = 0;                       // sub-ranges of the fine skip table (0 = not built: block scan only)
-    void release() { indptr.release(); doc_ids.release(); payload.release(); tile_off.release(); fine_off.release(); tf.release(); post.release(); }
+    void release() { indptr.release(); doc_ids.release(); payload.release(); tile_off.release(); fine_off.release(); tf.release(); post.release(); tile_off16.release(); }
 };
 
 }  // namespace
@@ -91,6 +93,7 @@ struct erh_handle {
     int opt_bm25_segs = 0;                // document-range segments per query (0: enough to give the chip >= 512 workgroups)
     int opt_bm25_crossing = 1;            // wave-owned scan: threshold crossings instead of the accumulator sweep (indices with positive
                                           // payloads); 1 = fp32 sums only (the fp64 kernel runs out of registers with it: +12 % time), 2 = both
+    int opt_bm25_small = 1;               // fixed-point scan: 512-thread workgroups, two per CU, when k allows (0: always the 1024-thread shape)
     int opt_bm25_ascan = 1;               // approximate-order scan + exact re-score when the index qualifies (positive payloads)
     int opt_bm25_wscan = 0;               // otherwise: wave-owned scan when the batch qualifies (needs the fine skip table, built at the
                                           // next erh_set_bm25_*), else the block scan
@@ -124,7 +127,7 @@ struct erh_handle {
     int opt_dense_gemv = 1;                // batches of <= 16 queries: skinny-GEMM stream instead of the padded 256-query scan
     int opt_n0_auto = 0;                   // seed prefix snapped down to a whole number of scan rounds (less seed work, more candidates: a wash at 1M chunks)
     int opt_dense_sync = 0;                // the query-tile workgroups of a stream meet at a counter every four tiles (measured: no gain)
-    int opt_dense_tiled = 1;               // keep a tiled, pre-swizzled copy of the chunk matrix for the ping-pong scan (+ N * d * 2 bytes)
+    int opt_dense_tiled = 0;               // keep a tiled, pre-swizzled copy of the chunk matrix for the ping-pong scan (+ N * d * 2 bytes; no measurable gain: off)
     int opt_dense_speculate = 1;           // speculative (verified) first threshold + a single scan stage; 0: guaranteed bounds, refined in stages
     int opt_dense_var = 0;                 // dense_scan_pp2_kernel VAR (bit 0: two barriers per stage, bit 1: static priority)
     int opt_dense_rot = 0;                 // K-rotation between the query tiles of a stream, in stages per query tile (-1: nk / n_qt)
@@ -475,9 +478,15 @@ int bm25_topk_dev(erh_handle *h, const int32_t *qptr_dev, const int32_t *qtok_de
     const bool ascan = h->opt_bm25_ascan && S.ascan_ok;
     const bool wscan = !ascan && h->opt_bm25_wscan && S.n_fine > 0 && max_qlen <= erh::bm25_wscan_max_tokens() &&
                        h->opt_bm25_ablate == 0;
-    const int tiles = ascan ? erh::bm25_ascan_tiles(S.Nb) : S.n_tiles;
-    int segs = h->opt_bm25_segs > 0 ? h->opt_bm25_segs : (512 + B - 1) / B;
-    segs = std::max(1, std::min(segs, tiles));
+    // fixed-point scan: the 512-thread shape (two workgroups = two queries per CU) whenever its list holds k and a skip
+    // table at its tile size exists
+    const int small_docs = erh::bm25_ascan_tile_docs(1);
+    const bool have16 = S.tile_docs == small_docs || S.n_tiles16 > 0;
+    const bool small = ascan && h->opt_bm25_small && have16 && k <= erh::bm25_ascan_small_max_k() && B >= 8;   // (a handful of queries: 16 waves per query finish sooner)
+    const int as_docs = erh::bm25_ascan_tile_docs(small ? 1 : 0);
+    const int tiles = ascan ? (int)((S.Nb + as_docs - 1) / as_docs) : S.n_tiles;
+    int segs = h->opt_bm25_segs > 0 ? h->opt_bm25_segs : ((small ? 1024 : 512) + B - 1) / B;
+    segs = std::max(1, std::min(segs, ascan ? std::min(tiles, std::max(S.n_tiles, 1)) : tiles));
     while (segs > 1 && (int64_t)segs * k > 8192) --segs;
     unsigned long long *dbg = h->opt_debug_counters ? h->dbg.as<unsigned long long>() : nullptr;
     const int32_t *q_order = (h->qorder_valid && qptr_dev == h->qptr.as<int32_t>()) ? h->qorder.as<int32_t>() : nullptr;
@@ -487,18 +496,26 @@ int bm25_topk_dev(erh_handle *h, const int32_t *qptr_dev, const int32_t *qtok_de
     }
     auto scan = [&](double *p_sc, int32_t *p_ids, int32_t *p_len) -> hipError_t {
         if (ascan) {
-            const int tshift = S.tile_docs == erh::kBm25TileF32 ? 0 : 1;
-            hipError_t e = erh::launch_bm25_ascan(S.variant, S.indptr.as<int64_t>(), S.doc_ids.as<int32_t>(), S.payload.p,
+            // the skip table the scan walks: at its own tile size (tshift 0) or finer by one power of two (tshift 1)
+            const bool use16 = small && S.tile_docs != small_docs;
+            const int32_t *tab = use16 ? S.tile_off16.as<int32_t>() : S.tile_off.as<int32_t>();
+            const int n_tab = use16 ? S.n_tiles16 : S.n_tiles;
+            const int tshift = (use16 || S.tile_docs == as_docs) ? 0 : 1;
+            const int cut_mul = S.tile_docs > as_docs ? 2 : 1;                 // segment cuts on the exact scan's (larger) tiles
+            hipError_t e = erh::launch_bm25_ascan(S.variant, small ? 1 : 0, S.indptr.as<int64_t>(), S.doc_ids.as<int32_t>(), S.payload.p,
                                                   S.post.p, (uint32_t)S.nnz, S.qmax,
-                                                  S.tile_off.as<int32_t>(), S.n_tiles, tshift, S.Nb, qptr_dev, qtok_dev, q_order,
-                                                  B, k, segs, filter_dev, dir, p_sc, p_ids, p_len, h->bm_redo.as<uint32_t>(),
+                                                  tab, n_tab, tshift, S.Nb, qptr_dev, qtok_dev, q_order,
+                                                  B, k, segs, cut_mul, filter_dev, dir, p_sc, p_ids, p_len, h->bm_redo.as<uint32_t>(),
                                                   h->opt_bm25_ablate, dbg, st);
             if (e != hipSuccess) return e;
             // near-tie floods (rare): those workgroups are scanned again by the exact block scan (same document ranges per
-            // segment), the others exit at once
+            // segment: the cuts are expressed in the block scan's own tiles), the others exit at once
+            int cut_tiles = tiles, cut_shift = 0;
+            if (S.tile_docs < as_docs) cut_shift = 1;                          // block-scan tiles are half a scan tile
+            else if (S.tile_docs > as_docs) cut_tiles = S.n_tiles;             // ... or two of them (cut_mul = 2 above)
             return erh::launch_bm25_scan(S.variant, S.indptr.as<int64_t>(), S.doc_ids.as<int32_t>(), S.payload.p,
                                          S.tile_off.as<int32_t>(), S.n_tiles, S.Nb, qptr_dev, qtok_dev, q_order, B, k, segs,
-                                         filter_dev, dir, p_sc, p_ids, p_len, h->bm_redo.as<uint32_t>(), tiles, tshift, 0,
+                                         filter_dev, dir, p_sc, p_ids, p_len, h->bm_redo.as<uint32_t>(), cut_tiles, cut_shift, 0,
                                          nullptr, st);
         }
         if (wscan)
@@ -672,6 +689,7 @@ int erh_set_option(erh_handle *h, const char *name, int64_t value) {
     if (!strcmp(name, "bm25_segs")) { if (value < 0 || value > 64) return h->fail(ERH_ERR_INVALID, "bm25_segs"); h->opt_bm25_segs = (int)value; return ERH_OK; }
     if (!strcmp(name, "bm25_crossing")) { if (value < 0 || value > 2) return h->fail(ERH_ERR_INVALID, "bm25_crossing"); h->opt_bm25_crossing = (int)value; return ERH_OK; }
     if (!strcmp(name, "bm25_ascan")) { h->opt_bm25_ascan = value != 0; return ERH_OK; }
+    if (!strcmp(name, "bm25_small")) { h->opt_bm25_small = value != 0; return ERH_OK; }
     if (!strcmp(name, "bm25_wscan")) { h->opt_bm25_wscan = value != 0; return ERH_OK; }   // the fine table is built at the next erh_set_bm25_*
     if (!strcmp(name, "bm25_fine_max_mb")) { if (value < 0) return h->fail(ERH_ERR_INVALID, "bm25_fine_max_mb < 0"); h->opt_bm25_fine_max_mb = value; return ERH_OK; }
     if (!strcmp(name, "debug_counters")) {
@@ -834,6 +852,15 @@ static int bm25_finish_tables(erh_handle *h, int variant, int64_t V, int64_t N, 
     HIPCHK(h, S.tile_off.ensure((size_t)V * (S.n_tiles + 1) * 4));
     HIPCHK(h, erh::launch_bm25_tile_off(S.indptr.as<int64_t>(), S.doc_ids.as<int32_t>(), V, S.tile_docs, S.n_tiles,
                                         S.tile_off.as<int32_t>(), st));
+    S.tile_off16.release();
+    S.n_tiles16 = 0;
+    if (S.tile_docs != erh::bm25_ascan_tile_docs(1) && h->opt_bm25_ascan && h->opt_bm25_small) {
+        const int td = erh::bm25_ascan_tile_docs(1);
+        S.n_tiles16 = (int)((N + td - 1) / td);
+        HIPCHK(h, S.tile_off16.ensure((size_t)V * (S.n_tiles16 + 1) * 4));
+        HIPCHK(h, erh::launch_bm25_tile_off(S.indptr.as<int64_t>(), S.doc_ids.as<int32_t>(), V, td, S.n_tiles16,
+                                            S.tile_off16.as<int32_t>(), st));
+    }
     // fine skip table of the wave-owned scan: one int per (term, sub-range of tile_docs / 16 documents)
     S.n_fine = 0;
     const int sub = erh::bm25_wscan_sub_docs(variant);

@@ -184,7 +184,7 @@ __device__ __forceinline__ void bm_shrink(BmHdr *hdr, ST *cs, int32_t *ci, int k
 // The pass covers accumulators [i_begin, i_end) with `nthr` threads (ltid = this thread's rank among them): the whole
 // tile with the 1024 threads of the block scan, or one wave's own sub-range in the wave-owned scan.  *full_flag is
 // raised when the list is full; *want_flag (may be null) when it has grown past want_at entries.
-template <typename ST>
+template <typename ST, int CAPT = kBmCap>
 __device__ __forceinline__ void bm_sweep(BmHdr *hdr, ST *acc, ST *cs, int32_t *ci, int i_begin, int i_end, int nthr,
                                          int ltid, int64_t base_doc, int64_t N, int fd,
                                          const int16_t *__restrict__ dir_id, ST tau_s, int tau_idx, int *full_flag,
@@ -245,7 +245,7 @@ __device__ __forceinline__ void bm_sweep(BmHdr *hdr, ST *acc, ST *cs, int32_t *c
                     if (pass && (doc >= N || (fd >= 0 && (int)dir_id[doc] != fd))) pass = false;
                     if (pass) {
                         const int pos = atomicAdd(&hdr->ncand, 1);
-                        if (pos < kBmCap) {
+                        if (pos < CAPT) {
                             cs[pos] = sv;
                             ci[pos] = (int32_t)doc;
                             v[u][e] = (ST)0;
@@ -781,27 +781,38 @@ __global__ __launch_bounds__(kBmThreads) void bm25_wscan_kernel(
 // corpus of near-identical short documents) or a query whose sums could overflow sets redo[query, segment]: the host
 // launches the exact block scan for those workgroups only.  Indices with non-positive payloads never come here
 // (api.hip checks when an index is set).
-constexpr int kAsTile = erh::kBm25TileF32;
 constexpr int kAsU = 6;                                  // 128-posting pieces per wave and tile held in registers
-constexpr int kAsReserve = 256;                          // free list slots a shrink must leave
 constexpr int kAsTokChunk = 64;                          // lane j <-> query token j
-constexpr int kAsRegion = kAsTile / kWsWaves;            // accumulators a wave owns (notes, clears)
-constexpr int kAsXW = 96;                                // threshold crossings noted per region and tile
+constexpr int kAsRegion = 2048;                          // accumulators a wave owns (notes, clears)
+constexpr int kAsXW = 88;                                // threshold crossings noted per region and tile
 constexpr size_t kAsOffHdr2 = 64;
-constexpr size_t kAsOffXcnt = 128;                       // int xz[2][17]: crossings per region, then the largest position handed out
+constexpr size_t kAsOffXcnt = 128;                       // int xz[2][NW + 1]: crossings per region, then the largest position handed out
 constexpr size_t kAsOffTok = 320;                        // int32 tok[64]   (re-score stage)
 constexpr size_t kAsOffIp = 576;                         // uint32 ip[64]
 constexpr size_t kAsOffRng = 1024;                       // int4 rng[3][64]
 constexpr size_t kAsOffAcc = 4096;
-constexpr size_t kAsOffCa = kAsOffAcc + (size_t)kAsTile * 4;
-constexpr size_t kAsOffCi = kAsOffCa + (size_t)kBmCap * 4;
-constexpr size_t kAsOffXl = kAsOffCi + (size_t)kBmCap * 4;
-constexpr size_t kAsOffHist = kAsOffXl + (size_t)kWsWaves * kAsXW * 4;
-constexpr size_t kAsBytes = kAsOffHist + 256 * 4;
 static_assert(kAsOffXcnt + 2 * 17 * 4 <= kAsOffTok && kAsOffIp + 64 * 4 <= kAsOffRng, "header tables overlap");
 static_assert(kAsOffRng + 3 * 64 * 16 <= kAsOffAcc, "range tables overlap the accumulators");
-static_assert(kAsBytes <= 160 * 1024, "fixed-point scan LDS layout exceeds one CU");
-static_assert(kWsWaves == 16, "region bookkeeping assumes 16 waves");
+
+// Two shapes of the same kernel.  AsBig: one 1024-thread workgroup per CU over 32768-document tiles (list capacity 2048:
+// any k the API allows).  AsSmall: 512 threads over 16384-document tiles in 80 KiB of LDS, i.e. TWO workgroups (two
+// queries) per CU whose phases -- adds, barrier, list + clear, barrier -- fall at different times, so the LDS pipe, the
+// address path and the SIMDs of the CU are busy while one of them waits (list capacity 1024: k <= 384).
+template <int NT_, int TILE_>
+struct AsCfg {
+    static constexpr int NT = NT_, TILE = TILE_, NW = NT_ / 64, CAP = 2 * NT_, RESERVE = NT_ / 4;
+    static_assert(TILE_ / (NT_ / 64) == kAsRegion, "a wave owns 2048 accumulators");
+    static constexpr size_t OFF_CA = kAsOffAcc + (size_t)TILE_ * 4;
+    static constexpr size_t OFF_CI = OFF_CA + (size_t)CAP * 4;
+    static constexpr size_t OFF_XL = OFF_CI + (size_t)CAP * 4;
+    static constexpr size_t OFF_HIST = OFF_XL + (size_t)NW * kAsXW * 4;
+    static constexpr size_t OFF_DUMMY = OFF_HIST + 256 * 4;           // 64 words that lanes without a posting add 0 to
+    static constexpr size_t BYTES = OFF_DUMMY + 64 * 4;
+    static constexpr int TAB_SHIFT = TILE_ == 32768 ? 15 : 14;        // log2(TILE)
+};
+using AsBig = AsCfg<1024, 32768>;
+using AsSmall = AsCfg<512, 16384>;
+static_assert(AsBig::BYTES <= 160 * 1024 && 2 * AsSmall::BYTES <= 160 * 1024, "fixed-point scan LDS layouts");
 
 struct AsHdr {
     uint32_t thetaq;                // k-th best fixed-point sum seen so far (0: fewer than k candidates yet)
@@ -843,12 +854,13 @@ __device__ __forceinline__ as_int4 as_make_ranges(uint32_t ip, int a, int b, int
     return r;
 }
 
-// Piece descriptors of one tile, one per lane: lane u of wave w describes piece p = w + 16 u of the tile whose ranges
+// Piece descriptors of one tile, one per lane: lane u of wave w describes piece p = w + NW u of the tile whose ranges
 // lie in LDS at `rt` (64 x the vector above): first posting index and how many postings the piece holds (<= 0: none --
 // past the token's range or past the tile's last piece; > 128: the token goes on in its next piece).  Every lane scans
 // the tokens' piece offsets with broadcast reads; no wave-uniform control flow, no scalar work.
+template <int NW>
 __device__ __forceinline__ void as_describe(const as_int4 *rt, int nq, int lane, int wave, uint32_t &dstart, int &dcnt) {
-    const int p = wave + lane * kWsWaves;
+    const int p = wave + lane * NW;
     int j = -1;
     if (nq <= 16) {                                                       // all reads in flight together (lanes past nq hold 0x7fffffff)
         int px[16];
@@ -879,41 +891,45 @@ __device__ __forceinline__ void as_fill(AsSet &S, uint32_t dstart, int dcnt, int
     }
 }
 
-// rare: slot `sl` crossed the threshold -> list of the wave that owns the slot; xz[16] keeps the largest position
+// rare: slot `sl` crossed the threshold -> list of the wave that owns the slot; xz[NW] keeps the largest position
+template <int NW>
 __device__ __forceinline__ void as_note(bool cross, int sl, int32_t *xl, int *xz) {
     if (cross) {
         const int r = sl / kAsRegion;
         const int pos = atomicAdd(&xz[r], 1);
         if (pos < kAsXW) xl[r * kAsXW + pos] = sl;
-        atomicMax(&xz[16], pos + 1);
+        atomicMax(&xz[NW], pos + 1);
     }
 }
 
-// the same pieces onto the integer sums
-__device__ __forceinline__ void as_apply(const AsSet &S, int dcnt, int r0, int np, int lane, uint32_t *accu, int base_doc,
-                                         uint32_t thx, int32_t *xl, int *xz) {
-    uint32_t o0[kAsU], o1[kAsU];
-    bool any = false;
+// the same pieces onto the integer sums.  Nothing conditional around the adds: a lane without a posting (past the end of
+// its piece, or a piece the wave does not have) adds 0 to a word of its own in a dummy area, so the twelve atomics of a
+// round are issued back to back and their returns are collected afterwards -- behind branches or exec masks the
+// compiler waits for each return before it issues the next add.
+template <int NW>
+__device__ __forceinline__ void as_apply(const AsSet &S, int dcnt, int r0, int np, int lane, uint32_t *accu, uint32_t *dummy,
+                                         int base_doc, uint32_t thx, int32_t *xl, int *xz) {
+    uint32_t o0[kAsU], o1[kAsU], q0[kAsU], q1[kAsU];
+    uint32_t *mine = dummy + lane;
 #pragma unroll
-    for (int u = 0; u < kAsU; ++u) {                                      // all adds of the round in flight together
-        o0[u] = o1[u] = thx;                                              // (lanes without a posting: never a crossing)
-        if (r0 + u < np) {                                                // wave-uniform
-            const int cn = __builtin_amdgcn_readlane(dcnt, r0 + u);
-            if ((int)S.p[u].x >= 0) o0[u] = atomicAdd(&accu[(int)S.p[u].x - base_doc], S.p[u].y);
-            if (2 * lane + 1 < cn) o1[u] = atomicAdd(&accu[(int)S.p[u].z - base_doc], S.p[u].w);
-        }
+    for (int u = 0; u < kAsU; ++u) {
+        int cn = __builtin_amdgcn_readlane(dcnt, r0 + u < 64 ? r0 + u : 63);
+        cn = r0 + u < np ? cn : 0;                                        // scalar select
+        const bool v0 = 2 * lane < cn, v1 = 2 * lane + 1 < cn;
+        q0[u] = v0 ? S.p[u].y : 0u;
+        q1[u] = v1 ? S.p[u].w : 0u;
+        o0[u] = atomicAdd(v0 ? &accu[(int)S.p[u].x - base_doc] : mine, q0[u]);
+        o1[u] = atomicAdd(v1 ? &accu[(int)S.p[u].z - base_doc] : mine, q1[u]);
     }
     if (thx) {                                                            // (no threshold yet: nothing to note, the tile is swept)
+        bool any = false;
 #pragma unroll
-        for (int u = 0; u < kAsU; ++u)
-            if (r0 + u < np) any |= (thx - 1u - o0[u] < S.p[u].y) | (thx - 1u - o1[u] < S.p[u].w);   // old < thx <= old + q
+        for (int u = 0; u < kAsU; ++u) any |= (thx - 1u - o0[u] < q0[u]) | (thx - 1u - o1[u] < q1[u]);   // old < thx <= old + q
         if (__builtin_amdgcn_ballot_w64(any)) {                           // wave-uniform, rare once the threshold has settled
 #pragma unroll
             for (int u = 0; u < kAsU; ++u) {
-                if (r0 + u < np) {
-                    as_note(thx - 1u - o0[u] < S.p[u].y, (int)S.p[u].x - base_doc, xl, xz);
-                    as_note(thx - 1u - o1[u] < S.p[u].w, (int)S.p[u].z - base_doc, xl, xz);
-                }
+                as_note<NW>(thx - 1u - o0[u] < q0[u], (int)S.p[u].x - base_doc, xl, xz);
+                as_note<NW>(thx - 1u - o1[u] < q1[u], (int)S.p[u].z - base_doc, xl, xz);
             }
         }
     }
@@ -927,7 +943,7 @@ __device__ __forceinline__ uint32_t as_kth_largest(const uint32_t *v, int n, int
     for (int shift = 24; shift >= 0; shift -= 8) {
         if (tid < 256) hist[tid] = 0u;
         __syncthreads();
-        for (int i = tid; i < n; i += kBmThreads) {
+        for (int i = tid; i < n; i += (int)blockDim.x) {
             const uint32_t x = v[i];
             if ((x & mask) == prefix) atomicAdd(&hist[(x >> shift) & 255u], 1u);
         }
@@ -968,10 +984,11 @@ __device__ __forceinline__ uint32_t as_drop_threshold(uint32_t thetaq, double ke
 }
 
 // Refresh thetaq / the drop threshold from the list and keep what is not provably out (list order is arbitrary).
+template <int CAP>
 __device__ __forceinline__ void as_shrink(BmHdr *hdr, AsHdr *h2, uint32_t *ca, int32_t *ci, uint32_t *hist, int k,
                                           double keep_frac, int nq, int reserve) {
     __syncthreads();
-    const int n = hdr->ncand < kBmCap ? hdr->ncand : kBmCap;
+    const int n = hdr->ncand < CAP ? hdr->ncand : CAP;
     if (n >= k) {                                                         // uniform
         const uint32_t th = as_kth_largest(ca, n, k, hist, h2);
         if (threadIdx.x == 0 && th > h2->thetaq) { h2->thetaq = th; h2->thq = as_drop_threshold(th, keep_frac, nq); }
@@ -980,7 +997,7 @@ __device__ __forceinline__ void as_shrink(BmHdr *hdr, AsHdr *h2, uint32_t *ca, i
     __syncthreads();
     const uint32_t thq = h2->thq;
     // compaction in place: every thread holds its (at most two) entries in registers across the barrier
-    const int i0 = threadIdx.x, i1 = threadIdx.x + kBmThreads;
+    const int i0 = threadIdx.x, i1 = threadIdx.x + CAP / 2;       // (CAP = 2 x threads)
     uint32_t v0 = 0u, v1 = 0u;
     int32_t d0 = 0, d1 = 0;
     if (i0 < n) { v0 = ca[i0]; d0 = ci[i0]; }
@@ -992,23 +1009,25 @@ __device__ __forceinline__ void as_shrink(BmHdr *hdr, AsHdr *h2, uint32_t *ca, i
     __syncthreads();
     if (threadIdx.x == 0) {
         hdr->ncand = h2->keep;
-        if (h2->keep > kBmCap - reserve) h2->redo = 1;                    // near-tie flood: no room for the next tile
+        if (h2->keep > CAP - reserve) h2->redo = 1;                    // near-tie flood: no room for the next tile
     }
     __syncthreads();
 }
 
-// grid = (segs, B), block = 1024.  tile_off has n_tab + 1 entries per term at a granularity of kAsTile >> tshift documents;
-// post = the interleaved fixed-point postings with one sentinel {document -1, q 0} at index nnz.
-template <typename ST>
-__global__ __launch_bounds__(kBmThreads) void bm25_ascan_kernel(
+// grid = (segs, B), block = C::NT.  tile_off has n_tab + 1 entries per term at a granularity of C::TILE >> tshift documents;
+// post = the interleaved fixed-point postings with two sentinels {document -1, q 0} at index nnz.
+template <typename ST, class C>
+__global__ __launch_bounds__(C::NT) void bm25_ascan_kernel(
     const int64_t *__restrict__ indptr, const int32_t *__restrict__ doc_ids, const ST *__restrict__ payload,
     const as_uint2 *__restrict__ post, uint32_t nnz, double qmax /* largest fixed-point payload of the index */,
     const int32_t *__restrict__ tile_off, int n_tab, int tshift, int n_tiles, int64_t N,
     const int32_t *__restrict__ q_indptr, const int32_t *__restrict__ q_tok, const int32_t *__restrict__ q_order, int k,
-    int segs, const int16_t *__restrict__ filter_dir, const int16_t *__restrict__ dir_id,
+    int segs, int cut_mul /* segment boundaries fall on multiples of cut_mul tiles (the exact scan's tile may be larger) */,
+    const int16_t *__restrict__ filter_dir, const int16_t *__restrict__ dir_id,
     double *__restrict__ part_scores, int32_t *__restrict__ part_ids, int32_t *__restrict__ part_len,
     uint32_t *__restrict__ redo, int abl /* measurement builds: 1 no adds, 2 no posting loads, 4 no clear, 8 one descriptor set */,
     unsigned long long *__restrict__ dbg) {
+    constexpr int NT = C::NT, TILE = C::TILE, NW = C::NW, CAP = C::CAP;
 #ifdef ERH_MEASURE
 #define ERH_ABL(B) (abl & (B))
     long long t_sec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1026,10 +1045,11 @@ __global__ __launch_bounds__(kBmThreads) void bm25_ascan_kernel(
     uint32_t *s_ip = reinterpret_cast<uint32_t *>(smem + kAsOffIp);
     as_int4 *rng = reinterpret_cast<as_int4 *>(smem + kAsOffRng);
     uint32_t *accu = reinterpret_cast<uint32_t *>(smem + kAsOffAcc);
-    uint32_t *ca = reinterpret_cast<uint32_t *>(smem + kAsOffCa);
-    int32_t *ci = reinterpret_cast<int32_t *>(smem + kAsOffCi);
-    int32_t *xl = reinterpret_cast<int32_t *>(smem + kAsOffXl);
-    uint32_t *hist = reinterpret_cast<uint32_t *>(smem + kAsOffHist);
+    uint32_t *ca = reinterpret_cast<uint32_t *>(smem + C::OFF_CA);
+    int32_t *ci = reinterpret_cast<int32_t *>(smem + C::OFF_CI);
+    int32_t *xl = reinterpret_cast<int32_t *>(smem + C::OFF_XL);
+    uint32_t *hist = reinterpret_cast<uint32_t *>(smem + C::OFF_HIST);
+    uint32_t *dummy = reinterpret_cast<uint32_t *>(smem + C::OFF_DUMMY);
 
     const int seg = blockIdx.x, q = q_order ? q_order[blockIdx.y] : (int)blockIdx.y, tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1037,8 +1057,10 @@ __global__ __launch_bounds__(kBmThreads) void bm25_ascan_kernel(
     const int qs = q_indptr[q];
     const int nq = q_indptr[q + 1] - qs;
     const int fd = filter_dir ? (int)filter_dir[q] : -1;
-    const int t_begin = (int)((int64_t)n_tiles * seg / segs);
-    const int t_end = (int)((int64_t)n_tiles * (seg + 1) / segs);
+    const int n_cut = (n_tiles + cut_mul - 1) / cut_mul;
+    const int t_begin = (int)((int64_t)n_cut * seg / segs) * cut_mul;
+    int t_end = (int)((int64_t)n_cut * (seg + 1) / segs) * cut_mul;
+    t_end = t_end < n_tiles ? t_end : n_tiles;
     const int64_t out_base = ((int64_t)q * segs + seg) * k;
     const double keep_frac = 1.0 - 3.0 * 1.01 * (double)(nq + 2) * 5.9604644775390625e-08;   // 1 - 3 eps
 
@@ -1049,8 +1071,9 @@ __global__ __launch_bounds__(kBmThreads) void bm25_ascan_kernel(
         h2->thetaq = 0u; h2->thq = 1u; h2->keep = 0;
         h2->redo = ((double)nq * qmax >= 4294967296.0) ? 1 : 0;           // the sums could overflow: leave it to the exact scan
     }
-    if (tid < 2 * 17) xzb[tid] = 0;
-    for (int i = tid; i < kAsTile; i += kBmThreads) accu[i] = 0u;
+    if (tid < 2 * (NW + 1)) xzb[tid] = 0;
+    if (tid < 64) dummy[tid] = 0u;
+    for (int i = tid; i < TILE; i += NT) accu[i] = 0u;
     __syncthreads();
 
     int ph = 0;                                                           // sweep pass counter (workgroup-uniform)
@@ -1059,15 +1082,15 @@ __global__ __launch_bounds__(kBmThreads) void bm25_ascan_kernel(
     auto finish_tile = [&](int tile, int base_doc, uint32_t thq, int nc0) __attribute__((always_inline)) -> bool {
         if (h2->redo) return true;                                        // (wave 0 saw a tile it cannot describe)
         const int par = tile & 1;
-        const int *xz = xzb + par * 17;
-        const int xmax = xz[16];                                          // most crossings noted for one region
+        const int *xz = xzb + par * (NW + 1);
+        const int xmax = xz[NW];                                          // most crossings noted for one region
         const int cnt = xz[wave];                                         // ... for this wave's region
-        if (tid < 17) xzb[(par ^ 1) * 17 + tid] = 0;                      // the next tile's counters (idle until the next barrier)
+        if (tid < NW + 1) xzb[(par ^ 1) * (NW + 1) + tid] = 0;                      // the next tile's counters (idle until the next barrier)
         bool by_list = thq > 1u && xmax <= kAsXW;                         // workgroup-uniform
-        if (by_list && nc0 + kWsWaves * xmax > kBmCap) {                  // make room first (rare)
-            as_shrink(hdr, h2, ca, ci, hist, k, keep_frac, nq, kAsReserve);
+        if (by_list && nc0 + NW * xmax > CAP) {                  // make room first (rare)
+            as_shrink<CAP>(hdr, h2, ca, ci, hist, k, keep_frac, nq, C::RESERVE);
             if (h2->redo) return true;
-            by_list = hdr->ncand + kWsWaves * xmax <= kBmCap;             // (stable: read behind as_shrink's last barrier)
+            by_list = hdr->ncand + NW * xmax <= CAP;             // (stable: read behind as_shrink's last barrier)
         }
         if (by_list) {
             // this wave's own region: the noted slots hold final sums (>= the thq of the adds; the threshold may have moved
@@ -1081,7 +1104,7 @@ __global__ __launch_bounds__(kBmThreads) void bm25_ascan_kernel(
                     bool pass = av >= thn;
                     if (pass && (doc >= N || (fd >= 0 && (int)dir_id[doc] != fd))) pass = false;
                     if (pass) {
-                        const int pos = atomicAdd(&hdr->ncand, 1);        // fits: ncand + 16 xmax <= kBmCap
+                        const int pos = atomicAdd(&hdr->ncand, 1);        // fits: ncand + 16 xmax <= CAP
                         ca[pos] = av;
                         ci[pos] = (int32_t)doc;
                     }
@@ -1097,39 +1120,39 @@ __global__ __launch_bounds__(kBmThreads) void bm25_ascan_kernel(
             ERH_SEC(3);
             __syncthreads();
             ERH_SEC(4);
-            if (hdr->ncand > k + kBmThreads / 2) {                        // uniform: keep the list short, the threshold current
-                as_shrink(hdr, h2, ca, ci, hist, k, keep_frac, nq, kAsReserve);
+            if (hdr->ncand > k + NT / 2) {                        // uniform: keep the list short, the threshold current
+                as_shrink<CAP>(hdr, h2, ca, ci, hist, k, keep_frac, nq, C::RESERVE);
                 ERH_SEC(5);
                 if (h2->redo) return true;
             }
             return false;
         }
-        if (tile == t_begin && k <= kBmThreads && fd < 0) {
+        if (tile == t_begin && k <= NT && fd < 0) {
             // k-th largest of the per-thread maxima: k distinct documents reach it, so it is a valid first thetaq
             typedef uint32_t UT __attribute__((ext_vector_type(4)));
             uint32_t mx = 0u;
-            for (int i = tid * 4; i < kAsTile; i += kBmThreads * 4) {
+            for (int i = tid * 4; i < TILE; i += NT * 4) {
                 const UT v = *reinterpret_cast<const UT *>(accu + i);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) mx = v[e] > mx ? v[e] : mx;
             }
             ca[tid] = mx;                                                 // the list is still empty
-            const uint32_t p = as_kth_largest(ca, kBmThreads, k, hist, h2);   // begins and ends with barriers
+            const uint32_t p = as_kth_largest(ca, NT, k, hist, h2);   // begins and ends with barriers
             if (tid == 0 && p > 0u) { h2->thetaq = p; h2->thq = as_drop_threshold(p, keep_frac, nq); }
             __syncthreads();
         }
         for (;;) {
             const int slot = ph % 3;
             if (tid == 0) { hdr->full[(ph + 1) % 3] = 0; hdr->want[(ph + 1) % 3] = 0; }
-            bm_sweep<uint32_t>(hdr, accu, ca, ci, 0, kAsTile, kBmThreads, tid, (int64_t)base_doc, N, fd, dir_id, h2->thq,
-                               0x7fffffff, &hdr->full[slot], &hdr->want[slot], k + kBmThreads / 2);
+            bm_sweep<uint32_t, CAP>(hdr, accu, ca, ci, 0, TILE, NT, tid, (int64_t)base_doc, N, fd, dir_id, h2->thq,
+                               0x7fffffff, &hdr->full[slot], &hdr->want[slot], k + NT / 2);
             ERH_SEC(3);
             __syncthreads();
             ERH_SEC(4);
             const int full = hdr->full[slot], want = hdr->want[slot];
             ++ph;
             if (full || want) {
-                as_shrink(hdr, h2, ca, ci, hist, k, keep_frac, nq, kAsReserve);
+                as_shrink<CAP>(hdr, h2, ca, ci, hist, k, keep_frac, nq, C::RESERVE);
                 ERH_SEC(5);
                 if (h2->redo) return true;                                // (written before as_shrink's last barrier)
             }
@@ -1141,7 +1164,7 @@ __global__ __launch_bounds__(kBmThreads) void bm25_ascan_kernel(
     if (nq > 0 && t_begin < t_end && !stop) {
         AsSet S;
         auto pieces_of = [&](int pt) __attribute__((always_inline)) -> int {   // this wave's share of a tile's pt pieces
-            return pt > wave ? (pt - wave + kWsWaves - 1) / kWsWaves : 0;
+            return pt > wave ? (pt - wave + NW - 1) / NW : 0;
         };
         if (nq <= kAsTokChunk) {
             // wave 0, lane j: token j's posting base and its row of the skip table; ranges are published two tiles ahead
@@ -1164,7 +1187,7 @@ __global__ __launch_bounds__(kBmThreads) void bm25_ascan_kernel(
             auto publish = [&](int slot, int a, int b) __attribute__((always_inline)) {   // wave 0 only
                 const as_int4 r = as_make_ranges(ip, a, b, nq, lane);
                 rng[slot * 64 + lane] = r;
-                if (lane == 0 && r[3] > 64 * kWsWaves) h2->redo = 1;      // more pieces than a wave's lanes can describe
+                if (lane == 0 && r[3] > 64 * NW) h2->redo = 1;      // more pieces than a wave's lanes can describe
             };
             int ra = 0, rb = 0;
             if (wave == 0) {
@@ -1177,26 +1200,32 @@ __global__ __launch_bounds__(kBmThreads) void bm25_ascan_kernel(
             __syncthreads();
             uint32_t ds_c, ds_n = 0u;                                     // this tile's / the next tile's piece descriptors
             int dc_c, dc_n = 0;
-            as_describe(rng, nq, lane, wave, ds_c, dc_c);
+            as_describe<NW>(rng, nq, lane, wave, ds_c, dc_c);
             int np_c = pieces_of(__builtin_amdgcn_readfirstlane(rng[0][3])), np_n = 0;
             as_fill(S, ds_c, dc_c, 0, np_c, post, lane, nnz);
             int r3 = 0;                                                   // (tile - t_begin) % 3: slot of the current tile's ranges
             for (int tile = t_begin; tile < t_end && !stop; ++tile) {
-                const int base_doc = tile * kAsTile;
+                const int base_doc = tile * TILE;
                 const uint32_t thq = h2->thq;                             // fixed for the tile (it only moves in as_shrink)
                 const int nc0 = hdr->ncand;
-                int *xz = xzb + (tile & 1) * 17;
+                int *xz = xzb + (tile & 1) * (NW + 1);
                 const int r_n = r3 == 2 ? 0 : r3 + 1, r_nn = r_n == 2 ? 0 : r_n + 1;
                 if (!ERH_ABL(8)) {                                        // next tile (clamped past the end)
-                    as_describe(rng + r_n * 64, nq, lane, wave, ds_n, dc_n);
+                    as_describe<NW>(rng + r_n * 64, nq, lane, wave, ds_n, dc_n);
                     np_n = pieces_of(__builtin_amdgcn_readfirstlane(rng[r_n * 64][3]));
                 }
                 ERH_SEC(0);
+#ifdef ERH_MEASURE
+                if (dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); ERH_SEC(6); }   // (measurement: load wait on its own, booked under [6])
+#endif
                 const uint32_t thx = thq > 1u ? thq : 0u;
-                if (!ERH_ABL(1)) as_apply(S, dc_c, 0, np_c, lane, accu, base_doc, thx, xl, xz);   // (requested a tile ago)
+                if (!ERH_ABL(1)) as_apply<NW>(S, dc_c, 0, np_c, lane, accu, dummy, base_doc, thx, xl, xz);   // (requested a tile ago)
+#ifdef ERH_MEASURE
+                if (dbg) ERH_SEC(7);                                      // (measurement: the adds on their own, booked under [7])
+#endif
                 for (int r0 = kAsU; r0 < np_c; r0 += kAsU) {              // more pieces than the register slots hold (rare)
                     as_fill(S, ds_c, dc_c, r0, np_c, post, lane, nnz);
-                    as_apply(S, dc_c, r0, np_c, lane, accu, base_doc, thx, xl, xz);
+                    as_apply<NW>(S, dc_c, r0, np_c, lane, accu, dummy, base_doc, thx, xl, xz);
                 }
                 if (!ERH_ABL(2)) as_fill(S, ds_n, dc_n, 0, np_n, post, lane, nnz);   // lands during the bookkeeping below
                 if (wave == 0) {                                          // ranges of tile + 2 -> LDS, skip-table entries of tile + 3
@@ -1213,11 +1242,11 @@ __global__ __launch_bounds__(kBmThreads) void bm25_ascan_kernel(
         } else {
             // long queries: chunks of 64 tokens; wave 0 publishes the chunk's ranges, everybody fetches and applies on the spot
             for (int tile = t_begin; tile < t_end && !stop; ++tile) {
-                const int base_doc = tile * kAsTile;
+                const int base_doc = tile * TILE;
                 const uint32_t thq = h2->thq;
                 const int nc0 = hdr->ncand;
                 const uint32_t thx = thq > 1u ? thq : 0u;
-                int *xz = xzb + (tile & 1) * 17;
+                int *xz = xzb + (tile & 1) * (NW + 1);
                 for (int c0 = 0; c0 < nq; c0 += kAsTokChunk) {
                     const int nqc = nq - c0 < kAsTokChunk ? nq - c0 : kAsTokChunk;
                     if (wave == 0) {
@@ -1235,16 +1264,16 @@ __global__ __launch_bounds__(kBmThreads) void bm25_ascan_kernel(
                         }
                         const as_int4 r = as_make_ranges(ipc, a, b, nqc, lane);
                         rng[lane] = r;
-                        if (lane == 0 && r[3] > 64 * kWsWaves) h2->redo = 1;
+                        if (lane == 0 && r[3] > 64 * NW) h2->redo = 1;
                     }
                     __syncthreads();
                     uint32_t ds;
                     int dc;
-                    as_describe(rng, nqc, lane, wave, ds, dc);
+                    as_describe<NW>(rng, nqc, lane, wave, ds, dc);
                     const int np = pieces_of(__builtin_amdgcn_readfirstlane(rng[0][3]));
                     for (int r0 = 0; r0 < np; r0 += kAsU) {
                         as_fill(S, ds, dc, r0, np, post, lane, nnz);
-                        as_apply(S, dc, r0, np, lane, accu, base_doc, thx, xl, xz);
+                        as_apply<NW>(S, dc, r0, np, lane, accu, dummy, base_doc, thx, xl, xz);
                     }
                     __syncthreads();                                      // (the ranges are overwritten by the next chunk)
                 }
@@ -1253,7 +1282,7 @@ __global__ __launch_bounds__(kBmThreads) void bm25_ascan_kernel(
             }
         }
     }
-    if (!stop) as_shrink(hdr, h2, ca, ci, hist, k, keep_frac, nq, 0);     // final list: k entries + the near ties of the k-th
+    if (!stop) as_shrink<CAP>(hdr, h2, ca, ci, hist, k, keep_frac, nq, 0);     // final list: k entries + the near ties of the k-th
     if (h2->redo) {                                                       // workgroup-uniform
         if (tid == 0) { redo[(int64_t)q * segs + seg] = 1u; part_len[(int64_t)q * segs + seg] = 0; }
         return;
@@ -1263,11 +1292,10 @@ __global__ __launch_bounds__(kBmThreads) void bm25_ascan_kernel(
     // ---- exact re-score of the list, in query-token order, in the library's type ------------------------------------------
     const int n_keep = hdr->ncand;
     ST *fs = reinterpret_cast<ST *>(smem + kAsOffAcc);                    // the accumulators are dead: exact sums ...
-    ST *M = fs + kBmCap;                                                  // ... and the (entry, token) payload matrix
-    constexpr int kMCap = (int)(((size_t)kAsTile * 4 - (size_t)kBmCap * sizeof(ST)) / sizeof(ST));
-    const int tab_shift = 15 - tshift;                                    // log2 of the skip table's granularity
-    static_assert(kAsTile == 32768, "tab_shift assumes 32768-document tiles");
-    for (int i = tid; i < kBmCap; i += kBmThreads) fs[i] = (ST)0;
+    ST *M = fs + CAP;                                                  // ... and the (entry, token) payload matrix
+    constexpr int kMCap = (int)(((size_t)TILE * 4 - (size_t)CAP * sizeof(ST)) / sizeof(ST));
+    const int tab_shift = C::TAB_SHIFT - tshift;                          // log2 of the skip table's granularity
+    for (int i = tid; i < CAP; i += NT) fs[i] = (ST)0;
     for (int c0 = 0; c0 < nq; c0 += kAsTokChunk) {
         const int nqc = nq - c0 < kAsTokChunk ? nq - c0 : kAsTokChunk;
         const int ld = nqc | 1;                                           // odd row length: conflict-free column walk
@@ -1283,13 +1311,13 @@ __global__ __launch_bounds__(kBmThreads) void bm25_ascan_kernel(
             const int ec = n_keep - e0 < ec_max ? n_keep - e0 : ec_max;
             const int items = ec * nqc;
             constexpr int R = 4;                                          // searches in flight per thread
-            for (int w0 = tid; w0 < items; w0 += R * kBmThreads) {
+            for (int w0 = tid; w0 < items; w0 += R * NT) {
                 uint32_t lo[R], hi[R], hi0[R];
                 int32_t doc[R];
                 int mpos[R];
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
-                    const int w = w0 + r * kBmThreads;
+                    const int w = w0 + r * NT;
                     lo[r] = hi[r] = hi0[r] = 0u;
                     doc[r] = 0;
                     mpos[r] = -1;
@@ -1330,7 +1358,7 @@ __global__ __launch_bounds__(kBmThreads) void bm25_ascan_kernel(
                 }
             }
             __syncthreads();
-            for (int e = tid; e < ec; e += kBmThreads) {
+            for (int e = tid; e < ec; e += NT) {
                 ST s = fs[e0 + e];
                 for (int j = 0; j < nqc; ++j) s = s + M[e * ld + j];      // token order; + 0.0 for an absent token
                 fs[e0 + e] = s;
@@ -1338,16 +1366,16 @@ __global__ __launch_bounds__(kBmThreads) void bm25_ascan_kernel(
             __syncthreads();
         }
     }
-    ERH_SEC(6);
+    ERH_SEC(5);
     // ---- rank by counting: entry e goes to position #{entries that beat it} (keys (score, index) are distinct) -----------
     int *rank = reinterpret_cast<int *>(ca);                              // the approximate sums are dead
     __syncthreads();
-    for (int i = tid; i < n_keep; i += kBmThreads) rank[i] = 0;
+    for (int i = tid; i < n_keep; i += NT) rank[i] = 0;
     __syncthreads();
     if (n_keep > 0) {
-        const int parts = n_keep < kBmThreads ? kBmThreads / n_keep : 1;
+        const int parts = n_keep < NT ? NT / n_keep : 1;
         const int chunk = (n_keep + parts - 1) / parts;
-        for (int w = tid; w < n_keep * parts; w += kBmThreads) {
+        for (int w = tid; w < n_keep * parts; w += NT) {
             const int part = w / n_keep, e = w - part * n_keep;           // consecutive lanes: consecutive entries, same part
             const ST se = fs[e];
             const int32_t ie = ci[e];
@@ -1363,13 +1391,13 @@ __global__ __launch_bounds__(kBmThreads) void bm25_ascan_kernel(
     }
     __syncthreads();
     const int n = n_keep < k ? n_keep : k;
-    for (int e = tid; e < n_keep; e += kBmThreads) {
+    for (int e = tid; e < n_keep; e += NT) {
         const int r = rank[e];
         if (r < k) { part_scores[out_base + r] = (double)fs[e]; part_ids[out_base + r] = ci[e]; }
     }
-    for (int i = n + tid; i < k; i += kBmThreads) { part_scores[out_base + i] = 0.0; part_ids[out_base + i] = -1; }
+    for (int i = n + tid; i < k; i += NT) { part_scores[out_base + i] = 0.0; part_ids[out_base + i] = -1; }
     if (tid == 0) part_len[(int64_t)q * segs + seg] = n;
-    ERH_SEC(7);
+    ERH_SEC(5);
 #ifdef ERH_MEASURE
     if (dbg && tid == 0) {
 #pragma unroll
@@ -1490,9 +1518,13 @@ hipError_t bm25_init() {
     e = hipFuncSetAttribute((const void *)bm25_wscan_kernel<double, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)BmLds<double>::OFF_LO + kWsXBytes);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void *)bm25_ascan_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAsBytes);
+    e = hipFuncSetAttribute((const void *)bm25_ascan_kernel<float, AsBig>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AsBig::BYTES);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void *)bm25_ascan_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAsBytes);
+    e = hipFuncSetAttribute((const void *)bm25_ascan_kernel<double, AsBig>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AsBig::BYTES);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void *)bm25_ascan_kernel<float, AsSmall>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AsSmall::BYTES);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void *)bm25_ascan_kernel<double, AsSmall>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AsSmall::BYTES);
     if (e != hipSuccess) return e;
     return hipFuncSetAttribute((const void *)bm25_merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                8192 * 12 + 64);
@@ -1541,23 +1573,27 @@ hipError_t launch_bm25_scan(int variant, const int64_t *indptr, const int32_t *d
     return hipGetLastError();
 }
 
-hipError_t launch_bm25_ascan(int variant, const int64_t *indptr, const int32_t *doc_ids, const void *payload,
+int bm25_ascan_tile_docs(int small) { return small ? AsSmall::TILE : AsBig::TILE; }
+int bm25_ascan_small_max_k() { return AsSmall::CAP - AsSmall::NT / 2 - 3 * AsSmall::RESERVE; }   // 384: the shrink trigger (k + 256) leaves room for the notes of a tile
+
+hipError_t launch_bm25_ascan(int variant, int small, const int64_t *indptr, const int32_t *doc_ids, const void *payload,
                              const void *post, uint32_t nnz, double qmax, const int32_t *tile_off, int n_tab, int tshift,
                              int64_t N, const int32_t *q_indptr, const int32_t *q_tok, const int32_t *q_order, int B, int k,
-                             int segs, const int16_t *filter_dir, const int16_t *dir_id,
+                             int segs, int cut_mul, const int16_t *filter_dir, const int16_t *dir_id,
                              double *part_scores, int32_t *part_ids, int32_t *part_len, uint32_t *redo, int ablate,
                              unsigned long long *dbg, hipStream_t st) {
     if (B <= 0) return hipSuccess;
-    const int n_tiles = (int)((N + kAsTile - 1) / kAsTile);
-    dim3 grid(segs, B), block(kBmThreads);
-    if (variant == 0)
-        hipLaunchKernelGGL(bm25_ascan_kernel<double>, grid, block, kAsBytes, st, indptr, doc_ids, (const double *)payload,
-                           (const as_uint2 *)post, nnz, qmax, tile_off, n_tab, tshift, n_tiles, N, q_indptr, q_tok, q_order, k,
-                           segs, filter_dir, dir_id, part_scores, part_ids, part_len, redo, ablate, dbg);
-    else
-        hipLaunchKernelGGL(bm25_ascan_kernel<float>, grid, block, kAsBytes, st, indptr, doc_ids, (const float *)payload,
-                           (const as_uint2 *)post, nnz, qmax, tile_off, n_tab, tshift, n_tiles, N, q_indptr, q_tok, q_order, k,
-                           segs, filter_dir, dir_id, part_scores, part_ids, part_len, redo, ablate, dbg);
+    if (cut_mul < 1) cut_mul = 1;
+    const int tile = small ? AsSmall::TILE : AsBig::TILE;
+    const int n_tiles = (int)((N + tile - 1) / tile);
+    dim3 grid(segs, B);
+#define ERH_AS_LAUNCH(ST, CFG)                                                                                       \
+    hipLaunchKernelGGL((bm25_ascan_kernel<ST, CFG>), grid, dim3(CFG::NT), CFG::BYTES, st, indptr, doc_ids,           \
+                       (const ST *)payload, (const as_uint2 *)post, nnz, qmax, tile_off, n_tab, tshift, n_tiles, N, q_indptr, \
+                       q_tok, q_order, k, segs, cut_mul, filter_dir, dir_id, part_scores, part_ids, part_len, redo, ablate, dbg)
+    if (variant == 0) { if (small) ERH_AS_LAUNCH(double, AsSmall); else ERH_AS_LAUNCH(double, AsBig); }
+    else { if (small) ERH_AS_LAUNCH(float, AsSmall); else ERH_AS_LAUNCH(float, AsBig); }
+#undef ERH_AS_LAUNCH
     return hipGetLastError();
 }
 
@@ -1575,7 +1611,6 @@ hipError_t launch_bm25_post(const int32_t *doc_ids, const float *pay32, int64_t 
     return hipGetLastError();
 }
 
-int bm25_ascan_tiles(int64_t N) { return (int)((N + kAsTile - 1) / kAsTile); }
 
 hipError_t launch_bm25_payload_max(const float *pay32, int64_t nnz, uint32_t *bits, hipStream_t st) {
     if (nnz <= 0) return hipSuccess;

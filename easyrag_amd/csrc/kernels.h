@@ -113,13 +113,15 @@ hipError_t launch_bm25_scan(int variant, const int64_t *indptr, const int32_t *d
 // {document, fixed-point payload} postings built by launch_bm25_post (nnz + 1 entries, the last one a sentinel), qmax the
 // largest fixed-point payload; redo: zeroed [B][segs] words, set where the list overflowed with near ties or the sums
 // could overflow (those workgroups are then scanned by launch_bm25_scan(..., only = redo)).
-int bm25_ascan_tiles(int64_t N);
+int bm25_ascan_tile_docs(int small);   // 32768, or 16384 for the two-workgroups-per-CU shape
+int bm25_ascan_small_max_k();
 float bm25_post_scale(float pmax);
 hipError_t launch_bm25_post(const int32_t *doc_ids, const float *pay32, int64_t nnz, float scale, void *post, hipStream_t st);
-hipError_t launch_bm25_ascan(int variant, const int64_t *indptr, const int32_t *doc_ids, const void *payload,
+hipError_t launch_bm25_ascan(int variant, int small /* 512 threads, 16384-document tiles, two workgroups per CU */, const int64_t *indptr, const int32_t *doc_ids, const void *payload,
                              const void *post, uint32_t nnz, double qmax, const int32_t *tile_off, int n_tab, int tshift,
                              int64_t N, const int32_t *q_indptr, const int32_t *q_tok, const int32_t *q_order, int B, int k,
-                             int segs, const int16_t *filter_dir, const int16_t *dir_id,
+                             int segs, int cut_mul /* segment cuts on multiples of this many tiles */,
+                             const int16_t *filter_dir, const int16_t *dir_id,
                              double *part_scores, int32_t *part_ids, int32_t *part_len, uint32_t *redo,
                              int ablate /* measurement builds only */, unsigned long long *dbg, hipStream_t st);
 hipError_t launch_narrow_f64(const double *in, int64_t n, float *out, hipStream_t st);

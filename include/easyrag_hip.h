@@ -272,8 +272,8 @@ int erh_reset_kernel_time(erh_handle *h);
  *   dense_pp (3)          ping-pong persistent append scan: 3 = strict alternation (fragment reads inside the matrix segment),
  *                         2 = lean-issue kernel, 1 = the round-1 kernel; 0 = lock-step kernels (dense_persist 1 / 0 = persistent /
  *                         one workgroup per tile, dense_cfg 0..2 = their tile configuration, dense_readahead)
- *   dense_tiled (1)       keep a tiled, pre-swizzled copy of the chunk matrix for the ping-pong scan (+ N * d * 2 bytes; takes
- *                         effect at the next erh_set_dense)
+ *   dense_tiled (0)       keep a tiled, pre-swizzled copy of the chunk matrix for the ping-pong scan (+ N * d * 2 bytes; takes
+ *                         effect at the next erh_set_dense).  Off: within the run-to-run noise on this workload
  *   dense_var, dense_rot, dense_sync   schedule variants of the ping-pong kernels (measured, off: see DESIGN.md, dead ends)
  *   dense_gemv (1)        batches of at most 16 queries stream the chunk matrix through a 16x16x32 skinny-GEMM kernel
  *                         (the reference's one-query-at-a-time call pattern) instead of the padded 256-query scan
@@ -283,6 +283,8 @@ int erh_reset_kernel_time(erh_handle *h);
  *                         document and token, library summation order).  Needs an index whose payloads are all positive
  *                         normal numbers, else the kernels below run; keeps an interleaved copy of the postings (8
  *                         bytes each), built at the next erh_set_bm25_* / erh_build_bm25_index.  0 = off
+ *   bm25_small (1)        fixed-point scan in its 512-thread shape (16384-document tiles, 80 KiB of LDS: two workgroups = two
+ *                         queries per CU) for batches of >= 8 queries and k <= 384; 0 = always 1024 threads, 32768-document tiles
  *   bm25_crossing (1)     wave-owned scan: survivors from threshold crossings noted in the token loop instead of a sweep
  *                         over the accumulators (1 = fp32 sums only, 2 = fp64 too, 0 = always sweep); indices with a
  *                         non-positive payload always sweep

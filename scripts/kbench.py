@@ -252,9 +252,12 @@ def main():
             queries = synth.token_queries(flat, lens, vocab, 1024, seed=9)
             eng.set_bm25(idx, payload_on_device=True)
             for rep in "ab":
-                for Bq, k in ((1024, 192), (256, 100), (16, 192), (1, 192)):
-                    qi, qt = queries_to_csr(queries[:Bq])
-                    res[f"{name} ascan B={Bq} k={k} (run {rep})"] = timed(eng, lambda: eng.bm25_topk(qi, qt, k, device_out=True), 3)
+                for small in (1, 0):
+                    eng.set_option("bm25_small", small)
+                    for Bq, k in ((1024, 192), (256, 100), (16, 192), (1, 192)):
+                        qi, qt = queries_to_csr(queries[:Bq])
+                        res[f"{name} ascan small={small} B={Bq} k={k} (run {rep})"] = timed(eng, lambda: eng.bm25_topk(qi, qt, k, device_out=True), 3)
+            eng.set_option("bm25_small", 1)
             qi, qt = queries_to_csr(queries)
             if name == "bm25s":
                 for abl in (0, 1):                # 1 no adds, 4 no clear, 8 one descriptor set (cached loads, adds out of range)
@@ -266,7 +269,7 @@ def main():
             torch.cuda.synchronize()
             c = eng.debug_counters().astype(np.float64)
             eng.set_option("debug_counters", 0)
-            names = ["ranges+fill_issue", "apply", "apply_barrier", "sweep", "sweep_barrier", "shrink", "rescore", "final"]
+            names = ["describe", "extra rounds+fill+publish", "apply_barrier", "list+clear | sweep", "clear_barrier", "shrink+rescore+final", "load wait", "adds"]
             tot = c[:8].sum()
             res[f"{name} ascan sections (% of thread-0 cycles, k=192)"] = {n_: round(100 * v / tot, 1) for n_, v in zip(names, c[:8])}
             res[f"{name} ascan cycles per query (thread 0)"] = {"total": round(tot / 1024)}

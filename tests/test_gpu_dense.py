@@ -13,9 +13,9 @@ pytestmark = pytest.mark.gpu
 
 
 # (dense_cfg, dense_persist, dense_pp, dense_gemv, dense_speculate, dense_tiled)
-@pytest.fixture(params=[(0, 1, 3, 0, 1, 1), (0, 1, 3, 0, 0, 0), (0, 1, 2, 0, 1, 0), (0, 1, 1, 0, 0, 0), (0, 1, 0, 0, 1, 0),
+@pytest.fixture(params=[(0, 1, 3, 0, 1, 0), (0, 1, 3, 0, 1, 1), (0, 1, 3, 0, 0, 0), (0, 1, 2, 0, 1, 0), (0, 1, 1, 0, 0, 0), (0, 1, 0, 0, 1, 0),
                         (0, 0, 0, 0, 0, 0), (1, 0, 0, 0, 1, 0), (2, 1, 0, 0, 0, 0), (0, 1, 3, 1, 1, 1)],
-                ids=["pingpong-strict-tiled-256x256x32", "pingpong-strict-rowmajor-guaranteed-bounds", "pingpong-lean-256x256x32",
+                ids=["pingpong-strict-rowmajor-256x256x32", "pingpong-strict-tiled-256x256x32", "pingpong-strict-rowmajor-guaranteed-bounds", "pingpong-lean-256x256x32",
                      "pingpong-256x256x32-guaranteed-bounds", "cfg0-256x256x64-persistent", "cfg0-per-tile-guaranteed-bounds",
                      "cfg1-128x256x32-per-tile", "cfg2-256x256x32-persistent-guaranteed-bounds", "gemv-16x16x32-small-batch"])
 def scan_cfg(request, engine):
@@ -35,7 +35,7 @@ def scan_cfg(request, engine):
     engine.set_option("dense_pp", 3)
     engine.set_option("dense_gemv", 1)
     engine.set_option("dense_speculate", 1)
-    engine.set_option("dense_tiled", 1)
+    engine.set_option("dense_tiled", 0)
 
 
 def test_mfma_scores_match_plain_gpu_and_numpy(engine, scan_cfg):
