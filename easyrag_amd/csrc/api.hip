@@ -93,6 +93,11 @@ struct erh_handle {
     int opt_bm25_segs = 0;                // document-range segments per query (0: enough to give the chip >= 512 workgroups)
     int opt_bm25_crossing = 1;            // wave-owned scan: threshold crossings instead of the accumulator sweep (indices with positive
                                           // payloads); 1 = fp32 sums only (the fp64 kernel runs out of registers with it: +12 % time), 2 = both
+    int opt_hybrid_overlap = 0;           // erh_hybrid_topk: 1 = the sparse route on a side stream from the start, 2 = forked behind the dense scan
+                                          // (beside the selection kernels); joined before the fusion.  Measured slower than one stream: off
+    hipStream_t side = nullptr;           // ... created at first use
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool fork_after_scan = false;         // dense_topk_dev records ev_fork behind its last scan launch (hybrid_overlap 2)
     int opt_bm25_small = 1;               // fixed-point scan: 512-thread workgroups, two per CU, when k allows (0: always the 1024-thread shape)
     int opt_bm25_ascan = 1;               // approximate-order scan + exact re-score when the index qualifies (positive payloads)
     int opt_bm25_wscan = 0;               // otherwise: wave-owned scan when the batch qualifies (needs the fine skip table, built at the
@@ -415,6 +420,7 @@ int dense_topk_dev(erh_handle *h, const void *q_dev, int q_dtype, int normalize_
             cur = next;
         }
     }
+    if (h->fork_after_scan) HIPCHK(h, hipEventRecord(h->ev_fork, st));   // the sparse route may start beside the selection kernels
     { ProfScope ps(h, st, ERH_K_DENSE_SELECT, 0, 0);
       HIPCHK(h, erh::launch_dense_finalize(B, k, mode, h->qnorm.as<float>(), h->xnorm_max, d, X, Q16,
                                            h->cand.as<ErhCand>(), h->cand_cnt.as<uint32_t>(), cap, d_ids, d_sc, d_len,
@@ -633,6 +639,7 @@ int erh_destroy(erh_handle *h) {
     (void)hipDeviceSynchronize();
     drain_events(h);
     for (auto &ev : h->pool) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
+    if (h->side) { (void)hipStreamDestroy(h->side); (void)hipEventDestroy(h->ev_fork); (void)hipEventDestroy(h->ev_join); }
     DevBuf *bufs[] = {&h->X, &h->Xt, &h->scan_sync, &h->qorder, &h->content_id, &h->dir_id,
                       &h->qin, &h->Q16, &h->qnorm, &h->tau, &h->S0, &h->cand, &h->cand_cnt, &h->flags, &h->filt, &h->filt2,
                       &h->o_ids, &h->o_sc, &h->o_len, &h->qptr, &h->qtok, &h->part_sc, &h->part_ids, &h->part_len,
@@ -690,6 +697,7 @@ int erh_set_option(erh_handle *h, const char *name, int64_t value) {
     if (!strcmp(name, "bm25_crossing")) { if (value < 0 || value > 2) return h->fail(ERH_ERR_INVALID, "bm25_crossing"); h->opt_bm25_crossing = (int)value; return ERH_OK; }
     if (!strcmp(name, "bm25_ascan")) { h->opt_bm25_ascan = value != 0; return ERH_OK; }
     if (!strcmp(name, "bm25_small")) { h->opt_bm25_small = value != 0; return ERH_OK; }
+    if (!strcmp(name, "hybrid_overlap")) { if (value < 0 || value > 2) return h->fail(ERH_ERR_INVALID, "hybrid_overlap"); h->opt_hybrid_overlap = (int)value; return ERH_OK; }
     if (!strcmp(name, "bm25_wscan")) { h->opt_bm25_wscan = value != 0; return ERH_OK; }   // the fine table is built at the next erh_set_bm25_*
     if (!strcmp(name, "bm25_fine_max_mb")) { if (value < 0) return h->fail(ERH_ERR_INVALID, "bm25_fine_max_mb < 0"); h->opt_bm25_fine_max_mb = value; return ERH_OK; }
     if (!strcmp(name, "debug_counters")) {
@@ -1443,12 +1451,51 @@ int erh_hybrid_topk(erh_handle *h, const void *q, int q_dtype, int q_is_device, 
     HIPCHK(h, h->hy_dids.ensure((size_t)B * k_dense * 4));
     HIPCHK(h, h->hy_dsc.ensure((size_t)B * k_dense * 8));
     HIPCHK(h, h->hy_dlen.ensure((size_t)B * 4));
-    // sparse route (list a), dense route (list b), fusion -- all on the caller's stream, no host round trip
-    rc = bm25_topk_dev(h, h->qptr.as<int32_t>(), h->qtok.as<int32_t>(), B, k_sparse, filt, h->hy_sids.as<int32_t>(),
-                       h->hy_ssc.as<double>(), h->hy_slen.as<int32_t>(), bytes, max_qlen, st);
-    if (rc != ERH_OK) return rc;
+    // sparse route (list a), dense route (list b), fusion -- no host round trip.  The two routes do not depend on each
+    // other: with hybrid_overlap the sparse route is enqueued on a side stream that forks from the caller's stream (its
+    // inputs were staged there) and joins it again in front of the fusion; whatever the dense pipeline leaves idle --
+    // the under-filled seed grid, the selection kernels, the tail of the persistent scan -- the other route can use.
+    hipStream_t st_sparse = st;
+    const int ov = h->opt_hybrid_overlap;
+    if (ov) {
+        if (!h->side) {
+            HIPCHK(h, hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+            HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+            HIPCHK(h, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+        }
+        st_sparse = h->side;
+    }
+    auto sparse_route = [&]() -> int {
+        int r = bm25_topk_dev(h, h->qptr.as<int32_t>(), h->qtok.as<int32_t>(), B, k_sparse, filt, h->hy_sids.as<int32_t>(),
+                              h->hy_ssc.as<double>(), h->hy_slen.as<int32_t>(), bytes, max_qlen, st_sparse);
+        if (r == ERH_OK && st_sparse != st) {
+            hipError_t e_ = hipEventRecord(h->ev_join, st_sparse);
+            if (e_ != hipSuccess) r = h->fail(ERH_ERR_HIP, "hipEventRecord(join)", e_);
+        }
+        return r;
+    };
+    if (ov == 1) {                                   // fork at once: both routes compete for the CUs from the start
+        HIPCHK(h, hipEventRecord(h->ev_fork, st));
+        HIPCHK(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
+    }
+    if (ov != 2) {
+        rc = sparse_route();
+        if (rc != ERH_OK) { if (st_sparse != st) (void)hipStreamSynchronize(st_sparse); return rc; }
+    }
+    h->fork_after_scan = (ov == 2);
     rc = dense_topk_dev(h, qd, q_dtype, normalize_q, B, k_dense, filt_d, ERH_DENSE_EXACT, h->hy_dids.as<int32_t>(),
                         h->hy_dsc.as<double>(), h->hy_dlen.as<int32_t>(), st);
+    h->fork_after_scan = false;
+    if (ov == 2) {                                   // fork behind the dense scan: the sparse route runs beside the selection kernels
+        if (rc != ERH_OK) return rc;
+        HIPCHK(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
+        rc = sparse_route();
+        if (rc != ERH_OK) { (void)hipStreamSynchronize(st_sparse); return rc; }
+    }
+    if (st_sparse != st) {                           // join (also on the error path: nothing may outlive the call's buffers)
+        hipError_t e_ = hipStreamWaitEvent(st, h->ev_join, 0);
+        if (e_ != hipSuccess && rc == ERH_OK) rc = h->fail(ERH_ERR_HIP, "hipStreamWaitEvent(join)", e_);
+    }
     if (rc != ERH_OK) return rc;
     int32_t *d_ids = out_ids; double *d_sc = out_scores; int32_t *d_len = out_len;
     if (!out_is_device) {

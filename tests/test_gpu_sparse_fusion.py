@@ -342,8 +342,12 @@ def test_hybrid_dual_route_matches_oracle_composition(engine, variant):
     qi, qt = queries_to_csr([idx.tokens_to_ids(q) for q in queries])
     o_sparse = [bm25_filter(_oracle_scores(ora, variant, queries[b]), 192) for b in range(B)]
     o_dense = [dense_exact_topk(x, q16[b], 288) for b in range(B)]
-    for topk in (10, 256):
-        ids, sc, ln = engine.hybrid_topk(q16, qi, qt, k_dense=288, k_sparse=192, K=60, topk=topk)
+    for topk, overlap in ((10, 0), (256, 0), (10, 1), (10, 2)):      # (hybrid_overlap: the sparse route on a side stream)
+        engine.set_option("hybrid_overlap", overlap)
+        try:
+            ids, sc, ln = engine.hybrid_topk(q16, qi, qt, k_dense=288, k_sparse=192, K=60, topk=topk)
+        finally:
+            engine.set_option("hybrid_overlap", 0)
         for b in range(B):
             sp = o_sparse[b]
             did, dsc = o_dense[b]
