@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 cd /tmp
 for wl in hybrid dense bm25; do
   timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/traffic/$wl -o p -- \
-    python $GRAFT_REPO_ROOT/bench.py --workload $wl --steps 3 --warmup 1 --cpu-queries 0 > $GRAFT_REPO_ROOT/gpurun_out/traffic/$wl.log 2>&1
+    python $GRAFT_REPO_ROOT/bench.py --workload $wl --steps 3 --warmup 1 --cpu-queries 0 --sub 0 > $GRAFT_REPO_ROOT/gpurun_out/traffic/$wl.log 2>&1
   echo "$wl exit $?"
 done
 cd $GRAFT_REPO_ROOT
@@ -20,7 +20,7 @@ from easyrag_amd import _build
 out = {"_lib_digest": _build._digest()}      # bench.py attaches the figures only to runs of exactly these kernels
 import re
 for wl, match, pat in (("hybrid", "dense_scan", r"dense_(scan|gemv)"), ("dense", "dense_scan", r"dense_(scan|gemv)"),
-                       ("bm25", "bm25_scan", r"bm25_w?scan")):
+                       ("bm25", "bm25_scan", r"bm25_[wa]?scan")):
     f = glob.glob(f"gpurun_out/traffic/{wl}/**/*counter_collection.csv", recursive=True)
     if not f:
         continue
@@ -38,7 +38,7 @@ for wl, match, pat in (("hybrid", "dense_scan", r"dense_(scan|gemv)"), ("dense",
         "hbm_bytes_per_launch": 2.0 * 1024.0 * sum(vals) / len(vals),
         "correction": "FETCH_SIZE [KiB] x 1024 x 2 (gfx950: 128-byte requests tallied at 64 bytes)",
         "per_kernel_kib": {k: sum(v) / len(v) for k, v in per.items()},
-        "command": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python bench.py --workload {wl} --steps 3 --warmup 1 --cpu-queries 0",
+        "command": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python bench.py --workload {wl} --steps 3 --warmup 1 --cpu-queries 0 --sub 0",
     }
 json.dump(out, open("gpurun_out/pmc_traffic.json", "w"), indent=1)
 print(json.dumps(out, indent=1)[:3000])
