@@ -493,7 +493,9 @@ int bm25_topk_dev(erh_handle *h, const int32_t *qptr_dev, const int32_t *qtok_de
     const int tiles = ascan ? (int)((S.Nb + as_docs - 1) / as_docs) : S.n_tiles;
     int segs = h->opt_bm25_segs > 0 ? h->opt_bm25_segs : ((small ? 1024 : 512) + B - 1) / B;
     segs = std::max(1, std::min(segs, ascan ? std::min(tiles, std::max(S.n_tiles, 1)) : tiles));
-    while (segs > 1 && (int64_t)segs * k > 8192) --segs;
+    // the merge sorts pow2(segs * k) padded slots in one workgroup: beyond 2048 it costs more than the extra segments save
+    // (profiles/r03c_small_batch.log: one query, k = 192: 31 segments 0.038 + 0.106 ms, 10 segments 0.052 + 0.027 ms)
+    while (segs > 1 && (int64_t)segs * k > 2048) --segs;
     unsigned long long *dbg = h->opt_debug_counters ? h->dbg.as<unsigned long long>() : nullptr;
     const int32_t *q_order = (h->qorder_valid && qptr_dev == h->qptr.as<int32_t>()) ? h->qorder.as<int32_t>() : nullptr;
     if (ascan) {

@@ -36,6 +36,39 @@ def main():
         scan = eng.kernel_time(ERH_K_DENSE_SCAN)["ms"] / reps
         sel = eng.kernel_time(ERH_K_DENSE_SELECT)["ms"] / reps
         print(f"B={B:3d} k={k:3d}: scan {scan:.3f} ms ({2.048 / scan:.2f} TB/s of the 2 GB matrix)  select {sel:.3f} ms  wall {wall:.3f} ms per call")
+    # sparse route and the fused call at B = 1 / 16: how the number of document-range segments (workgroups per query, then
+    # one merge of their lists) trades scan time against merge time
+    from easyrag_amd._lib import ERH_K_BM25_MERGE, ERH_K_BM25_SCAN, ERH_K_FUSE
+    from easyrag_amd.engine import queries_to_csr
+    from easyrag_amd.index import BM25S, build_bm25_index_from_postings
+    vocab = 262_144
+    indptr, doc, tf, lens, flat = synth.token_csr_torch(n, vocab, seed=3, device=dev)
+    idx = build_bm25_index_from_postings(indptr, doc, tf, lens, BM25S, compute_payload=False)
+    eng.set_bm25(idx, payload_on_device=True)
+    eng.set_doc_meta(n, None, None)
+    queries = synth.token_queries(flat, lens, vocab, 16, seed=9)
+    for B in (1, 16):
+        q = synth.dense_queries_torch(x, B, seed=7)
+        qi, qt = queries_to_csr(queries[:B])
+        for segs in (0, 5, 10, 21, 31):
+            eng.set_option("bm25_segs", segs)
+            for what, fn in (("bm25 top-192", lambda: eng.bm25_topk(qi, qt, 192, device_out=True)),
+                             ("hybrid 288+192->10", lambda: eng.hybrid_topk(q, qi, qt, k_dense=288, k_sparse=192, K=60, topk=10, device_out=True))):
+                for _ in range(3):
+                    fn()
+                torch.cuda.synchronize()
+                eng.set_profiling(True)
+                eng.reset_kernel_time()
+                reps = 50
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    fn()
+                    torch.cuda.synchronize()
+                wall = (time.perf_counter() - t0) / reps * 1e3
+                eng.set_profiling(False)
+                ks = {nm: eng.kernel_time(c)["ms"] / reps for nm, c in (("scan", ERH_K_BM25_SCAN), ("merge", ERH_K_BM25_MERGE), ("fuse", ERH_K_FUSE))}
+                print(f"B={B:2d} bm25_segs={segs:2d} {what:20s}: bm25 scan {ks['scan']:.3f} merge {ks['merge']:.3f} fuse {ks['fuse']:.3f} ms  wall {wall:.3f} ms per call")
+    eng.set_option("bm25_segs", 0)
     eng.close()
 
 
