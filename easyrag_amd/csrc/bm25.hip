@@ -1014,6 +1014,168 @@ __device__ __forceinline__ void as_shrink(BmHdr *hdr, AsHdr *h2, uint32_t *ca, i
     __syncthreads();
 }
 
+// The tile's sums are complete and there is no threshold yet (or too many crossings were noted): sweep the whole tile
+// with the workgroup -- survivors (>= the drop threshold, passing the filter) to the list, everything else cleared; the
+// list is cut back (as_shrink) whenever it fills.  On the first tile of the segment the threshold is seeded from the
+// k-th largest of the per-thread maxima.  Ends behind a barrier.  true: give up (redo).
+template <class C>
+__device__ __forceinline__ bool as_sweep_tile(BmHdr *hdr, AsHdr *h2, uint32_t *accu, uint32_t *ca, int32_t *ci, uint32_t *hist,
+                                              bool first_tile, int base_doc, int64_t N, int fd,
+                                              const int16_t *__restrict__ dir_id, int k, double keep_frac, int nq, int &ph) {
+    constexpr int NT = C::NT, TILE = C::TILE, CAP = C::CAP;
+    const int tid = threadIdx.x;
+    if (first_tile && k <= NT && fd < 0) {
+        // k-th largest of the per-thread maxima: k distinct documents reach it, so it is a valid first thetaq
+        typedef uint32_t UT __attribute__((ext_vector_type(4)));
+        uint32_t mx = 0u;
+        for (int i = tid * 4; i < TILE; i += NT * 4) {
+            const UT v = *reinterpret_cast<const UT *>(accu + i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) mx = v[e] > mx ? v[e] : mx;
+        }
+        ca[tid] = mx;                                                     // the list is still empty
+        const uint32_t p = as_kth_largest(ca, NT, k, hist, h2);           // begins and ends with barriers
+        if (tid == 0 && p > 0u) { h2->thetaq = p; h2->thq = as_drop_threshold(p, keep_frac, nq); }
+        __syncthreads();
+    }
+    for (;;) {
+        const int slot = ph % 3;
+        if (tid == 0) { hdr->full[(ph + 1) % 3] = 0; hdr->want[(ph + 1) % 3] = 0; }
+        bm_sweep<uint32_t, CAP>(hdr, accu, ca, ci, 0, TILE, NT, tid, (int64_t)base_doc, N, fd, dir_id, h2->thq,
+                                0x7fffffff, &hdr->full[slot], &hdr->want[slot], k + NT / 2);
+        __syncthreads();
+        const int full = hdr->full[slot], want = hdr->want[slot];
+        ++ph;
+        if (full || want) {
+            as_shrink<CAP>(hdr, h2, ca, ci, hist, k, keep_frac, nq, C::RESERVE);
+            if (h2->redo) return true;                                    // (written before as_shrink's last barrier)
+        }
+        if (!full) return false;                                          // (full: survivors were left behind -- sweep again)
+    }
+}
+
+// The scan is over: hdr->ncand list entries (document ci[], approximate sum dead) hold the top k and the near ties of
+// the k-th.  Exact re-score in query-token order in the library's type (one binary search per (document, token) inside
+// the skip-table range of 2^tab_shift documents that holds the document), rank by counting, write the segment's list.
+template <typename ST, class C>
+__device__ __forceinline__ void as_finish_query(char *smem, BmHdr *hdr, uint32_t *ca, int32_t *ci,
+                                                const int64_t *__restrict__ indptr, const int32_t *__restrict__ doc_ids,
+                                                const ST *__restrict__ payload, const int32_t *__restrict__ tile_off, int n_tab,
+                                                int tab_shift, const int32_t *__restrict__ q_tok, int qs, int nq, int k,
+                                                int64_t out_base, int64_t out_slot, double *__restrict__ part_scores,
+                                                int32_t *__restrict__ part_ids, int32_t *__restrict__ part_len) {
+    constexpr int NT = C::NT, TILE = C::TILE, CAP = C::CAP;
+    const int tid = threadIdx.x;
+    int32_t *s_tok = reinterpret_cast<int32_t *>(smem + kAsOffTok);
+    uint32_t *s_ip = reinterpret_cast<uint32_t *>(smem + kAsOffIp);
+    // ---- exact re-score of the list, in query-token order, in the library's type ------------------------------------------
+    const int n_keep = hdr->ncand;
+    ST *fs = reinterpret_cast<ST *>(smem + kAsOffAcc);                    // the accumulators are dead: exact sums ...
+    ST *M = fs + CAP;                                                  // ... and the (entry, token) payload matrix
+    constexpr int kMCap = (int)(((size_t)TILE * 4 - (size_t)CAP * sizeof(ST)) / sizeof(ST));
+    for (int i = tid; i < CAP; i += NT) fs[i] = (ST)0;
+    for (int c0 = 0; c0 < nq; c0 += kAsTokChunk) {
+        const int nqc = nq - c0 < kAsTokChunk ? nq - c0 : kAsTokChunk;
+        const int ld = nqc | 1;                                           // odd row length: conflict-free column walk
+        __syncthreads();
+        if (tid < nqc) {
+            const int32_t tok = q_tok[qs + c0 + tid];
+            s_tok[tid] = tok;
+            s_ip[tid] = (uint32_t)indptr[tok];
+        }
+        __syncthreads();
+        const int ec_max = kMCap / ld;
+        for (int e0 = 0; e0 < n_keep; e0 += ec_max) {
+            const int ec = n_keep - e0 < ec_max ? n_keep - e0 : ec_max;
+            const int items = ec * nqc;
+            constexpr int R = 4;                                          // searches in flight per thread
+            for (int w0 = tid; w0 < items; w0 += R * NT) {
+                uint32_t lo[R], hi[R], hi0[R];
+                int32_t doc[R];
+                int mpos[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int w = w0 + r * NT;
+                    lo[r] = hi[r] = hi0[r] = 0u;
+                    doc[r] = 0;
+                    mpos[r] = -1;
+                    if (w < items) {
+                        const int e = w / nqc, j = w - e * nqc;
+                        doc[r] = ci[e0 + e];
+                        const int32_t *to = tile_off + (int64_t)s_tok[j] * (n_tab + 1) + (doc[r] >> tab_shift);
+                        lo[r] = s_ip[j] + (uint32_t)to[0];
+                        hi[r] = hi0[r] = s_ip[j] + (uint32_t)to[1];
+                        mpos[r] = e * ld + j;
+                    }
+                }
+                for (;;) {                                                // first posting with document >= doc, R at a time
+                    bool act[R];
+                    uint32_t mid[R];
+                    int32_t dv[R];
+                    bool any = false;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        act[r] = lo[r] < hi[r];
+                        mid[r] = (lo[r] + hi[r]) >> 1;
+                        dv[r] = act[r] ? doc_ids[mid[r]] : 0;
+                        any |= act[r];
+                    }
+                    if (!any) break;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        if (act[r]) { if (dv[r] < doc[r]) lo[r] = mid[r] + 1u; else hi[r] = mid[r]; }
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    if (mpos[r] >= 0) {
+                        ST val = (ST)0;
+                        if (lo[r] < hi0[r] && doc_ids[lo[r]] == doc[r]) val = payload[lo[r]];
+                        M[mpos[r]] = val;
+                    }
+                }
+            }
+            __syncthreads();
+            for (int e = tid; e < ec; e += NT) {
+                ST s = fs[e0 + e];
+                for (int j = 0; j < nqc; ++j) s = s + M[e * ld + j];      // token order; + 0.0 for an absent token
+                fs[e0 + e] = s;
+            }
+            __syncthreads();
+        }
+    }
+    // ---- rank by counting: entry e goes to position #{entries that beat it} (keys (score, index) are distinct) -----------
+    int *rank = reinterpret_cast<int *>(ca);                              // the approximate sums are dead
+    __syncthreads();
+    for (int i = tid; i < n_keep; i += NT) rank[i] = 0;
+    __syncthreads();
+    if (n_keep > 0) {
+        const int parts = n_keep < NT ? NT / n_keep : 1;
+        const int chunk = (n_keep + parts - 1) / parts;
+        for (int w = tid; w < n_keep * parts; w += NT) {
+            const int part = w / n_keep, e = w - part * n_keep;           // consecutive lanes: consecutive entries, same part
+            const ST se = fs[e];
+            const int32_t ie = ci[e];
+            const int j1 = (part + 1) * chunk < n_keep ? (part + 1) * chunk : n_keep;
+            int cnt = 0;
+            for (int j = part * chunk; j < j1; ++j) {
+                const ST sj = fs[j];
+                const int32_t ij = ci[j];
+                cnt += (sj > se || (sj == se && ij < ie)) ? 1 : 0;
+            }
+            if (cnt) atomicAdd(&rank[e], cnt);
+        }
+    }
+    __syncthreads();
+    const int n = n_keep < k ? n_keep : k;
+    for (int e = tid; e < n_keep; e += NT) {
+        const int r = rank[e];
+        if (r < k) { part_scores[out_base + r] = (double)fs[e]; part_ids[out_base + r] = ci[e]; }
+    }
+    for (int i = n + tid; i < k; i += NT) { part_scores[out_base + i] = 0.0; part_ids[out_base + i] = -1; }
+    if (tid == 0) part_len[out_slot] = n;
+}
+
 // grid = (segs, B), block = C::NT.  tile_off has n_tab + 1 entries per term at a granularity of C::TILE >> tshift documents;
 // post = the interleaved fixed-point postings with two sentinels {document -1, q 0} at index nnz.
 template <typename ST, class C>
@@ -1041,8 +1203,6 @@ __global__ __launch_bounds__(C::NT) void bm25_ascan_kernel(
     BmHdr *hdr = reinterpret_cast<BmHdr *>(smem);
     AsHdr *h2 = reinterpret_cast<AsHdr *>(smem + kAsOffHdr2);
     int *xzb = reinterpret_cast<int *>(smem + kAsOffXcnt);
-    int32_t *s_tok = reinterpret_cast<int32_t *>(smem + kAsOffTok);
-    uint32_t *s_ip = reinterpret_cast<uint32_t *>(smem + kAsOffIp);
     as_int4 *rng = reinterpret_cast<as_int4 *>(smem + kAsOffRng);
     uint32_t *accu = reinterpret_cast<uint32_t *>(smem + kAsOffAcc);
     uint32_t *ca = reinterpret_cast<uint32_t *>(smem + C::OFF_CA);
@@ -1127,37 +1287,7 @@ __global__ __launch_bounds__(C::NT) void bm25_ascan_kernel(
             }
             return false;
         }
-        if (tile == t_begin && k <= NT && fd < 0) {
-            // k-th largest of the per-thread maxima: k distinct documents reach it, so it is a valid first thetaq
-            typedef uint32_t UT __attribute__((ext_vector_type(4)));
-            uint32_t mx = 0u;
-            for (int i = tid * 4; i < TILE; i += NT * 4) {
-                const UT v = *reinterpret_cast<const UT *>(accu + i);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) mx = v[e] > mx ? v[e] : mx;
-            }
-            ca[tid] = mx;                                                 // the list is still empty
-            const uint32_t p = as_kth_largest(ca, NT, k, hist, h2);   // begins and ends with barriers
-            if (tid == 0 && p > 0u) { h2->thetaq = p; h2->thq = as_drop_threshold(p, keep_frac, nq); }
-            __syncthreads();
-        }
-        for (;;) {
-            const int slot = ph % 3;
-            if (tid == 0) { hdr->full[(ph + 1) % 3] = 0; hdr->want[(ph + 1) % 3] = 0; }
-            bm_sweep<uint32_t, CAP>(hdr, accu, ca, ci, 0, TILE, NT, tid, (int64_t)base_doc, N, fd, dir_id, h2->thq,
-                               0x7fffffff, &hdr->full[slot], &hdr->want[slot], k + NT / 2);
-            ERH_SEC(3);
-            __syncthreads();
-            ERH_SEC(4);
-            const int full = hdr->full[slot], want = hdr->want[slot];
-            ++ph;
-            if (full || want) {
-                as_shrink<CAP>(hdr, h2, ca, ci, hist, k, keep_frac, nq, C::RESERVE);
-                ERH_SEC(5);
-                if (h2->redo) return true;                                // (written before as_shrink's last barrier)
-            }
-            if (!full) return false;                                      // (full: survivors were left behind -- sweep again)
-        }
+        return as_sweep_tile<C>(hdr, h2, accu, ca, ci, hist, tile == t_begin, base_doc, N, fd, dir_id, k, keep_frac, nq, ph);
     };
 
     bool stop = h2->redo != 0;
@@ -1289,114 +1419,8 @@ __global__ __launch_bounds__(C::NT) void bm25_ascan_kernel(
     }
     if (ERH_ABL(0xff)) { if (tid == 0) part_len[(int64_t)q * segs + seg] = 0; return; }   // (ablations: the list is garbage)
     ERH_SEC(5);
-    // ---- exact re-score of the list, in query-token order, in the library's type ------------------------------------------
-    const int n_keep = hdr->ncand;
-    ST *fs = reinterpret_cast<ST *>(smem + kAsOffAcc);                    // the accumulators are dead: exact sums ...
-    ST *M = fs + CAP;                                                  // ... and the (entry, token) payload matrix
-    constexpr int kMCap = (int)(((size_t)TILE * 4 - (size_t)CAP * sizeof(ST)) / sizeof(ST));
-    const int tab_shift = C::TAB_SHIFT - tshift;                          // log2 of the skip table's granularity
-    for (int i = tid; i < CAP; i += NT) fs[i] = (ST)0;
-    for (int c0 = 0; c0 < nq; c0 += kAsTokChunk) {
-        const int nqc = nq - c0 < kAsTokChunk ? nq - c0 : kAsTokChunk;
-        const int ld = nqc | 1;                                           // odd row length: conflict-free column walk
-        __syncthreads();
-        if (tid < nqc) {
-            const int32_t tok = q_tok[qs + c0 + tid];
-            s_tok[tid] = tok;
-            s_ip[tid] = (uint32_t)indptr[tok];
-        }
-        __syncthreads();
-        const int ec_max = kMCap / ld;
-        for (int e0 = 0; e0 < n_keep; e0 += ec_max) {
-            const int ec = n_keep - e0 < ec_max ? n_keep - e0 : ec_max;
-            const int items = ec * nqc;
-            constexpr int R = 4;                                          // searches in flight per thread
-            for (int w0 = tid; w0 < items; w0 += R * NT) {
-                uint32_t lo[R], hi[R], hi0[R];
-                int32_t doc[R];
-                int mpos[R];
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const int w = w0 + r * NT;
-                    lo[r] = hi[r] = hi0[r] = 0u;
-                    doc[r] = 0;
-                    mpos[r] = -1;
-                    if (w < items) {
-                        const int e = w / nqc, j = w - e * nqc;
-                        doc[r] = ci[e0 + e];
-                        const int32_t *to = tile_off + (int64_t)s_tok[j] * (n_tab + 1) + (doc[r] >> tab_shift);
-                        lo[r] = s_ip[j] + (uint32_t)to[0];
-                        hi[r] = hi0[r] = s_ip[j] + (uint32_t)to[1];
-                        mpos[r] = e * ld + j;
-                    }
-                }
-                for (;;) {                                                // first posting with document >= doc, R at a time
-                    bool act[R];
-                    uint32_t mid[R];
-                    int32_t dv[R];
-                    bool any = false;
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        act[r] = lo[r] < hi[r];
-                        mid[r] = (lo[r] + hi[r]) >> 1;
-                        dv[r] = act[r] ? doc_ids[mid[r]] : 0;
-                        any |= act[r];
-                    }
-                    if (!any) break;
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        if (act[r]) { if (dv[r] < doc[r]) lo[r] = mid[r] + 1u; else hi[r] = mid[r]; }
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    if (mpos[r] >= 0) {
-                        ST val = (ST)0;
-                        if (lo[r] < hi0[r] && doc_ids[lo[r]] == doc[r]) val = payload[lo[r]];
-                        M[mpos[r]] = val;
-                    }
-                }
-            }
-            __syncthreads();
-            for (int e = tid; e < ec; e += NT) {
-                ST s = fs[e0 + e];
-                for (int j = 0; j < nqc; ++j) s = s + M[e * ld + j];      // token order; + 0.0 for an absent token
-                fs[e0 + e] = s;
-            }
-            __syncthreads();
-        }
-    }
-    ERH_SEC(5);
-    // ---- rank by counting: entry e goes to position #{entries that beat it} (keys (score, index) are distinct) -----------
-    int *rank = reinterpret_cast<int *>(ca);                              // the approximate sums are dead
-    __syncthreads();
-    for (int i = tid; i < n_keep; i += NT) rank[i] = 0;
-    __syncthreads();
-    if (n_keep > 0) {
-        const int parts = n_keep < NT ? NT / n_keep : 1;
-        const int chunk = (n_keep + parts - 1) / parts;
-        for (int w = tid; w < n_keep * parts; w += NT) {
-            const int part = w / n_keep, e = w - part * n_keep;           // consecutive lanes: consecutive entries, same part
-            const ST se = fs[e];
-            const int32_t ie = ci[e];
-            const int j1 = (part + 1) * chunk < n_keep ? (part + 1) * chunk : n_keep;
-            int cnt = 0;
-            for (int j = part * chunk; j < j1; ++j) {
-                const ST sj = fs[j];
-                const int32_t ij = ci[j];
-                cnt += (sj > se || (sj == se && ij < ie)) ? 1 : 0;
-            }
-            if (cnt) atomicAdd(&rank[e], cnt);
-        }
-    }
-    __syncthreads();
-    const int n = n_keep < k ? n_keep : k;
-    for (int e = tid; e < n_keep; e += NT) {
-        const int r = rank[e];
-        if (r < k) { part_scores[out_base + r] = (double)fs[e]; part_ids[out_base + r] = ci[e]; }
-    }
-    for (int i = n + tid; i < k; i += NT) { part_scores[out_base + i] = 0.0; part_ids[out_base + i] = -1; }
-    if (tid == 0) part_len[(int64_t)q * segs + seg] = n;
+    as_finish_query<ST, C>(smem, hdr, ca, ci, indptr, doc_ids, payload, tile_off, n_tab, C::TAB_SHIFT - tshift, q_tok, qs, nq, k,
+                           out_base, (int64_t)q * segs + seg, part_scores, part_ids, part_len);
     ERH_SEC(5);
 #ifdef ERH_MEASURE
     if (dbg && tid == 0) {
