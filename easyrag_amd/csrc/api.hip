@@ -93,7 +93,8 @@ struct erh_handle {
     int opt_bm25_segs = 0;                // document-range segments per query (0: enough to give the chip >= 512 workgroups)
     int opt_bm25_crossing = 1;            // wave-owned scan: threshold crossings instead of the accumulator sweep (indices with positive
                                           // payloads); 1 = fp32 sums only (the fp64 kernel runs out of registers with it: +12 % time), 2 = both
-    int opt_hybrid_overlap = 0;           // erh_hybrid_topk: 1 = the sparse route on a side stream from the start, 2 = forked behind the dense scan
+    int opt_hybrid_overlap = -1;          // erh_hybrid_topk: 1 = the sparse route on a side stream from the start, 2 = forked behind the dense scan,
+                                          // 0 = one stream, -1 = by batch size (1 up to 256 queries: neither scan fills the chip; 0 above)
                                           // (beside the selection kernels); joined before the fusion.  Measured slower than one stream: off
     hipStream_t side = nullptr;           // ... created at first use
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -699,7 +700,7 @@ int erh_set_option(erh_handle *h, const char *name, int64_t value) {
     if (!strcmp(name, "bm25_crossing")) { if (value < 0 || value > 2) return h->fail(ERH_ERR_INVALID, "bm25_crossing"); h->opt_bm25_crossing = (int)value; return ERH_OK; }
     if (!strcmp(name, "bm25_ascan")) { h->opt_bm25_ascan = value != 0; return ERH_OK; }
     if (!strcmp(name, "bm25_small")) { h->opt_bm25_small = value != 0; return ERH_OK; }
-    if (!strcmp(name, "hybrid_overlap")) { if (value < 0 || value > 2) return h->fail(ERH_ERR_INVALID, "hybrid_overlap"); h->opt_hybrid_overlap = (int)value; return ERH_OK; }
+    if (!strcmp(name, "hybrid_overlap")) { if (value < -1 || value > 2) return h->fail(ERH_ERR_INVALID, "hybrid_overlap"); h->opt_hybrid_overlap = (int)value; return ERH_OK; }
     if (!strcmp(name, "bm25_wscan")) { h->opt_bm25_wscan = value != 0; return ERH_OK; }   // the fine table is built at the next erh_set_bm25_*
     if (!strcmp(name, "bm25_fine_max_mb")) { if (value < 0) return h->fail(ERH_ERR_INVALID, "bm25_fine_max_mb < 0"); h->opt_bm25_fine_max_mb = value; return ERH_OK; }
     if (!strcmp(name, "debug_counters")) {
@@ -1458,7 +1459,7 @@ int erh_hybrid_topk(erh_handle *h, const void *q, int q_dtype, int q_is_device, 
     // inputs were staged there) and joins it again in front of the fusion; whatever the dense pipeline leaves idle --
     // the under-filled seed grid, the selection kernels, the tail of the persistent scan -- the other route can use.
     hipStream_t st_sparse = st;
-    const int ov = h->opt_hybrid_overlap;
+    const int ov = h->opt_hybrid_overlap >= 0 ? h->opt_hybrid_overlap : (B <= 256 ? 1 : 0);
     if (ov) {
         if (!h->side) {
             HIPCHK(h, hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));

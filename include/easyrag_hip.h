@@ -283,10 +283,11 @@ int erh_reset_kernel_time(erh_handle *h);
  *                         document and token, library summation order).  Needs an index whose payloads are all positive
  *                         normal numbers, else the kernels below run; keeps an interleaved copy of the postings (8
  *                         bytes each), built at the next erh_set_bm25_* / erh_build_bm25_index.  0 = off
- *   hybrid_overlap (0)    erh_hybrid_topk: the sparse route on a side stream -- 1 = beside the whole dense pipeline, 2 = forked
- *                         behind the dense scan (beside the selection kernels) -- joined before the fusion.  Both measured
- *                         SLOWER than one stream (3.25 / 3.31 against 2.95 ms per 1024 queries: the scans need a whole CU's LDS
- *                         each, so they time-slice instead of sharing): off
+ *   hybrid_overlap (-1)   erh_hybrid_topk: the sparse route on a side stream -- 1 = beside the whole dense pipeline, 2 = forked
+ *                         behind the dense scan (beside the selection kernels) -- joined before the fusion; 0 = one stream;
+ *                         -1 = by batch size: 1 up to 256 queries, where neither scan fills the chip (one query: 0.59 -> 0.54
+ *                         ms per call, 64: 0.85 -> 0.77), 0 above (1024 queries: 3.25 / 3.31 against 2.95 ms -- the scans need
+ *                         a whole CU's LDS each, so they time-slice instead of sharing)
  *   bm25_small (1)        fixed-point scan in its 512-thread shape (16384-document tiles, 80 KiB of LDS: two workgroups = two
  *                         queries per CU) for batches of >= 8 queries and k <= 384; 0 = always 1024 threads, 32768-document tiles
  *   bm25_crossing (1)     wave-owned scan: survivors from threshold crossings noted in the token loop instead of a sweep

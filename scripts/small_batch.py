@@ -69,6 +69,25 @@ def main():
                 ks = {nm: eng.kernel_time(c)["ms"] / reps for nm, c in (("scan", ERH_K_BM25_SCAN), ("merge", ERH_K_BM25_MERGE), ("fuse", ERH_K_FUSE))}
                 print(f"B={B:2d} bm25_segs={segs:2d} {what:20s}: bm25 scan {ks['scan']:.3f} merge {ks['merge']:.3f} fuse {ks['fuse']:.3f} ms  wall {wall:.3f} ms per call")
     eng.set_option("bm25_segs", 0)
+    # the two routes are independent until the fusion: sparse route on a side stream (hybrid_overlap 1) or forked behind
+    # the dense scan (2) -- at these batch sizes neither scan fills the chip
+    for B in (1, 4, 16, 64, 128, 256, 512):
+        q = synth.dense_queries_torch(x, B, seed=7)
+        qi, qt = queries_to_csr(synth.token_queries(flat, lens, vocab, 512, seed=9)[:B])
+        for ov in (0, 1, 2):
+            eng.set_option("hybrid_overlap", ov)
+            fn = lambda: eng.hybrid_topk(q, qi, qt, k_dense=288, k_sparse=192, K=60, topk=10, device_out=True)
+            for _ in range(5):
+                fn()
+            torch.cuda.synchronize()
+            reps = 100
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+                torch.cuda.synchronize()
+            wall = (time.perf_counter() - t0) / reps * 1e3
+            print(f"B={B:2d} hybrid 288+192->10 hybrid_overlap={ov}: wall {wall:.3f} ms per call")
+    eng.set_option("hybrid_overlap", -1)
     eng.close()
 
 

@@ -347,7 +347,7 @@ def test_hybrid_dual_route_matches_oracle_composition(engine, variant):
         try:
             ids, sc, ln = engine.hybrid_topk(q16, qi, qt, k_dense=288, k_sparse=192, K=60, topk=topk)
         finally:
-            engine.set_option("hybrid_overlap", 0)
+            engine.set_option("hybrid_overlap", -1)
         for b in range(B):
             sp = o_sparse[b]
             did, dsc = o_dense[b]
