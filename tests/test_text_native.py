@@ -181,3 +181,26 @@ def test_encode_texts_equals_cut_filter_and_dict_loop():
     ids, n = cutter.encode_texts([q], vocab, stop, add=False)
     want = [v_py[t] for t in tokenize_and_remove_stopwords(cutter, q, stop) if t in v_py]
     assert list(ids) == want and n[0] == len(want) and len(vocab) == len(v_py)
+
+
+def test_cutter_survives_arbitrary_bytes():
+    """Raw C-ABI callers may hand over anything: malformed UTF-8 must neither crash nor lose bytes -- the token ends are
+    strictly increasing byte offsets that finish at the length of the input."""
+    import ctypes as C
+
+    from easyrag_amd import _lib
+    lib = _lib.load()
+    cutter = NativeCutter(MINI_DICT)
+    rng = np.random.default_rng(11)
+    pool = [b"\xe5\x8c\x97\xe4\xba\xac", b"\xe5\xa4\xa7\xe5\xad\xa6", b"abc", b" ", b"\r\n", b"\xff", b"\xc0\x80", b"\xe5\x8c",
+            b"\xf0\x9f\x98\x80", b"\xed\xa0\x80", b"\xf4\x90\x80\x80", b"C++", b"\x00", b"\x80\x80"]
+    for _ in range(300):
+        raw = b"".join(pool[i] for i in rng.integers(0, len(pool), size=int(rng.integers(0, 24))))
+        if rng.random() < 0.3:
+            raw = bytes(rng.integers(0, 256, size=int(rng.integers(0, 40)), dtype=np.uint8))
+        ends = np.empty(len(raw) + 1, np.int64)
+        n = C.c_int64(0)
+        assert lib.erh_cutter_cut(cutter._h, raw, len(raw), ends.ctypes.data, len(ends), C.byref(n)) == 0
+        e = ends[: n.value]
+        assert np.all(np.diff(np.concatenate([[0], e])) > 0)
+        assert (n.value == 0) == (len(raw) == 0) and (len(raw) == 0 or e[-1] == len(raw))
