@@ -103,8 +103,8 @@ def cpu_baseline(x_dev, q16_dev, idx, payload, queries, k_dense, k_sparse, topk,
     what = {"hybrid": "BM25(add.at over CSR, argsort, walk) + dense(np.dot fp32 1Mx1024, argsort, walk) + RRF",
             "dense": "dense(np.dot fp32, argsort, walk)", "bm25": "BM25(add.at over CSR, argsort, walk)"}[workload]
     out = {"value": n_sample / dt, "unit": "queries/s", "cores": int(threads), "kind": "port",
-           "sample": f"{n_sample} queries of the same batch, one at a time as the reference does; {what}; "
-                     f"{dt:.1f} s of CPU work"}
+           "sample": f"{n_sample} queries of the same batch, one at a time as the reference does ({int(threads)}-thread BLAS "
+                     f"inside np.dot, everything else one Python thread); {what}; {dt:.1f} s of CPU work"}
     if x32 is not None:
         # what a batching CPU implementation would do with the dense route (the reference does not): one fp32 GEMM for
         # the whole sample, top-k per row by partition + sort; the sparse route and the fusion as timed above
@@ -425,6 +425,8 @@ def main():
                 tot += len(want)
                 hit += len(set(want) & set(int(v) for v in g_ids[b] if v >= 0))
             cpu["recall_at_topk_vs_cpu"] = (hit / tot) if tot else None
+            cpu["recall_note"] = ("id sets of the two results; below 1.0 only where documents tie at the k-th score: the CPU "
+                                  "walk orders equal scores as numpy's argsort happens to, the GPU by index")
         total_q = B * world * args.steps
         workload_name = {
             "hybrid": f"configs[3]: 1M chunks, dual-route dense(top-{k_dense})+BM25(top-{k_sparse}) with RRF top-{topk}",
