@@ -781,7 +781,7 @@ __global__ __launch_bounds__(kBmThreads) void bm25_wscan_kernel(
 // corpus of near-identical short documents) or a query whose sums could overflow sets redo[query, segment]: the host
 // launches the exact block scan for those workgroups only.  Indices with non-positive payloads never come here
 // (api.hip checks when an index is set).
-constexpr int kAsU = 6;                                  // 128-posting pieces per wave and tile held in registers
+constexpr int kAsU = 3;                                  // 128-posting pieces per wave and tile held in registers
 constexpr int kAsTokChunk = 64;                          // lane j <-> query token j
 constexpr int kAsRegion = 2048;                          // accumulators a wave owns (notes, clears)
 constexpr int kAsXW = 88;                                // threshold crossings noted per region and tile
@@ -789,9 +789,10 @@ constexpr size_t kAsOffHdr2 = 64;
 constexpr size_t kAsOffXcnt = 128;                       // int xz[2][NW + 1]: crossings per region, then the largest position handed out
 constexpr size_t kAsOffTok = 320;                        // int32 tok[64]   (re-score stage)
 constexpr size_t kAsOffIp = 576;                         // uint32 ip[64]
+constexpr size_t kAsOffPx = 832;                         // int px[3][16]: the first 16 tokens' piece offsets of each range table, packed
 constexpr size_t kAsOffRng = 1024;                       // int4 rng[3][64]
 constexpr size_t kAsOffAcc = 4096;
-static_assert(kAsOffXcnt + 2 * 17 * 4 <= kAsOffTok && kAsOffIp + 64 * 4 <= kAsOffRng, "header tables overlap");
+static_assert(kAsOffXcnt + 2 * 17 * 4 <= kAsOffTok && kAsOffIp + 64 * 4 <= kAsOffPx && kAsOffPx + 3 * 16 * 4 <= kAsOffRng, "header tables overlap");
 static_assert(kAsOffRng + 3 * 64 * 16 <= kAsOffAcc, "range tables overlap the accumulators");
 
 // Two shapes of the same kernel.  AsBig: one 1024-thread workgroup per CU over 32768-document tiles (list capacity 2048:
@@ -859,15 +860,16 @@ __device__ __forceinline__ as_int4 as_make_ranges(uint32_t ip, int a, int b, int
 // past the token's range or past the tile's last piece; > 128: the token goes on in its next piece).  Every lane scans
 // the tokens' piece offsets with broadcast reads; no wave-uniform control flow, no scalar work.
 template <int NW>
-__device__ __forceinline__ void as_describe(const as_int4 *rt, int nq, int lane, int wave, uint32_t &dstart, int &dcnt) {
-    const int p = wave + lane * NW;
+__device__ __forceinline__ void as_describe(const as_int4 *rt, const as_int4 *px16, int nq, int lane, int wave, uint32_t &dstart,
+                                            int &dcnt) {
+    const int p = wave + lane * NW;                                      // (NW = the number of waves the pieces are dealt to)
     int j = -1;
-    if (nq <= 16) {                                                       // all reads in flight together (lanes past nq hold 0x7fffffff)
-        int px[16];
+    if (nq <= 16 && px16) {                                               // four 16-byte broadcast reads (lanes past nq hold 0x7fffffff)
+        as_int4 px[4];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) px[i] = rt[i][0];
+        for (int i = 0; i < 4; ++i) px[i] = px16[i];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) j += (px[i] <= p) ? 1 : 0;
+        for (int i = 0; i < 16; ++i) j += (px[i >> 2][i & 3] <= p) ? 1 : 0;
     } else {
         for (int i = 0; i < nq; ++i) j += (rt[i][0] <= p) ? 1 : 0;        // non-decreasing: last token with offset <= p
     }
@@ -1063,9 +1065,16 @@ __device__ __forceinline__ void as_finish_query(char *smem, BmHdr *hdr, uint32_t
                                                 const ST *__restrict__ payload, const int32_t *__restrict__ tile_off, int n_tab,
                                                 int tab_shift, const int32_t *__restrict__ q_tok, int qs, int nq, int k,
                                                 int64_t out_base, int64_t out_slot, double *__restrict__ part_scores,
-                                                int32_t *__restrict__ part_ids, int32_t *__restrict__ part_len) {
+                                                int32_t *__restrict__ part_ids, int32_t *__restrict__ part_len,
+                                                unsigned long long *__restrict__ dbg = nullptr /* measurement builds: stage clocks -> dbg[10..15] */) {
     constexpr int NT = C::NT, TILE = C::TILE, CAP = C::CAP;
     const int tid = threadIdx.x;
+#ifdef ERH_MEASURE
+    long long fq_mark = dbg ? clock64() : 0;
+#define ERH_FQ(I) do { if (dbg && tid == 0) { const long long n_ = clock64(); atomicAdd(&dbg[I], (unsigned long long)(n_ - fq_mark)); fq_mark = n_; } } while (0)
+#else
+#define ERH_FQ(I) do { } while (0)
+#endif
     int32_t *s_tok = reinterpret_cast<int32_t *>(smem + kAsOffTok);
     uint32_t *s_ip = reinterpret_cast<uint32_t *>(smem + kAsOffIp);
     // ---- exact re-score of the list, in query-token order, in the library's type ------------------------------------------
@@ -1084,11 +1093,12 @@ __device__ __forceinline__ void as_finish_query(char *smem, BmHdr *hdr, uint32_t
             s_ip[tid] = (uint32_t)indptr[tok];
         }
         __syncthreads();
+        ERH_FQ(10);                                                       // token table
         const int ec_max = kMCap / ld;
         for (int e0 = 0; e0 < n_keep; e0 += ec_max) {
             const int ec = n_keep - e0 < ec_max ? n_keep - e0 : ec_max;
             const int items = ec * nqc;
-            constexpr int R = 4;                                          // searches in flight per thread
+            constexpr int R = 6;                                          // searches in flight per thread (one round for <= 3072 items)
             for (int w0 = tid; w0 < items; w0 += R * NT) {
                 uint32_t lo[R], hi[R], hi0[R];
                 int32_t doc[R];
@@ -1108,7 +1118,11 @@ __device__ __forceinline__ void as_finish_query(char *smem, BmHdr *hdr, uint32_t
                         mpos[r] = e * ld + j;
                     }
                 }
-                for (;;) {                                                // first posting with document >= doc, R at a time
+                ERH_FQ(11);                                               // search set-up (list entry, two skip-table entries)
+                // first posting with document >= doc, R at a time.  (Binary on purpose: what this stage costs is the number of
+                // cache lines the probes touch -- about one per cycle and CU -- not the round trips; a 4-ary search has half
+                // the steps and 1.5 x the probes, and measured the same.)
+                for (;;) {
                     bool act[R];
                     uint32_t mid[R];
                     int32_t dv[R];
@@ -1126,6 +1140,7 @@ __device__ __forceinline__ void as_finish_query(char *smem, BmHdr *hdr, uint32_t
                         if (act[r]) { if (dv[r] < doc[r]) lo[r] = mid[r] + 1u; else hi[r] = mid[r]; }
                     }
                 }
+                ERH_FQ(12);                                               // searches
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     if (mpos[r] >= 0) {
@@ -1135,6 +1150,7 @@ __device__ __forceinline__ void as_finish_query(char *smem, BmHdr *hdr, uint32_t
                     }
                 }
             }
+            ERH_FQ(13);                                                   // payloads
             __syncthreads();
             for (int e = tid; e < ec; e += NT) {
                 ST s = fs[e0 + e];
@@ -1144,24 +1160,29 @@ __device__ __forceinline__ void as_finish_query(char *smem, BmHdr *hdr, uint32_t
             __syncthreads();
         }
     }
+    ERH_FQ(14);                                                           // sums
     // ---- rank by counting: entry e goes to position #{entries that beat it} (keys (score, index) are distinct) -----------
     int *rank = reinterpret_cast<int *>(ca);                              // the approximate sums are dead
     __syncthreads();
     for (int i = tid; i < n_keep; i += NT) rank[i] = 0;
     __syncthreads();
     if (n_keep > 0) {
+        typedef ST SV __attribute__((ext_vector_type(4)));
+        typedef int32_t IV __attribute__((ext_vector_type(4)));
         const int parts = n_keep < NT ? NT / n_keep : 1;
-        const int chunk = (n_keep + parts - 1) / parts;
+        const int chunk = (((n_keep + parts - 1) / parts) + 3) & ~3;     // a multiple of four: the walk reads 16-byte groups
         for (int w = tid; w < n_keep * parts; w += NT) {
             const int part = w / n_keep, e = w - part * n_keep;           // consecutive lanes: consecutive entries, same part
             const ST se = fs[e];
             const int32_t ie = ci[e];
             const int j1 = (part + 1) * chunk < n_keep ? (part + 1) * chunk : n_keep;
             int cnt = 0;
-            for (int j = part * chunk; j < j1; ++j) {
-                const ST sj = fs[j];
-                const int32_t ij = ci[j];
-                cnt += (sj > se || (sj == se && ij < ie)) ? 1 : 0;
+            for (int j = part * chunk; j < j1; j += 4) {                  // (entries past n_keep: stale, masked)
+                const SV sj = *reinterpret_cast<const SV *>(fs + j);
+                const IV ij = *reinterpret_cast<const IV *>(ci + j);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    cnt += (j + u < j1 && (sj[u] > se || (sj[u] == se && ij[u] < ie))) ? 1 : 0;
             }
             if (cnt) atomicAdd(&rank[e], cnt);
         }
@@ -1174,6 +1195,8 @@ __device__ __forceinline__ void as_finish_query(char *smem, BmHdr *hdr, uint32_t
     }
     for (int i = n + tid; i < k; i += NT) { part_scores[out_base + i] = 0.0; part_ids[out_base + i] = -1; }
     if (tid == 0) part_len[out_slot] = n;
+    ERH_FQ(15);                                                           // rank + output
+#undef ERH_FQ
 }
 
 // grid = (segs, B), block = C::NT.  tile_off has n_tab + 1 entries per term at a granularity of C::TILE >> tshift documents;
@@ -1192,7 +1215,7 @@ __global__ __launch_bounds__(C::NT) void bm25_ascan_kernel(
     constexpr int NT = C::NT, TILE = C::TILE, NW = C::NW, CAP = C::CAP;
 #ifdef ERH_MEASURE
 #define ERH_ABL(B) (abl & (B))
-    long long t_sec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long t_sec[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // [8] the final shrink, [9] exact re-score + rank + output
     long long t_mark = dbg ? clock64() : 0;
 #define ERH_SEC(I) do { if (dbg) { const long long n_ = clock64(); t_sec[I] += n_ - t_mark; t_mark = n_; } } while (0)
 #else
@@ -1204,6 +1227,7 @@ __global__ __launch_bounds__(C::NT) void bm25_ascan_kernel(
     AsHdr *h2 = reinterpret_cast<AsHdr *>(smem + kAsOffHdr2);
     int *xzb = reinterpret_cast<int *>(smem + kAsOffXcnt);
     as_int4 *rng = reinterpret_cast<as_int4 *>(smem + kAsOffRng);
+    int *pxs = reinterpret_cast<int *>(smem + kAsOffPx);
     uint32_t *accu = reinterpret_cast<uint32_t *>(smem + kAsOffAcc);
     uint32_t *ca = reinterpret_cast<uint32_t *>(smem + C::OFF_CA);
     int32_t *ci = reinterpret_cast<int32_t *>(smem + C::OFF_CI);
@@ -1240,7 +1264,7 @@ __global__ __launch_bounds__(C::NT) void bm25_ascan_kernel(
     // The tile's sums are complete (barrier behind the adds): survivors -> list, accumulators cleared.
     // nc0 = hdr->ncand as it was before the tile (nobody changes it during the adds).  true: give up (redo).
     auto finish_tile = [&](int tile, int base_doc, uint32_t thq, int nc0) __attribute__((always_inline)) -> bool {
-        if (h2->redo) return true;                                        // (wave 0 saw a tile it cannot describe)
+        if (h2->redo) return true;                                        // (the publishing wave saw a tile it cannot describe)
         const int par = tile & 1;
         const int *xz = xzb + par * (NW + 1);
         const int xmax = xz[NW];                                          // most crossings noted for one region
@@ -1293,20 +1317,22 @@ __global__ __launch_bounds__(C::NT) void bm25_ascan_kernel(
     bool stop = h2->redo != 0;
     if (nq > 0 && t_begin < t_end && !stop) {
         AsSet S;
-        auto pieces_of = [&](int pt) __attribute__((always_inline)) -> int {   // this wave's share of a tile's pt pieces
-            return pt > wave ? (pt - wave + NW - 1) / NW : 0;
+        auto pieces_of = [&](int pt, int nd) __attribute__((always_inline)) -> int {   // this wave's share of a tile's pt pieces, dealt to waves 0 .. nd - 1
+            return (wave < nd && pt > wave) ? (pt - wave + nd - 1) / nd : 0;
         };
         if (nq <= kAsTokChunk) {
-            // wave 0, lane j: token j's posting base and its row of the skip table; ranges are published two tiles ahead
+            // the publishing wave, lane j: token j's posting base and its row of the skip table; ranges are published two tiles ahead
             uint32_t ip = 0u;
             const int32_t *fo = tile_off;
-            const bool tokl = wave == 0 && lane < nq;
+            constexpr int PW = NW - 1;                                    // the publishing wave: pieces are dealt round-robin from wave 0, the last wave has the fewest
+            constexpr int ND = NW;                                        // waves the tile's pieces are dealt to (a publishing wave WITHOUT pieces measured +2 %)
+            const bool tokl = wave == PW && lane < nq;
             if (tokl) {
                 const int64_t tok = q_tok[qs + lane];
                 ip = (uint32_t)indptr[tok];
                 fo = tile_off + tok * (int64_t)(n_tab + 1);
             }
-            auto raw = [&](int t, int &a, int &b) __attribute__((always_inline)) {   // wave 0 only; t is clamped
+            auto raw = [&](int t, int &a, int &b) __attribute__((always_inline)) {   // publishing wave only; t is clamped
                 t = t < t_end ? t : t_end - 1;
                 int i0 = t << tshift, i1 = (t + 1) << tshift;
                 i0 = i0 < n_tab ? i0 : n_tab;
@@ -1314,13 +1340,14 @@ __global__ __launch_bounds__(C::NT) void bm25_ascan_kernel(
                 a = tokl ? fo[i0] : 0;
                 b = tokl ? fo[i1] : 0;
             };
-            auto publish = [&](int slot, int a, int b) __attribute__((always_inline)) {   // wave 0 only
+            auto publish = [&](int slot, int a, int b) __attribute__((always_inline)) {   // publishing wave only
                 const as_int4 r = as_make_ranges(ip, a, b, nq, lane);
                 rng[slot * 64 + lane] = r;
-                if (lane == 0 && r[3] > 64 * NW) h2->redo = 1;      // more pieces than a wave's lanes can describe
+                if (lane < 16) pxs[slot * 16 + lane] = r[0];
+                if (lane == 0 && r[3] > 64 * ND) h2->redo = 1;      // more pieces than the waves' lanes can describe
             };
             int ra = 0, rb = 0;
-            if (wave == 0) {
+            if (wave == PW) {
                 raw(t_begin, ra, rb);
                 publish(0, ra, rb);
                 raw(t_begin + 1, ra, rb);
@@ -1330,8 +1357,8 @@ __global__ __launch_bounds__(C::NT) void bm25_ascan_kernel(
             __syncthreads();
             uint32_t ds_c, ds_n = 0u;                                     // this tile's / the next tile's piece descriptors
             int dc_c, dc_n = 0;
-            as_describe<NW>(rng, nq, lane, wave, ds_c, dc_c);
-            int np_c = pieces_of(__builtin_amdgcn_readfirstlane(rng[0][3])), np_n = 0;
+            as_describe<ND>(rng, reinterpret_cast<const as_int4 *>(pxs), nq, lane, wave, ds_c, dc_c);
+            int np_c = pieces_of(__builtin_amdgcn_readfirstlane(rng[0][3]), ND), np_n = 0;
             as_fill(S, ds_c, dc_c, 0, np_c, post, lane, nnz);
             int r3 = 0;                                                   // (tile - t_begin) % 3: slot of the current tile's ranges
             for (int tile = t_begin; tile < t_end && !stop; ++tile) {
@@ -1341,8 +1368,8 @@ __global__ __launch_bounds__(C::NT) void bm25_ascan_kernel(
                 int *xz = xzb + (tile & 1) * (NW + 1);
                 const int r_n = r3 == 2 ? 0 : r3 + 1, r_nn = r_n == 2 ? 0 : r_n + 1;
                 if (!ERH_ABL(8)) {                                        // next tile (clamped past the end)
-                    as_describe<NW>(rng + r_n * 64, nq, lane, wave, ds_n, dc_n);
-                    np_n = pieces_of(__builtin_amdgcn_readfirstlane(rng[r_n * 64][3]));
+                    as_describe<ND>(rng + r_n * 64, reinterpret_cast<const as_int4 *>(pxs + r_n * 16), nq, lane, wave, ds_n, dc_n);
+                    np_n = pieces_of(__builtin_amdgcn_readfirstlane(rng[r_n * 64][3]), ND);
                 }
                 ERH_SEC(0);
 #ifdef ERH_MEASURE
@@ -1357,11 +1384,13 @@ __global__ __launch_bounds__(C::NT) void bm25_ascan_kernel(
                     as_fill(S, ds_c, dc_c, r0, np_c, post, lane, nnz);
                     as_apply<NW>(S, dc_c, r0, np_c, lane, accu, dummy, base_doc, thx, xl, xz);
                 }
-                if (!ERH_ABL(2)) as_fill(S, ds_n, dc_n, 0, np_n, post, lane, nnz);   // lands during the bookkeeping below
-                if (wave == 0) {                                          // ranges of tile + 2 -> LDS, skip-table entries of tile + 3
+                if (wave == PW) {                                          // ranges of tile + 2 -> LDS, skip-table entries of tile + 3
                     publish(r_nn, ra, rb);
                     raw(tile + 3, ra, rb);
                 }
+                // (the next tile's postings are requested LAST: the publishing wave's wait for its two table entries would otherwise
+                // -- the counter is in order -- also wait for them)
+                if (!ERH_ABL(2)) as_fill(S, ds_n, dc_n, 0, np_n, post, lane, nnz);   // lands during the bookkeeping below
                 ERH_SEC(1);
                 __syncthreads();                                          // every posting of the tile is in its sum
                 ERH_SEC(2);
@@ -1399,8 +1428,8 @@ __global__ __launch_bounds__(C::NT) void bm25_ascan_kernel(
                     __syncthreads();
                     uint32_t ds;
                     int dc;
-                    as_describe<NW>(rng, nqc, lane, wave, ds, dc);
-                    const int np = pieces_of(__builtin_amdgcn_readfirstlane(rng[0][3]));
+                    as_describe<NW>(rng, nullptr, nqc, lane, wave, ds, dc);
+                    const int np = pieces_of(__builtin_amdgcn_readfirstlane(rng[0][3]), NW);
                     for (int r0 = 0; r0 < np; r0 += kAsU) {
                         as_fill(S, ds, dc, r0, np, post, lane, nnz);
                         as_apply<NW>(S, dc, r0, np, lane, accu, dummy, base_doc, thx, xl, xz);
@@ -1418,14 +1447,14 @@ __global__ __launch_bounds__(C::NT) void bm25_ascan_kernel(
         return;
     }
     if (ERH_ABL(0xff)) { if (tid == 0) part_len[(int64_t)q * segs + seg] = 0; return; }   // (ablations: the list is garbage)
-    ERH_SEC(5);
+    ERH_SEC(8);
     as_finish_query<ST, C>(smem, hdr, ca, ci, indptr, doc_ids, payload, tile_off, n_tab, C::TAB_SHIFT - tshift, q_tok, qs, nq, k,
-                           out_base, (int64_t)q * segs + seg, part_scores, part_ids, part_len);
-    ERH_SEC(5);
+                           out_base, (int64_t)q * segs + seg, part_scores, part_ids, part_len, dbg);
+    ERH_SEC(9);
 #ifdef ERH_MEASURE
     if (dbg && tid == 0) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) atomicAdd(&dbg[i], (unsigned long long)t_sec[i]);
+        for (int i = 0; i < 10; ++i) atomicAdd(&dbg[i], (unsigned long long)t_sec[i]);
     }
 #endif
 #undef ERH_SEC

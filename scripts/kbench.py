@@ -269,10 +269,13 @@ def main():
             torch.cuda.synchronize()
             c = eng.debug_counters().astype(np.float64)
             eng.set_option("debug_counters", 0)
-            names = ["describe", "extra rounds+fill+publish", "apply_barrier", "list+clear | sweep", "clear_barrier", "shrink+rescore+final", "load wait", "adds"]
-            tot = c[:8].sum()
-            res[f"{name} ascan sections (% of thread-0 cycles, k=192)"] = {n_: round(100 * v / tot, 1) for n_, v in zip(names, c[:8])}
+            names = ["describe", "publish+fill (+extra rounds)", "apply_barrier", "list+clear | sweep", "clear_barrier", "list shrinks", "load wait", "adds",
+                     "final shrink", "re-score+rank+output"]
+            tot = c[:10].sum()
+            res[f"{name} ascan sections (% of thread-0 cycles, k=192)"] = {n_: round(100 * v / tot, 1) for n_, v in zip(names, c[:10])}
             res[f"{name} ascan cycles per query (thread 0)"] = {"total": round(tot / 1024)}
+            fq = ["token table", "search set-up", "searches", "payloads", "sums", "rank+output"]
+            res[f"{name} ascan tail (thread-0 cycles per query)"] = {n_: round(v / 1024) for n_, v in zip(fq, c[10:16])}
     if what == "bm25x":                                      # wave-owned scan: sweep / threshold crossings / free-running waves
         indptr, doc, tf, lens, flat = synth.token_csr_torch(n, vocab, seed=3, device=dev)
         for variant, name in ((BM25S, "bm25s"), (OKAPI, "okapi")):
