@@ -82,6 +82,7 @@ SIGNATURES = {
     "erh_cutter_destroy": (_i32, [_vp]),
     "erh_cutter_cut": (_i32, [_vp, _vp, _i64, _vp, _i64, C.POINTER(_i64)]),
     "erh_text_encode": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _i64, _vp, C.POINTER(_i64)]),
+    "erh_text_encode_mt": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _i64, _vp, C.POINTER(_i64)]),
 }
 
 

@@ -18,6 +18,8 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <system_error>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -349,14 +351,26 @@ int erh_cutter_cut(const erh_cutter *c, const char *text, int64_t n_bytes, int64
 
 int erh_text_encode(const erh_cutter *c, erh_vocab *v, const erh_vocab *stop, const char *bytes, const int64_t *text_off,
                     int64_t n_texts, int add, int32_t *out_ids, int64_t cap, int32_t *out_lens, int64_t *n_out) {
-    if (!c || !v || !text_off || n_texts < 0 || !n_out || (n_texts > 0 && !out_lens)) return ERH_ERR_INVALID;
-    int64_t w = 0;
-    try {
+    return erh_text_encode_mt(c, v, stop, bytes, text_off, n_texts, add, 1, out_ids, cap, out_lens, n_out);
+}
+
+// n_threads > 1 (add != 0 only): the texts are cut into contiguous chunks, one per thread.  Every thread cuts its chunk and
+// numbers its tokens in a vocabulary of its own (first appearance inside the chunk); the chunk vocabularies are then
+// merged into `v` chunk by chunk, each in its local id order -- which IS first-appearance order over the whole corpus,
+// so the ids are those of the one-thread walk -- and every thread rewrites its ids through its local -> global table.
+// The dictionary and the stop set are only read.
+int erh_text_encode_mt(const erh_cutter *c, erh_vocab *v, const erh_vocab *stop, const char *bytes, const int64_t *text_off,
+                       int64_t n_texts, int add, int n_threads, int32_t *out_ids, int64_t cap, int32_t *out_lens,
+                       int64_t *n_out) {
+    if (!c || !v || !text_off || n_texts < 0 || !n_out || (n_texts > 0 && !out_lens) || n_threads < 1) return ERH_ERR_INVALID;
+    for (int64_t d = 0; d < n_texts; ++d)
+        if (text_off[d + 1] < text_off[d] || (text_off[d + 1] > text_off[d] && !bytes)) return ERH_ERR_INVALID;
+    // one chunk: tokens of texts [d0, d1) through `voc` (add) -> ids appended to `ids`, token counts to out_lens
+    auto run = [&](int64_t d0, int64_t d1, erh_vocab *voc, bool add_, std::vector<int32_t> &ids) -> int {
         std::vector<uint32_t> cp;
         std::vector<int64_t> off, ends;
-        for (int64_t d = 0; d < n_texts; ++d) {
+        for (int64_t d = d0; d < d1; ++d) {
             const int64_t b = text_off[d], e = text_off[d + 1];
-            if (e < b || (e > b && !bytes)) return ERH_ERR_INVALID;
             cut_text(c, bytes + b, e - b, cp, off, ends);
             int32_t cnt = 0;
             int64_t t0 = 0;
@@ -367,17 +381,78 @@ int erh_text_encode(const erh_cutter *c, erh_vocab *v, const erh_vocab *stop, co
                 t0 = t1;
                 if (tn == 1 && tp[0] == ' ') continue;                   // `word != ' '` (retrievers.py:75)
                 if (stop && const_cast<erh_vocab *>(stop)->find_or_add(tp, tn, false) >= 0) continue;   // `word not in stopwords`
-                const int32_t id = v->find_or_add(tp, tn, add != 0);
+                const int32_t id = voc->find_or_add(tp, tn, add_);
                 if (id == -2) return ERH_ERR_UNSUPPORTED;
                 if (id < 0) continue;                                    // add == 0: out-of-vocabulary query token
-                if (w < cap && out_ids) out_ids[w] = id;
-                ++w;
+                ids.push_back(id);
                 ++cnt;
             }
             out_lens[d] = cnt;
         }
+        return ERH_OK;
+    };
+    int64_t w = 0;
+    try {
+        int T = n_threads;
+        if (!add || n_texts < 2 * (int64_t)T) T = 1;                     // (queries: unknown tokens are dropped -- one thread)
+        if (T == 1) {
+            std::vector<int32_t> ids;
+            const int rc = run(0, n_texts, v, add != 0, ids);
+            if (rc != ERH_OK) return rc;
+            w = (int64_t)ids.size();
+            if (out_ids) memcpy(out_ids, ids.data(), (size_t)(w < cap ? w : cap) * 4);
+        } else {
+            // chunks of about equal bytes
+            std::vector<int64_t> cut((size_t)T + 1, n_texts);
+            cut[0] = 0;
+            const int64_t total = text_off[n_texts] - text_off[0];
+            for (int t = 1, d = 0; t < T; ++t) {
+                const int64_t want = text_off[0] + total * t / T;
+                while (d < n_texts && text_off[d] < want) ++d;
+                cut[(size_t)t] = d;
+            }
+            std::vector<erh_vocab> local((size_t)T);
+            std::vector<std::vector<int32_t>> ids((size_t)T);
+            std::vector<int> rcs((size_t)T, ERH_OK);
+            std::vector<std::thread> th;
+            for (int t = 0; t < T; ++t)
+                th.emplace_back([&, t]() {
+                    try { rcs[(size_t)t] = run(cut[(size_t)t], cut[(size_t)t + 1], &local[(size_t)t], true, ids[(size_t)t]); }
+                    catch (const std::bad_alloc &) { rcs[(size_t)t] = ERH_ERR_NOMEM; }
+                });
+            for (auto &x : th) x.join();
+            for (int t = 0; t < T; ++t) if (rcs[(size_t)t] != ERH_OK) return rcs[(size_t)t];
+            // merge the chunk vocabularies in chunk order, each in its local id order
+            std::vector<std::vector<int32_t>> map((size_t)T);
+            for (int t = 0; t < T; ++t) {
+                const erh_vocab &lv = local[(size_t)t];
+                map[(size_t)t].resize(lv.hashes.size());
+                for (size_t id = 0; id < lv.hashes.size(); ++id) {
+                    const int64_t b = lv.tok_off[id], e = lv.tok_off[id + 1];
+                    const int32_t g = v->find_or_add(lv.hashes[id], lv.arena.data() + b, (size_t)(e - b), true);
+                    if (g == -2) return ERH_ERR_UNSUPPORTED;
+                    map[(size_t)t][id] = g;
+                }
+            }
+            std::vector<int64_t> base((size_t)T + 1, 0);
+            for (int t = 0; t < T; ++t) base[(size_t)t + 1] = base[(size_t)t] + (int64_t)ids[(size_t)t].size();
+            w = base[(size_t)T];
+            if (out_ids) {
+                th.clear();
+                for (int t = 0; t < T; ++t)
+                    th.emplace_back([&, t]() {
+                        const std::vector<int32_t> &src = ids[(size_t)t];
+                        const std::vector<int32_t> &m = map[(size_t)t];
+                        const int64_t o = base[(size_t)t];
+                        for (size_t i = 0; i < src.size() && o + (int64_t)i < cap; ++i) out_ids[o + (int64_t)i] = m[(size_t)src[i]];
+                    });
+                for (auto &x : th) x.join();
+            }
+        }
     } catch (const std::bad_alloc &) {
         return ERH_ERR_NOMEM;
+    } catch (const std::system_error &) {
+        return ERH_ERR_NOMEM;                                            // (no thread to be had)
     }
     *n_out = w;
     return (out_ids && w > cap) ? ERH_ERR_OVERFLOW : ERH_OK;

@@ -13,7 +13,8 @@ erh_cutter_*).  Host code, no GPU involved.
 from __future__ import annotations
 
 import ctypes as C
-from typing import Hashable, Iterable, List, Sequence, Tuple
+import os
+from typing import Hashable, Iterable, List, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -145,8 +146,8 @@ class NativeCutter:
 
     lcut = cut
 
-    def encode_texts(self, texts: Sequence[str], vocab: NativeVocab, stopwords: Iterable[str] = (), add: bool = True
-                     ) -> Tuple[np.ndarray, np.ndarray]:
+    def encode_texts(self, texts: Sequence[str], vocab: NativeVocab, stopwords: Iterable[str] = (), add: bool = True,
+                     threads: Optional[int] = None) -> Tuple[np.ndarray, np.ndarray]:
         """``[tokenize_and_remove_stopwords(self, t, stopwords) for t in texts]`` -> term ids, without a Python object per
         token (erh_text_encode): returns (flat int32 ids, int32 tokens per text)."""
         stop = NativeVocab()
@@ -162,8 +163,11 @@ class NativeCutter:
         cap = int(off[-1]) + 1
         need = C.c_int64(0)
         ids = np.empty(cap, np.int32)
-        rc = self._lib.erh_text_encode(self._h, vocab._h, stop._h if sw else None, blob, off.ctypes.data, len(blobs),
-                                       1 if add else 0, ids.ctypes.data, cap, lens.ctypes.data, C.byref(need))
+        if threads is None:                      # corpus side: the host's cores (the ids do not depend on the thread count)
+            threads = min(os.cpu_count() or 1, 64) if add else 1
+        rc = self._lib.erh_text_encode_mt(self._h, vocab._h, stop._h if sw else None, blob, off.ctypes.data, len(blobs),
+                                          1 if add else 0, max(int(threads), 1), ids.ctypes.data, cap, lens.ctypes.data,
+                                          C.byref(need))
         if rc != 0:
-            raise _lib.ErhError(rc, "erh_text_encode failed")
+            raise _lib.ErhError(rc, "erh_text_encode_mt failed")
         return ids[: int(need.value)].copy(), lens[: len(blobs)].copy()

@@ -173,6 +173,11 @@ int     erh_cutter_cut(const erh_cutter *c, const char *text, int64_t n_bytes, i
  * tokens are dropped -- the query side).  Same output convention as erh_vocab_encode. */
 int     erh_text_encode(const erh_cutter *c, erh_vocab *v, const erh_vocab *stop, const char *bytes, const int64_t *text_off,
                         int64_t n_texts, int add, int32_t *out_ids, int64_t cap, int32_t *out_lens, int64_t *n_out);
+/* the same on n_threads host threads (add != 0; otherwise, and for fewer than 2 n_threads texts, one thread): contiguous
+ * chunks of texts, chunk vocabularies merged in order -- ids identical to the one-thread call.  c and stop are only read. */
+int     erh_text_encode_mt(const erh_cutter *c, erh_vocab *v, const erh_vocab *stop, const char *bytes, const int64_t *text_off,
+                           int64_t n_texts, int add, int n_threads, int32_t *out_ids, int64_t cap, int32_t *out_lens,
+                           int64_t *n_out);
 
 /* ---- queries ------------------------------------------------------------------------- */
 

@@ -31,15 +31,25 @@ def main():
     stop = set(words[:50])
     t0 = time.perf_counter()
     vocab = NativeVocab()
-    f2, l2 = cutter.encode_texts(texts, vocab, stop)
+    f2, l2 = cutter.encode_texts(texts, vocab, stop, threads=1)
     t_nat = time.perf_counter() - t0
+    for threads in (2, 4, 8, 16, 32, 64):
+        if threads > 2 * (os.cpu_count() or 1):
+            break
+        t0 = time.perf_counter()
+        vt = NativeVocab()
+        ft, lt = cutter.encode_texts(texts, vt, stop, threads=threads)
+        dt = time.perf_counter() - t0
+        assert np.array_equal(ft, f2) and np.array_equal(lt, l2) and len(vt) == len(vocab)
+        print(f"erh_text_encode_mt, {threads:2d} threads: {dt:.2f} s (same ids; of which the Python side -- utf-8 encode and join of "
+              f"{n_docs} strings -- is the same in every row)")
     sample = texts[: max(1, n_docs // 20)]
     t0 = time.perf_counter()
     toks = [[w for w in cutter.cut(t) if w not in stop and w != " "] for t in sample]   # (the native cut, Python around it)
     _ = vocab_ids_python(toks)
     t_py = (time.perf_counter() - t0) * (n_docs / len(sample))
     print(f"texts -> cut -> stop words -> ids   {n_docs} texts / {f2.shape[0]} tokens kept / {len(vocab)} terms: "
-          f"erh_text_encode {t_nat:.2f} s; per-text cut() + Python filter + dict loop {t_py:.2f} s "
+          f"erh_text_encode (one thread) {t_nat:.2f} s; per-text cut() + Python filter + dict loop {t_py:.2f} s "
           f"(measured on {len(sample)} texts, scaled)")
 
 

@@ -176,6 +176,18 @@ def test_encode_texts_equals_cut_filter_and_dict_loop():
     vocab = NativeVocab()
     flat, lens = cutter.encode_texts(texts, vocab, stop)
     assert np.array_equal(flat, flat_py) and np.array_equal(lens, lens_py) and len(vocab) == len(v_py)
+    # any number of host threads gives the same ids (chunk vocabularies merged in first-appearance order)
+    for threads in (1, 2, 3, 8, 64):
+        vt = NativeVocab()
+        ft, lt = cutter.encode_texts(texts, vt, stop, threads=threads)
+        assert np.array_equal(ft, flat_py) and np.array_equal(lt, lens_py) and len(vt) == len(v_py), threads
+        assert [vt.token(i) for i in range(len(vt))] == [vocab.token(i) for i in range(len(vocab))]
+    # ... also into a vocabulary that already holds terms
+    half = len(texts) // 2
+    vt = NativeVocab()
+    f1, l1 = cutter.encode_texts(texts[:half], vt, stop, threads=4)
+    f2, l2 = cutter.encode_texts(texts[half:], vt, stop, threads=5)
+    assert np.array_equal(np.concatenate([f1, f2]), flat_py) and np.array_equal(np.concatenate([l1, l2]), lens_py)
     # query side: unknown tokens vanish, order and repeats stay
     q = texts[5] + "𠀀未知" + texts[5]
     ids, n = cutter.encode_texts([q], vocab, stop, add=False)
