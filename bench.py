@@ -168,7 +168,7 @@ def pmc_traffic(args, kernel_class, algorithmic_bytes):
     except (OSError, KeyError, ValueError):
         return {"traffic": None}
     from easyrag_amd import _build
-    if table.get("_lib_digest") != _build._digest():
+    if table.get("_kernel_digest", table.get("_lib_digest")) != _build._kernel_digest():
         return {"traffic": None, "traffic_note": "profiles/pmc_traffic.json was collected on different kernel sources (stale)"}
     if not default_shape or rec.get("kernel_class") != kernel_class:
         return {"traffic": None}

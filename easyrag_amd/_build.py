@@ -53,6 +53,17 @@ def _digest() -> str:
     return h.hexdigest()
 
 
+def _kernel_digest() -> str:
+    """Digest of what decides the device side of a run (every source but the host-only text side, the internal headers,
+    the flags): what profiles/pmc_traffic.json is keyed by, so that a change to the text ABI or to the public header does
+    not orphan the PMC figures of unchanged kernels."""
+    h = hashlib.sha256()
+    for name in [n for n in SOURCES if n != "text.hip"] + HEADERS:
+        h.update((CSRC / name).read_bytes())
+    h.update(" ".join(_flags()).encode())
+    return h.hexdigest()
+
+
 def build(force: bool = False, verbose: bool = False) -> Path:
     """Compile every HIP translation unit for gfx950 and link the shared library. Idempotent; concurrent callers (the
     ranks of a multi-GPU launch) serialise on a lock file, and a box without hipcc keeps using a library that exists."""

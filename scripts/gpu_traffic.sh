@@ -17,7 +17,7 @@ python - <<'PY'
 import csv, glob, json, collections, sys
 sys.path.insert(0, ".")
 from easyrag_amd import _build
-out = {"_lib_digest": _build._digest()}      # bench.py attaches the figures only to runs of exactly these kernels
+out = {"_kernel_digest": _build._kernel_digest()}      # bench.py attaches the figures only to runs of exactly these kernels
 import re
 for wl, match, pat in (("hybrid", "dense_scan", r"dense_(scan|gemv)"), ("dense", "dense_scan", r"dense_(scan|gemv)"),
                        ("bm25", "bm25_scan", r"bm25_[wa]?scan")):
