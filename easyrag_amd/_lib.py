@@ -81,6 +81,9 @@ SIGNATURES = {
     "erh_cutter_create": (_i32, [_vp, _i64, C.POINTER(_vp)]),
     "erh_cutter_destroy": (_i32, [_vp]),
     "erh_cutter_cut": (_i32, [_vp, _vp, _i64, _vp, _i64, C.POINTER(_i64)]),
+    "erh_cutter_set_hmm": (_i32, [_vp, _vp, _i64]),
+    "erh_cutter_has_hmm": (_i32, [_vp]),
+    "erh_cutter_cut_mode": (_i32, [_vp, _vp, _i64, _i32, _vp, _i64, C.POINTER(_i64)]),
     "erh_text_encode": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _i64, _vp, C.POINTER(_i64)]),
     "erh_text_encode_mt": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _i64, _vp, C.POINTER(_i64)]),
 }

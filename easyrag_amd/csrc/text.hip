@@ -5,10 +5,11 @@
 //                  like the Python dict loop they replace (easyrag_amd/index.py: vocab_ids), so the CSR built from them
 //                  is bit-identical;
 //   erh_cutter_*   a dictionary cutter with jieba's sentence-splitting rules and its DAG / maximum-log-probability route
-//                  (jieba 0.42.1, Tokenizer.cut(sentence, cut_all=False, HMM=False)) over a caller-supplied dictionary in
-//                  jieba's "word freq [tag]" text format.  jieba's default call also runs an HMM over runs of
-//                  out-of-dictionary characters; its model tables ship with jieba and are not reproduced here, so this
-//                  cutter is the HMM=False algorithm.
+//                  (jieba 0.42.1, Tokenizer.cut(sentence, cut_all=False)) over a caller-supplied dictionary in jieba's
+//                  "word freq [tag]" text format.  jieba's default call (HMM=True) also runs an HMM over runs of
+//                  out-of-dictionary characters (jieba/finalseg); the algorithm is here (viterbi over B M E S, finalseg's
+//                  own block splitting), its trained tables ship with jieba and are supplied by the caller as text
+//                  (erh_cutter_set_hmm; INTEGRATION.md shows the dump).  Without them the cutter is HMM=False.
 // No device code in this file; it is part of libeasyrag_hip.so so that one library serves the whole retriever shim.
 #include "../../include/easyrag_hip.h"
 
@@ -20,6 +21,7 @@
 #include <string>
 #include <system_error>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 namespace {
@@ -87,10 +89,17 @@ struct erh_vocab {
     }
 };
 
+constexpr double kHmmMin = -3.14e100;       // jieba.finalseg.MIN_FLOAT
+struct erh_hmm_emit { double p[4]; };        // states in the order B, E, M, S (alphabetical: ties go to the later letter, as Python's tuple max does)
 struct erh_cutter {
     erh_vocab words;                         // jieba's FREQ keys: every word and every prefix of a word ...
     std::vector<int64_t> freq;               // ... and their frequencies by id (prefixes that are not words: 0)
     double total = 0.0;
+    // jieba.finalseg: the HMM that regroups runs of out-of-dictionary single characters (cut(..., HMM=True), jieba's default)
+    bool has_hmm = false;
+    double hmm_start[4] = {kHmmMin, kHmmMin, kHmmMin, kHmmMin};
+    double hmm_trans[4][4];
+    std::unordered_map<uint32_t, erh_hmm_emit> hmm_emit;
 
     void set(const char *p, size_t n, int64_t f, bool overwrite) {
         const int32_t id = words.find_or_add(p, n, true);
@@ -151,8 +160,82 @@ inline bool is_eng(uint32_t c) { return (c >= 'a' && c <= 'z') || (c >= 'A' && c
 
 // one block of han-class characters [b, e): jieba's get_DAG + calc + __cut_DAG_NO_HMM; appends token END positions
 // (character indices) to `ends`
+inline bool is_pure_han(uint32_t c) { return c >= 0x4E00 && c <= 0x9FD5; }   // finalseg.re_han: [\u4E00-\u9FD5]
+
+// jieba.finalseg.viterbi + __cut over the pure-han run cp[b, e): appends token END positions
+void hmm_cut_han(const erh_cutter *c, const std::vector<uint32_t> &cp, int64_t b, int64_t e, std::vector<int64_t> &ends) {
+    const int64_t n = e - b;
+    static const int prev[4][2] = {{1, 3}, {0, 2}, {2, 0}, {3, 1}};      // PrevStatus: B <- E S, E <- B M, M <- M B, S <- S E
+    std::vector<double> V((size_t)n * 4);
+    std::vector<int8_t> from((size_t)n * 4, -1);
+    auto emit = [&](uint32_t ch, int y) -> double {
+        const auto it = c->hmm_emit.find(ch);
+        return it == c->hmm_emit.end() ? kHmmMin : it->second.p[y];
+    };
+    for (int y = 0; y < 4; ++y) V[(size_t)y] = c->hmm_start[y] + emit(cp[b], y);
+    for (int64_t t = 1; t < n; ++t) {
+        for (int y = 0; y < 4; ++y) {
+            const double em = emit(cp[b + t], y);
+            double best = 0.0;
+            int bs = -1;
+            for (int j = 0; j < 2; ++j) {                                // max over (prob, state): the later letter wins a tie
+                const int y0 = prev[y][j];
+                const double v = V[(size_t)(t - 1) * 4 + (size_t)y0] + c->hmm_trans[y0][y] + em;
+                if (bs < 0 || v > best || (v == best && y0 > bs)) { best = v; bs = y0; }
+            }
+            V[(size_t)t * 4 + (size_t)y] = best;
+            from[(size_t)t * 4 + (size_t)y] = (int8_t)bs;
+        }
+    }
+    const double ve = V[(size_t)(n - 1) * 4 + 1], vs = V[(size_t)(n - 1) * 4 + 3];
+    int st = (vs >= ve) ? 3 : 1;                                         // max((V[E], 'E'), (V[S], 'S'))
+    std::vector<int8_t> path((size_t)n);
+    for (int64_t t = n - 1; t >= 0; --t) { path[(size_t)t] = (int8_t)st; if (t > 0) st = from[(size_t)t * 4 + (size_t)st]; }
+    int64_t nexti = 0;
+    for (int64_t i = 0; i < n; ++i) {                                    // 'B' opens, 'E' closes [begin, i], 'S' stands alone
+        const int y = path[(size_t)i];
+        if (y == 1 || y == 3) { ends.push_back(b + i + 1); nexti = i + 1; }
+    }
+    if (nexti < n) ends.push_back(b + n);
+}
+
+// jieba.finalseg.cut over cp[b, e) (characters of the han class): pure-han runs through the HMM, the rest split by
+// re_skip = ([a-zA-Z0-9]+(?:\.\d+)?%?) with the text between two matches kept whole
+void hmm_cut(const erh_cutter *c, const std::vector<uint32_t> &cp, int64_t b, int64_t e, std::vector<int64_t> &ends) {
+    int64_t i = b;
+    while (i < e) {
+        if (is_pure_han(cp[i])) {
+            int64_t j = i;
+            while (j < e && is_pure_han(cp[j])) ++j;
+            hmm_cut_han(c, cp, i, j, ends);
+            i = j;
+            continue;
+        }
+        int64_t stop = i;
+        while (stop < e && !is_pure_han(cp[stop])) ++stop;                 // the non-han block [i, stop)
+        int64_t run = i;                                                  // start of the pending unmatched text
+        while (i < stop) {
+            if (is_eng(cp[i])) {
+                if (run < i) ends.push_back(i);                           // text before the match
+                int64_t j = i;
+                while (j < stop && is_eng(cp[j])) ++j;
+                if (j + 1 < stop && cp[j] == '.' && cp[j + 1] >= '0' && cp[j + 1] <= '9') {
+                    ++j;
+                    while (j < stop && cp[j] >= '0' && cp[j] <= '9') ++j;
+                }
+                if (j < stop && cp[j] == '%') ++j;
+                ends.push_back(j);
+                i = run = j;
+            } else {
+                ++i;
+            }
+        }
+        if (run < stop) ends.push_back(stop);
+    }
+}
+
 void cut_block(const erh_cutter *c, const char *s, const std::vector<int64_t> &off, const std::vector<uint32_t> &cp, int64_t b,
-               int64_t e, std::vector<int64_t> &ends) {
+               int64_t e, std::vector<int64_t> &ends, bool hmm) {
     const int64_t N = e - b;
     // DAG edges k -> i (sentence[k : i + 1] is a word) with the word's frequency, found by extending the fragment's
     // hash one character at a time; dag_off[k] .. dag_off[k + 1] index the edge arrays
@@ -186,6 +269,34 @@ void cut_block(const erh_cutter *c, const char *s, const std::vector<int64_t> &o
         rp[idx] = best;
         rx[idx] = bx;
     }
+    if (hmm) {
+        // __cut_DAG: single characters collect in buf; when a longer word (or the end) arrives, a one-character buf is a
+        // token, a buf that is itself a dictionary word goes out character by character, anything else through the HMM
+        int64_t x = 0, bs = -1;                                          // buf = characters [bs, x)
+        auto flush = [&](int64_t be) {
+            if (bs < 0) return;
+            if (be - bs == 1) {
+                ends.push_back(b + be);
+            } else {
+                const int32_t id = const_cast<erh_vocab &>(c->words).find_or_add(s + off[b + bs], (size_t)(off[b + be] - off[b + bs]), false);
+                if (id >= 0 && c->freq[id]) { for (int64_t q = bs; q < be; ++q) ends.push_back(b + q + 1); }
+                else hmm_cut(c, cp, b + bs, b + be, ends);
+            }
+            bs = -1;
+        };
+        while (x < N) {
+            const int64_t y = rx[x] + 1;
+            if (y - x == 1) {
+                if (bs < 0) bs = x;
+            } else {
+                flush(x);
+                ends.push_back(b + y);
+            }
+            x = y;
+        }
+        flush(N);
+        return;
+    }
     int64_t x = 0;
     bool buf = false;                                                    // a run of single ASCII letters / digits is open
     while (x < N) {
@@ -203,7 +314,7 @@ void cut_block(const erh_cutter *c, const char *s, const std::vector<int64_t> &o
 
 // whole sentence: jieba's cut() block splitting around cut_block; token END positions in characters
 void cut_text(const erh_cutter *c, const char *text, int64_t n_bytes, std::vector<uint32_t> &cp, std::vector<int64_t> &off,
-              std::vector<int64_t> &ends) {
+              std::vector<int64_t> &ends, bool hmm) {
     ends.clear();
     decode_utf8(text, n_bytes, cp, off);
     const int64_t n = (int64_t)cp.size();
@@ -212,7 +323,7 @@ void cut_text(const erh_cutter *c, const char *text, int64_t n_bytes, std::vecto
         if (is_han_class(cp[i])) {                                       // re_han.split: maximal runs of the han class
             int64_t e = i;
             while (e < n && is_han_class(cp[e])) ++e;
-            cut_block(c, text, off, cp, i, e, ends);
+            cut_block(c, text, off, cp, i, e, ends, hmm);
             i = e;
         } else if (cp[i] == '\r' && i + 1 < n && cp[i + 1] == '\n') {   // re_skip: (\r\n|\s), the pair first
             ends.push_back(i + 2);
@@ -332,12 +443,81 @@ int erh_cutter_destroy(erh_cutter *c) {
     return ERH_OK;
 }
 
+int erh_cutter_set_hmm(erh_cutter *c, const char *model_text, int64_t n_bytes) {
+    if (!c || n_bytes < 0 || (n_bytes > 0 && !model_text)) return ERH_ERR_INVALID;
+    c->has_hmm = false;
+    c->hmm_emit.clear();
+    for (int a = 0; a < 4; ++a) { c->hmm_start[a] = kHmmMin; for (int b = 0; b < 4; ++b) c->hmm_trans[a][b] = kHmmMin; }
+    if (n_bytes == 0) return ERH_OK;                                     // (model removed: HMM=False again)
+    auto state_of = [](const std::string &t) -> int {
+        if (t.size() != 1) return -1;
+        switch (t[0]) { case 'B': return 0; case 'E': return 1; case 'M': return 2; case 'S': return 3; default: return -1; }
+    };
+    try {
+        int64_t i = 0;
+        std::vector<uint32_t> cp;
+        std::vector<int64_t> off;
+        int64_t n_emit = 0;
+        while (i < n_bytes) {
+            int64_t e = i;
+            while (e < n_bytes && model_text[e] != '\n') ++e;
+            std::vector<std::string> f;                                  // fields split on single spaces / tabs
+            int64_t p = i;
+            while (p < e) {
+                while (p < e && (model_text[p] == ' ' || model_text[p] == '\t' || model_text[p] == '\r')) ++p;
+                int64_t q = p;
+                while (q < e && model_text[q] != ' ' && model_text[q] != '\t' && model_text[q] != '\r') ++q;
+                if (q > p) f.emplace_back(model_text + p, (size_t)(q - p));
+                p = q;
+            }
+            i = e + 1;
+            if (f.empty() || f[0][0] == '#') continue;
+            auto num = [&](const std::string &t, double &out) -> bool {
+                char *endp = nullptr;
+                out = strtod(t.c_str(), &endp);
+                return !t.empty() && *endp == '\0';
+            };
+            double v = 0.0;
+            if (f[0] == "start" && f.size() == 3 && state_of(f[1]) >= 0 && num(f[2], v)) {
+                c->hmm_start[state_of(f[1])] = v;
+            } else if (f[0] == "trans" && f.size() == 4 && state_of(f[1]) >= 0 && state_of(f[2]) >= 0 && num(f[3], v)) {
+                c->hmm_trans[state_of(f[1])][state_of(f[2])] = v;
+            } else if (f[0] == "emit" && f.size() == 4 && state_of(f[1]) >= 0 && num(f[3], v)) {
+                decode_utf8(f[2].data(), (int64_t)f[2].size(), cp, off);
+                if (cp.size() != 1) return ERH_ERR_INVALID;
+                auto it = c->hmm_emit.find(cp[0]);
+                if (it == c->hmm_emit.end()) it = c->hmm_emit.emplace(cp[0], erh_hmm_emit{{kHmmMin, kHmmMin, kHmmMin, kHmmMin}}).first;
+                it->second.p[state_of(f[1])] = v;
+                ++n_emit;
+            } else {
+                c->hmm_emit.clear();
+                return ERH_ERR_INVALID;
+            }
+        }
+        if (n_emit == 0) return ERH_ERR_INVALID;
+    } catch (const std::bad_alloc &) {
+        c->hmm_emit.clear();
+        return ERH_ERR_NOMEM;
+    }
+    c->has_hmm = true;
+    return ERH_OK;
+}
+
+int erh_cutter_has_hmm(const erh_cutter *c) { return (c && c->has_hmm) ? 1 : 0; }
+
 int erh_cutter_cut(const erh_cutter *c, const char *text, int64_t n_bytes, int64_t *out_ends, int64_t cap, int64_t *n_tokens) {
-    if (!c || !n_tokens || n_bytes < 0 || (n_bytes > 0 && !text)) return ERH_ERR_INVALID;
+    return erh_cutter_cut_mode(c, text, n_bytes, -1, out_ends, cap, n_tokens);
+}
+
+int erh_cutter_cut_mode(const erh_cutter *c, const char *text, int64_t n_bytes, int hmm, int64_t *out_ends, int64_t cap,
+                        int64_t *n_tokens) {
+    if (!c || !n_tokens || n_bytes < 0 || (n_bytes > 0 && !text) || hmm < -1 || hmm > 1) return ERH_ERR_INVALID;
+    if (hmm == 1 && !c->has_hmm) return ERH_ERR_STATE;                   // HMM=True needs the model (erh_cutter_set_hmm)
+    const bool use_hmm = hmm < 0 ? c->has_hmm : hmm == 1;
     try {
         std::vector<uint32_t> cp;
         std::vector<int64_t> off, ends;
-        cut_text(c, text, n_bytes, cp, off, ends);
+        cut_text(c, text, n_bytes, cp, off, ends, use_hmm);
         *n_tokens = (int64_t)ends.size();
         if (out_ends) {
             if ((int64_t)ends.size() > cap) return ERH_ERR_OVERFLOW;
@@ -371,7 +551,7 @@ int erh_text_encode_mt(const erh_cutter *c, erh_vocab *v, const erh_vocab *stop,
         std::vector<int64_t> off, ends;
         for (int64_t d = d0; d < d1; ++d) {
             const int64_t b = text_off[d], e = text_off[d + 1];
-            cut_text(c, bytes + b, e - b, cp, off, ends);
+            cut_text(c, bytes + b, e - b, cp, off, ends, c->has_hmm);
             int32_t cnt = 0;
             int64_t t0 = 0;
             for (int64_t end_ch : ends) {

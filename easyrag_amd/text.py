@@ -103,7 +103,7 @@ class NativeCutter:
     """``cut(text)`` like ``jieba.Tokenizer().cut(text, HMM=False)`` over the given dictionary (jieba text format: one
     ``word freq [tag]`` per line)."""
 
-    def __init__(self, dict_text: str):
+    def __init__(self, dict_text: str, hmm_text: Optional[str] = None):
         self._lib = _lib.load()
         raw = dict_text.encode("utf-8")
         h = C.c_void_p()
@@ -111,11 +111,29 @@ class NativeCutter:
         if rc != 0:
             raise _lib.ErhError(rc, "erh_cutter_create failed (dictionary lines must read 'word freq [tag]')")
         self._h = h
+        if hmm_text is not None:
+            self.set_hmm(hmm_text)
 
     @classmethod
-    def from_file(cls, path: str) -> "NativeCutter":
+    def from_file(cls, path: str, hmm_path: Optional[str] = None) -> "NativeCutter":
+        hmm = None
+        if hmm_path is not None:
+            with open(hmm_path, encoding="utf-8") as f:
+                hmm = f.read()
         with open(path, encoding="utf-8") as f:
-            return cls(f.read())
+            return cls(f.read(), hmm)
+
+    def set_hmm(self, hmm_text: Optional[str]):
+        """jieba.finalseg's model as text lines ``start S lp`` / ``trans S S lp`` / ``emit S char lp`` (see
+        `hmm_model_text`); with it ``cut(text)`` behaves like jieba's default ``cut(text, HMM=True)``.  None removes it."""
+        raw = (hmm_text or "").encode("utf-8", "surrogatepass")
+        rc = self._lib.erh_cutter_set_hmm(self._h, raw, len(raw))
+        if rc != 0:
+            raise _lib.ErhError(rc, "erh_cutter_set_hmm failed (lines: 'start S lp', 'trans S S lp', 'emit S char lp')")
+
+    @property
+    def has_hmm(self) -> bool:
+        return bool(self._lib.erh_cutter_has_hmm(self._h))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -128,16 +146,21 @@ class NativeCutter:
         except Exception:
             pass
 
-    def cut(self, text: str, cut_all: bool = False, HMM: bool = False) -> List[str]:
-        if cut_all or HMM:
-            raise NotImplementedError("NativeCutter implements jieba's cut(sentence, cut_all=False, HMM=False)")
+    def cut(self, text: str, cut_all: bool = False, HMM: Optional[bool] = None) -> List[str]:
+        """jieba.Tokenizer.cut(sentence, cut_all=False, HMM=...).  HMM=None: True when a model is set (jieba's default call),
+        else False."""
+        if cut_all:
+            raise NotImplementedError("NativeCutter implements jieba's cut(sentence, cut_all=False)")
+        if HMM and not self.has_hmm:
+            raise NotImplementedError("HMM=True needs jieba's finalseg model: NativeCutter(dict_text, hmm_text) / set_hmm()")
         raw = text.encode("utf-8", "surrogatepass")
         cap = len(text) + 1
         ends = np.empty(cap, np.int64)
         n = C.c_int64(0)
-        rc = self._lib.erh_cutter_cut(self._h, raw, len(raw), ends.ctypes.data, cap, C.byref(n))
+        mode = -1 if HMM is None else (1 if HMM else 0)
+        rc = self._lib.erh_cutter_cut_mode(self._h, raw, len(raw), mode, ends.ctypes.data, cap, C.byref(n))
         if rc != 0:
-            raise _lib.ErhError(rc, "erh_cutter_cut failed")
+            raise _lib.ErhError(rc, "erh_cutter_cut_mode failed")
         out, b = [], 0
         for e in ends[: n.value].tolist():
             out.append(raw[b:e].decode("utf-8", "surrogatepass"))
@@ -171,3 +194,15 @@ class NativeCutter:
         if rc != 0:
             raise _lib.ErhError(rc, "erh_text_encode_mt failed")
         return ids[: int(need.value)].copy(), lens[: len(blobs)].copy()
+
+
+def hmm_model_text(start_p, trans_p, emit_p) -> str:
+    """jieba.finalseg's three tables -> the text NativeCutter.set_hmm takes.  With jieba installed:
+
+        from jieba.finalseg import prob_start, prob_trans, prob_emit
+        text = hmm_model_text(prob_start.P, prob_trans.P, prob_emit.P)
+    """
+    lines = [f"start {s} {float(p)!r}" for s, p in start_p.items()]
+    lines += [f"trans {a} {b} {float(p)!r}" for a, row in trans_p.items() for b, p in row.items()]
+    lines += [f"emit {s} {ch} {float(p)!r}" for s, row in emit_p.items() for ch, p in row.items()]
+    return "\n".join(lines) + "\n"

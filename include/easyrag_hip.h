@@ -167,6 +167,16 @@ int     erh_cutter_create(const char *dict_text, int64_t n_bytes, erh_cutter **o
 int     erh_cutter_destroy(erh_cutter *c);
 int     erh_cutter_cut(const erh_cutter *c, const char *text, int64_t n_bytes, int64_t *out_ends, int64_t cap,
                        int64_t *n_tokens);
+/* jieba's default call, cut(sentence) = cut(sentence, HMM=True), regroups runs of out-of-dictionary single characters
+ * with an HMM (jieba/finalseg: viterbi over the states B M E S).  Its model tables ship with jieba; the caller supplies
+ * them as text, one entry per line -- "start <state> <log p>", "trans <from> <to> <log p>", "emit <state> <char> <log p>"
+ * (anything absent counts as jieba's MIN_FLOAT, -3.14e100; INTEGRATION.md shows the three-line dump from an installed
+ * jieba).  With a model set, erh_cutter_cut and erh_text_encode* cut as HMM=True; n_bytes == 0 removes it.
+ * erh_cutter_cut_mode: hmm = 1 / 0 forces the mode for one call (1 without a model: ERH_ERR_STATE), -1 = the default. */
+int     erh_cutter_set_hmm(erh_cutter *c, const char *model_text, int64_t n_bytes);
+int     erh_cutter_has_hmm(const erh_cutter *c);
+int     erh_cutter_cut_mode(const erh_cutter *c, const char *text, int64_t n_bytes, int hmm, int64_t *out_ends, int64_t cap,
+                            int64_t *n_tokens);
 /* tokenize_and_remove_stopwords + the id walk in one pass, nothing per token on the caller's side: text i =
  * bytes[text_off[i], text_off[i+1]) is cut, tokens equal to ' ' or present in `stop` (a vocabulary used as a set, may be
  * NULL) are dropped (retrievers.py:72-76), the rest is encoded through `v` as erh_vocab_encode does (add == 0: unknown

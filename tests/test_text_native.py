@@ -216,3 +216,79 @@ def test_cutter_survives_arbitrary_bytes():
         e = ends[: n.value]
         assert np.all(np.diff(np.concatenate([[0], e])) > 0)
         assert (n.value == 0) == (len(raw) == 0) and (len(raw) == 0 or e[-1] == len(raw))
+
+
+def _synthetic_hmm(rng, chars):
+    """A random but well-formed finalseg model over `chars` (what jieba ships is trained; the algorithm does not care)."""
+    start = {"B": -0.26, "E": -3.14e100, "M": -3.14e100, "S": -1.46}
+    trans = {"B": {"E": -0.51, "M": -0.92}, "E": {"B": -0.59, "S": -0.81}, "M": {"E": -0.33, "M": -1.26}, "S": {"B": -0.72, "S": -0.67}}
+    emit = {s: {} for s in "BMES"}
+    for ch in chars:
+        for s in "BMES":
+            if rng.random() < 0.8:                                        # some characters are unknown to some states
+                emit[s][ch] = -float(rng.integers(2, 14)) - float(rng.integers(0, 4)) / 4.0   # quarter steps: ties do happen
+    return start, trans, emit
+
+
+def test_cutter_hmm_mode_equals_python_restatement():
+    """jieba's default call cut(sentence) = HMM=True: runs of out-of-dictionary single characters go through
+    finalseg (viterbi over B M E S, then its own re_han / re_skip splitting) -- native against the restatement, on a
+    dictionary that leaves most characters out so that the HMM has work to do."""
+    from easyrag_amd.text import hmm_model_text
+    from oracle.jieba_cut import HmmModel
+    rng = np.random.default_rng(23)
+    chars = [chr(c) for c in range(0x4E00, 0x4E00 + 60)]
+    words = sorted({"".join(chars[int(i)] for i in rng.integers(0, 25, size=int(rng.integers(2, 4)))) for _ in range(40)})
+    dict_text = "\n".join(f"{w} {int(rng.integers(1, 500))}" for w in words)
+    start, trans, emit = _synthetic_hmm(rng, chars)
+    native = NativeCutter(dict_text, hmm_model_text(start, trans, emit))
+    ref = DictCutter(dict_text, HmmModel(start, trans, emit))
+    assert native.has_hmm
+    extra = list("abcXYZ0123456789+#&._%- \t\r\n，。") + ["\r\n", "3.14%", "C++", "a.b"]
+    n_hmm_tokens = 0
+    for _ in range(400):
+        parts = []
+        for _ in range(int(rng.integers(1, 12))):
+            r = rng.random()
+            if r < 0.3:
+                parts.append(words[int(rng.integers(0, len(words)))])
+            elif r < 0.8:
+                parts.append("".join(chars[int(i)] for i in rng.integers(0, len(chars), size=int(rng.integers(1, 6)))))
+            else:
+                parts.append(extra[int(rng.integers(0, len(extra)))])
+        text = "".join(parts)
+        want = ref.cut(text)
+        got = native.cut(text)
+        assert got == want, (text, got, want)
+        assert "".join(got) == text
+        assert native.cut(text, HMM=False) == ref.cut(text, HMM=False)
+        n_hmm_tokens += sum(1 for a, b in zip(got, native.cut(text, HMM=False)) if a != b)
+    assert n_hmm_tokens > 100                                             # the HMM path really changed segmentations
+    # the fused corpus pass follows the cutter's mode, on any number of threads
+    texts = ["".join(chars[int(i)] for i in rng.integers(0, len(chars), size=int(rng.integers(3, 30)))) for _ in range(200)]
+    want_tokens = [[w for w in ref.cut(t) if w != " "] for t in texts]
+    v_py, flat_py, lens_py = vocab_ids_python(want_tokens)
+    for threads in (1, 4):
+        vt = NativeVocab()
+        ft, lt = native.encode_texts(texts, vt, threads=threads)
+        assert np.array_equal(ft, flat_py) and np.array_equal(lt, lens_py)
+    # without a model HMM=True is refused, and removing the model restores the HMM=False default
+    with pytest.raises(NotImplementedError):
+        NativeCutter(dict_text).cut("x", HMM=True)
+    native.set_hmm(None)
+    assert not native.has_hmm and native.cut(texts[0]) == ref.cut(texts[0], HMM=False)
+    with pytest.raises(Exception):
+        native.set_hmm("emit Q 好 -1.0\n")
+
+
+def test_cutter_hmm_hand_derived():
+    """Two unknown characters with a model that makes 'B then E' the best path are glued, 'S S' keeps them apart."""
+    from easyrag_amd.text import hmm_model_text
+    d = "北京 100\n"
+    start = {"B": -1.0, "S": -1.0}
+    trans = {"B": {"E": -0.1, "M": -5.0}, "E": {"B": -1.0, "S": -1.0}, "M": {"E": -1.0, "M": -1.0}, "S": {"B": -1.0, "S": -1.0}}
+    glue = {"B": {"甲": -1.0}, "E": {"乙": -1.0}, "M": {}, "S": {"甲": -9.0, "乙": -9.0}}
+    apart = {"B": {"甲": -9.0}, "E": {"乙": -9.0}, "M": {}, "S": {"甲": -1.0, "乙": -1.0}}
+    assert NativeCutter(d, hmm_model_text(start, trans, glue)).cut("北京甲乙北京") == ["北京", "甲乙", "北京"]
+    assert NativeCutter(d, hmm_model_text(start, trans, apart)).cut("北京甲乙北京") == ["北京", "甲", "乙", "北京"]
+    assert NativeCutter(d).cut("北京甲乙北京") == ["北京", "甲", "乙", "北京"]
