@@ -95,7 +95,6 @@ struct erh_handle {
                                           // payloads); 1 = fp32 sums only (the fp64 kernel runs out of registers with it: +12 % time), 2 = both
     int opt_hybrid_overlap = -1;          // erh_hybrid_topk: 1 = the sparse route on a side stream from the start, 2 = forked behind the dense scan,
                                           // 0 = one stream, -1 = by batch size (1 up to 256 queries: neither scan fills the chip; 0 above)
-                                          // (beside the selection kernels); joined before the fusion.  Measured slower than one stream: off
     hipStream_t side = nullptr;           // ... created at first use
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool fork_after_scan = false;         // dense_topk_dev records ev_fork behind its last scan launch (hybrid_overlap 2)
