@@ -128,8 +128,8 @@ __global__ __launch_bounds__(256) void row_norm_max_kernel(const _Float16 *__res
 // grid = B, block = 1024.  Exact k-th largest without sorting the row: every thread keeps the maximum of its
 // (strided) keys; the k-th largest of those 1024 maxima (one small bitonic sort) is a lower bound p of the true
 // k-th value, and only ~k*(1+k/2048) keys are >= p.  Those are compacted and sorted.
-// Fast kernel (`seed_select_kernel`): the row is read three times from memory (it was written by the store kernel a
-// moment ago and sits in L2 / Infinity Cache) and only 20 KiB of LDS are used, so two workgroups share a CU.
+// Fast kernel (`seed_select_kernel`): the row is read twice from memory -- thread maxima, then the gather above the pivot
+// (it was written by the store kernel a moment ago and sits in L2 / Infinity Cache); 36 KiB of LDS, two workgroups per CU.
 // Inputs that defeat the pivot (more than kSeedBuf keys >= p, or fewer than k threads holding a valid key) are
 // flagged in need_full[q] and redone by `seed_select_full_kernel`, which stages the whole row in LDS and sorts it
 // (it returns at once for every other query).
@@ -146,7 +146,7 @@ __device__ __forceinline__ uint32_t seed_key(const float *__restrict__ row, int 
 
 // Visit every prefix score of the row once: f(ordered key or 0, score, index).  Thread t takes the 16-byte groups
 // t, t + 1024, ... (the row is 16-byte aligned: ld_s0 is a multiple of 256), the first threads the ragged tail.
-// (Keeping the thread's 32 scores in registers across the three passes instead of re-reading the row measured
+// (Keeping the thread's 32 scores in registers across the passes instead of re-reading the row measured
 // SLOWER -- 0.146 vs 0.106 ms per 1024 queries: the row comes from L2 / Infinity Cache, the unrolled register walk costs
 // more than the reads.)
 template <class F>

@@ -4,6 +4,8 @@
 # GPU suite + smoke, the driver-style bench line (with sub_benchmarks), the per-workload lines, rocprofv3 kernel stats of
 # the same commands, the BM25 / dense PMC passes, the FETCH_SIZE traffic table, the determinism screen, the BM25 kernel
 # bench (section clocks) and the shim latency log.
+# (the bench lines of this script are taken BEFORE its FETCH_SIZE pass: for lines with roofline.traffic attached run
+# scripts/gpu_final.sh afterwards)
 set -u
 TAG=${1:-r00}
 OUT=gpurun_out/round
