@@ -47,13 +47,60 @@ DEFAULT_SIMILARITY_TOP_K = 2   # llama_index.core.constants.DEFAULT_SIMILARITY_T
 
 # ---------------------------------------------------------------------------------------------------
 # text variants and tokenisation (host side, as in the reference)
-def get_node_content(node, embed_type: int = 0) -> str:
+def _join_overlapping(head: str, tail: str) -> str:
+    """`head` followed by `tail` with the longest suffix-of-head == prefix-of-tail written once (ref ingestion.py:20-31)."""
+    keep = 0
+    for i in range(1, min(len(head), len(tail)) + 1):
+        if head[-i:] == tail[:i]:
+            keep = i
+    return head + tail[keep:]
+
+
+def _previous_node_id(node):
+    """node_id of the PREVIOUS relationship of a NodeWithScore's node (llama_index keys the dict by the
+    NodeRelationship enum, whose value is the string "2"; the stand-in nodes may use either or the name)."""
+    rel = node.node.relationships
+    try:
+        from llama_index.core.schema import NodeRelationship  # type: ignore
+        return rel[NodeRelationship.PREVIOUS].node_id
+    except ImportError:
+        for key in ("PREVIOUS", "2", 2):
+            if key in rel:
+                return rel[key].node_id
+        raise KeyError("PREVIOUS")
+
+
+def _table_with_header(node, text: str, nodes, nodeid2idx) -> str:
+    """embed_type 6 (ref ingestion.py:36-57): a chunk that looks like the body of a markdown table (>= 5 '|', no '---'
+    rule) is joined with up to three preceding chunks until one of them carries the table's header rule; the result is the
+    header line + everything from the rule on.  Without a rule within three chunks the text stays as it was."""
+    if text.count("|") < 5 or text.count("---") != 0:
+        return text
+    cur, found = text, False
+    for _ in range(3):
+        # (the reference never advances past the first PREVIOUS link: it re-reads node.node's relationship on every
+        # turn, so the same predecessor is merged up to three times -- kept, the merge is idempotent after the first)
+        pre_text = nodes[nodeid2idx[_previous_node_id(node)]].text
+        cur = _join_overlapping(pre_text, cur)
+        if pre_text.count("---") >= 2:
+            found = True
+            break
+    if not found:
+        return text
+    at = cur.index("---")
+    return cur[:at].strip().split("\n")[-1] + cur[at:]
+
+
+def get_node_content(node, embed_type: int = 0, nodes=None, nodeid2idx=None) -> str:
     """Text fed to a route, by embed_type (ref: src/easyrag/pipeline/ingestion.py:34-76).
     0 raw text; 1 '###\\n<file_path>\\n\\n<text>'; 2 same with know_path; 3 image captions expanded;
-    4 file_path only; 5 know_path only.  (6 = 3 plus a table-header merge that needs node
-    relationships; it degrades to 3 here.)"""
+    4 file_path only; 5 know_path only; 6 = 3 after the table-header merge over the PREVIOUS relationship, which
+    needs a NodeWithScore plus the pipeline's `nodes` / `nodeid2idx` (as the reference does: with a bare TextNode a
+    table-like chunk raises AttributeError there and here)."""
     text = node.get_content()
     meta = node.metadata
+    if embed_type == 6:
+        text = _table_with_header(node, text, nodes, nodeid2idx)
     if embed_type == 1 and "file_path" in meta:
         return "###\n" + meta["file_path"] + "\n\n" + text
     if embed_type == 2 and "know_path" in meta:
@@ -207,17 +254,39 @@ class HipVectorStore:
         return [self.corpus.nodes[i] for i in ids[0, :n]], [float(s) for s in sc[0, :n]]
 
 
-class _RetrieverBase:
-    """The slice of llama_index's BaseRetriever the pipeline uses: retrieve / aretrieve accept str or QueryBundle."""
+try:  # the reference's base class (ref retrievers.py:7,23,80,223) whenever llama_index is installed
+    from llama_index.core.base.base_retriever import BaseRetriever as _LlamaBaseRetriever  # type: ignore
+except Exception:  # pragma: no cover - the build container has no llama_index
+    _LlamaBaseRetriever = None
 
-    def retrieve(self, str_or_query_bundle) -> List[NodeWithScore]:
-        return self._retrieve(_as_bundle(str_or_query_bundle))
+if _LlamaBaseRetriever is not None:
+    class _RetrieverBase(_LlamaBaseRetriever):
+        """llama_index's BaseRetriever itself: `retrieve` / `aretrieve` (callback events, recursive retrieval over
+        `objects`) come from it, so `AutoMergingRetriever(sparse_retriever, ...)` (ref pipeline.py:212-217) and RETRIEVE
+        callbacks work as with the reference's classes; this file supplies `_retrieve` / `_aretrieve`."""
 
-    async def aretrieve(self, str_or_query_bundle) -> List[NodeWithScore]:
-        return await self._aretrieve(_as_bundle(str_or_query_bundle))
+        def _init_base(self, callback_manager=None, object_map=None, objects=None, verbose: bool = False) -> None:
+            _LlamaBaseRetriever.__init__(self, callback_manager=callback_manager, object_map=object_map,
+                                         objects=objects, verbose=verbose)
+else:
+    class _RetrieverBase:
+        """Fallback without llama_index: the slice of BaseRetriever the pipeline uses -- retrieve / aretrieve accept str
+        or QueryBundle; the ctor arguments of the real base class are kept as attributes."""
 
-    async def _aretrieve(self, query_bundle: QueryBundle) -> List[NodeWithScore]:
-        return self._retrieve(query_bundle)
+        def _init_base(self, callback_manager=None, object_map=None, objects=None, verbose: bool = False) -> None:
+            self.callback_manager = callback_manager
+            self.object_map = object_map or {}
+            self.objects = objects
+            self._verbose = verbose
+
+        def retrieve(self, str_or_query_bundle) -> List[NodeWithScore]:
+            return self._retrieve(_as_bundle(str_or_query_bundle))
+
+        async def aretrieve(self, str_or_query_bundle) -> List[NodeWithScore]:
+            return await self._aretrieve(_as_bundle(str_or_query_bundle))
+
+        async def _aretrieve(self, query_bundle: QueryBundle) -> List[NodeWithScore]:
+            return self._retrieve(query_bundle)
 
 
 class QdrantRetriever(_RetrieverBase):
@@ -226,6 +295,7 @@ class QdrantRetriever(_RetrieverBase):
         self._embed_model = embed_model
         self._similarity_top_k = similarity_top_k
         self.filters = filters
+        self._init_base()
 
     def _retrieve(self, query_bundle: QueryBundle) -> List[NodeWithScore]:
         emb = self._embed_model.get_query_embedding(query_bundle.query_str)
@@ -253,7 +323,8 @@ class BM25Retriever(_RetrieverBase):
         self.stopwords = stopwords
         # a NativeCutter tokenises, drops stop words and numbers the tokens inside the library (erh_text_encode): no Python
         # object per token.  Any other tokenizer (jieba.Tokenizer(), as the pipeline passes) goes through its own cut().
-        native_text = device_build and hasattr(tokenizer, "encode_texts") and "" not in self._str_stopwords(stopwords)[1]
+        # (a stop word the native side cannot express -- one with a NUL inside -- sends the build through the Python loop)
+        native_text = device_build and hasattr(tokenizer, "encode_texts") and not self._str_stopwords(stopwords)[1]
         self._corpus = None if native_text else [
             tokenize_and_remove_stopwords(tokenizer, get_node_content(n, embed_type), stopwords) for n in self._nodes]
         self.bm25_type = bm25_type
@@ -282,6 +353,7 @@ class BM25Retriever(_RetrieverBase):
                                          compute_payload=not payload_on_device)
             self.engine.set_bm25(self.bm25, payload_on_device=payload_on_device, slot=self._slot)
         self.filter_dict = None
+        self._init_base(callback_manager=callback_manager, object_map=object_map, objects=objects, verbose=verbose)
 
     @staticmethod
     def _str_stopwords(stopwords):
@@ -403,6 +475,7 @@ class HybridRetriever(_RetrieverBase):
         self.filters = None
         self.filter_dict = None
         self.topk = topk
+        self._init_base()
 
     # -- classmethods over already-retrieved lists (ref retrievers.py:239-274) ----------------------------
     # The pipeline calls them once per query on a few hundred NodeWithScore objects it already holds on the host

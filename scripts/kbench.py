@@ -186,6 +186,31 @@ def main():
                             n_: round(v / stages, 1) for n_, v in zip(names, c[g * 8:g * 8 + 6])} if stages else {}
             eng.set_option("dense_var", 0)
         del x
+    if what == "b256":                                       # configs[1] (256 queries, top-100): the scan's own ablation round
+        x = synth.dense_corpus_torch(n, d, seed=2, device=dev)
+        eng.set_dense(x)
+        names = ["matrix", "wait", "barrier", "memory", "epilogue", "epi_barrier"]
+        q = synth.dense_queries_torch(x, 256, seed=7)
+        eng.set_option("dense_pp", 3)
+        eng.set_option("dense_var", 0)
+        for rep in "ab":
+            for abl in (0, 7, 14, 13, 15, 12, 23, 16, 11, 17, 18):
+                eng.set_option("dense_ablate", abl)
+                res[f"dense B=256 pp=3 pabl={abl} (run {rep})"] = timed(eng, lambda: eng.dense_topk(q, 100, device_out=True))
+        for abl in (21, 20, 22, 24):
+            eng.set_option("debug_counters", 1)
+            eng.set_option("dense_ablate", abl)
+            eng.dense_topk(q, 100, device_out=True)
+            torch.cuda.synchronize()
+            c = eng.debug_counters().astype(np.float64)
+            eng.set_option("dense_ablate", 0)
+            eng.set_option("debug_counters", 0)
+            for g in (0, 1):
+                stages = c[g * 8 + 6]
+                res[f"dense B=256 pp=3 pabl={abl} phase clocks per stage, group {g}"] = {
+                    n_: round(v / stages, 1) for n_, v in zip(names, c[g * 8:g * 8 + 6])} if stages else {}
+        eng.set_option("dense_ablate", 0)
+        del x
     if what == "p3":                                         # strict-alternation ping-pong (dense_pp=3) vs the lean one (2)
         x = synth.dense_corpus_torch(n, d, seed=2, device=dev)
         eng.set_dense(x)
