@@ -31,7 +31,7 @@ MFMA_F16_PEAK_TF = 2500.0    # dense fp16/bf16 MFMA peak (no sparsity)
 RIDGE = MFMA_F16_PEAK_TF * 1e12 / (HBM_PEAK_GBS * 1e9)   # FLOP per byte
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -49,7 +49,36 @@ def parse_args():
     ap.add_argument("--sub", type=int, default=1, help="1 (default): after the headline run, time the other BASELINE.json configs and the "
                                                        "single-query latencies on the same corpus (sub_benchmarks in the JSON line; "
                                                        "hybrid workload, one GPU, default sizes only)")
-    return ap.parse_args()
+    return ap.parse_args(argv)
+
+
+class GpuPlatform:
+    """Everything main() needs that touches the GPU or the library: device selection, synchronisation, timing events, the
+    engine, the synthetic data and the index builder.  The CPU tests pass a stand-in with the same surface
+    (tests/test_bench_multi_gpu.py: two gloo ranks through main()'s world > 1 control flow); the product path is this class."""
+
+    def __init__(self):
+        import torch
+        from easyrag_amd import synth
+        from easyrag_amd.engine import RetrievalEngine, queries_to_csr
+        from easyrag_amd.index import build_bm25_index_from_postings
+        self.torch, self.synth = torch, synth
+        self._engine_cls = RetrievalEngine
+        self.queries_to_csr = queries_to_csr
+        self.build_index = build_bm25_index_from_postings
+
+    def set_device(self, local: int):
+        self.torch.cuda.set_device(local)
+        return self.torch.device("cuda", local)
+
+    def synchronize(self):
+        self.torch.cuda.synchronize()
+
+    def event(self):
+        return self.torch.cuda.Event(enable_timing=True)
+
+    def make_engine(self, local: int):
+        return self._engine_cls(local)
 
 
 def cpu_baseline(x_dev, q16_dev, idx, payload, queries, k_dense, k_sparse, topk, n_sample, workload):
@@ -275,7 +304,7 @@ def sub_benchmarks(eng, synth, queries_to_csr, build_index, OKAPI, q16_pool, tok
     return out
 
 
-def spawn_ranks(args) -> int:
+def spawn_ranks(args, argv) -> int:
     """`python bench.py --gpus N` without a launcher: start N ranks under torch.distributed.run on this node (what
     the driver's wrapped form does) and relay their output."""
     import socket
@@ -290,29 +319,31 @@ def spawn_ranks(args) -> int:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL needs it on this driver
     return subprocess.call(cmd, env=env)
 
 
-def main():
-    args = parse_args()
+def main(argv=None, platform=None):
+    """The benchmark.  `argv` / `platform` default to the command line and the GPU (GpuPlatform); rank 0 prints ONE JSON line
+    and every rank returns {"record": that line's dict (rank 0) or None, "out": the last step's (global) result}."""
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = parse_args(argv)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        raise SystemExit(spawn_ranks(args))
+        raise SystemExit(spawn_ranks(args, argv))
     import torch
     from easyrag_amd import dist as erd
-    from easyrag_amd import synth
     from easyrag_amd._lib import ERH_K_BM25_MERGE, ERH_K_BM25_SCAN, ERH_K_DENSE_SCAN, ERH_K_DENSE_SELECT, ERH_K_FUSE
-    from easyrag_amd.engine import RetrievalEngine, queries_to_csr
-    from easyrag_amd.index import BM25S, OKAPI, build_bm25_index_from_postings
+    from easyrag_amd.index import BM25S, OKAPI
+    plat = platform if platform is not None else GpuPlatform()
+    synth, queries_to_csr, build_bm25_index_from_postings = plat.synth, plat.queries_to_csr, plat.build_index
 
     rank, world = erd.init_from_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    dev = plat.set_device(local)
     n, d, vocab = args.chunks, args.dim, args.vocab
     B = args.batch or (1024 if args.workload == "hybrid" else 256)
     k_dense, k_sparse, topk = (100, 0, 100) if args.workload == "dense" else (288, 192, 10)
@@ -324,7 +355,7 @@ def main():
 
     # ---- synthetic corpus, replicated on every rank (same seeds); the global query batches are the same on every
     # rank too, and each rank answers its contiguous shard of them -------------------------------------------------
-    eng = RetrievalEngine(local)
+    eng = plat.make_engine(local)
     for opt in args.option:
         name, val = opt.split("=")
         eng.set_option(name, int(val))
@@ -345,7 +376,7 @@ def main():
             csr_pool.append(queries_to_csr(tok_pool[-1]))
         del flat
     eng.set_doc_meta(n, None, None)
-    torch.cuda.synchronize()
+    plat.synchronize()
     q16 = q16_pool[0] if q16_pool else None
     queries = tok_pool[0] if tok_pool else []
 
@@ -367,16 +398,17 @@ def main():
         counter[0] += 1
         out = local_step(p)
         if world > 1:
-            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev = (plat.event(), plat.event())
             ev[0].record()
             out = shards.gather(*out)                         # erh_dense_check, pack -> ONE all-gather -> unpack
             ev[1].record()
             gather_events.append(ev)
         return out
 
+    out = None
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
+    plat.synchronize()
     if args.workload != "bm25":
         eng.dense_check()                                     # raises on candidate overflow
     eng.set_profiling(True)
@@ -384,11 +416,11 @@ def main():
     gather_events.clear()
     if world > 1:
         torch.distributed.barrier()
-    torch.cuda.synchronize()
+    plat.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
-    torch.cuda.synchronize()
+    plat.synchronize()
     if world > 1:
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
@@ -400,6 +432,7 @@ def main():
     if args.workload != "bm25":
         eng.dense_check()
 
+    rec = None
     if rank == 0:
         kt = {name: eng.kernel_time(cls) for name, cls in
               (("dense_scan", ERH_K_DENSE_SCAN), ("dense_select", ERH_K_DENSE_SELECT), ("bm25_scan", ERH_K_BM25_SCAN),
@@ -412,19 +445,32 @@ def main():
             roof.update(pmc_traffic(args, dom, roof["algorithmic_bytes_per_launch"]))
         cpu = None
         if world == 1 and args.cpu_queries > 0:
-            payload = eng.get_bm25_payload() if idx is not None else None
+            payload = payload_check = None
+            if idx is not None:
+                # the CPU baseline scores with a payload evaluated on the HOST (easyrag_amd.index: the libraries' arithmetic in
+                # numpy), not with what the GPU computed; the two must agree bit for bit, and the line says whether they did
+                host_idx = build_bm25_index_from_postings(indptr, doc, tf, lens, variant, compute_payload=True)
+                payload = host_idx.payload
+                gpu_payload = eng.get_bm25_payload()
+                payload_check = bool(payload.dtype == gpu_payload.dtype and np.array_equal(payload, gpu_payload))
+                if not payload_check:
+                    raise SystemExit("bench.py: the GPU's BM25 payload differs from the host evaluation (parity broken)")
+                del host_idx, gpu_payload
             cpu, ref_ids = cpu_baseline(x, q16, idx, payload, queries, k_dense, k_sparse, topk, args.cpu_queries,
                                         args.workload)
             # recall@topk of the GPU result against the CPU restatement on the same sample (sets: the CPU walk
             # orders equal scores as numpy's argsort happens to, the GPU by index)
             got = local_step(0)
-            torch.cuda.synchronize()
+            plat.synchronize()
             g_ids = got[0][: len(ref_ids)].cpu().numpy()
             hit = tot = 0
             for b, want in enumerate(ref_ids):
                 tot += len(want)
                 hit += len(set(want) & set(int(v) for v in g_ids[b] if v >= 0))
             cpu["recall_at_topk_vs_cpu"] = (hit / tot) if tot else None
+            if payload_check is not None:
+                cpu["payload"] = ("host payload (numpy evaluation of idf * tf-saturation per posting, easyrag_amd.index); the GPU's "
+                                  "payload array is bit-identical to it" if payload_check else "MISMATCH")
             cpu["recall_note"] = ("id sets of the two results; below 1.0 only where documents tie at the k-th score: the CPU "
                                   "walk orders equal scores as numpy's argsort happens to, the GPU by index")
         total_q = B * world * args.steps
@@ -465,6 +511,7 @@ def main():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
     eng.close()
+    return {"record": rec, "out": out}
 
 
 if __name__ == "__main__":

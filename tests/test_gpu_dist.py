@@ -115,3 +115,25 @@ def test_gather_completes_the_exhaustive_rounds_first(engine):
         engine.set_option("dense_shuffle", 1)
         engine.set_option("dense_n0", 32768)
         engine.set_option("dense_gemv", 1)
+
+
+def test_two_ranks_rccl_gather_modes():
+    """Two RCCL ranks (skipped on a one-GPU box): tests/_rccl_rank_main.py under torch.distributed.run -- both gather modes
+    ("torch": pack -> all_gather_into_tensor -> unpack; "native": erh_comm_init -> ncclAllGather inside the library) against
+    the unsharded result on every rank.  north_star's split; the reference is single-process (src/main.py:48-52)."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL does not share a device between ranks)")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_rccl_rank_main.py")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), script], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "RCCL-GATHER-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
