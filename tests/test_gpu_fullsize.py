@@ -4,6 +4,9 @@ composition on sampled queries, for the configurations round 1 only property-che
   configs[3]  dense(288) + BM25(192) + RRF -> top-10, B = 1024, both BM25 variants      (32 sampled queries each)
   configs[2]  BM25 only, B = 256 (two document segments per query + merge), k = 100 / 192 (32 sampled queries)
   Okapi       float64 accumulation, 61 tiles of 16384 documents                          (12 sampled queries)
+  configs[3]  bm25s, ALL 1024 queries of the batch (round 4; ~2 minutes of oracle work on the host)
+  configs[3]  with a `dir` filter on both routes (one column per route, as the reference keeps them apart) and 1 % of the
+              documents sharing their content with another one (SURVEY.md 8(d) config 4 variant), 32 sampled queries
 
 How the oracle stays affordable at 1M documents without weakening it:
   sparse  the per-posting payload comes from the host index (easyrag_amd/index.py, bit-equal to the dict-loop
@@ -68,14 +71,28 @@ def sparse_oracle_scores(idx, q_tokens):
     return acc
 
 
-def dense_oracle_topk(x, q16_rows, k):
-    """Exact (pinned-order fp64, index-ascending ties) top-k of each query row over the whole matrix."""
+def sparse_oracle_topk(idx, q_tokens, k, keep_mask=None):
+    """bm25_filter over the documents the query touches at all (the walk stops at the first score <= 0, so the others never
+    appear; the index map is monotone, so (score desc, index asc) is the same order): 7 x cheaper than sorting 1M scores."""
+    acc = sparse_oracle_scores(idx, q_tokens)
+    nz = np.nonzero(acc)[0]
+    got = bm25_filter(acc[nz], k, keep_mask=None if keep_mask is None else keep_mask[nz])
+    return [(int(nz[i]), s) for i, s in got]
+
+
+def dense_oracle_topk(x, q16_rows, k, allowed=None):
+    """Exact (pinned-order fp64, index-ascending ties) top-k of each query row over the whole matrix (`allowed`: per query
+    a boolean row mask or None -- the payload filter of the Qdrant search, applied before the limit)."""
     import torch
     out = []
     qf = q16_rows.float()
     s32 = torch.empty((qf.shape[0], x.shape[0]), dtype=torch.float32, device=x.device)
     for s in range(0, x.shape[0], 131072):
         s32[:, s:s + 131072] = qf @ x[s:s + 131072].float().T
+    if allowed is not None:
+        for i, m in enumerate(allowed):
+            if m is not None:
+                s32[i, ~m] = -float("inf")
     kth = torch.topk(s32, k, dim=1).values[:, -1]
     for i in range(qf.shape[0]):
         cand = torch.nonzero(s32[i] >= kth[i] - 2e-3).reshape(-1)
@@ -153,3 +170,104 @@ def test_device_index_build_full_size(engine, sparse_data, variant):
     assert np.array_equal(got.indptr, indptr) and np.array_equal(got.doc_ids, doc) and np.array_equal(got.tf, tf)
     assert np.array_equal(got.idf, want.idf) and got.avgdl == want.avgdl
     assert np.array_equal(got.payload, want.payload)
+
+
+def test_hybrid_configs3_all_queries(engine, dense_data, sparse_data):
+    """every one of the 1024 queries of configs[3] (bm25s), not a sample: fused ids and fp64 RRF scores."""
+    import torch
+    x, q = dense_data
+    queries = sparse_data[4]
+    idx = host_index(sparse_data, BM25S)
+    engine.set_dense(x)
+    engine.set_bm25(idx, payload_on_device=True)
+    engine.set_doc_meta(N, None, None)
+    qi, qt = queries_to_csr(queries)
+    ids, sc, ln = engine.hybrid_topk(q, qi, qt, k_dense=288, k_sparse=192, K=60, topk=10)
+    assert np.all(ln == 10)
+    bad = []
+    for lo in range(0, 1024, 128):                                                   # the fp32 proposal matrix in slabs of 128 queries
+        dense_want = dense_oracle_topk(x, q[lo:lo + 128], 288)
+        torch.cuda.empty_cache()
+        for r, (did, dsc) in enumerate(dense_want):
+            b = lo + r
+            sp = sparse_oracle_topk(idx, queries[b], 192)
+            want = reciprocal_rank_fusion([[Item(i, i, s) for i, s in sp],
+                                           [Item(int(i), int(i), float(s)) for i, s in zip(did, dsc)]], K=60, topk=10)
+            if list(ids[b, :ln[b]]) != [w.idx for w in want] or list(sc[b, :ln[b]]) != [w.score for w in want]:
+                bad.append(b)
+    assert not bad, f"{len(bad)} of 1024 queries differ from the oracle: {bad[:20]}"
+
+
+def test_hybrid_configs3_filters_and_duplicate_contents(engine, dense_data, sparse_data):
+    """VERDICT r3 4(b) / SURVEY.md 8(d) config 4 variant at 1M: a `dir` equality filter pushed into both routes (per query:
+    none / the same class on both / sparse route only / a different class per route -- the reference keeps filter_dict and
+    filters apart, retrievers.py:278,283) and 1 % of the documents sharing their content with an earlier one, with the
+    shared contents planted INSIDE the top lists of the sampled queries so that the RRF really merges them (key = content,
+    += per occurrence, the last-seen node is returned: retrievers.py:256-274)."""
+    import torch
+    from collections import Counter
+    x, q = dense_data
+    queries = sparse_data[4]
+    idx = host_index(sparse_data, BM25S)
+    rng = np.random.default_rng(77)
+    dir_id = rng.choice(4, size=N, p=[0.40, 0.35, 0.15, 0.10]).astype(np.int16)     # the reference's four manuals, unevenly sized
+    fs = np.full(1024, -1, np.int16)
+    fd = np.full(1024, -1, np.int16)
+    cls = rng.integers(0, 4, size=1024).astype(np.int16)
+    b_idx = np.arange(1024)
+    fs[b_idx % 4 == 1] = cls[b_idx % 4 == 1]; fd[b_idx % 4 == 1] = cls[b_idx % 4 == 1]
+    fs[b_idx % 4 == 2] = cls[b_idx % 4 == 2]
+    fs[b_idx % 4 == 3] = cls[b_idx % 4 == 3]; fd[b_idx % 4 == 3] = (cls[b_idx % 4 == 3] + 1) % 4
+    sample = list(range(0, 1024, 33))[:32]
+    engine.set_dense(x)
+    engine.set_bm25(idx, payload_on_device=True)
+    engine.set_doc_meta(N, None, dir_id)
+    qi, qt = queries_to_csr(queries)
+    # the filtered route lists of the sampled queries (no content ids yet): where the duplicates are planted
+    allowed = [None if fd[b] < 0 else torch.from_numpy(dir_id == fd[b]).to(x.device) for b in sample]
+    dense_want = dense_oracle_topk(x, q[sample], 288, allowed)
+    sparse_want = [sparse_oracle_topk(idx, queries[b], 192, None if fs[b] < 0 else (dir_id == fs[b])) for b in sample]
+    content = np.arange(N, dtype=np.int32)
+    used = set()
+
+    def tie(a, b2):
+        a, b2 = int(a), int(b2)
+        if a == b2 or a in used or b2 in used:
+            return
+        used.update((a, b2))
+        content[max(a, b2)] = min(a, b2)                                           # content id = smallest index with that text
+
+    for (did, _), sp in zip(dense_want, sparse_want):
+        for j in range(0, 40, 2):
+            tie(did[j], did[j + 1])                                                 # two dense hits with one text
+        for j in range(min(20, len(sp))):
+            tie(sp[j][0], did[100 + j])                                             # a sparse hit and a dense hit with one text
+        for j in range(60, min(100, len(sp)) - 1, 2):
+            tie(sp[j][0], sp[j + 1][0])                                             # two sparse hits with one text
+    planted = len(used) // 2
+    while len(used) < 20000:                                                        # up to 1 % of the corpus: 10,000 shared pairs
+        a, b2 = rng.integers(0, N, size=2)
+        tie(a, b2)
+    assert planted > 1500 and int((content != np.arange(N)).sum()) == 10000
+    engine.set_doc_meta(N, content, dir_id)
+    try:
+        ids, sc, ln = engine.hybrid_topk(q, qi, qt, k_dense=288, k_sparse=192, K=60, topk=10, filter_dir=fs, filter_dense=fd)
+        merged = 0
+        for (did, dsc), sp, b in zip(dense_want, sparse_want, sample):
+            lists = [[Item(i, int(content[i]), s) for i, s in sp],
+                     [Item(int(i), int(content[i]), float(s)) for i, s in zip(did, dsc)]]
+            want = reciprocal_rank_fusion(lists, K=60, topk=10)
+            assert list(ids[b, :ln[b]]) == [w.idx for w in want], f"query {b}: fused ids differ"
+            assert list(sc[b, :ln[b]]) == [w.score for w in want], f"query {b}: fused scores differ"
+            seen = Counter(it.content for lst in lists for it in lst)
+            merged += sum(1 for w in want if seen[int(content[w.idx])] > 1)
+        assert merged > 0                                                           # shared contents reached the fused top-10
+        d_ids, d_sc, d_ln = engine.dense_topk(q[sample], 288, filter_dir=fd[sample])
+        for r, (did, dsc) in enumerate(dense_want):
+            assert np.array_equal(d_ids[r, :d_ln[r]], did) and np.array_equal(d_sc[r, :d_ln[r]], dsc)
+        qi_s, qt_s = queries_to_csr([queries[b] for b in sample])
+        s_ids, s_sc, s_ln = engine.bm25_topk(qi_s, qt_s, 192, filter_dir=fs[sample])
+        for r, sp in enumerate(sparse_want):
+            assert list(s_ids[r, :s_ln[r]]) == [i for i, _ in sp] and list(s_sc[r, :s_ln[r]]) == [s for _, s in sp]
+    finally:
+        engine.set_doc_meta(N, None, None)
