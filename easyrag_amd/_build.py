@@ -71,7 +71,17 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     if not force and LIB_PATH.exists() and STAMP.exists() and STAMP.read_text().strip() == dig:
         return LIB_PATH
     import fcntl
-    with open(str(LIB_PATH) + ".lock", "w") as lock:
+    try:
+        lock = open(str(LIB_PATH) + ".lock", "w")
+    except OSError:
+        # a read-only install: nothing can be (re)built here; a library that exists is used as it is
+        if LIB_PATH.exists():
+            import warnings
+            warnings.warn(f"{LIB_PATH.parent} is not writable: using the existing {LIB_PATH.name} although its source "
+                          f"digest stamp is missing or stale")
+            return LIB_PATH
+        raise
+    with lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
             if not force and LIB_PATH.exists() and STAMP.exists() and STAMP.read_text().strip() == dig:

@@ -73,7 +73,9 @@ struct erh_handle {
     bool qorder_valid = false;
     DevBuf scan_sync;                        // one counter per chunk-tile stream of the ping-pong scan (dense_sync)
     DevBuf Xt;                               // tiled copy of X for the ping-pong scan (option dense_tiled), valid iff xt_valid
+    DevBuf Qt;                               // tiled copy of the query block of the current call (dense_pp = 4)
     bool xt_valid = false;
+    bool qt_valid = false;                   // Qt holds the tiled copy of the CURRENT call's Q16
     int64_t N = 0;
     int d = 0;
     float xnorm_max = 0.f;
@@ -129,6 +131,8 @@ struct erh_handle {
     int opt_dense_cfg = 0;                 // dense scan tile configuration (dense_scan.hip)
     int opt_dense_readahead = 1;           // cfg 2 only: fragments of the next K-step are read before its barrier
     int opt_small_single = 1;              // small batches: skip the refinement boundaries when the lists can take it
+    int opt_gemv_pipe = -1;                  // ... software-pipelined loads: -1 by batch (2 / 4 column groups), 0 off, 1 on
+    int opt_gemv_kb = 32, opt_gemv_wgs = 2;  // skinny-GEMM stream: steps whose loads are in flight together, workgroups per CU at most
     int opt_dense_gemv = 1;                // batches of <= 16 queries: skinny-GEMM stream instead of the padded 256-query scan
     int opt_n0_auto = 0;                   // seed prefix snapped down to a whole number of scan rounds (less seed work, more candidates: a wash at 1M chunks)
     int opt_dense_sync = 0;                // the query-tile workgroups of a stream meet at a counter every four tiles (measured: no gain)
@@ -246,12 +250,22 @@ hipError_t scan_append(erh_handle *h, const _Float16 *X, int64_t N, int d, int64
     // small batches: the skinny-GEMM stream (dense_gemv.hip) instead of a 256-query tile that is mostly padding
     if (h->opt_dense_gemv && h->opt_dense_ablate == 0 && B <= erh::dense_gemv_max_queries()) {
         hipError_t e = erh::launch_dense_gemv_append(X, N, d, c0, c1, Q16, B, tau, filt, dir, cand, cnt, cap, flags,
-                                                     h->n_cus, st);
+                                                     h->n_cus, h->opt_gemv_kb, h->opt_gemv_wgs, h->opt_gemv_pipe, st);
         if (e != hipErrorInvalidValue) return e;
         (void)hipGetLastError();
     }
     const int abl = h->opt_dense_ablate;
     const bool pp_code = abl == 0 || abl == 7 || abl == 8 || (abl >= 11 && abl <= 18) || (abl >= 20 && abl <= 24);
+    if (h->opt_dense_pp >= 4 && pp_code && X == h->X.as<_Float16>() && h->xt_valid && h->qt_valid) {
+        // both operands from their tiled copies (dense_scan_pp4_kernel)
+        hipError_t e = erh::launch_dense_scan_pp4(h->Xt.as<_Float16>(), N, d, c0, c1, h->Qt.as<_Float16>(), Bpad, B, tau, filt,
+                                                  dir, cand, cnt, cap, flags, h->n_cus, h->opt_dense_ablate,
+                                                  h->opt_debug_counters ? h->dbg.as<unsigned long long>() : nullptr,
+                                                  h->opt_dense_rot >= 0 ? h->opt_dense_rot : (Bpad > erh::dense_scan_q_tile() ? (d / 32) / (Bpad / erh::dense_scan_q_tile()) : 0),
+                                                  st);
+        if (e != hipErrorInvalidValue) return e;
+        (void)hipGetLastError();
+    }
     if (h->opt_dense_pp && pp_code) {
         const bool own = X == h->X.as<_Float16>();
         const int QT = erh::dense_scan_q_tile();
@@ -320,9 +334,16 @@ int dense_topk_dev(erh_handle *h, const void *q_dev, int q_dtype, int normalize_
     uint32_t *flags = h->flags.as<uint32_t>();   // [0] overflow, [1] maxerr (float bits), [2] uncertified
     HIPCHK(h, hipMemsetAsync(flags, 0, 64, st));
 
+    h->qt_valid = false;
     { ProfScope ps(h, st, ERH_K_DENSE_SELECT, 0, 0);
       HIPCHK(h, erh::launch_prep_queries(q_dev, q_dtype, normalize_q, B, Bpad, d, h->Q16.as<_Float16>(),
-                                         h->qnorm.as<float>(), st)); }
+                                         h->qnorm.as<float>(), st));
+      // the tiled-operand scan reads the query block as stage images too (512 KiB per 256 queries, once per call)
+      if (h->opt_dense_pp >= 4 && h->xt_valid && d % 64 == 0 && B > erh::dense_gemv_max_queries()) {
+          HIPCHK(h, h->Qt.ensure((size_t)Bpad * d * 2));
+          HIPCHK(h, erh::launch_dense_tile_rows(h->Q16.as<_Float16>(), Bpad, d, h->Qt.p, st));
+          h->qt_valid = true;
+      } }
     const _Float16 *X = h->X.as<_Float16>();
     const _Float16 *Q16 = h->Q16.as<_Float16>();
     const int16_t *dir = nullptr;                 // dir id by stored position, only needed when a filter is present
@@ -348,7 +369,8 @@ int dense_topk_dev(erh_handle *h, const void *q_dev, int q_dtype, int normalize_
     const bool small = h->opt_dense_gemv && h->opt_dense_ablate == 0 && B <= erh::dense_gemv_max_queries();
     { ProfScope ps(h, st, ERH_K_DENSE_SCAN, wb, wf);
       hipError_t e = hipErrorInvalidValue;
-      if (small) e = erh::launch_dense_gemv_store(X, N, d, 0, (int)n0, Q16, B, h->S0.as<float>(), ld, h->n_cus, st);
+      if (small) e = erh::launch_dense_gemv_store(X, N, d, 0, (int)n0, Q16, B, h->S0.as<float>(), ld, h->n_cus,
+                                                  h->opt_gemv_kb, h->opt_gemv_wgs, h->opt_gemv_pipe, st);
       if (e == hipErrorInvalidValue) {
           (void)hipGetLastError();
           // one 256 x 256 tile per workgroup leaves CUs idle when the seed grid is small (B = 256: 128 tiles on 256 CUs);
@@ -642,7 +664,7 @@ int erh_destroy(erh_handle *h) {
     drain_events(h);
     for (auto &ev : h->pool) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
     if (h->side) { (void)hipStreamDestroy(h->side); (void)hipEventDestroy(h->ev_fork); (void)hipEventDestroy(h->ev_join); }
-    DevBuf *bufs[] = {&h->X, &h->Xt, &h->scan_sync, &h->qorder, &h->content_id, &h->dir_id,
+    DevBuf *bufs[] = {&h->X, &h->Xt, &h->Qt, &h->scan_sync, &h->qorder, &h->content_id, &h->dir_id,
                       &h->qin, &h->Q16, &h->qnorm, &h->tau, &h->S0, &h->cand, &h->cand_cnt, &h->flags, &h->filt, &h->filt2,
                       &h->o_ids, &h->o_sc, &h->o_len, &h->qptr, &h->qtok, &h->part_sc, &h->part_ids, &h->part_len,
                       &h->hy_sids, &h->hy_ssc, &h->hy_slen, &h->hy_dids, &h->hy_dsc, &h->hy_dlen,
@@ -674,7 +696,7 @@ int erh_set_option(erh_handle *h, const char *name, int64_t value) {
     if (!strcmp(name, "dense_readahead")) { h->opt_dense_readahead = value != 0; return ERH_OK; }
     if (!strcmp(name, "dense_shuffle")) { h->opt_dense_shuffle = value != 0; return ERH_OK; }   // takes effect at the next erh_set_dense
     if (!strcmp(name, "dense_n1_auto")) { h->opt_n1_auto = value != 0; return ERH_OK; }
-    if (!strcmp(name, "dense_pp")) { if (value < 0 || value > 3) return h->fail(ERH_ERR_INVALID, "dense_pp"); h->opt_dense_pp = (int)value; return ERH_OK; }
+    if (!strcmp(name, "dense_pp")) { if (value < 0 || value > 4) return h->fail(ERH_ERR_INVALID, "dense_pp"); h->opt_dense_pp = (int)value; return ERH_OK; }
     if (!strcmp(name, "dense_n0_auto")) { h->opt_n0_auto = value != 0; return ERH_OK; }
     if (!strcmp(name, "dense_sync")) { h->opt_dense_sync = value != 0; return ERH_OK; }
     if (!strcmp(name, "dense_tiled")) { h->opt_dense_tiled = value != 0; return ERH_OK; }   // building the copy: at the next erh_set_dense
@@ -682,8 +704,9 @@ int erh_set_option(erh_handle *h, const char *name, int64_t value) {
     if (!strcmp(name, "dense_var")) { if (value < 0 || value > 3) return h->fail(ERH_ERR_INVALID, "dense_var"); h->opt_dense_var = (int)value; return ERH_OK; }
     if (!strcmp(name, "dense_rot")) { if (value < -1 || value > 4096) return h->fail(ERH_ERR_INVALID, "dense_rot"); h->opt_dense_rot = (int)value; return ERH_OK; }
     if (!strcmp(name, "dense_gemv")) { h->opt_dense_gemv = value != 0; return ERH_OK; }
-    if (!strcmp(name, "dense_gemv_kb")) { erh::dense_gemv_tune((int)value, 0); return ERH_OK; }       // process-wide tuning
-    if (!strcmp(name, "dense_gemv_wgs")) { erh::dense_gemv_tune(0, (int)value); return ERH_OK; }
+    if (!strcmp(name, "dense_gemv_kb")) { if (value != 16 && value != 32) return h->fail(ERH_ERR_INVALID, "dense_gemv_kb"); h->opt_gemv_kb = (int)value; return ERH_OK; }
+    if (!strcmp(name, "dense_gemv_pipe")) { if (value < -1 || value > 1) return h->fail(ERH_ERR_INVALID, "dense_gemv_pipe"); h->opt_gemv_pipe = (int)value; return ERH_OK; }
+    if (!strcmp(name, "dense_gemv_wgs")) { if (value < 1 || value > 5) return h->fail(ERH_ERR_INVALID, "dense_gemv_wgs"); h->opt_gemv_wgs = (int)value; return ERH_OK; }
     if (!strcmp(name, "dense_small_single_stage")) { h->opt_small_single = value != 0; return ERH_OK; }
     if (!strcmp(name, "dense_persist")) { h->opt_dense_persist = value != 0; return ERH_OK; }
 #ifdef ERH_MEASURE

@@ -1,21 +1,24 @@
-// Sparse route, kernels K2/K3: BM25 scored over CSR inverted postings with a deterministic, atomics-free
-// scatter-add into LDS accumulators and a running top-k.  Replaces BM25Retriever.get_scores + filter
+// Sparse route, kernels K2/K3: BM25 scored over CSR inverted postings.  Replaces BM25Retriever.get_scores + filter
 // (/root/reference/src/easyrag/custom/retrievers.py:128-151, 191-210), whose arithmetic is
 // rank_bm25.BM25Okapi.get_scores (float64) or bm25s.BM25.get_scores (float32) -- SURVEY.md A.1/A.2.
 //
-// Bit parity rule: for every document the per-term contributions must be added in query-token order,
-// repeats included, in the library's accumulation type.  So:
-//   - postings carry the precomputed per-(term, doc) contribution ("eager" payload, as bm25s stores it;
-//     for Okapi the same thing in float64), built on the host or by bm25_payload_kernel below;
-//   - a workgroup owns one query and walks document tiles; a tile's accumulators live in LDS
-//     (32768 fp32 / 16384 fp64 sums); query tokens are applied one after the other with a barrier in
-//     between; inside one token every document occurs at most once, so plain LDS read-add-write by the
-//     thread that holds the posting is race free and needs no atomics;
-//   - per-term tile boundaries come from a skip table tile_off[term][tile] built once per index, so a
-//     tile touches exactly its postings (algorithmic bytes = 8 or 12 per posting touched);
-//   - the tile is then swept once: entries that beat the running k-th best (score desc, index asc;
-//     score > 0 only, retrievers.py:195-196; optional dir filter, retrievers.py:198-202) are compacted
-//     into an LDS candidate list that is re-sorted and cut to k whenever it fills.
+// Bit parity rule: a document's per-term contributions are added in query-token order, repeats included, in the library's
+// accumulation type.  Postings carry the precomputed per-(term, doc) contribution ("eager" payload, as bm25s stores it; for
+// Okapi the same thing in float64), built on the host or by bm25_payload_kernel below.  Two ways to honour the rule:
+//   - DEFAULT (bm25_ascan_kernel, since round 3): the scan only GENERATES candidates -- postings are scattered into
+//     fixed-point integer sums in LDS with ds_add_rtn_u32 in any order (integer sums do not depend on it), a document is
+//     listed at the one add that takes its sum over the threshold, and the short final list (k + the near ties of the k-th)
+//     is then scored exactly: per (document, token) one binary search in the posting list, payloads summed in token order in
+//     the library's type.  ids and scores equal the order-keeping scans' bit for bit.
+//   - FALLBACK / parity arms (bm25_scan_kernel, bm25_wscan_kernel): a workgroup owns one query and walks document tiles; a
+//     tile's accumulators live in LDS (32768 fp32 / 16384 fp64 sums); query tokens are applied one after the other (block
+//     scan: barrier in between; wave-owned scan: each wave owns a sub-range of the tile), so plain LDS read-add-write by the
+//     thread that holds the posting is race free; the tile is swept once and entries that beat the running k-th best
+//     (score desc, index asc; score > 0 only, retrievers.py:195-196; optional dir filter, retrievers.py:198-202) are
+//     compacted into an LDS candidate list that is re-sorted and cut to k whenever it fills.  Indices with a non-positive
+//     payload always take this path.
+// Per-term tile boundaries come from a skip table tile_off[term][tile] built once per index, so a tile touches exactly its
+// postings (algorithmic bytes = 8 or 12 per posting touched).
 #include <algorithm>
 #include "common.h"
 #include "kernels.h"

@@ -24,6 +24,7 @@
 //   0: 256 x 256, BK 64, 8 waves, A ring 3 / B ring 2, 160 KiB LDS  -> one workgroup per CU
 //   1: 128 x 256, BK 32, 4 waves, A ring 4 / B ring 3,  80 KiB LDS  -> two independent workgroups per CU,
 //      whose barrier / issue bubbles overlap each other's MFMA phases
+#include <algorithm>
 #include "common.h"
 #include "kernels.h"
 
@@ -1692,6 +1693,242 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp3_kernel(
 #undef ERH_PP2_ISSUE_A
 #undef ERH_PP2_ISSUE_B
 
+// ---------------------------------------------------------------------------------------------
+// Ping-pong scan over TILED operands (option "dense_pp" = 4).  Same tile, waves, strict alternation (two barriers per
+// stage), fragment-read placement and epilogue as dense_scan_pp3_kernel; what changes is the memory side, rebuilt from the
+// mainloop of scripts/ubench/scan_sync.hip (SYNC 0), which on the same box runs ~10 % faster than pp3 without its epilogue:
+//   - BOTH operands come from tiled copies -- per 256-row tile and 32-half stage one 16 KiB block that IS the LDS stage
+//     image (swizzle included): the chunk matrix' copy Xt (dense_tile_rows_kernel at erh_set_dense) and a copy Qt of the
+//     query block made per call by the same kernel (512 KiB per query tile).  Every DMA instruction moves 1 KiB of
+//     consecutive bytes; stages are issued one at a time, so nothing relies on an L1 hit of a line's second half;
+//   - every memory segment issues the same four instructions: two of chunk stage g+4 (ring 5), two of query stage g+3 (ring
+//     4); before the barrier that ends stage g all but those four have landed (vmcnt(4)), i.e. stage g+2 is complete one
+//     whole stage before its fragments are read;
+//   - the bookkeeping is two running byte pointers and two ring offsets: ~100 VGPRs fewer than pp3, nothing spills.
+// K-rotation (rot_stages): query tile qt starts every chunk tile at stage k0 = qt * rot_stages mod nk (any stage, not only
+// even ones), so the workgroups of a stream miss on different lines.
+template <int PABL>
+__global__ __launch_bounds__(pp::NT) void dense_scan_pp4_kernel(
+    const _Float16 *__restrict__ Xt, int64_t N, int d, int64_t c0, int64_t c1,
+    const _Float16 *__restrict__ Qt, int Bpad, int B,
+    const float *__restrict__ tau, const int16_t *__restrict__ filter_dir, const int16_t *__restrict__ dir_id,
+    ErhCand *__restrict__ cand, uint32_t *__restrict__ cand_cnt, int cap, uint32_t *__restrict__ overflow,
+    unsigned long long *__restrict__ dbg /* kPpClocks only */, int rot_stages) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp = wave >> 2, wave_n = wave & 3;
+    long long tph[6] = {0, 0, 0, 0, 0, 0};
+    long long t_mark = (PABL & kPpClocks) ? clock64() : 0;
+#define ERH_PH(I) do { if (PABL & kPpClocks) { const long long n_ = clock64(); tph[I] += n_ - t_mark; t_mark = n_; } } while (0)
+    const int nk = d / pp::BK;
+    const int n_qt = Bpad / pp::BN;
+    const int64_t n_ct = (c1 - c0 + pp::BM - 1) / pp::BM;
+    const int xcd = blockIdx.x & 7;
+    const int jx = blockIdx.x >> 3;
+    const int qt = jx % n_qt;
+    const int stream = (jx / n_qt) * 8 + xcd;
+    const int n_streams = (gridDim.x / (8 * n_qt)) * 8;
+    if (stream >= n_ct) return;                                        // whole workgroup, before any barrier
+    const int n_tiles = (int)((n_ct - stream + n_streams - 1) / n_streams);
+    const int total = n_tiles * nk;                                    // flattened (tile, stage) sequence
+    const int64_t q_row0 = (int64_t)qt * pp::BN;
+    const int64_t lim = (c1 < N) ? c1 : N;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int k0 = (qt * rot_stages) % nk;
+    float t_q[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int q = (int)q_row0 + wave_n * 64 + nt * 32 + l31;
+        t_q[nt] = (q < B && !(PABL & kPpTauInf)) ? tau[q] : INFINITY;
+    }
+    asm volatile("" ::"v"(t_q[0]), "v"(t_q[1]));                      // loaded before the DMA stream starts (keeps vmcnt countable)
+
+    // this lane's 16 bytes of a stage image: instruction 0 moves bytes [wave * 1024, +1024), instruction 1 the same + 8 KiB
+    const int64_t tile_bytes = (int64_t)nk * pp::A_BYTES;
+    const char *xa = reinterpret_cast<const char *>(Xt) + ((c0 / pp::BM + stream) * (int64_t)nk + k0) * pp::A_BYTES + wave * 1024 + lane * 16;
+    const char *const qb = reinterpret_cast<const char *>(Qt) + (int64_t)qt * tile_bytes + wave * 1024 + lane * 16;
+    const int64_t a_jump = (int64_t)n_streams * tile_bytes;           // a stage -> the same stage of the stream's next tile
+    const int sw = row_swizzle<pp::PR>(l31);
+    const int a_rd0 = (grp * 128 + l31) * pp::RB + ((hh ^ sw) << 4);
+    const int a_rd1 = (grp * 128 + l31) * pp::RB + (((2 + hh) ^ sw) << 4);
+    const int b_rd0 = pp::B_BASE + (wave_n * 64 + l31) * pp::RB + ((hh ^ sw) << 4);
+    const int b_rd1 = pp::B_BASE + (wave_n * 64 + l31) * pp::RB + (((2 + hh) ^ sw) << 4);
+    char *const rec = lds + pp::REC_BASE + wave * pp::REC_BYTES;
+    if (threadIdx.x == 0) { ERH_PP_FLAG(0) = 0; ERH_PP_FLAG(1) = 0; }
+
+    constexpr int kABytes = pp::AST * pp::A_BYTES, kBBytes = pp::BST * pp::B_BYTES;
+    int a_dst = 0, b_dst = 0, ka = k0, kb = k0;
+    int a_left = total, b_left = total;
+    int fa_off = 0, fb_off = 0;                                        // ring offsets of the next stage to read
+    half8 fa[4][2], fb[2][2];
+    char *const my_dst = lds + wave * 1024;
+#define ERH_PP4_GLDS(SRC, DST) __builtin_amdgcn_global_load_lds((const void *)(SRC), ERH_LDS_PTR(DST), 16, 0, 0)
+#define ERH_PP4_ISSUE_A()                                                                             \
+    do {                                                                                              \
+        if (a_left > 0) {                                                                             \
+            if (!(PABL & kPpNoDmaA)) {                                                                \
+                ERH_PP4_GLDS(xa, my_dst + a_dst);                                                     \
+                ERH_PP4_GLDS(xa + 8192, my_dst + a_dst + 8192);                                       \
+            }                                                                                         \
+            xa += pp::A_BYTES;                                                                        \
+            if (++ka == nk) { ka = 0; xa -= tile_bytes; }                  /* wrap to stage 0 of the same tile */ \
+            if (ka == k0) xa += a_jump;                                    /* tile complete: the stream's next tile */ \
+            a_dst += pp::A_BYTES;                                                                     \
+            if (a_dst == kABytes) a_dst = 0;                                                          \
+            --a_left;                                                                                 \
+        }                                                                                             \
+    } while (0)
+#define ERH_PP4_ISSUE_B()                                                                             \
+    do {                                                                                              \
+        if (b_left > 0) {                                                                             \
+            if (!(PABL & kPpNoDmaB)) {                                                                \
+                const char *q_ = qb + (int64_t)kb * pp::B_BYTES;                                      \
+                ERH_PP4_GLDS(q_, my_dst + pp::B_BASE + b_dst);                                        \
+                ERH_PP4_GLDS(q_ + 8192, my_dst + pp::B_BASE + b_dst + 8192);                          \
+            }                                                                                         \
+            if (++kb == nk) kb = 0;                                                                   \
+            b_dst = (b_dst + pp::B_BYTES) & (kBBytes - 1);                                            \
+            --b_left;                                                                                 \
+        }                                                                                             \
+    } while (0)
+#define ERH_PP4_ADVANCE_READ()                                                                        \
+    do {                                                                                              \
+        fa_off += pp::A_BYTES;                                                                        \
+        if (fa_off == kABytes) fa_off = 0;                                                            \
+        fb_off = (fb_off + pp::B_BYTES) & (kBBytes - 1);                                              \
+    } while (0)
+#define ERH_PP4_READ_ALL()                                                                            \
+    do {                                                                                              \
+        const char *pa0_ = lds + (a_rd0 + fa_off), *pa1_ = lds + (a_rd1 + fa_off);                    \
+        const char *pb0_ = lds + (b_rd0 + fb_off), *pb1_ = lds + (b_rd1 + fb_off);                    \
+        _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                            \
+            fa[mt][0] = *reinterpret_cast<const half8 *>(pa0_ + mt * 32 * pp::RB);                    \
+            fa[mt][1] = *reinterpret_cast<const half8 *>(pa1_ + mt * 32 * pp::RB);                    \
+        }                                                                                             \
+        _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                                            \
+            fb[nt][0] = *reinterpret_cast<const half8 *>(pb0_ + nt * 32 * pp::RB);                    \
+            fb[nt][1] = *reinterpret_cast<const half8 *>(pb1_ + nt * 32 * pp::RB);                    \
+        }                                                                                             \
+        ERH_PP4_ADVANCE_READ();                                                                       \
+    } while (0)
+// one K sub-step of the matrix segment; each fragment register is re-loaded with the NEXT stage's contents right behind the
+// last MFMA that reads it (past the end of the stream the reads fetch stale ring bytes that nothing uses)
+#define ERH_PP4_HALF(J, PA_, PB_, FIRST)                                                              \
+    do {                                                                                              \
+        _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                            \
+            if (!(PABL & kPpNoMfma)) {                                                                \
+                if (FIRST) {                                                                          \
+                    const f32x16 z_ = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; \
+                    acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mt][J], fb[0][J], z_, 0, 0, 0);  \
+                    acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mt][J], fb[1][J], z_, 0, 0, 0);  \
+                } else {                                                                              \
+                    acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mt][J], fb[0][J], acc[mt][0], 0, 0, 0); \
+                    acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mt][J], fb[1][J], acc[mt][1], 0, 0, 0); \
+                }                                                                                     \
+            } else {                                                                                  \
+                asm volatile("" ::"v"(fa[mt][J]), "v"(fb[0][J]), "v"(fb[1][J]));                      \
+                if (FIRST) { _Pragma("unroll") for (int r = 0; r < 16; ++r) { acc[mt][0][r] = 0.f; acc[mt][1][r] = 0.f; } } \
+            }                                                                                         \
+            if (!(PABL & kPpNoFrag)) fa[mt][J] = *reinterpret_cast<const half8 *>(PA_ + mt * 32 * pp::RB); \
+            __builtin_amdgcn_sched_barrier(0);                                                        \
+        }                                                                                             \
+        if (!(PABL & kPpNoFrag)) {                                                                    \
+            fb[0][J] = *reinterpret_cast<const half8 *>(PB_);                                         \
+            fb[1][J] = *reinterpret_cast<const half8 *>(PB_ + 32 * pp::RB);                           \
+        }                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+    } while (0)
+#define ERH_PP4_COMPUTE(FIRST)                                                                        \
+    do {                                                                                              \
+        const char *pa0_ = lds + (a_rd0 + fa_off), *pa1_ = lds + (a_rd1 + fa_off);                    \
+        const char *pb0_ = lds + (b_rd0 + fb_off), *pb1_ = lds + (b_rd1 + fb_off);                    \
+        ERH_PP4_HALF(0, pa0_, pb0_, FIRST);                                                           \
+        ERH_PP4_HALF(1, pa1_, pb1_, false);                                                           \
+        ERH_PP4_ADVANCE_READ();                                                                       \
+    } while (0)
+// after M_g (chunk stage g+4, query stage g+3 issued): everything but those four instructions has landed, i.e. stage g+2;
+// the fragment reads of this wave's last matrix segment have retired (ring slots may be overwritten after the barrier)
+#define ERH_PP4_WAIT(G)                                                                               \
+    do {                                                                                              \
+        if ((G) + 4 >= total) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");             \
+        else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");                              \
+    } while (0)
+
+    // prologue: A0 B0 A1 B1 A2 B2 A3; stages 0 and 1 complete = the last 6 instructions may stay in flight
+    ERH_PP4_ISSUE_A(); ERH_PP4_ISSUE_B(); ERH_PP4_ISSUE_A(); ERH_PP4_ISSUE_B(); ERH_PP4_ISSUE_A(); ERH_PP4_ISSUE_B();
+    ERH_PP4_ISSUE_A();
+    if (total >= 4) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ERH_PP_BARRIER();
+    ERH_PP4_READ_ALL();                                                // stage 0
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    ERH_PP_BARRIER();
+
+    f32x16 acc[4][2];
+    int fill = 0;                                                      // records buffered in this wave's area
+    int flush_now = 0;                                                 // workgroup-uniform, decided one tile ahead
+    int g = 0;
+    if (grp == 0) {
+        for (int i = 0; i < n_tiles; ++i) {
+            for (int kt = 0; kt < nk; ++kt, ++g) {
+                ERH_PP4_COMPUTE(kt == 0);                              // C(g)
+                ERH_PH(0);
+                ERH_PP_BARRIER();                                      // |A|
+                ERH_PH(2);
+                ERH_PP4_ISSUE_A();                                     // M_g
+                ERH_PP4_ISSUE_B();
+                __builtin_amdgcn_sched_barrier(0);
+                ERH_PH(3);
+                ERH_PP4_WAIT(g);
+                ERH_PH(1);
+                ERH_PP_BARRIER();                                      // |B|
+                ERH_PH(2);
+            }
+            ERH_PP_EPILOGUE();
+            ERH_PH(4);
+            ERH_PP_BARRIER();
+            ERH_PH(5);
+            if (!(PABL & kPpNoEpi)) flush_now = __builtin_amdgcn_readfirstlane(ERH_PP_FLAG(i & 1));
+        }
+    } else {
+        for (int i = 0; i < n_tiles; ++i) {
+            for (int kt = 0; kt < nk; ++kt, ++g) {
+                ERH_PP4_ISSUE_A();                                     // M_g
+                ERH_PP4_ISSUE_B();
+                __builtin_amdgcn_sched_barrier(0);
+                ERH_PH(3);
+                ERH_PP_BARRIER();                                      // |A|
+                ERH_PH(2);
+                ERH_PP4_COMPUTE(kt == 0);                              // C(g)
+                ERH_PH(0);
+                ERH_PP4_WAIT(g);
+                ERH_PH(1);
+                ERH_PP_BARRIER();                                      // |B|
+                ERH_PH(2);
+            }
+            ERH_PP_EPILOGUE();
+            ERH_PH(4);
+            ERH_PP_BARRIER();
+            ERH_PH(5);
+            if (!(PABL & kPpNoEpi)) flush_now = __builtin_amdgcn_readfirstlane(ERH_PP_FLAG(i & 1));
+        }
+    }
+    if ((PABL & kPpClocks) && dbg && lane == 0 && (wave == 0 || wave == 4)) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) atomicAdd(&dbg[grp * 8 + i], (unsigned long long)tph[i]);
+        atomicAdd(&dbg[grp * 8 + 6], (unsigned long long)total);
+    }
+#undef ERH_PH
+#undef ERH_PP4_GLDS
+#undef ERH_PP4_ISSUE_A
+#undef ERH_PP4_ISSUE_B
+#undef ERH_PP4_ADVANCE_READ
+#undef ERH_PP4_READ_ALL
+#undef ERH_PP4_HALF
+#undef ERH_PP4_COMPUTE
+#undef ERH_PP4_WAIT
+}
+
 using Cfg0 = ScanCfg<256, 256, 2, 4, 64, 3, 2>;   // one 8-wave workgroup per CU, 160 KiB LDS
 using Cfg1 = ScanCfg<128, 256, 1, 4, 32, 4, 3>;   // two 4-wave workgroups per CU, 80 KiB LDS each
 using Cfg2 = ScanCfg<256, 256, 2, 4, 32, 5, 5>;   // one workgroup per CU, BK 32, both operands 4 half-steps ahead
@@ -1938,8 +2175,14 @@ hipError_t dense_scan_init() {
     e = hipFuncSetAttribute((const void *)dense_scan_pp2_kernel<A, V>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                             pp::LDS_BYTES);                                                                \
     if (e != hipSuccess) return e;
+#define ERH_SET_PP4(A)                                                                                     \
+    e = hipFuncSetAttribute((const void *)dense_scan_pp4_kernel<A>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                            pp::LDS_BYTES);                                                                \
+    if (e != hipSuccess) return e;
     ERH_SET_PP(0)
+    ERH_SET_PP4(0)
 #ifdef ERH_MEASURE
+    ERH_PP_MASKS(ERH_SET_PP4)
     ERH_PP_MASKS(ERH_SET_PP)
     ERH_SET_PP2V(0, 1) ERH_SET_PP2V(0, 2) ERH_SET_PP2V(0, 3)
     ERH_SET_PP2V(1, 1) ERH_SET_PP2V(1, 2) ERH_SET_PP2V(1, 3)
@@ -1950,6 +2193,7 @@ hipError_t dense_scan_init() {
 #endif
 #undef ERH_SET_PP2V
 #undef ERH_SET_PP
+#undef ERH_SET_PP4
     return hipSuccess;
 }
 
@@ -1965,10 +2209,44 @@ hipError_t launch_dense_scan_pp(const _Float16 *X, int64_t N, int d, int64_t c0,
                      dbg, lean, stream_sync, st);
 }
 
+// The tiled-operand ping-pong scan (dense_scan_pp4_kernel): Xt / Qt are the tiled copies (launch_dense_tile_rows) of the
+// chunk matrix and of the query block; c0 must be a multiple of 256.  hipErrorInvalidValue when the shape does not qualify.
+hipError_t launch_dense_scan_pp4(const _Float16 *Xt, int64_t N, int d, int64_t c0, int64_t c1, const _Float16 *Qt,
+                                 int Bpad, int B, const float *tau, const int16_t *filter_dir, const int16_t *dir_id,
+                                 ErhCand *cand, uint32_t *cand_cnt, int cap, uint32_t *overflow, int n_cus, int pabl,
+                                 unsigned long long *dbg, int rot_stages, hipStream_t st) {
+    if (c1 <= c0) return hipSuccess;
+    if (d % pp::BK != 0 || d / pp::BK < 8 || c0 % pp::BM != 0) return hipErrorInvalidValue;
+    const int n_qt = Bpad / pp::BN;
+    const int grid_n = n_cus / (8 * n_qt) * (8 * n_qt);
+    if (grid_n <= 0) return hipErrorInvalidValue;
+    const int64_t n_ct = (c1 - c0 + pp::BM - 1) / pp::BM;
+    if (n_ct / (grid_n / n_qt) + 1 >= (1ll << pp::TILE_BITS)) return hipErrorInvalidValue;   // tile index must fit the record
+    dim3 grid((unsigned)grid_n), block(pp::NT);
+#define ERH_LAUNCH_PP4(A)                                                                                  \
+    hipLaunchKernelGGL((dense_scan_pp4_kernel<A>), grid, block, pp::LDS_BYTES, st, Xt, N, d, c0, c1, Qt, Bpad, B, tau, \
+                       filter_dir, dir_id, cand, cand_cnt, cap, overflow, dbg, rot_stages)
+#ifdef ERH_MEASURE
+    switch (pp_mask_of(pabl)) {
+#define ERH_PP_CASE(M) case M: ERH_LAUNCH_PP4(M); break;
+        ERH_PP_MASKS(ERH_PP_CASE)
+#undef ERH_PP_CASE
+        default: ERH_LAUNCH_PP4(0); break;
+    }
+#else
+    (void)pabl;
+    ERH_LAUNCH_PP4(0);
+#endif
+#undef ERH_LAUNCH_PP4
+    return hipGetLastError();
+}
+
 hipError_t launch_dense_tile_rows(const _Float16 *X, int64_t N, int d, void *Xt, hipStream_t st) {
     if (d % 64 != 0) return hipErrorInvalidValue;
     const int64_t n_tiles = (N + pp::BM - 1) / pp::BM;
-    hipLaunchKernelGGL(dense_tile_rows_kernel, dim3(8192), dim3(256), 0, st, X, d, n_tiles, reinterpret_cast<int4 *>(Xt));
+    const int64_t pieces = n_tiles * (d / 64) * 2048;                 // 16-byte pieces to move
+    const unsigned blocks = (unsigned)std::min<int64_t>(8192, (pieces + 255) / 256);
+    hipLaunchKernelGGL(dense_tile_rows_kernel, dim3(blocks), dim3(256), 0, st, X, d, n_tiles, reinterpret_cast<int4 *>(Xt));
     return hipGetLastError();
 }
 

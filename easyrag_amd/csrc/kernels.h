@@ -24,6 +24,10 @@ hipError_t launch_dense_scan_pp(const _Float16 *X, int64_t N, int d, int64_t c0,
                                 hipStream_t st);
 // tiled copy of the chunk matrix for the ping-pong scan: ceil(N / 256) * 256 * d halves (see dense_tile_rows_kernel)
 hipError_t launch_dense_tile_rows(const _Float16 *X, int64_t N, int d, void *Xt, hipStream_t st);
+hipError_t launch_dense_scan_pp4(const _Float16 *Xt, int64_t N, int d, int64_t c0, int64_t c1, const _Float16 *Qt,
+                                 int Bpad, int B, const float *tau, const int16_t *filter_dir, const int16_t *dir_id,
+                                 ErhCand *cand, uint32_t *cand_cnt, int cap, uint32_t *overflow, int n_cus, int pabl,
+                                 unsigned long long *dbg, int rot_stages, hipStream_t st);
 constexpr int kDensePadRows = 256;   // zero rows erh_set_dense keeps behind the matrix (tiles past N read them)
 hipError_t launch_dense_scan_persist(int cfg, const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1,
                                      const _Float16 *Q, int Bpad, int B, const float *tau,
@@ -36,13 +40,12 @@ hipError_t launch_dense_naive(const _Float16 *Q, int B, const _Float16 *X, int64
 // ---- dense_gemv.hip: append scan for batches of at most dense_gemv_max_queries() queries ----------------------------
 int dense_gemv_max_queries();
 hipError_t dense_gemv_init();
-void dense_gemv_tune(int kb, int wgs);   // loads in flight per wave (16 / 32 steps), workgroups per CU
 hipError_t launch_dense_gemv_append(const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1, const _Float16 *Q, int B,
                                     const float *tau, const int16_t *filter_dir, const int16_t *dir_id, ErhCand *cand,
-                                    uint32_t *cand_cnt, int cap, uint32_t *overflow, int n_cus, hipStream_t st);
-
+                                    uint32_t *cand_cnt, int cap, uint32_t *overflow, int n_cus, int kb, int wgs,
+                                    int pipe, hipStream_t st);
 hipError_t launch_dense_gemv_store(const _Float16 *X, int64_t N, int d, int64_t c0, int nc, const _Float16 *Q, int B,
-                                   float *S0, int ld_s0, int n_cus, hipStream_t st);
+                                   float *S0, int ld_s0, int n_cus, int kb, int wgs, int pipe, hipStream_t st);
 
 // ---- select.hip ------------------------------------------------------------------------------
 constexpr int kDenseN0Max = 32768;    // seed prefix: one fp32 score row must fit LDS for the k-th select

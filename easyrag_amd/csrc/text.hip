@@ -112,6 +112,8 @@ namespace {
 
 // UTF-8 -> code points + byte offset of each (offsets has one more entry: the end).  Malformed bytes decode as
 // themselves (one "character" per byte, value 0xDC80 + byte, Python's surrogateescape convention), so cutting never fails.
+// The three-byte form of a surrogate code point (what str.encode("utf-8", "surrogatepass") writes for a lone surrogate in a
+// Python str) is ONE character, as it is for jieba, which walks the str.
 void decode_utf8(const char *s, int64_t n, std::vector<uint32_t> &cp, std::vector<int64_t> &off) {
     cp.clear();
     off.clear();
@@ -128,7 +130,7 @@ void decode_utf8(const char *s, int64_t n, std::vector<uint32_t> &cp, std::vecto
                    ((unsigned char)s[i + 2] & 0xC0) == 0x80) {
             const uint32_t w = ((uint32_t)(c & 0x0F) << 12) | (((uint32_t)(unsigned char)s[i + 1] & 0x3F) << 6) |
                                ((unsigned char)s[i + 2] & 0x3F);
-            if (w >= 0x800 && !(w >= 0xD800 && w <= 0xDFFF)) { v = w; len = 3; }
+            if (w >= 0x800) { v = w; len = 3; }
         } else if ((c & 0xF8) == 0xF0 && i + 3 < n && ((unsigned char)s[i + 1] & 0xC0) == 0x80 &&
                    ((unsigned char)s[i + 2] & 0xC0) == 0x80 && ((unsigned char)s[i + 3] & 0xC0) == 0x80) {
             const uint32_t w = ((uint32_t)(c & 0x07) << 18) | (((uint32_t)(unsigned char)s[i + 1] & 0x3F) << 12) |

@@ -7,8 +7,9 @@ erh_cutter_*).  Host code, no GPU involved.
   NativeCutter   a tokenizer object with jieba's ``cut`` interface (what ``tokenize_and_remove_stopwords`` calls,
                  retrievers.py:72-76; the pipeline passes ``jieba.Tokenizer()``, pipeline.py:176-178) running jieba
                  0.42.1's dictionary-DAG algorithm for ``cut(sentence, cut_all=False, HMM=False)`` over a caller-supplied
-                 dictionary in jieba's text format.  jieba's default (HMM=True) also re-cuts runs of out-of-dictionary
-                 characters with an HMM whose tables ship with jieba; that step is not reproduced here.
+                 dictionary in jieba's text format, and jieba's default call (HMM=True: runs of out-of-dictionary single
+                 characters re-cut by finalseg's viterbi) once the caller has supplied the model tables that ship with jieba
+                 (``NativeCutter(dict_text, hmm_text)`` / ``set_hmm``; INTEGRATION.md shows the dump).
 """
 from __future__ import annotations
 
@@ -100,8 +101,8 @@ class NativeVocab:
 
 
 class NativeCutter:
-    """``cut(text)`` like ``jieba.Tokenizer().cut(text, HMM=False)`` over the given dictionary (jieba text format: one
-    ``word freq [tag]`` per line)."""
+    """``cut(text)`` like ``jieba.Tokenizer().cut(text)`` over the given dictionary (jieba text format: one ``word freq
+    [tag]`` per line): HMM=False without a model, jieba's default HMM=True with one (``hmm_text`` / ``set_hmm``)."""
 
     def __init__(self, dict_text: str, hmm_text: Optional[str] = None):
         self._lib = _lib.load()
@@ -154,7 +155,7 @@ class NativeCutter:
         if HMM and not self.has_hmm:
             raise NotImplementedError("HMM=True needs jieba's finalseg model: NativeCutter(dict_text, hmm_text) / set_hmm()")
         raw = text.encode("utf-8", "surrogatepass")
-        cap = len(text) + 1
+        cap = len(raw) + 1                                   # never more tokens than bytes
         ends = np.empty(cap, np.int64)
         n = C.c_int64(0)
         mode = -1 if HMM is None else (1 if HMM else 0)

@@ -151,8 +151,8 @@ int erh_set_doc_meta(erh_handle *h, int64_t N, const int32_t *content_id, const 
  * dictionary DAG (runs of single ASCII letters / digits are glued back together), "\r\n" and single white-space
  * characters are tokens of their own (the reference drops ' ' afterwards, retrievers.py:74-75), every other character is
  * a token.  The dictionary is the caller's, in jieba's text format ("word freq [tag]" per line).  jieba's DEFAULT call
- * (HMM=True) additionally re-cuts runs of out-of-dictionary characters with an HMM whose tables ship with jieba; that
- * step is not reproduced.
+ * (HMM=True) additionally re-cuts runs of out-of-dictionary characters with an HMM whose tables ship with jieba: see
+ * erh_cutter_set_hmm below.
  *   erh_cutter_cut    byte offsets of the token ENDS (token t = text[end[t-1], end[t]), end[-1] = 0), at most `cap`;
  *                     *n_tokens = how many there are (ERH_ERR_OVERFLOW if more than cap); out_ends may be NULL. */
 typedef struct erh_vocab erh_vocab;

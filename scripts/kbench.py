@@ -186,6 +186,43 @@ def main():
                             n_: round(v / stages, 1) for n_, v in zip(names, c[g * 8:g * 8 + 6])} if stages else {}
             eng.set_option("dense_var", 0)
         del x
+    if what == "pp4":                                        # tiled-operand ping-pong scan (dense_pp = 4) against pp3, both bench shapes
+        eng.set_option("dense_tiled", 1)
+        x = synth.dense_corpus_torch(n, d, seed=2, device=dev)
+        eng.set_dense(x)
+        names = ["matrix", "wait", "barrier", "memory", "epilogue", "epi_barrier"]
+        for B, k in ((256, 100), (1024, 288)):
+            q = synth.dense_queries_torch(x, B, seed=7)
+            ref = None
+            for rep in "abc":
+                for pp, tiled in ((3, 0), (3, 1), (4, 1)):
+                    eng.set_option("dense_pp", pp)
+                    eng.set_option("dense_tiled", tiled)
+                    for abl in (0, 7):
+                        eng.set_option("dense_ablate", abl)
+                        res[f"dense B={B} pp={pp} tiled={tiled} pabl={abl} (run {rep})"] = timed(eng, lambda: eng.dense_topk(q, k, device_out=True))
+                    eng.set_option("dense_ablate", 0)
+                    ids, sc, ln = eng.dense_topk(q, k)
+                    if ref is None:
+                        ref = (ids.copy(), sc.copy(), ln.copy())
+                    else:
+                        same = bool(np.array_equal(ids, ref[0]) and np.array_equal(sc, ref[1]) and np.array_equal(ln, ref[2]))
+                        res[f"dense B={B} pp={pp} tiled={tiled} identical to the first result (run {rep})"] = same
+            eng.set_option("dense_pp", 4)
+            eng.set_option("dense_tiled", 1)
+            for abl in (21, 20):
+                eng.set_option("debug_counters", 1)
+                eng.set_option("dense_ablate", abl)
+                eng.dense_topk(q, k, device_out=True)
+                torch.cuda.synchronize()
+                c = eng.debug_counters().astype(np.float64)
+                eng.set_option("dense_ablate", 0)
+                eng.set_option("debug_counters", 0)
+                for g in (0, 1):
+                    stages = c[g * 8 + 6]
+                    res[f"dense B={B} pp=4 pabl={abl} phase clocks per stage, group {g}"] = {
+                        n_: round(v / stages, 1) for n_, v in zip(names, c[g * 8:g * 8 + 6])} if stages else {}
+        del x
     if what == "b256":                                       # configs[1] (256 queries, top-100): the scan's own ablation round
         x = synth.dense_corpus_torch(n, d, seed=2, device=dev)
         eng.set_dense(x)

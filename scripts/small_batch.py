@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""Latency of the small-batch dense path (skinny-GEMM stream) at 1M x 1024: B = 1, 4, 16 and, for comparison, 17 (the
-padded 256-query scan).  Library event timers per kernel class + wall time per call."""
+"""Latency of the small-batch dense path (skinny-GEMM stream, 1 / 2 / 4 column groups of 16 queries) at 1M x 1024:
+B = 1 ... 64 and, for comparison, 65 ... 256 (the padded 256-query scan).  Library event timers per kernel class + wall time per call."""
 import os
 import sys
 import time
@@ -19,23 +19,28 @@ def main():
     eng = RetrievalEngine(0)
     x = synth.dense_corpus_torch(n, d, seed=2, device=dev)
     eng.set_dense(x)
-    for B, k in ((1, 288), (1, 10), (4, 288), (16, 288), (17, 288)):
-        q = synth.dense_queries_torch(x, B, seed=7)
-        for _ in range(3):
-            eng.dense_topk(q, k, device_out=True)
-        torch.cuda.synchronize()
-        eng.set_profiling(True)
-        eng.reset_kernel_time()
-        reps = 20
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            eng.dense_topk(q, k, device_out=True)
-        torch.cuda.synchronize()
-        wall = (time.perf_counter() - t0) / reps * 1e3
-        eng.set_profiling(False)
-        scan = eng.kernel_time(ERH_K_DENSE_SCAN)["ms"] / reps
-        sel = eng.kernel_time(ERH_K_DENSE_SELECT)["ms"] / reps
-        print(f"B={B:3d} k={k:3d}: scan {scan:.3f} ms ({2.048 / scan:.2f} TB/s of the 2 GB matrix)  select {sel:.3f} ms  wall {wall:.3f} ms per call")
+    for pipe in (-1, 0, 1):
+        eng.set_option("dense_gemv_pipe", pipe)
+        for B, k in ((1, 288), (1, 10), (4, 288), (16, 288), (17, 288), (32, 288), (48, 288), (64, 288), (65, 288), (128, 288), (256, 288)):
+            if pipe >= 0 and (B > 64 or k == 10):
+                continue
+            q = synth.dense_queries_torch(x, B, seed=7)
+            for _ in range(3):
+                eng.dense_topk(q, k, device_out=True)
+            torch.cuda.synchronize()
+            eng.set_profiling(True)
+            eng.reset_kernel_time()
+            reps = 20
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                eng.dense_topk(q, k, device_out=True)
+            torch.cuda.synchronize()
+            wall = (time.perf_counter() - t0) / reps * 1e3
+            eng.set_profiling(False)
+            scan = eng.kernel_time(ERH_K_DENSE_SCAN)["ms"] / reps
+            sel = eng.kernel_time(ERH_K_DENSE_SELECT)["ms"] / reps
+            print(f"gemv_pipe={pipe:2d} B={B:3d} k={k:3d}: scan {scan:.3f} ms ({2.048 / scan:.2f} TB/s of the 2 GB matrix)  select {sel:.3f} ms  wall {wall:.3f} ms per call")
+    eng.set_option("dense_gemv_pipe", -1)
     # sparse route and the fused call at B = 1 / 16: how the number of document-range segments (workgroups per query, then
     # one merge of their lists) trades scan time against merge time
     from easyrag_amd._lib import ERH_K_BM25_MERGE, ERH_K_BM25_SCAN, ERH_K_FUSE

@@ -37,12 +37,19 @@ constexpr int kLds = kFlags + 256;
         if (lane == 0) asm volatile("ds_add_u32 %0, %1" ::"v"(addr_), "v"(1u) : "memory");                          \
     } while (0)
 
-__global__ void fill_kernel(uint16_t *p, size_t n, uint32_t seed) {
+// MODE 0: one binade (+-[2^-6, 2^-5), random mantissa and sign); MODE 1: approximately N(0, 1/32) like a unit-norm row of
+// 1024 components (sum of four uniforms), the bench corpus' distribution -- the matrix pipe's power draw depends on the data
+__global__ void fill_kernel(uint16_t *p, size_t n, uint32_t seed, int mode) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         uint32_t h = (uint32_t)i * 2654435761u + seed;
-        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
-        // fp16 in +-[2^-6, 2^-5): sign, exponent 9 or ... keep it simple: exponent field 9 (2^-6), random mantissa, random sign
-        p[i] = (uint16_t)(((h & 1u) << 15) | (9u << 10) | ((h >> 8) & 0x3ffu));
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+        if (mode == 0) {
+            p[i] = (uint16_t)(((h & 1u) << 15) | (9u << 10) | ((h >> 8) & 0x3ffu));
+        } else {
+            const float u = (float)(h & 255u) + (float)((h >> 8) & 255u) + (float)((h >> 16) & 255u) + (float)(h >> 24);   // mean 510, sd 147.8
+            const _Float16 v = (_Float16)((u - 510.f) * (1.f / (147.8f * 32.f)));
+            p[i] = *reinterpret_cast<const uint16_t *>(&v);
+        }
     }
 }
 
@@ -285,23 +292,23 @@ int main() {
     hipMalloc(&X, (size_t)n_tiles * kTileBytes + (1 << 20));
     hipMalloc(&Q, 4 * kTileBytes);
     hipMalloc(&sink, 64);
-    fill_kernel<<<4096, 256>>>((uint16_t *)X, ((size_t)n_tiles * kTileBytes + (1 << 20)) / 2, 1u);
-    fill_kernel<<<256, 256>>>((uint16_t *)Q, (size_t)4 * kTileBytes / 2, 7u);
-    hipDeviceSynchronize();
-    for (int round = 0; round < 2; ++round) {
-        run<0, 1, 0, 1>(X, n_tiles, Q, sink, "strict alternation, 2 barriers");
-        run<1, 1, 0, 1>(X, n_tiles, Q, sink, "one barrier, ping-pong order");
-        run<2, 1, 0, 1>(X, n_tiles, Q, sink, "free-running, DMA ahead of MFMAs");
-        run<2, 1, 1, 1>(X, n_tiles, Q, sink, "free-running, DMA between MFMAs");
-        run<0, 0, 0, 1>(X, n_tiles, Q, sink, "strict, register operands");
-        run<1, 0, 0, 1>(X, n_tiles, Q, sink, "one barrier, register operands");
-        run<2, 0, 0, 1>(X, n_tiles, Q, sink, "free-running, register operands");
-    }
-    for (int round = 0; round < 2; ++round) {
-        run<0, 1, 0, 4>(X, n_tiles, Q, sink, "strict alternation, 2 barriers");
-        run<1, 1, 0, 4>(X, n_tiles, Q, sink, "one barrier, ping-pong order");
-        run<2, 1, 0, 4>(X, n_tiles, Q, sink, "free-running, DMA ahead of MFMAs");
-        run<2, 1, 1, 4>(X, n_tiles, Q, sink, "free-running, DMA between MFMAs");
+    for (int mode = 0; mode < 2; ++mode) {
+        printf("--- data: %s ---\n", mode == 0 ? "one binade, random mantissa and sign" : "approximately normal, sd 1/32 (the bench corpus' distribution)");
+        fill_kernel<<<4096, 256>>>((uint16_t *)X, ((size_t)n_tiles * kTileBytes + (1 << 20)) / 2, 1u, mode);
+        fill_kernel<<<256, 256>>>((uint16_t *)Q, (size_t)4 * kTileBytes / 2, 7u, mode);
+        hipDeviceSynchronize();
+        for (int round = 0; round < 2; ++round) {
+            run<0, 1, 0, 1>(X, n_tiles, Q, sink, "strict alternation, 2 barriers");
+            run<1, 1, 0, 1>(X, n_tiles, Q, sink, "one barrier, ping-pong order");
+            run<2, 1, 0, 1>(X, n_tiles, Q, sink, "free-running, DMA ahead of MFMAs");
+            run<2, 1, 1, 1>(X, n_tiles, Q, sink, "free-running, DMA between MFMAs");
+            run<0, 0, 0, 1>(X, n_tiles, Q, sink, "strict, register operands");
+        }
+        for (int round = 0; round < 2; ++round) {
+            run<0, 1, 0, 4>(X, n_tiles, Q, sink, "strict alternation, 2 barriers");
+            run<1, 1, 0, 4>(X, n_tiles, Q, sink, "one barrier, ping-pong order");
+            run<2, 1, 1, 4>(X, n_tiles, Q, sink, "free-running, DMA between MFMAs");
+        }
     }
     return 0;
 }

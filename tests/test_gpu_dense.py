@@ -17,11 +17,11 @@ pytestmark = pytest.mark.gpu
                         (0, 0, 0, 0, 0, 0), (1, 0, 0, 0, 1, 0), (2, 1, 0, 0, 0, 0), (0, 1, 3, 1, 1, 1)],
                 ids=["pingpong-strict-rowmajor-256x256x32", "pingpong-strict-tiled-256x256x32", "pingpong-strict-rowmajor-guaranteed-bounds", "pingpong-lean-256x256x32",
                      "pingpong-256x256x32-guaranteed-bounds", "cfg0-256x256x64-persistent", "cfg0-per-tile-guaranteed-bounds",
-                     "cfg1-128x256x32-per-tile", "cfg2-256x256x32-persistent-guaranteed-bounds", "gemv-16x16x32-small-batch"])
+                     "cfg1-128x256x32-per-tile", "cfg2-256x256x32-persistent-guaranteed-bounds", "gemv-16x16x32-up-to-64-queries"])
 def scan_cfg(request, engine):
     """Every dense-scan kernel / tile configuration / launch style / chunk layout must satisfy every parity test, with
     the speculative (verified) first threshold and with guaranteed bounds refined in stages.  The last arm lets batches of
-    at most 16 queries take the skinny-GEMM stream (larger batches use the ping-pong scan); the other arms pin the padded
+    at most 64 queries take the skinny-GEMM stream in 1 / 2 / 4 column groups of 16 (larger batches use the ping-pong scan); the other arms pin the padded
     256-query scans for every batch size.  (dense_tiled takes effect at the next set_dense: every test sets its own.)"""
     engine.set_option("dense_cfg", request.param[0])
     engine.set_option("dense_persist", request.param[1])
@@ -64,7 +64,10 @@ CASES = [
     (20000, 256, 33, 50, 256, 1024),        # three append stages: boundaries 1024 and 4096 (x4 while 8x fits)
     (60000, 256, 9, 100, 256, 32768),       # loose seed: ~12k candidates per query reach the refinement (full-capacity launch)
     (257, 64, 1, 288, 32768, 0),            # k > N
-    (30000, 768, 16, 100, 1024, 4096),      # small batches: the skinny-GEMM stream in the gemv arm (16 = its widest)
+    (30000, 768, 16, 100, 1024, 4096),      # small batches: the skinny-GEMM stream in the gemv arm (16 = one column group)
+    (30000, 1024, 64, 100, 1024, 4096),     # ... four column groups, 128 KiB of query fragments (its widest)
+    (30000, 1024, 48, 288, 2048, 0),        # ... three of four groups populated
+    (30000, 512, 32, 100, 1024, 0),         # ... two column groups
     (12000, 1024, 5, 288, 512, 0),
     (9000, 192, 2, 20, 256, 0),             # d = 6 steps of 32
     (40000, 1280, 1, 50, 2048, 8192),       # one query, d > 1024: two blocks of K

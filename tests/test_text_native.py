@@ -109,6 +109,19 @@ def test_cutter_on_reference_queries_when_present():
     assert len(qs) == 103 and n_multi > 200
 
 
+def test_cutter_lone_surrogate_is_one_character():
+    """a lone surrogate in a Python str is ONE character for jieba (it walks the str); its surrogatepass encoding is
+    three bytes, which the native decoder must not split into three one-byte tokens (nor overflow the output)."""
+    c = NativeCutter(MINI_DICT)
+    ora = DictCutter(MINI_DICT)
+    for text in ("a\ud800b", "\udfff", "中\ud83d文 x\udc00"):
+        assert c.cut(text) == list(ora.cut(text, HMM=False))
+    assert c.cut("a\ud800b") == ["a", "\ud800", "b"]
+    vocab = NativeVocab()
+    flat, lens = c.encode_texts(["a\ud800b"], vocab)
+    assert lens.tolist() == [3] and len(vocab) == 3
+
+
 def test_cutter_rejects_bad_dictionary():
     from easyrag_amd._lib import ErhError
     for bad in ("词", "词 x1", "", "词 -3"):
