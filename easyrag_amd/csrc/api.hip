@@ -6,6 +6,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <future>
@@ -62,6 +63,9 @@ struct Bm25State {
 };
 
 }  // namespace
+
+// ncclCommInitRank runs on a helper thread (erh_comm_init); the state outlives a timed-out call
+struct CommInitState { void *comm = nullptr; int rc = -1; std::atomic<int> finished{0}; };
 
 struct erh_handle {
     int device = 0;
@@ -122,6 +126,7 @@ struct erh_handle {
     // multi-GPU exchange (erh_comm_* / erh_allgather_topk): RCCL communicator + packed send / receive rows
     void *comm = nullptr;
     int comm_rank = 0, comm_world = 1;
+    std::shared_ptr<CommInitState> comm_pending;   // an init that timed out: its communicator (if it ever arrives) is destroyed later
     int opt_comm_timeout_s = 120;            // bounded wait of erh_comm_init
     DevBuf gather_send, gather_recv;
     // options
@@ -657,6 +662,8 @@ int erh_create(int device, erh_handle **out) {
     return ERH_OK;
 }
 
+int erh_comm_destroy(erh_handle *h);
+
 int erh_destroy(erh_handle *h) {
     if (!h) return ERH_ERR_INVALID;
     (void)hipSetDevice(h->device);
@@ -672,7 +679,7 @@ int erh_destroy(erh_handle *h) {
                       &h->scores_tmp, &h->scores_wide, &h->dbg, &h->dir_pos, &h->seed_need, &h->bad, &h->ex_ws, &h->bm_redo};
     for (DevBuf *b : bufs) b->release();
     for (auto &b : h->bm) b.release();
-    if (h->comm) (void)erh_comm_destroy(h);
+    if (h->comm || h->comm_pending) (void)erh_comm_destroy(h);
     h->gather_send.release();
     h->gather_recv.release();
     delete h;
@@ -928,7 +935,9 @@ static int bm25_check_payload_sign(erh_handle *h, hipStream_t st) {
     // 1.2e-38 would round to a subnormal or to zero).  8 bytes per posting on top of the index.
     S.ascan_ok = false;
     S.post.release();
-    if (S.payload_positive && h->opt_bm25_ascan && S.nnz < (1LL << 28)) {         // (32-bit byte offsets into post[])
+    // (a throw-away index of a handful of sentences -- BM25Retriever.get_scores(query, docs) -- is scanned by the block scan:
+    // building the fixed-point copy would cost an allocation and three stream synchronisations per call)
+    if (S.payload_positive && h->opt_bm25_ascan && S.nnz >= 2048 && S.nnz < (1LL << 28)) {         // (32-bit byte offsets into post[])
         DevBuf p32buf;
         const float *p32 = S.payload.as<float>();
         bool ok = true;
@@ -1616,6 +1625,16 @@ Rccl &rccl() {
     return r;
 }
 
+// a timed-out erh_comm_init whose helper has meanwhile returned: destroy the communicator nobody will use
+void comm_reap_pending(erh_handle *h) {
+    if (!h->comm_pending || !h->comm_pending->finished.load(std::memory_order_acquire)) return;
+    if (h->comm_pending->rc == 0 && h->comm_pending->comm) {
+        (void)hipSetDevice(h->device);
+        (void)rccl().CommDestroy(h->comm_pending->comm);
+    }
+    h->comm_pending.reset();
+}
+
 int rccl_fail(erh_handle *h, const char *what, int rc) {
     char buf[256];
     Rccl &r = rccl();
@@ -1650,8 +1669,11 @@ int erh_comm_init(erh_handle *h, int rank, int world, const void *id128) {
     // the others for ever: the call runs on a helper thread and this one waits at most comm_timeout_s seconds (option,
     // default 120).  After a timeout the helper is abandoned (it may still be blocked inside RCCL) and the handle stays
     // without a communicator -- callers fall back to the torch.distributed gather (easyrag_amd.dist.QueryShards).
-    struct InitState { void *comm = nullptr; int rc = -1; };
-    auto state = std::make_shared<InitState>();
+    // A communicator that arrives late is destroyed by the next erh_comm_init / erh_comm_destroy / erh_destroy that finds the
+    // helper finished; a helper still inside RCCL at process exit is the caller's problem -- after a timeout the process
+    // should exit (the peers hold a communicator this rank never joined).
+    comm_reap_pending(h);
+    auto state = std::make_shared<CommInitState>();
     auto done = std::make_shared<std::promise<void>>();
     std::future<void> fut = done->get_future();
     const int dev = h->device;
@@ -1659,10 +1681,13 @@ int erh_comm_init(erh_handle *h, int rank, int world, const void *id128) {
     std::thread([state, done, init_fn, id, world, rank, dev]() {
         (void)hipSetDevice(dev);
         state->rc = init_fn(&state->comm, world, id, rank);
+        state->finished.store(1, std::memory_order_release);
         done->set_value();
     }).detach();
-    if (fut.wait_for(std::chrono::seconds(h->opt_comm_timeout_s)) != std::future_status::ready)
+    if (fut.wait_for(std::chrono::seconds(h->opt_comm_timeout_s)) != std::future_status::ready) {
+        h->comm_pending = state;
         return h->fail(ERH_ERR_HIP, "erh_comm_init: ncclCommInitRank did not return within comm_timeout_s (a rank is missing?)");
+    }
     const int rc = state->rc;
     void *c = state->comm;
     if (rc != 0) return rccl_fail(h, "ncclCommInitRank", rc);
@@ -1674,6 +1699,7 @@ int erh_comm_init(erh_handle *h, int rank, int world, const void *id128) {
 
 int erh_comm_destroy(erh_handle *h) {
     if (!h) return ERH_ERR_INVALID;
+    comm_reap_pending(h);
     if (h->comm) {
         (void)hipSetDevice(h->device);
         (void)rccl().CommDestroy(h->comm);

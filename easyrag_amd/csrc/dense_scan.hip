@@ -387,6 +387,7 @@ __global__ __launch_bounds__(C::NT) void dense_scan_append_kernel(
     }
 }
 
+#ifdef ERH_MEASURE   // superseded by the ping-pong scan: measurement builds only (comparison arm of scripts/kbench.py)
 // ---------------------------------------------------------------------------------------------
 // Persistent APPEND scan.  One workgroup per CU walks a strided list of chunk tiles against ONE fixed query
 // tile, and the LDS-DMA pipeline runs continuously over the flattened (tile, K-step) sequence: while the
@@ -639,6 +640,8 @@ __global__ __launch_bounds__(C::NT) void dense_scan_persist_kernel(
     }
 }
 
+#endif  // ERH_MEASURE
+
 // ---------------------------------------------------------------------------------------------
 // Plain VALU reference on the device (debug / layout triangulation only): one thread per score.
 __global__ void dense_naive_kernel(const _Float16 *__restrict__ Q, int B, const _Float16 *__restrict__ X,
@@ -802,11 +805,60 @@ __device__ __forceinline__ float erh_max4(float a, float b, float c, float d) {
     } while (0)
 
 
+// The row-major memory segment of the ping-pong kernels (local names of the kernel that expands them): the stage pair
+// (s, s+1) of one operand = the two 64-byte halves of the same 128-byte lines, issued back to back so that the second half
+// hits in L1.  Used by dense_scan_pp3_kernel (and by the lean kernel of the measurement builds).
+#define ERH_PP2_GLDS(SRC, DST) __builtin_amdgcn_global_load_lds((const void *)(SRC), ERH_LDS_PTR(DST), 16, 0, 0)
+#define ERH_PP2_ISSUE_A()                                                                             \
+    do {                                                                                              \
+        if (a_left > 0) {                                                                             \
+            if (!(PABL & kPpNoDmaA)) {                                                                \
+                int d1_ = a_dst + pp::A_BYTES;                                                        \
+                if (d1_ == kABytes) d1_ = 0;                                                          \
+                ERH_PP2_GLDS(pa[0], my_dst + a_dst);                                                  \
+                ERH_PP2_GLDS(pa[0] + 32, my_dst + d1_);                                               \
+                ERH_PP2_GLDS(pa[1], my_dst + a_dst + 8192);                                           \
+                ERH_PP2_GLDS(pa[1] + 32, my_dst + d1_ + 8192);                                        \
+            }                                                                                         \
+            ka += 2;                                                                                  \
+            int64_t inc_ = 64;                                                                        \
+            if (ka == nk) { ka = 0; inc_ = 64 - (int64_t)d; }       /* wrap to column 0 of the same rows */ \
+            if (ka == k0) inc_ += a_jump;                           /* tile complete: same column, next tile */ \
+            pa[0] += inc_; pa[1] += inc_;                                                             \
+            a_dst += 2 * pp::A_BYTES;                                                                 \
+            if (a_dst >= kABytes) a_dst -= kABytes;                                                   \
+            --a_left;                                                                                 \
+        }                                                                                             \
+    } while (0)
+#define ERH_PP2_ISSUE_B()                                                                             \
+    do {                                                                                              \
+        if (b_left > 0) {                                                                             \
+            if (!(PABL & kPpNoDmaB)) {                                                                \
+                const int d0_ = pp::B_BASE + b_dst, d1_ = pp::B_BASE + ((b_dst + pp::B_BYTES) & (kBBytes - 1)); \
+                ERH_PP2_GLDS(pb[0], my_dst + d0_);                                                    \
+                ERH_PP2_GLDS(pb[0] + 32, my_dst + d1_);                                               \
+                ERH_PP2_GLDS(pb[1], my_dst + d0_ + 8192);                                             \
+                ERH_PP2_GLDS(pb[1] + 32, my_dst + d1_ + 8192);                                        \
+            }                                                                                         \
+            kb += 2;                                                                                  \
+            int64_t inc_ = 64;                                                                        \
+            if (kb == nk) { kb = 0; inc_ = 64 - (int64_t)d; }       /* same query rows for every tile */ \
+            pb[0] += inc_; pb[1] += inc_;                                                             \
+            b_dst = (b_dst + 2 * pp::B_BYTES) & (kBBytes - 1);                                        \
+            --b_left;                                                                                 \
+        }                                                                                             \
+    } while (0)
+
 // PABL (measurement builds only, -DERH_MEASURE): bit mask -- 1 no epilogue, 2 thresholds forced to +inf, 4 no MFMA,
 // 8 no chunk-side DMA, 16 no query-side DMA, 32 no fragment reads, 64 phase clocks.  Anything but 0 and 64 gives
 // invalid results.  The option "dense_ablate" keeps its round-1 codes (pp_mask_of below maps them).
-constexpr int kPpVarProduct = 0;   // VAR of dense_scan_pp2_kernel the product build carries besides 0
+#ifdef ERH_MEASURE
+constexpr int kPp3LockStep = 1;    // VAR bit 0 of dense_scan_pp3_kernel (DMA inside the matrix segment, one barrier per stage)
+#else
+constexpr int kPp3LockStep = 0;    // ... a measured dead end: not in the product build
+#endif
 constexpr int kPpNoEpi = 1, kPpTauInf = 2, kPpNoMfma = 4, kPpNoDmaA = 8, kPpNoDmaB = 16, kPpNoFrag = 32, kPpClocks = 64;
+#ifdef ERH_MEASURE   // the first two generations of the ping-pong scan: measurement builds only
 template <int PABL>
 __global__ __launch_bounds__(pp::NT) void dense_scan_pp_kernel(
     const _Float16 *__restrict__ X, int64_t N, int d, int64_t c0, int64_t c1,
@@ -1105,46 +1157,6 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp2_kernel(
     half8 fa[4][2], fb[2][2];
     char *const my_dst = lds + wave * 1024;                            // + it * 8192 + ring offset
 
-#define ERH_PP2_GLDS(SRC, DST) __builtin_amdgcn_global_load_lds((const void *)(SRC), ERH_LDS_PTR(DST), 16, 0, 0)
-#define ERH_PP2_ISSUE_A()                                                                             \
-    do {                                                                                              \
-        if (a_left > 0) {                                                                             \
-            if (!(PABL & kPpNoDmaA)) {                                                                \
-                int d1_ = a_dst + pp::A_BYTES;                                                        \
-                if (d1_ == kABytes) d1_ = 0;                                                          \
-                ERH_PP2_GLDS(pa[0], my_dst + a_dst);                                                  \
-                ERH_PP2_GLDS(pa[0] + 32, my_dst + d1_);                                               \
-                ERH_PP2_GLDS(pa[1], my_dst + a_dst + 8192);                                           \
-                ERH_PP2_GLDS(pa[1] + 32, my_dst + d1_ + 8192);                                        \
-            }                                                                                         \
-            ka += 2;                                                                                  \
-            int64_t inc_ = 64;                                                                        \
-            if (ka == nk) { ka = 0; inc_ = 64 - (int64_t)d; }       /* wrap to column 0 of the same rows */ \
-            if (ka == k0) inc_ += a_jump;                           /* tile complete: same column, next tile */ \
-            pa[0] += inc_; pa[1] += inc_;                                                             \
-            a_dst += 2 * pp::A_BYTES;                                                                 \
-            if (a_dst >= kABytes) a_dst -= kABytes;                                                   \
-            --a_left;                                                                                 \
-        }                                                                                             \
-    } while (0)
-#define ERH_PP2_ISSUE_B()                                                                             \
-    do {                                                                                              \
-        if (b_left > 0) {                                                                             \
-            if (!(PABL & kPpNoDmaB)) {                                                                \
-                const int d0_ = pp::B_BASE + b_dst, d1_ = pp::B_BASE + ((b_dst + pp::B_BYTES) & (kBBytes - 1)); \
-                ERH_PP2_GLDS(pb[0], my_dst + d0_);                                                    \
-                ERH_PP2_GLDS(pb[0] + 32, my_dst + d1_);                                               \
-                ERH_PP2_GLDS(pb[1], my_dst + d0_ + 8192);                                             \
-                ERH_PP2_GLDS(pb[1] + 32, my_dst + d1_ + 8192);                                        \
-            }                                                                                         \
-            kb += 2;                                                                                  \
-            int64_t inc_ = 64;                                                                        \
-            if (kb == nk) { kb = 0; inc_ = 64 - (int64_t)d; }       /* same query rows for every tile */ \
-            pb[0] += inc_; pb[1] += inc_;                                                             \
-            b_dst = (b_dst + 2 * pp::B_BYTES) & (kBBytes - 1);                                        \
-            --b_left;                                                                                 \
-        }                                                                                             \
-    } while (0)
 // fragments of the next stage to read (the stage after the one the matrix segment is working on)
 #define ERH_PP2_READ()                                                                                \
     do {                                                                                              \
@@ -1291,6 +1303,8 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp2_kernel(
 #undef ERH_PP2_COMPUTE
 #undef ERH_PP2_WAIT
 }
+
+#endif  // ERH_MEASURE
 
 // ---------------------------------------------------------------------------------------------
 // Tiled copy of the chunk matrix for the ping-pong scan (option "dense_tiled").  For the 256-row tile T and the
@@ -1693,6 +1707,7 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp3_kernel(
 #undef ERH_PP2_ISSUE_A
 #undef ERH_PP2_ISSUE_B
 
+#ifdef ERH_MEASURE   // measured equal to pp3 (profiles/r04e_kbench_pp4.log): measurement builds only
 // ---------------------------------------------------------------------------------------------
 // Ping-pong scan over TILED operands (option "dense_pp" = 4).  Same tile, waves, strict alternation (two barriers per
 // stage), fragment-read placement and epilogue as dense_scan_pp3_kernel; what changes is the memory side, rebuilt from the
@@ -1929,6 +1944,8 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp4_kernel(
 #undef ERH_PP4_WAIT
 }
 
+#endif  // ERH_MEASURE
+
 using Cfg0 = ScanCfg<256, 256, 2, 4, 64, 3, 2>;   // one 8-wave workgroup per CU, 160 KiB LDS
 using Cfg1 = ScanCfg<128, 256, 1, 4, 32, 4, 3>;   // two 4-wave workgroups per CU, 80 KiB LDS each
 using Cfg2 = ScanCfg<256, 256, 2, 4, 32, 5, 5>;   // one workgroup per CU, BK 32, both operands 4 half-steps ahead
@@ -1957,12 +1974,15 @@ hipError_t set_attrs() {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);                  \
         if (e != hipSuccess) return e;                                                                     \
     }
+#ifdef ERH_MEASURE
     ERH_SET_P(0)
     if constexpr (C::MEASURE) { ERH_SET_P(7) ERH_SET_P(8) ERH_SET_P(10) }
+#endif
 #undef ERH_SET_P
     return hipSuccess;
 }
 
+#ifdef ERH_MEASURE
 // Persistent launch: `ctas` = workgroups that are co-resident (CUs x workgroups per CU for this configuration).
 template <class C>
 hipError_t launch_persist(const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1, const _Float16 *Q, int Bpad,
@@ -1994,6 +2014,8 @@ hipError_t launch_persist(const _Float16 *X, int64_t N, int d, int64_t c0, int64
 #undef ERH_LAUNCH_P
     return hipGetLastError();
 }
+
+#endif  // ERH_MEASURE
 
 template <class C>
 hipError_t launch_store(const _Float16 *Q, int Bpad, const _Float16 *X, int64_t N, int d, int64_t c0, int nc,
@@ -2078,13 +2100,14 @@ hipError_t launch_pp(const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1
         if (var & 2)                                                                                       \
             hipLaunchKernelGGL((dense_scan_pp3_kernel<A, 2>), grid, block, pp::LDS_BYTES, st, X, N, d, c0, c1, Q, Bpad, \
                                B, tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow, dbg, rot, stream_sync); \
-        else if (var & 1)                                                                                  \
-            hipLaunchKernelGGL((dense_scan_pp3_kernel<A, 1>), grid, block, pp::LDS_BYTES, st, X, N, d, c0, c1, Q, Bpad, \
-                               B, tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow, dbg, rot, stream_sync); \
+        else if ((var & 1) && kPp3LockStep)                                                                \
+            hipLaunchKernelGGL((dense_scan_pp3_kernel<A, kPp3LockStep>), grid, block, pp::LDS_BYTES, st, X, N, d, c0, c1, Q, \
+                               Bpad, B, tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow, dbg, rot, stream_sync); \
         else                                                                                               \
             hipLaunchKernelGGL((dense_scan_pp3_kernel<A, 0>), grid, block, pp::LDS_BYTES, st, X, N, d, c0, c1, Q, Bpad, \
                                B, tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow, dbg, rot, stream_sync); \
     } while (0)
+#ifdef ERH_MEASURE
 #define ERH_LAUNCH_PP(A)                                                                                   \
     do {                                                                                                   \
         if (lean & 8)                                                                                      \
@@ -2095,6 +2118,7 @@ hipError_t launch_pp(const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1
             hipLaunchKernelGGL((dense_scan_pp_kernel<0>), grid, block, pp::LDS_BYTES, st, X, N, d, c0, c1, Q, Bpad, B, \
                                tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow, dbg);                \
     } while (0)
+#endif
 #define ERH_LAUNCH_PP2V(A)                                                                                 \
     do {                                                                                                   \
         switch (var) {                                                                                     \
@@ -2123,16 +2147,7 @@ hipError_t launch_pp(const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1
     }
 #else
     (void)pabl;
-    if (lean & 8) {
-        ERH_LAUNCH_PP3(0);
-    } else if (lean & 1) {
-        switch (var) {
-            case kPpVarProduct: ERH_LAUNCH_PP2(0, kPpVarProduct); break;
-            default: ERH_LAUNCH_PP2(0, 0); break;
-        }
-    } else {
-        ERH_LAUNCH_PP(0);
-    }
+    ERH_LAUNCH_PP3(0);                      // the product build carries the strict ping-pong kernel only (dense_pp 1 ... 3)
 #endif
 #undef ERH_LAUNCH_PP2V
 #undef ERH_LAUNCH_PP2
@@ -2155,21 +2170,15 @@ hipError_t dense_scan_init() {
     if (e != hipSuccess) return e;
     e = set_attrs<Cfg2>();
     if (e != hipSuccess) return e;
+#define ERH_SET_PP3(A, V)                                                                                  \
+    e = hipFuncSetAttribute((const void *)dense_scan_pp3_kernel<A, V>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                            pp::LDS_BYTES);                                                                \
+    if (e != hipSuccess) return e;
+#define ERH_SET_PP(A) ERH_SET_PP3(A, 0) ERH_SET_PP3(A, 2)
+    ERH_SET_PP(0)
+#ifdef ERH_MEASURE
     e = hipFuncSetAttribute((const void *)dense_scan_pp_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             pp::LDS_BYTES);
-    if (e != hipSuccess) return e;
-#define ERH_SET_PP(A)                                                                                      \
-    e = hipFuncSetAttribute((const void *)dense_scan_pp2_kernel<A, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                            pp::LDS_BYTES);                                                                \
-    if (e != hipSuccess) return e;                                                                         \
-    e = hipFuncSetAttribute((const void *)dense_scan_pp3_kernel<A, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                            pp::LDS_BYTES);                                                                \
-    if (e != hipSuccess) return e;                                                                         \
-    e = hipFuncSetAttribute((const void *)dense_scan_pp3_kernel<A, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                            pp::LDS_BYTES);                                                                \
-    if (e != hipSuccess) return e;                                                                         \
-    e = hipFuncSetAttribute((const void *)dense_scan_pp3_kernel<A, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                            pp::LDS_BYTES);                                                                \
     if (e != hipSuccess) return e;
 #define ERH_SET_PP2V(A, V)                                                                                 \
     e = hipFuncSetAttribute((const void *)dense_scan_pp2_kernel<A, V>, hipFuncAttributeMaxDynamicSharedMemorySize, \
@@ -2179,21 +2188,19 @@ hipError_t dense_scan_init() {
     e = hipFuncSetAttribute((const void *)dense_scan_pp4_kernel<A>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                             pp::LDS_BYTES);                                                                \
     if (e != hipSuccess) return e;
-    ERH_SET_PP(0)
-    ERH_SET_PP4(0)
-#ifdef ERH_MEASURE
-    ERH_PP_MASKS(ERH_SET_PP4)
-    ERH_PP_MASKS(ERH_SET_PP)
+#define ERH_SET_MEASURE(A) ERH_SET_PP(A) ERH_SET_PP3(A, 1) ERH_SET_PP2V(A, 0) ERH_SET_PP4(A)
+    ERH_SET_PP3(0, 1) ERH_SET_PP2V(0, 0) ERH_SET_PP4(0)
+    ERH_PP_MASKS(ERH_SET_MEASURE)
     ERH_SET_PP2V(0, 1) ERH_SET_PP2V(0, 2) ERH_SET_PP2V(0, 3)
     ERH_SET_PP2V(1, 1) ERH_SET_PP2V(1, 2) ERH_SET_PP2V(1, 3)
     ERH_SET_PP2V(64, 1) ERH_SET_PP2V(64, 2) ERH_SET_PP2V(64, 3)
     ERH_SET_PP2V(65, 1) ERH_SET_PP2V(65, 2) ERH_SET_PP2V(65, 3)
-#else
-    if (kPpVarProduct != 0) { ERH_SET_PP2V(0, kPpVarProduct) }
-#endif
+#undef ERH_SET_MEASURE
 #undef ERH_SET_PP2V
-#undef ERH_SET_PP
 #undef ERH_SET_PP4
+#endif
+#undef ERH_SET_PP
+#undef ERH_SET_PP3
     return hipSuccess;
 }
 
@@ -2215,6 +2222,9 @@ hipError_t launch_dense_scan_pp4(const _Float16 *Xt, int64_t N, int d, int64_t c
                                  int Bpad, int B, const float *tau, const int16_t *filter_dir, const int16_t *dir_id,
                                  ErhCand *cand, uint32_t *cand_cnt, int cap, uint32_t *overflow, int n_cus, int pabl,
                                  unsigned long long *dbg, int rot_stages, hipStream_t st) {
+#ifndef ERH_MEASURE
+    return hipErrorInvalidValue;            // measurement builds only: the caller falls through to the strict ping-pong scan
+#else
     if (c1 <= c0) return hipSuccess;
     if (d % pp::BK != 0 || d / pp::BK < 8 || c0 % pp::BM != 0) return hipErrorInvalidValue;
     const int n_qt = Bpad / pp::BN;
@@ -2226,19 +2236,15 @@ hipError_t launch_dense_scan_pp4(const _Float16 *Xt, int64_t N, int d, int64_t c
 #define ERH_LAUNCH_PP4(A)                                                                                  \
     hipLaunchKernelGGL((dense_scan_pp4_kernel<A>), grid, block, pp::LDS_BYTES, st, Xt, N, d, c0, c1, Qt, Bpad, B, tau, \
                        filter_dir, dir_id, cand, cand_cnt, cap, overflow, dbg, rot_stages)
-#ifdef ERH_MEASURE
     switch (pp_mask_of(pabl)) {
 #define ERH_PP_CASE(M) case M: ERH_LAUNCH_PP4(M); break;
         ERH_PP_MASKS(ERH_PP_CASE)
 #undef ERH_PP_CASE
         default: ERH_LAUNCH_PP4(0); break;
     }
-#else
-    (void)pabl;
-    ERH_LAUNCH_PP4(0);
-#endif
 #undef ERH_LAUNCH_PP4
     return hipGetLastError();
+#endif
 }
 
 hipError_t launch_dense_tile_rows(const _Float16 *X, int64_t N, int d, void *Xt, hipStream_t st) {
@@ -2281,6 +2287,9 @@ hipError_t launch_dense_scan_persist(int cfg, const _Float16 *X, int64_t N, int 
                                      const int16_t *filter_dir, const int16_t *dir_id,
                                      ErhCand *cand, uint32_t *cand_cnt, int cap, uint32_t *overflow, int n_cus,
                                      int pabl, int readahead, hipStream_t st) {
+#ifndef ERH_MEASURE
+    return hipErrorInvalidValue;                 // the lock-step persistent kernel exists in measurement builds only
+#else
     if (c1 <= c0) return hipSuccess;
     if (cfg == 1) return hipErrorInvalidValue;   // the two-workgroup configuration keeps the per-tile launch
     if (cfg == 2) {
@@ -2291,6 +2300,7 @@ hipError_t launch_dense_scan_persist(int cfg, const _Float16 *X, int64_t N, int 
     if (d / Cfg0::BK <= Cfg0::DA) return hipErrorInvalidValue;
     return launch_persist<Cfg0>(X, N, d, c0, c1, Q, Bpad, B, tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow, n_cus,
                                 pabl, false, st);
+#endif
 }
 
 hipError_t launch_dense_naive(const _Float16 *Q, int B, const _Float16 *X, int64_t row0, int rows, int d,

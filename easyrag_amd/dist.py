@@ -147,7 +147,7 @@ class QueryShards:
             if not all_ok(reason is None):
                 reason = reason or "erh_comm_init failed on another rank"
                 try:
-                    eng.comm_destroy()
+                    eng.comm_destroy()                    # (a rank whose own init timed out: the library reaps the late communicator)
                 except Exception:                         # noqa: BLE001
                     pass
         else:

@@ -119,6 +119,15 @@ class RetrievalEngine:
                 return i
         raise RuntimeError(f"all {_lib.ERH_BM25_SLOTS} BM25 index slots of this engine are in use")
 
+    def scratch_bm25_slot(self) -> int:
+        """The engine's scratch slot for throw-away indices (BM25Retriever.get_scores(query, docs): a handful of sentences per
+        call on the compressor's per-query path).  Allocated on first use and kept: re-setting an index re-uses the slot's
+        device buffers, whereas alloc / free per call costs device allocations, frees and a full synchronisation each time."""
+        if getattr(self, "_scratch_slot", None) is None:
+            self._scratch_slot = self.alloc_bm25_slot()
+            self._bm25_slots[self._scratch_slot] = "scratch"            # reserved even while no index is set
+        return self._scratch_slot
+
     def free_bm25_slot(self, slot: int):
         """Empty a slot: the device copies of its index are freed as well (erh_bm25_release)."""
         if self._bm25_slots[slot] is not None and getattr(self, "_h", None):
@@ -372,8 +381,9 @@ class RetrievalEngine:
         self.rank, self.world = int(rank), int(world)
 
     def comm_destroy(self):
+        """Leave the library's RCCL communicator (also reaps one whose erh_comm_init timed out and returned later).  The
+        engine's rank / world describe the JOB's sharding, not the communicator: they stay as they are."""
         self._check(self._lib.erh_comm_destroy(self._h))
-        self.rank, self.world = 0, 1
 
     def topk_row_bytes(self, k: int) -> int:
         return int(self._lib.erh_topk_row_bytes(int(k)))

@@ -396,15 +396,13 @@ class BM25Retriever(_RetrieverBase):
             return self._cast(self.engine.bm25_scores(self._query_ids(query), slot=self._slot))
         corpus = [tokenize_and_remove_stopwords(self._tokenizer, d, self.stopwords) for d in docs]
         idx = build_bm25_index(corpus, variant=1 if self.bm25_type == 1 else 0, k1=self.k1, b=self.b, epsilon=self.epsilon)
-        # the throw-away index of a handful of sentences goes into a scratch slot of the SAME handle (no handle
-        # creation, no kernel-attribute setup per call: this sits on the per-query path of the compressor)
+        # the throw-away index of a handful of sentences goes into the engine's scratch slot (kept across calls: no handle
+        # creation, no kernel-attribute setup, no device allocation / free / synchronisation per call -- this sits on the
+        # per-query path of the compressor)
         with _SCRATCH_LOCK:
-            scratch = self.engine.alloc_bm25_slot()
-            try:
-                self.engine.set_bm25(idx, slot=scratch)
-                return self._cast(self.engine.bm25_scores(self._query_ids(query, idx), slot=scratch))
-            finally:
-                self.engine.free_bm25_slot(scratch)
+            scratch = self.engine.scratch_bm25_slot()
+            self.engine.set_bm25(idx, slot=scratch)
+            return self._cast(self.engine.bm25_scores(self._query_ids(query, idx), slot=scratch))
 
     def _cast(self, s: np.ndarray) -> np.ndarray:
         return s.astype(np.float32) if self.bm25_type == 1 else s

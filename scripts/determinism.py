@@ -47,9 +47,11 @@ def main():
                 bad += 1
                 print(f"{name}: repeat {r} differs from repeat 0")
         if name != "bm25":                                    # every other scan kernel / pruning scheme must give the same exact result
-            variants = (("lean ping-pong", {"dense_pp": 2}), ("round-1 ping-pong", {"dense_pp": 1}),
-                        ("lock-step persistent", {"dense_pp": 0, "dense_persist": 1}),
-                        ("lock-step per tile", {"dense_pp": 0, "dense_persist": 0}),
+            # (the product library carries the strict ping-pong scan and the per-tile fallbacks; the superseded kernels are
+            # measurement-build arms of scripts/kbench.py)
+            variants = (("lock-step per tile 256x256x64", {"dense_pp": 0, "dense_persist": 0}),
+                        ("per tile 128x256x32, two workgroups per CU", {"dense_pp": 0, "dense_persist": 0, "dense_cfg": 1}),
+                        ("per tile 256x256x32", {"dense_pp": 0, "dense_persist": 0, "dense_cfg": 2}),
                         ("strict ping-pong, guaranteed bounds", {"dense_speculate": 0}),
                         ("strict ping-pong, stream sync + K rotation", {"dense_sync": 1, "dense_rot": -1}))
             for label, opts in variants:
@@ -65,7 +67,7 @@ def main():
                 if not all(np.array_equal(a.view(np.uint8), b.view(np.uint8)) for a, b in zip(ref, cur)):
                     bad += 1
                     print(f"{name}: {label} differs from the default kernel")
-                for o, v in (("dense_pp", 3), ("dense_persist", 1), ("dense_speculate", 1), ("dense_sync", 0), ("dense_rot", 0)):
+                for o, v in (("dense_pp", 3), ("dense_persist", 1), ("dense_cfg", 0), ("dense_speculate", 1), ("dense_sync", 0), ("dense_rot", 0)):
                     eng.set_option(o, v)
         if name == "bm25":                                    # every BM25 scan kernel must give the same exact result
             for label, opts in (("fixed-point scan, 1024-thread shape", {"bm25_small": 0}),

@@ -13,13 +13,14 @@ pytestmark = pytest.mark.gpu
 
 
 # (dense_cfg, dense_persist, dense_pp, dense_gemv, dense_speculate, dense_tiled)
-@pytest.fixture(params=[(0, 1, 3, 0, 1, 0), (0, 1, 3, 0, 1, 1), (0, 1, 3, 0, 0, 0), (0, 1, 2, 0, 1, 0), (0, 1, 1, 0, 0, 0), (0, 1, 0, 0, 1, 0),
-                        (0, 0, 0, 0, 0, 0), (1, 0, 0, 0, 1, 0), (2, 1, 0, 0, 0, 0), (0, 1, 3, 1, 1, 1)],
-                ids=["pingpong-strict-rowmajor-256x256x32", "pingpong-strict-tiled-256x256x32", "pingpong-strict-rowmajor-guaranteed-bounds", "pingpong-lean-256x256x32",
-                     "pingpong-256x256x32-guaranteed-bounds", "cfg0-256x256x64-persistent", "cfg0-per-tile-guaranteed-bounds",
-                     "cfg1-128x256x32-per-tile", "cfg2-256x256x32-persistent-guaranteed-bounds", "gemv-16x16x32-up-to-64-queries"])
+@pytest.fixture(params=[(0, 1, 3, 0, 1, 0), (0, 1, 3, 0, 1, 1), (0, 1, 3, 0, 0, 0), (0, 0, 0, 0, 1, 0), (0, 0, 0, 0, 0, 0),
+                        (1, 0, 0, 0, 1, 0), (2, 0, 0, 0, 0, 0), (0, 1, 3, 1, 1, 1)],
+                ids=["pingpong-strict-rowmajor-256x256x32", "pingpong-strict-tiled-256x256x32", "pingpong-strict-rowmajor-guaranteed-bounds",
+                     "cfg0-256x256x64-per-tile", "cfg0-per-tile-guaranteed-bounds", "cfg1-128x256x32-per-tile",
+                     "cfg2-256x256x32-per-tile-guaranteed-bounds", "gemv-16x16x32-up-to-64-queries"])
 def scan_cfg(request, engine):
-    """Every dense-scan kernel / tile configuration / launch style / chunk layout must satisfy every parity test, with
+    """Every dense-scan kernel of the product library (the strict ping-pong scan, the per-tile fallbacks in their three tile
+    configurations, the skinny-GEMM stream) / chunk layout must satisfy every parity test, with
     the speculative (verified) first threshold and with guaranteed bounds refined in stages.  The last arm lets batches of
     at most 64 queries take the skinny-GEMM stream in 1 / 2 / 4 column groups of 16 (larger batches use the ping-pong scan); the other arms pin the padded
     256-query scans for every batch size.  (dense_tiled takes effect at the next set_dense: every test sets its own.)"""
