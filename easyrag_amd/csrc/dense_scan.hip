@@ -712,7 +712,31 @@ __device__ __forceinline__ float erh_max4(float a, float b, float c, float d) {
 
 // Epilogue of tile i for this wave (acc final); shared by both ping-pong kernels (it uses their local names).  See the
 // header comment of the ping-pong scan above.
-#define ERH_PP_EPILOGUE()                                                                             \
+// the survivors of four accumulator registers (one 32 x 32 block row group): ballot + mbcnt compaction into the wave's records
+#define ERH_PP_EPI_QUAD(MT, NT, R4)                                                                   \
+    do {                                                                                              \
+        _Pragma("unroll") for (int r = (R4); r < (R4) + 4; ++r) {                                     \
+            const float sc_ = acc[MT][NT][r];                                                         \
+            const bool hit_ = sc_ >= t_;                                                              \
+            const unsigned long long m_ = __builtin_amdgcn_ballot_w64(hit_);                          \
+            if (m_) {                                                                                 \
+                const int pos_ = cnt_ - shift_ +                                                      \
+                    (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m_ >> 32),                              \
+                                                   __builtin_amdgcn_mbcnt_lo((uint32_t)m_, 0u));      \
+                if (hit_ && (unsigned)pos_ < (unsigned)pp::CAPW) {                                    \
+                    *reinterpret_cast<float *>(rec + pos_ * 4) = sc_;                                 \
+                    *reinterpret_cast<uint32_t *>(rec + 1024 + pos_ * 4) =                            \
+                        pk_l_ + ((uint32_t)((MT) * 32 + (r & 3) + 8 * (r >> 2)) << 6);                \
+                }                                                                                     \
+                cnt_ += __builtin_popcountll(m_);                                                     \
+            }                                                                                         \
+            __builtin_amdgcn_sched_barrier(0);   /* keeps one ballot mask live at a time */           \
+        }                                                                                             \
+    } while (0)
+#define ERH_PP_EPILOGUE() ERH_PP_EPILOGUE_V(false)
+// EPI2: the sixteen group tests of a query half are evaluated FIRST, branch-free, into sixteen wave masks (v_max3 + v_max +
+// v_cmp with a scalar destination each: no VALU -> SALU round trip between them); the branches then run on finished masks
+#define ERH_PP_EPILOGUE_V(EPI2)                                                                       \
     do {                                                                                              \
         if (PABL & kPpNoEpi) {                                                        \
             float keep_ = 0.f;                                                                        \
@@ -734,33 +758,32 @@ __device__ __forceinline__ float erh_max4(float a, float b, float c, float d) {
                 uint32_t pk_l_ = (uint32_t)(nt * 32 + l31) | ((uint32_t)(grp * 128 + 4 * hh) << 6) |     \
                                  ((uint32_t)i << 14);                                                 \
                 asm volatile("" : "+v"(pk_l_));                                                       \
+                if (EPI2) {                                                                           \
+                    unsigned long long qm_[16];                                                       \
+                    _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                  \
+                        _Pragma("unroll") for (int r4 = 0; r4 < 16; r4 += 4)                          \
+                            qm_[mt * 4 + (r4 >> 2)] = __builtin_amdgcn_ballot_w64(                    \
+                                erh_max4(acc[mt][nt][r4], acc[mt][nt][r4 + 1], acc[mt][nt][r4 + 2], acc[mt][nt][r4 + 3]) >= t_); \
+                    unsigned long long or_ = 0ull;                                                    \
+                    _Pragma("unroll") for (int j = 0; j < 16; ++j) or_ |= qm_[j];                     \
+                    if (or_) {                                                                        \
+                        _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                            \
+                            _Pragma("unroll") for (int r4 = 0; r4 < 16; r4 += 4) {                    \
+                                if (qm_[mt * 4 + (r4 >> 2)]) ERH_PP_EPI_QUAD(mt, nt, r4);             \
+                            }                                                                         \
+                        }                                                                             \
+                    }                                                                                 \
+                } else {                                                                              \
                 _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                    \
                     /* four accumulator registers per wave-uniform test: their maximum (v_max3 + v_max), one    \
                        compare and one branch in the common no-survivor case */                                 \
                     _Pragma("unroll") for (int r4 = 0; r4 < 16; r4 += 4) {                            \
                         const bool any_ = erh_max4(acc[mt][nt][r4], acc[mt][nt][r4 + 1], acc[mt][nt][r4 + 2],   \
                                                    acc[mt][nt][r4 + 3]) >= t_;                                 \
-                        if (__builtin_amdgcn_ballot_w64(any_)) {                                      \
-                            _Pragma("unroll") for (int r = r4; r < r4 + 4; ++r) {                     \
-                                const float sc_ = acc[mt][nt][r];                                     \
-                                const bool hit_ = sc_ >= t_;                                          \
-                                const unsigned long long m_ = __builtin_amdgcn_ballot_w64(hit_);      \
-                                if (m_) {                                                             \
-                                    const int pos_ = cnt_ - shift_ +                                  \
-                                        (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m_ >> 32),          \
-                                                                       __builtin_amdgcn_mbcnt_lo((uint32_t)m_, 0u)); \
-                                    if (hit_ && (unsigned)pos_ < (unsigned)pp::CAPW) {                \
-                                        *reinterpret_cast<float *>(rec + pos_ * 4) = sc_;             \
-                                        *reinterpret_cast<uint32_t *>(rec + 1024 + pos_ * 4) =        \
-                                            pk_l_ + ((uint32_t)(mt * 32 + (r & 3) + 8 * (r >> 2)) << 6); \
-                                    }                                                                 \
-                                    cnt_ += __builtin_popcountll(m_);                                 \
-                                }                                                                     \
-                                __builtin_amdgcn_sched_barrier(0);   /* keeps one ballot mask live at a time */ \
-                            }                                                                         \
-                        }                                                                             \
+                        if (__builtin_amdgcn_ballot_w64(any_)) ERH_PP_EPI_QUAD(mt, nt, r4);           \
                         __builtin_amdgcn_sched_barrier(0);                                            \
                     }                                                                                 \
+                }                                                                                     \
                 }                                                                                     \
             }                                                                                         \
             const int avail_ = cnt_ - shift_;                                                         \
@@ -1611,7 +1634,7 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp3_kernel(
                 ERH_PP_BARRIER();                                                                     \
                 ERH_PH(2);                                                                            \
             }                                                                                         \
-            ERH_PP_EPILOGUE();                                                                        \
+            ERH_PP_EPILOGUE_V(true);     /* mask-first group tests: profiles/r04k_kbench_epi2.log */                                                                        \
             ERH_PH(4);                                                                                \
             ERH_PP_BARRIER();                                                                         \
             ERH_PH(5);                                                                                \
@@ -1646,7 +1669,7 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp3_kernel(
                 ERH_PP_BARRIER();
                 ERH_PH(2);
             }
-            ERH_PP_EPILOGUE();
+            ERH_PP_EPILOGUE_V(true);     /* mask-first group tests: profiles/r04k_kbench_epi2.log */
             ERH_PH(4);
             ERH_PP_BARRIER();
             ERH_PH(5);
@@ -1679,7 +1702,7 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp3_kernel(
                 ERH_PP_BARRIER();
                 ERH_PH(2);
             }
-            ERH_PP_EPILOGUE();
+            ERH_PP_EPILOGUE_V(true);     /* mask-first group tests: profiles/r04k_kbench_epi2.log */
             ERH_PH(4);
             ERH_PP_BARRIER();
             ERH_PH(5);
@@ -2095,6 +2118,9 @@ hipError_t launch_pp(const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1
 #define ERH_LAUNCH_PP2(A, V)                                                                               \
     hipLaunchKernelGGL((dense_scan_pp2_kernel<A, V>), grid, block, pp::LDS_BYTES, st, X, N, d, c0, c1, Q, Bpad, B, \
                        tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow, dbg, rot)
+#define ERH_LAUNCH_PP3V(A, V)                                                                              \
+    hipLaunchKernelGGL((dense_scan_pp3_kernel<A, V>), grid, block, pp::LDS_BYTES, st, X, N, d, c0, c1, Q, Bpad, B, tau, \
+                       filter_dir, dir_id, cand, cand_cnt, cap, overflow, dbg, rot, stream_sync)
 #define ERH_LAUNCH_PP3(A)                                                                                  \
     do {                                                                                                   \
         if (var & 2)                                                                                       \
@@ -2152,6 +2178,7 @@ hipError_t launch_pp(const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1
 #undef ERH_LAUNCH_PP2V
 #undef ERH_LAUNCH_PP2
 #undef ERH_LAUNCH_PP3
+#undef ERH_LAUNCH_PP3V
 #undef ERH_LAUNCH_PP
     return hipGetLastError();
 }
