@@ -198,11 +198,17 @@ class _FilteredCorpus:
         self.engine.set_doc_meta(len(self.nodes), self.content_id, None if self._classes is None else self._classes.ids)
 
     def filter_class(self, filter_dict: Optional[Dict[str, Any]]) -> int:
+        """Class id of `filter_dict` in the column over ITS key set.  The device holds one column at a time; the host tables
+        are kept per key set, so alternating between two key sets (filter_dict on one route, filters on the other with
+        different keys) costs the 2-bytes-per-node upload but not the walk over all nodes' metadata."""
         if not filter_dict:
             return -1
         keys = tuple(sorted(filter_dict))
         if self._classes is None or self._classes.keys != keys:
-            self._classes = _MetaClasses(self.nodes, keys)
+            cache = self.__dict__.setdefault("_class_tables", {})
+            if keys not in cache:
+                cache[keys] = _MetaClasses(self.nodes, keys)
+            self._classes = cache[keys]
             self._push_meta()
         return self._classes.class_of(filter_dict)
 
