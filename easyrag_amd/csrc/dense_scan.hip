@@ -733,15 +733,15 @@ __device__ __forceinline__ float erh_max4(float a, float b, float c, float d) {
             __builtin_amdgcn_sched_barrier(0);   /* keeps one ballot mask live at a time */           \
         }                                                                                             \
     } while (0)
-#define ERH_PP_EPILOGUE() ERH_PP_EPILOGUE_V(false)
+#define ERH_PP_EPILOGUE() ERH_PP_EPILOGUE_V(false, 0, 2)
 // EPI2: the sixteen group tests of a query half are evaluated FIRST, branch-free, into sixteen wave masks (v_max3 + v_max +
 // v_cmp with a scalar destination each: no VALU -> SALU round trip between them); the branches then run on finished masks
-#define ERH_PP_EPILOGUE_V(EPI2)                                                                       \
+#define ERH_PP_EPILOGUE_V(EPI2, QMAP, NTL_)                                                                     \
     do {                                                                                              \
         if (PABL & kPpNoEpi) {                                                        \
             float keep_ = 0.f;                                                                        \
             _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                          \
-                _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                      \
+                _Pragma("unroll") for (int nt = 0; nt < (NTL_); ++nt)                                 \
                     _Pragma("unroll") for (int r = 0; r < 16; ++r) keep_ += acc[mt][nt][r];           \
             if (keep_ == 1.2345e-30f) *overflow = 7u;                                                 \
             break;                                                                                    \
@@ -753,7 +753,7 @@ __device__ __forceinline__ float erh_max4(float a, float b, float c, float d) {
             int cnt_ = fill0_;                                                                        \
             float tt_[2] = {t_q[0], t_q[1]};                                                          \
             asm volatile("" : "+v"(tt_[0]), "+v"(tt_[1]));   /* opaque per pass: nothing of the pass is hoisted out of the loop */ \
-            _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                                        \
+            _Pragma("unroll") for (int nt = 0; nt < (NTL_); ++nt) {                                   \
                 const float t_ = tt_[nt];                                                             \
                 uint32_t pk_l_ = (uint32_t)(nt * 32 + l31) | ((uint32_t)(grp * 128 + 4 * hh) << 6) |     \
                                  ((uint32_t)i << 14);                                                 \
@@ -796,7 +796,8 @@ __device__ __forceinline__ float erh_max4(float a, float b, float c, float d) {
                         uint2 rc_;                                                                    \
                         rc_.x = *reinterpret_cast<const uint32_t *>(rec + j_ * 4);                    \
                         rc_.y = *reinterpret_cast<const uint32_t *>(rec + 1024 + j_ * 4);             \
-                        const int q_ = (int)q_row0 + wave_n * 64 + (int)(rc_.y & 63u);                \
+                        const int q_ = (QMAP) ? (int)q_row0 + (int)((rc_.y >> 5) & 1u) * 128 + wave_n * 32 + (int)(rc_.y & 31u) \
+                                              : (int)q_row0 + wave_n * 64 + (int)(rc_.y & 63u);               \
                         const int64_t chunk_ = c0 + ((int64_t)stream + (int64_t)(rc_.y >> 14) * n_streams) * pp::BM + \
                                                (int64_t)((rc_.y >> 6) & 255u);                        \
                         bool ok_ = chunk_ < lim;                                                      \
@@ -1404,11 +1405,17 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp3_kernel(
 
     const int l31 = lane & 31, hh = lane >> 5;
     const int k0 = ((qt * rot_stages) % nk) & ~1;                      // first K stage of every tile for this query tile
+    // Query -> wave mapping: wave column wave_n holds queries wave_n * 32 + l31 (nt = 0) and 128 + wave_n * 32 + l31 (nt = 1) of
+    // the tile, so a batch of at most 128 queries occupies nt = 0 of EVERY wave.  HALFQ (VAR bit 3; batches of 65 ... 128
+    // queries): the nt = 1 half of the tile is not computed at all -- half the MFMAs, no fragment reads and no DMA for query
+    // rows 128 ... 255 (8 KiB instead of 16 KiB per query stage) -- same chunk stream, barriers and epilogue.
+    constexpr bool HALFQ = (VAR & 8) != 0;
+    constexpr int NTL = HALFQ ? 1 : 2;
     float t_q[2];
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
-        const int q = (int)q_row0 + wave_n * 64 + nt * 32 + l31;
-        t_q[nt] = (q < B && !(PABL & kPpTauInf)) ? tau[q] : INFINITY;
+        const int q = (int)q_row0 + nt * 128 + wave_n * 32 + l31;
+        t_q[nt] = (nt < NTL && q < B && !(PABL & kPpTauInf)) ? tau[q] : INFINITY;
     }
     asm volatile("" ::"v"(t_q[0]), "v"(t_q[1]));                      // loaded before the DMA stream starts (keeps vmcnt countable)
 
@@ -1429,8 +1436,8 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp3_kernel(
     const int sw = row_swizzle<pp::PR>(l31);
     const int a_rd0 = (grp * 128 + l31) * pp::RB + ((hh ^ sw) << 4);
     const int a_rd1 = (grp * 128 + l31) * pp::RB + (((2 + hh) ^ sw) << 4);
-    const int b_rd0 = pp::B_BASE + (wave_n * 64 + l31) * pp::RB + ((hh ^ sw) << 4);
-    const int b_rd1 = pp::B_BASE + (wave_n * 64 + l31) * pp::RB + (((2 + hh) ^ sw) << 4);
+    const int b_rd0 = pp::B_BASE + (wave_n * 32 + l31) * pp::RB + ((hh ^ sw) << 4);      // + nt * 128 rows
+    const int b_rd1 = pp::B_BASE + (wave_n * 32 + l31) * pp::RB + (((2 + hh) ^ sw) << 4);
     char *const rec = lds + pp::REC_BASE + wave * pp::REC_BYTES;
     if (threadIdx.x == 0) { ERH_PP_FLAG(0) = 0; ERH_PP_FLAG(1) = 0; }
 
@@ -1464,6 +1471,25 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp3_kernel(
         }                                                                                             \
     } while (0)
 #define ERH_PP3_ISSUE_A() do { if (TILED) ERH_PP3_ISSUE_AT(); else ERH_PP2_ISSUE_A(); } while (0)
+// the query-side stage pair; HALFQ: query rows 0 ... 127 only (this wave's pieces of them are the two instructions of pb[0])
+#define ERH_PP3_ISSUE_B()                                                                             \
+    do {                                                                                              \
+        if (!HALFQ) {                                                                                 \
+            ERH_PP2_ISSUE_B();                                                                        \
+        } else if (b_left > 0) {                                                                      \
+            if (!(PABL & kPpNoDmaB)) {                                                                \
+                const int d0_ = pp::B_BASE + b_dst, d1_ = pp::B_BASE + ((b_dst + pp::B_BYTES) & (kBBytes - 1)); \
+                ERH_PP2_GLDS(pb[0], my_dst + d0_);                                                    \
+                ERH_PP2_GLDS(pb[0] + 32, my_dst + d1_);                                               \
+            }                                                                                         \
+            kb += 2;                                                                                  \
+            int64_t inc_ = 64;                                                                        \
+            if (kb == nk) { kb = 0; inc_ = 64 - (int64_t)d; }                                         \
+            pb[0] += inc_;                                                                            \
+            b_dst = (b_dst + 2 * pp::B_BYTES) & (kBBytes - 1);                                        \
+            --b_left;                                                                                 \
+        }                                                                                             \
+    } while (0)
 // one instruction (PART 0..3) of the A / B stage pair, then the pair's bookkeeping (VAR bit 0: issued from inside the
 // matrix segment)
 #define ERH_PP3_PART_A(PART)                                                                          \
@@ -1518,9 +1544,9 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp3_kernel(
             fa[mt][0] = *reinterpret_cast<const half8 *>(pa0_ + mt * 32 * pp::RB);                    \
             fa[mt][1] = *reinterpret_cast<const half8 *>(pa1_ + mt * 32 * pp::RB);                    \
         }                                                                                             \
-        _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                                            \
-            fb[nt][0] = *reinterpret_cast<const half8 *>(pb0_ + nt * 32 * pp::RB);                    \
-            fb[nt][1] = *reinterpret_cast<const half8 *>(pb1_ + nt * 32 * pp::RB);                    \
+        _Pragma("unroll") for (int nt = 0; nt < NTL; ++nt) {                                          \
+            fb[nt][0] = *reinterpret_cast<const half8 *>(pb0_ + nt * 128 * pp::RB);                   \
+            fb[nt][1] = *reinterpret_cast<const half8 *>(pb1_ + nt * 128 * pp::RB);                   \
         }                                                                                             \
         fa_off += pp::A_BYTES;                                                                        \
         if (fa_off == kABytes) fa_off = 0;                                                            \
@@ -1535,14 +1561,15 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp3_kernel(
                 if (FIRST) {                                                                          \
                     const f32x16 z_ = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; \
                     acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mt][J], fb[0][J], z_, 0, 0, 0);  \
-                    acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mt][J], fb[1][J], z_, 0, 0, 0);  \
+                    if (!HALFQ) acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mt][J], fb[1][J], z_, 0, 0, 0);  \
                 } else {                                                                              \
                     acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mt][J], fb[0][J], acc[mt][0], 0, 0, 0); \
-                    acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mt][J], fb[1][J], acc[mt][1], 0, 0, 0); \
+                    if (!HALFQ) acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mt][J], fb[1][J], acc[mt][1], 0, 0, 0); \
                 }                                                                                     \
             } else {                                                                                  \
-                asm volatile("" ::"v"(fa[mt][J]), "v"(fb[0][J]), "v"(fb[1][J]));                      \
-                if (FIRST) { _Pragma("unroll") for (int r = 0; r < 16; ++r) { acc[mt][0][r] = 0.f; acc[mt][1][r] = 0.f; } } \
+                asm volatile("" ::"v"(fa[mt][J]), "v"(fb[0][J]));                                     \
+                if (!HALFQ) asm volatile("" ::"v"(fb[1][J]));                                         \
+                if (FIRST) { _Pragma("unroll") for (int r = 0; r < 16; ++r) { acc[mt][0][r] = 0.f; if (!HALFQ) acc[mt][1][r] = 0.f; } } \
             }                                                                                         \
             if (!(PABL & kPpNoFrag)) fa[mt][J] = *reinterpret_cast<const half8 *>(PA_ + mt * 32 * pp::RB); \
             if (DMA == 1) ERH_PP3_PART_A(mt);                                                         \
@@ -1551,7 +1578,7 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp3_kernel(
         }                                                                                             \
         if (!(PABL & kPpNoFrag)) {                                                                    \
             fb[0][J] = *reinterpret_cast<const half8 *>(PB_);                                         \
-            fb[1][J] = *reinterpret_cast<const half8 *>(PB_ + 32 * pp::RB);                           \
+            if (!HALFQ) fb[1][J] = *reinterpret_cast<const half8 *>(PB_ + 128 * pp::RB);              \
         }                                                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                            \
     } while (0)
@@ -1572,6 +1599,7 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp3_kernel(
 #define ERH_PP3_WAIT(H, ODD)                                                                          \
     do {                                                                                              \
         if ((H) + 6 >= total) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");             \
+        else if ((ODD) && HALFQ) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");   /* the B pair is two instructions */ \
         else if (ODD) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");                     \
         else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");                              \
     } while (0)
@@ -1600,10 +1628,10 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp3_kernel(
 
     // prologue: A(0,1) B(0,1) A(2,3) B(2,3); stages 0 and 1 complete = the last 8 instructions may stay in flight
     ERH_PP3_ISSUE_A();
-    ERH_PP2_ISSUE_B();
+    ERH_PP3_ISSUE_B();
     ERH_PP3_ISSUE_A();
-    ERH_PP2_ISSUE_B();
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    ERH_PP3_ISSUE_B();
+    if (HALFQ) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     ERH_PP_BARRIER();
     ERH_PP3_READ_ALL();                                                // stage 0
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1634,7 +1662,7 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp3_kernel(
                 ERH_PP_BARRIER();                                                                     \
                 ERH_PH(2);                                                                            \
             }                                                                                         \
-            ERH_PP_EPILOGUE_V(true);     /* mask-first group tests: profiles/r04k_kbench_epi2.log */                                                                        \
+            ERH_PP_EPILOGUE_V(true, 1, NTL);     /* mask-first group tests: profiles/r04k_kbench_epi2.log */                                                                        \
             ERH_PH(4);                                                                                \
             ERH_PP_BARRIER();                                                                         \
             ERH_PH(5);                                                                                \
@@ -1661,7 +1689,7 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp3_kernel(
                 ERH_PH(0);
                 ERH_PP_BARRIER();
                 ERH_PH(2);
-                ERH_PP2_ISSUE_B();                                     // M_{g+1}
+                ERH_PP3_ISSUE_B();                                     // M_{g+1}
                 __builtin_amdgcn_sched_barrier(0);
                 ERH_PH(3);
                 ERH_PP3_WAIT(g + 1, true);
@@ -1669,7 +1697,7 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp3_kernel(
                 ERH_PP_BARRIER();
                 ERH_PH(2);
             }
-            ERH_PP_EPILOGUE_V(true);     /* mask-first group tests: profiles/r04k_kbench_epi2.log */
+            ERH_PP_EPILOGUE_V(true, 1, NTL);     /* mask-first group tests: profiles/r04k_kbench_epi2.log */
             ERH_PH(4);
             ERH_PP_BARRIER();
             ERH_PH(5);
@@ -1690,7 +1718,7 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp3_kernel(
                 ERH_PH(1);
                 ERH_PP_BARRIER();                                      // |B|
                 ERH_PH(2);
-                ERH_PP2_ISSUE_B();                                     // M_{g+1}
+                ERH_PP3_ISSUE_B();                                     // M_{g+1}
                 __builtin_amdgcn_sched_barrier(0);
                 ERH_PH(3);
                 ERH_PP_BARRIER();
@@ -1702,7 +1730,7 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp3_kernel(
                 ERH_PP_BARRIER();
                 ERH_PH(2);
             }
-            ERH_PP_EPILOGUE_V(true);     /* mask-first group tests: profiles/r04k_kbench_epi2.log */
+            ERH_PP_EPILOGUE_V(true, 1, NTL);     /* mask-first group tests: profiles/r04k_kbench_epi2.log */
             ERH_PH(4);
             ERH_PP_BARRIER();
             ERH_PH(5);
@@ -1720,6 +1748,7 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp3_kernel(
 #undef ERH_PP3_STREAM_SYNC
 #undef ERH_PP3_ISSUE_A
 #undef ERH_PP3_ISSUE_AT
+#undef ERH_PP3_ISSUE_B
 #undef ERH_PP3_PART_A
 #undef ERH_PP3_PART_B
 #undef ERH_PP3_HALF
@@ -2103,6 +2132,10 @@ constexpr int pp_mask_of(int code) {
 #define ERH_PP_MASKS(X) X(1) X(2) X(5) X(25) X(9) X(33) X(17) X(37) X(29) X(61) X(65) X(64) X(89) X(57) X(121)
 #endif
 
+// the half-query-tile mode (VAR bit 3) is instantiated for the full kernel and, in measurement builds, for "no epilogue"
+constexpr bool pp3_halfq_ok(int mask) { return mask == 0 || mask == 1; }
+constexpr int pp3_halfq_mask(int mask) { return pp3_halfq_ok(mask) ? mask : 0; }
+
 hipError_t launch_pp(const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1, const _Float16 *Q, int Bpad, int B,
                      const float *tau, const int16_t *filter_dir, const int16_t *dir_id, ErhCand *cand,
                      uint32_t *cand_cnt, int cap, uint32_t *overflow, int ctas, int pabl, unsigned long long *dbg,
@@ -2115,6 +2148,7 @@ hipError_t launch_pp(const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1
     dim3 grid((unsigned)grid_n), block(pp::NT);
     // lean: bit 0 = lean-issue kernel, bits 1-2 = its VAR, bits 8.. = rot_stages (see dense_scan_pp2_kernel)
     const int var = (lean >> 1) & 3, rot = lean >> 8;
+    const bool halfq = (lean & 8) && B <= pp::BN / 2 && Bpad == pp::BN;
 #define ERH_LAUNCH_PP2(A, V)                                                                               \
     hipLaunchKernelGGL((dense_scan_pp2_kernel<A, V>), grid, block, pp::LDS_BYTES, st, X, N, d, c0, c1, Q, Bpad, B, \
                        tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow, dbg, rot)
@@ -2123,7 +2157,9 @@ hipError_t launch_pp(const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1
                        filter_dir, dir_id, cand, cand_cnt, cap, overflow, dbg, rot, stream_sync)
 #define ERH_LAUNCH_PP3(A)                                                                                  \
     do {                                                                                                   \
-        if (var & 2)                                                                                       \
+        if (halfq && pp3_halfq_ok(A)) {                    /* 65 ... 128 queries: the nt = 1 half of the tile is not computed */ \
+            if (var & 2) ERH_LAUNCH_PP3V(pp3_halfq_mask(A), 10); else ERH_LAUNCH_PP3V(pp3_halfq_mask(A), 8); \
+        } else if (var & 2)                                                                                \
             hipLaunchKernelGGL((dense_scan_pp3_kernel<A, 2>), grid, block, pp::LDS_BYTES, st, X, N, d, c0, c1, Q, Bpad, \
                                B, tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow, dbg, rot, stream_sync); \
         else if ((var & 1) && kPp3LockStep)                                                                \
@@ -2203,6 +2239,7 @@ hipError_t dense_scan_init() {
     if (e != hipSuccess) return e;
 #define ERH_SET_PP(A) ERH_SET_PP3(A, 0) ERH_SET_PP3(A, 2)
     ERH_SET_PP(0)
+    ERH_SET_PP3(0, 8) ERH_SET_PP3(0, 10)
 #ifdef ERH_MEASURE
     e = hipFuncSetAttribute((const void *)dense_scan_pp_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             pp::LDS_BYTES);
@@ -2216,7 +2253,7 @@ hipError_t dense_scan_init() {
                             pp::LDS_BYTES);                                                                \
     if (e != hipSuccess) return e;
 #define ERH_SET_MEASURE(A) ERH_SET_PP(A) ERH_SET_PP3(A, 1) ERH_SET_PP2V(A, 0) ERH_SET_PP4(A)
-    ERH_SET_PP3(0, 1) ERH_SET_PP2V(0, 0) ERH_SET_PP4(0)
+    ERH_SET_PP3(0, 1) ERH_SET_PP2V(0, 0) ERH_SET_PP4(0) ERH_SET_PP3(1, 8) ERH_SET_PP3(1, 10)
     ERH_PP_MASKS(ERH_SET_MEASURE)
     ERH_SET_PP2V(0, 1) ERH_SET_PP2V(0, 2) ERH_SET_PP2V(0, 3)
     ERH_SET_PP2V(1, 1) ERH_SET_PP2V(1, 2) ERH_SET_PP2V(1, 3)

@@ -26,8 +26,11 @@ for wl in hybrid dense bm25; do
 done
 bash scripts/gpu_pmc.sh bm25 "--batch 1024 --sub 0" $TAG > $OUT/${TAG}_pmc_bm25.txt 2>&1
 bash scripts/gpu_pmc.sh dense "--batch 1024 --sub 0" $TAG > $OUT/${TAG}_pmc_dense_b1024.txt 2>&1
+bash scripts/gpu_pmc.sh dense "--batch 256 --sub 0" ${TAG}b > $OUT/${TAG}_pmc_dense_b256.txt 2>&1
 bash scripts/gpu_traffic.sh > $OUT/${TAG}_traffic.log 2>&1; cp gpurun_out/pmc_traffic.json $OUT/pmc_traffic.json
 timeout 600 python scripts/determinism.py 20 > $OUT/${TAG}_determinism.log 2>&1; echo "determinism exit $?"; tail -3 $OUT/${TAG}_determinism.log
 timeout 600 python scripts/kbench.py bm25a > $OUT/${TAG}_kbench_bm25a.log 2>&1
 timeout 400 python scripts/shim_latency.py 100000 > $OUT/${TAG}_shim_latency.log 2>&1
+timeout 300 python scripts/small_batch.py > $OUT/${TAG}_small_batch.log 2>&1
+timeout 200 scripts/ubench/scan_sync > $OUT/${TAG}_ubench_scan_sync.log 2>&1
 ls $OUT | head -50

@@ -69,6 +69,9 @@ CASES = [
     (30000, 1024, 64, 100, 1024, 4096),     # ... four column groups, 128 KiB of query fragments (its widest)
     (30000, 1024, 48, 288, 2048, 0),        # ... three of four groups populated
     (30000, 512, 32, 100, 1024, 0),         # ... two column groups
+    (30000, 1024, 100, 100, 1024, 4096),    # 65 ... 128 queries: the ping-pong scan computes half of its query tile (every arm but
+    (20000, 512, 128, 288, 2048, 0),        #   the per-tile ones; with dense_gemv = 0 every batch of <= 128 queries takes that mode)
+    (20000, 256, 200, 50, 512, 0),          # 129 ... 256 queries: one full query tile
     (12000, 1024, 5, 288, 512, 0),
     (9000, 192, 2, 20, 256, 0),             # d = 6 steps of 32
     (40000, 1280, 1, 50, 2048, 8192),       # one query, d > 1024: two blocks of K
