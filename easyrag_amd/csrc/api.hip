@@ -104,7 +104,8 @@ struct erh_handle {
     hipStream_t side = nullptr;           // ... created at first use
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool fork_after_scan = false;         // dense_topk_dev records ev_fork behind its last scan launch (hybrid_overlap 2)
-    int opt_bm25_small = 1;               // fixed-point scan: 512-thread workgroups, two per CU, when k allows (0: always the 1024-thread shape)
+    int opt_bm25_small = 2;               // fixed-point scan, when k allows: 2 the 512-thread shape with packed 16-bit sums over 32768-document
+                                          // tiles (two workgroups per CU), 1 the 512-thread shape over 16384-document tiles, 0 always 1024 threads
     int opt_bm25_ascan = 1;               // approximate-order scan + exact re-score when the index qualifies (positive payloads)
     int opt_bm25_wscan = 0;               // otherwise: wave-owned scan when the batch qualifies (needs the fine skip table, built at the
                                           // next erh_set_bm25_*), else the block scan
@@ -515,8 +516,10 @@ int bm25_topk_dev(erh_handle *h, const int32_t *qptr_dev, const int32_t *qtok_de
     // table at its tile size exists
     const int small_docs = erh::bm25_ascan_tile_docs(1);
     const bool have16 = S.tile_docs == small_docs || S.n_tiles16 > 0;
-    const bool small = ascan && h->opt_bm25_small && have16 && k <= erh::bm25_ascan_small_max_k() && B >= 8;   // (a handful of queries: 16 waves per query finish sooner)
-    const int as_docs = erh::bm25_ascan_tile_docs(small ? 1 : 0);
+    const bool small_k = ascan && k <= erh::bm25_ascan_small_max_k() && B >= 8;   // (a handful of queries: 16 waves per query finish sooner)
+    const int shape = !small_k ? 0 : h->opt_bm25_small == 2 ? 2 : (h->opt_bm25_small == 1 && have16) ? 1 : 0;
+    const bool small = shape != 0;                                        // two workgroups per CU
+    const int as_docs = erh::bm25_ascan_tile_docs(shape);
     const int tiles = ascan ? (int)((S.Nb + as_docs - 1) / as_docs) : S.n_tiles;
     int segs = h->opt_bm25_segs > 0 ? h->opt_bm25_segs : ((small ? 1024 : 512) + B - 1) / B;
     segs = std::max(1, std::min(segs, ascan ? std::min(tiles, std::max(S.n_tiles, 1)) : tiles));
@@ -532,12 +535,12 @@ int bm25_topk_dev(erh_handle *h, const int32_t *qptr_dev, const int32_t *qtok_de
     auto scan = [&](double *p_sc, int32_t *p_ids, int32_t *p_len) -> hipError_t {
         if (ascan) {
             // the skip table the scan walks: at its own tile size (tshift 0) or finer by one power of two (tshift 1)
-            const bool use16 = small && S.tile_docs != small_docs;
+            const bool use16 = shape == 1 && S.tile_docs != small_docs;
             const int32_t *tab = use16 ? S.tile_off16.as<int32_t>() : S.tile_off.as<int32_t>();
             const int n_tab = use16 ? S.n_tiles16 : S.n_tiles;
             const int tshift = (use16 || S.tile_docs == as_docs) ? 0 : 1;
             const int cut_mul = S.tile_docs > as_docs ? 2 : 1;                 // segment cuts on the exact scan's (larger) tiles
-            hipError_t e = erh::launch_bm25_ascan(S.variant, small ? 1 : 0, S.indptr.as<int64_t>(), S.doc_ids.as<int32_t>(), S.payload.p,
+            hipError_t e = erh::launch_bm25_ascan(S.variant, shape, S.indptr.as<int64_t>(), S.doc_ids.as<int32_t>(), S.payload.p,
                                                   S.post.p, (uint32_t)S.nnz, S.qmax,
                                                   tab, n_tab, tshift, S.Nb, qptr_dev, qtok_dev, q_order,
                                                   B, k, segs, cut_mul, filter_dev, dir, p_sc, p_ids, p_len, h->bm_redo.as<uint32_t>(),
@@ -728,7 +731,7 @@ int erh_set_option(erh_handle *h, const char *name, int64_t value) {
     if (!strcmp(name, "bm25_segs")) { if (value < 0 || value > 64) return h->fail(ERH_ERR_INVALID, "bm25_segs"); h->opt_bm25_segs = (int)value; return ERH_OK; }
     if (!strcmp(name, "bm25_crossing")) { if (value < 0 || value > 2) return h->fail(ERH_ERR_INVALID, "bm25_crossing"); h->opt_bm25_crossing = (int)value; return ERH_OK; }
     if (!strcmp(name, "bm25_ascan")) { h->opt_bm25_ascan = value != 0; return ERH_OK; }
-    if (!strcmp(name, "bm25_small")) { h->opt_bm25_small = value != 0; return ERH_OK; }
+    if (!strcmp(name, "bm25_small")) { h->opt_bm25_small = value < 0 ? 0 : value > 2 ? 2 : (int)value; return ERH_OK; }
     if (!strcmp(name, "hybrid_overlap")) { if (value < -1 || value > 2) return h->fail(ERH_ERR_INVALID, "hybrid_overlap"); h->opt_hybrid_overlap = (int)value; return ERH_OK; }
     if (!strcmp(name, "bm25_wscan")) { h->opt_bm25_wscan = value != 0; return ERH_OK; }   // the fine table is built at the next erh_set_bm25_*
     if (!strcmp(name, "bm25_fine_max_mb")) { if (value < 0) return h->fail(ERH_ERR_INVALID, "bm25_fine_max_mb < 0"); h->opt_bm25_fine_max_mb = value; return ERH_OK; }

@@ -776,6 +776,9 @@ __global__ __launch_bounds__(kBmThreads) void bm25_wscan_kernel(
 //            aq < thq = floor(thetaq (1 - 3 eps)) - nq - 1 has f strictly below all k of them: it can never be in the
 //            top k.  Everything else stays on the list (k entries plus the near ties of the k-th); thetaq is the exact
 //            k-th largest listed sum (LDS radix select, no sort);
+//            Packed shape (two documents per word, 16-bit sums, q16 = (q >> sh) + 1): q16 2^sh > q and <= q + 2^sh, so the
+//            sum exceeds the real one by < 2 n units of its own grid instead of n: thq = floor(thetaq (1 - 3 eps)) - 2 nq - 1,
+//            everything else as above;
 //   re-score the final list is scored EXACTLY: one binary search per (document, query token) inside the tile range of the
 //            skip table (four searches in flight per thread), the payloads summed in query-token order in the library's
 //            type (adding 0.0 for an absent token changes nothing), then ranked by (score desc, index asc) by counting.
@@ -784,8 +787,9 @@ __global__ __launch_bounds__(kBmThreads) void bm25_wscan_kernel(
 // corpus of near-identical short documents) or a query whose sums could overflow sets redo[query, segment]: the host
 // launches the exact block scan for those workgroups only.  Indices with non-positive payloads never come here
 // (api.hip checks when an index is set).
-constexpr int kAsU = 3;                                  // 128-posting pieces per wave and tile held in registers (a tile leaves a wave 2.6
-                                                         // on average; six slots measured 4 % slower: every empty one is two dummy adds)
+constexpr int kAsU = 3;                                  // 128-posting pieces per wave and tile held in registers (a 16384-document tile leaves
+                                                         // a wave 2.6 on average; six slots measured 4 % slower there: every empty one is two
+                                                         // dummy adds).  The packed shape (32768 documents per tile and 8 waves) holds six.
 constexpr int kAsTokChunk = 64;                          // lane j <-> query token j
 constexpr int kAsRegion = 2048;                          // accumulators a wave owns (notes, clears)
 constexpr int kAsXW = 88;                                // threshold crossings noted per region and tile
@@ -803,11 +807,19 @@ static_assert(kAsOffRng + 3 * 64 * 16 <= kAsOffAcc, "range tables overlap the ac
 // any k the API allows).  AsSmall: 512 threads over 16384-document tiles in 80 KiB of LDS, i.e. TWO workgroups (two
 // queries) per CU whose phases -- adds, barrier, list + clear, barrier -- fall at different times, so the LDS pipe, the
 // address path and the SIMDs of the CU are busy while one of them waits (list capacity 1024: k <= 384).
-template <int NT_, int TILE_>
+//   AsPack: the 512-thread shape over 32768-document tiles: TWO documents per accumulator word (document slot sl of the tile
+// lives in half sl >> 14 of word sl & 16383), sums of 16 bits.  The stored fixed-point payloads are shifted right per query
+// (as_pack_shift) until nq of them fit 16 bits, so a low half never carries into the high one.  The work per tile that
+// does not depend on the postings (ranges, descriptors, barriers, list, clear) is paid once per 32768 documents.
+template <int NT_, int TILE_, bool PACK_ = false>
 struct AsCfg {
     static constexpr int NT = NT_, TILE = TILE_, NW = NT_ / 64, CAP = 2 * NT_, RESERVE = NT_ / 4;
-    static_assert(TILE_ / (NT_ / 64) == kAsRegion, "a wave owns 2048 accumulators");
-    static constexpr size_t OFF_CA = kAsOffAcc + (size_t)TILE_ * 4;
+    static constexpr bool PACK = PACK_;
+    static constexpr int WORDS = PACK_ ? TILE_ / 2 : TILE_;          // 32-bit accumulator words of a tile
+    static constexpr int U = PACK_ ? 2 * kAsU : kAsU;                // posting pieces per wave and tile held in registers
+    static_assert(WORDS / (NT_ / 64) == kAsRegion, "a wave owns 2048 accumulator words");
+    static_assert(!PACK_ || WORDS == 16384, "the packed slot -> (word, half) split is written for 16384 words");
+    static constexpr size_t OFF_CA = kAsOffAcc + (size_t)WORDS * 4;
     static constexpr size_t OFF_CI = OFF_CA + (size_t)CAP * 4;
     static constexpr size_t OFF_XL = OFF_CI + (size_t)CAP * 4;
     static constexpr size_t OFF_HIST = OFF_XL + (size_t)NW * kAsXW * 4;
@@ -817,7 +829,8 @@ struct AsCfg {
 };
 using AsBig = AsCfg<1024, 32768>;
 using AsSmall = AsCfg<512, 16384>;
-static_assert(AsBig::BYTES <= 160 * 1024 && 2 * AsSmall::BYTES <= 160 * 1024, "fixed-point scan LDS layouts");
+using AsPack = AsCfg<512, 32768, true>;
+static_assert(AsBig::BYTES <= 160 * 1024 && 2 * AsSmall::BYTES <= 160 * 1024 && 2 * AsPack::BYTES <= 160 * 1024, "fixed-point scan LDS layouts");
 
 struct AsHdr {
     uint32_t thetaq;                // k-th best fixed-point sum seen so far (0: fewer than k candidates yet)
@@ -832,7 +845,16 @@ typedef int as_int4 __attribute__((ext_vector_type(4)));
 typedef uint32_t as_uint2 __attribute__((ext_vector_type(2)));
 typedef uint32_t as_uint4 __attribute__((ext_vector_type(4)));
 constexpr int kAsPiece = 128;                            // postings per piece: two consecutive ones per lane, one 16-byte load
-struct AsSet { as_uint4 p[kAsU]; };  // two postings per lane: .x/.z document, .y/.w fixed-point payload
+template <int U>
+struct AsSet { as_uint4 p[U]; };     // two postings per lane: .x/.z document, .y/.w fixed-point payload
+
+// packed sums: smallest right shift of the stored payloads with nq ((qmax >> sh) + 1) <= 65535; 32: there is none
+__device__ __forceinline__ int as_pack_shift(int nq, double qmax) {
+    const uint64_t qm = (uint64_t)qmax;
+    int sh = 0;
+    while (sh < 32 && (uint64_t)nq * ((qm >> sh) + 1ull) > 65535ull) ++sh;
+    return sh;
+}
 
 // inclusive prefix sum over the 64 lanes (DPP: four shifts inside the rows of 16, two row broadcasts)
 __device__ __forceinline__ int as_wave_scan(int x) {
@@ -884,10 +906,11 @@ __device__ __forceinline__ void as_describe(const as_int4 *rt, const as_int4 *px
 }
 
 // pieces [r0, r0 + kAsU) of this wave (np of them exist) -> registers; lanes without a posting read the sentinel pair
-__device__ __forceinline__ void as_fill(AsSet &S, uint32_t dstart, int dcnt, int r0, int np, const as_uint2 *__restrict__ post,
+template <int U>
+__device__ __forceinline__ void as_fill(AsSet<U> &S, uint32_t dstart, int dcnt, int r0, int np, const as_uint2 *__restrict__ post,
                                         int lane, uint32_t sentinel) {
 #pragma unroll
-    for (int u = 0; u < kAsU; ++u) {
+    for (int u = 0; u < U; ++u) {
         if (r0 + u < np) {                                                // wave-uniform
             const uint32_t st = (uint32_t)__builtin_amdgcn_readlane((int)dstart, r0 + u);
             const int cn = __builtin_amdgcn_readlane(dcnt, r0 + u);
@@ -901,7 +924,7 @@ __device__ __forceinline__ void as_fill(AsSet &S, uint32_t dstart, int dcnt, int
 template <int NW>
 __device__ __forceinline__ void as_note(bool cross, int sl, int32_t *xl, int *xz) {
     if (cross) {
-        const int r = sl / kAsRegion;
+        const int r = (sl & (NW * kAsRegion - 1)) / kAsRegion;           // (packed: the word's region; plain: sl < NW * kAsRegion)
         const int pos = atomicAdd(&xz[r], 1);
         if (pos < kAsXW) xl[r * kAsXW + pos] = sl;
         atomicMax(&xz[NW], pos + 1);
@@ -912,28 +935,39 @@ __device__ __forceinline__ void as_note(bool cross, int sl, int32_t *xl, int *xz
 // its piece, or a piece the wave does not have) adds 0 to a word of its own in a dummy area, so the 2 kAsU atomics of a
 // round are issued back to back and their returns are collected afterwards -- behind branches or exec masks the
 // compiler waits for each return before it issues the next add.
-template <int NW>
-__device__ __forceinline__ void as_apply(const AsSet &S, int dcnt, int r0, int np, int lane, uint32_t *accu, uint32_t *dummy,
-                                         int base_doc, uint32_t thx, int32_t *xl, int *xz) {
-    uint32_t o0[kAsU], o1[kAsU], q0[kAsU], q1[kAsU];
+template <int NW, int U, bool PACK>
+__device__ __forceinline__ void as_apply(const AsSet<U> &S, int dcnt, int r0, int np, int lane, uint32_t *accu, uint32_t *dummy,
+                                         int base_doc, uint32_t thx, int32_t *xl, int *xz, int sh) {
+    uint32_t o0[U], o1[U], q0[U], q1[U];
     uint32_t *mine = dummy + lane;
 #pragma unroll
-    for (int u = 0; u < kAsU; ++u) {
+    for (int u = 0; u < U; ++u) {
         int cn = __builtin_amdgcn_readlane(dcnt, r0 + u < 64 ? r0 + u : 63);
         cn = r0 + u < np ? cn : 0;                                        // scalar select
         const bool v0 = 2 * lane < cn, v1 = 2 * lane + 1 < cn;
-        q0[u] = v0 ? S.p[u].y : 0u;
-        q1[u] = v1 ? S.p[u].w : 0u;
-        o0[u] = atomicAdd(v0 ? &accu[(int)S.p[u].x - base_doc] : mine, q0[u]);
-        o1[u] = atomicAdd(v1 ? &accu[(int)S.p[u].z - base_doc] : mine, q1[u]);
+        if constexpr (PACK) {
+            const uint32_t s0 = (uint32_t)((int)S.p[u].x - base_doc), s1 = (uint32_t)((int)S.p[u].z - base_doc);
+            const uint32_t h0 = ((s0 >> 14) & 1u) << 4, h1 = ((s1 >> 14) & 1u) << 4;   // 0 / 16: the half's bit offset
+            q0[u] = v0 ? (S.p[u].y >> sh) + 1u : 0u;
+            q1[u] = v1 ? (S.p[u].w >> sh) + 1u : 0u;
+            o0[u] = atomicAdd(v0 ? &accu[s0 & 16383u] : mine, v0 ? q0[u] << h0 : 0u);
+            o1[u] = atomicAdd(v1 ? &accu[s1 & 16383u] : mine, v1 ? q1[u] << h1 : 0u);
+            o0[u] = (o0[u] >> h0) & 0xffffu;                              // the half's own old sum
+            o1[u] = (o1[u] >> h1) & 0xffffu;
+        } else {
+            q0[u] = v0 ? S.p[u].y : 0u;
+            q1[u] = v1 ? S.p[u].w : 0u;
+            o0[u] = atomicAdd(v0 ? &accu[(int)S.p[u].x - base_doc] : mine, q0[u]);
+            o1[u] = atomicAdd(v1 ? &accu[(int)S.p[u].z - base_doc] : mine, q1[u]);
+        }
     }
     if (thx) {                                                            // (no threshold yet: nothing to note, the tile is swept)
         bool any = false;
 #pragma unroll
-        for (int u = 0; u < kAsU; ++u) any |= (thx - 1u - o0[u] < q0[u]) | (thx - 1u - o1[u] < q1[u]);   // old < thx <= old + q
+        for (int u = 0; u < U; ++u) any |= (thx - 1u - o0[u] < q0[u]) | (thx - 1u - o1[u] < q1[u]);   // old < thx <= old + q
         if (__builtin_amdgcn_ballot_w64(any)) {                           // wave-uniform, rare once the threshold has settled
 #pragma unroll
-            for (int u = 0; u < kAsU; ++u) {
+            for (int u = 0; u < U; ++u) {
                 as_note<NW>(thx - 1u - o0[u] < q0[u], (int)S.p[u].x - base_doc, xl, xz);
                 as_note<NW>(thx - 1u - o1[u] < q1[u], (int)S.p[u].z - base_doc, xl, xz);
             }
@@ -984,8 +1018,10 @@ __device__ __forceinline__ uint32_t as_kth_largest(const uint32_t *v, int n, int
     return prefix;
 }
 
-__device__ __forceinline__ uint32_t as_drop_threshold(uint32_t thetaq, double keep_frac, int nq) {
-    const long long t = (long long)((double)thetaq * keep_frac) - nq - 1;
+// n_err: how many units a sum can exceed the real one by -- nq (one per posting: the + 1 behind the truncation) or, for
+// the packed sums, 2 nq (the stored payload is truncated a second time by the shift, + 1 again)
+__device__ __forceinline__ uint32_t as_drop_threshold(uint32_t thetaq, double keep_frac, int n_err) {
+    const long long t = (long long)((double)thetaq * keep_frac) - n_err - 1;
     return t > 1 ? (uint32_t)t : 1u;
 }
 
@@ -1020,6 +1056,82 @@ __device__ __forceinline__ void as_shrink(BmHdr *hdr, AsHdr *h2, uint32_t *ca, i
     __syncthreads();
 }
 
+// bm_sweep for the packed sums: a 16-byte vector holds eight documents (word w: slots w and w + 16384 of the tile).
+template <class C>
+__device__ __forceinline__ void as_sweep_packed(BmHdr *hdr, uint32_t *accu, uint32_t *ca, int32_t *ci, int tid, int64_t base_doc,
+                                                int64_t N, int fd, const int16_t *__restrict__ dir_id, uint32_t thq,
+                                                int *full_flag, int *want_flag, int want_at) {
+    typedef uint32_t UT __attribute__((ext_vector_type(4)));
+    constexpr int UNR = 4, NT = C::NT, W = C::WORDS, CAP = C::CAP;
+    for (int i0 = tid * 4; i0 < W; i0 += NT * 4 * UNR) {
+        UT v[UNR];
+        bool cand[UNR], touched[UNR];
+        bool any = false;
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {                                   // (all reads before the first store: see bm_sweep)
+            const int i = i0 + u * NT * 4;
+            if (i < W) v[u] = *reinterpret_cast<UT *>(accu + i);
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int i = i0 + u * NT * 4;
+            cand[u] = touched[u] = false;
+            if (i < W) {
+                touched[u] = (v[u][0] | v[u][1] | v[u][2] | v[u][3]) != 0u;
+                uint32_t m = 0u;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t lo = v[u][e] & 0xffffu, hi = v[u][e] >> 16;
+                    m = lo > m ? lo : m;
+                    m = hi > m ? hi : m;
+                }
+                cand[u] = touched[u] && m >= thq;
+                any |= cand[u];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            if (touched[u] && !cand[u]) {
+                const UT z = {0u, 0u, 0u, 0u};
+                *reinterpret_cast<UT *>(accu + i0 + u * NT * 4) = z;
+            }
+        }
+        if (__builtin_amdgcn_ballot_w64(any) == 0) continue;                // wave-uniform
+        // rare: a vector with a possible survivor is taken apart word by word, from LDS again (a rolled loop: few registers)
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            if (!cand[u]) continue;
+            const int i = i0 + u * NT * 4;
+#pragma unroll 1
+            for (int e = 0; e < 4; ++e) {
+                uint32_t w = accu[i + e];
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    const uint32_t sv = (w >> (16 * hf)) & 0xffffu;
+                    if (sv == 0u) continue;
+                    const int64_t doc = base_doc + i + e + hf * W;
+                    bool pass = sv >= thq;
+                    if (pass && (doc >= N || (fd >= 0 && (int)dir_id[doc] != fd))) pass = false;
+                    bool keep = false;
+                    if (pass) {
+                        const int pos = atomicAdd(&hdr->ncand, 1);
+                        if (pos < CAP) {
+                            ca[pos] = sv;
+                            ci[pos] = (int32_t)doc;
+                            if (want_flag && pos >= want_at) *want_flag = 1;
+                        } else {
+                            *full_flag = 1;                                 // list full: the sum stays for the next sweep
+                            keep = true;
+                        }
+                    }
+                    if (!keep) w &= hf ? 0x0000ffffu : 0xffff0000u;
+                }
+                accu[i + e] = w;
+            }
+        }
+    }
+}
+
 // The tile's sums are complete and there is no threshold yet (or too many crossings were noted): sweep the whole tile
 // with the workgroup -- survivors (>= the drop threshold, passing the filter) to the list, everything else cleared; the
 // list is cut back (as_shrink) whenever it fills.  On the first tile of the segment the threshold is seeded from the
@@ -1028,16 +1140,24 @@ template <class C>
 __device__ __forceinline__ bool as_sweep_tile(BmHdr *hdr, AsHdr *h2, uint32_t *accu, uint32_t *ca, int32_t *ci, uint32_t *hist,
                                               bool first_tile, int base_doc, int64_t N, int fd,
                                               const int16_t *__restrict__ dir_id, int k, double keep_frac, int nq, int &ph) {
-    constexpr int NT = C::NT, TILE = C::TILE, CAP = C::CAP;
+    constexpr int NT = C::NT, WORDS = C::WORDS, CAP = C::CAP;
     const int tid = threadIdx.x;
     if (first_tile && k <= NT && fd < 0) {
         // k-th largest of the per-thread maxima: k distinct documents reach it, so it is a valid first thetaq
         typedef uint32_t UT __attribute__((ext_vector_type(4)));
         uint32_t mx = 0u;
-        for (int i = tid * 4; i < TILE; i += NT * 4) {
+        for (int i = tid * 4; i < WORDS; i += NT * 4) {
             const UT v = *reinterpret_cast<const UT *>(accu + i);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) mx = v[e] > mx ? v[e] : mx;
+            for (int e = 0; e < 4; ++e) {
+                if constexpr (C::PACK) {
+                    const uint32_t lo = v[e] & 0xffffu, hi = v[e] >> 16;
+                    mx = lo > mx ? lo : mx;
+                    mx = hi > mx ? hi : mx;
+                } else {
+                    mx = v[e] > mx ? v[e] : mx;
+                }
+            }
         }
         ca[tid] = mx;                                                     // the list is still empty
         const uint32_t p = as_kth_largest(ca, NT, k, hist, h2);           // begins and ends with barriers
@@ -1047,8 +1167,12 @@ __device__ __forceinline__ bool as_sweep_tile(BmHdr *hdr, AsHdr *h2, uint32_t *a
     for (;;) {
         const int slot = ph % 3;
         if (tid == 0) { hdr->full[(ph + 1) % 3] = 0; hdr->want[(ph + 1) % 3] = 0; }
-        bm_sweep<uint32_t, CAP>(hdr, accu, ca, ci, 0, TILE, NT, tid, (int64_t)base_doc, N, fd, dir_id, h2->thq,
-                                0x7fffffff, &hdr->full[slot], &hdr->want[slot], k + NT / 2);
+        if constexpr (C::PACK)
+            as_sweep_packed<C>(hdr, accu, ca, ci, tid, (int64_t)base_doc, N, fd, dir_id, h2->thq, &hdr->full[slot], &hdr->want[slot],
+                               k + NT / 2);
+        else
+            bm_sweep<uint32_t, CAP>(hdr, accu, ca, ci, 0, WORDS, NT, tid, (int64_t)base_doc, N, fd, dir_id, h2->thq,
+                                    0x7fffffff, &hdr->full[slot], &hdr->want[slot], k + NT / 2);
         __syncthreads();
         const int full = hdr->full[slot], want = hdr->want[slot];
         ++ph;
@@ -1085,7 +1209,7 @@ __device__ __forceinline__ void as_finish_query(char *smem, BmHdr *hdr, uint32_t
     const int n_keep = hdr->ncand;
     ST *fs = reinterpret_cast<ST *>(smem + kAsOffAcc);                    // the accumulators are dead: exact sums ...
     ST *M = fs + CAP;                                                  // ... and the (entry, token) payload matrix
-    constexpr int kMCap = (int)(((size_t)TILE * 4 - (size_t)CAP * sizeof(ST)) / sizeof(ST));
+    constexpr int kMCap = (int)(((size_t)C::WORDS * 4 - (size_t)CAP * sizeof(ST)) / sizeof(ST));
     for (int i = tid; i < CAP; i += NT) fs[i] = (ST)0;
     for (int c0 = 0; c0 < nq; c0 += kAsTokChunk) {
         const int nqc = nq - c0 < kAsTokChunk ? nq - c0 : kAsTokChunk;
@@ -1206,7 +1330,7 @@ __device__ __forceinline__ void as_finish_query(char *smem, BmHdr *hdr, uint32_t
 // grid = (segs, B), block = C::NT.  tile_off has n_tab + 1 entries per term at a granularity of C::TILE >> tshift documents;
 // post = the interleaved fixed-point postings with two sentinels {document -1, q 0} at index nnz.
 template <typename ST, class C>
-__global__ __launch_bounds__(C::NT) void bm25_ascan_kernel(
+__global__ __launch_bounds__(C::NT, 4 /* waves per SIMD: two 512-thread workgroups per CU */) void bm25_ascan_kernel(
     const int64_t *__restrict__ indptr, const int32_t *__restrict__ doc_ids, const ST *__restrict__ payload,
     const as_uint2 *__restrict__ post, uint32_t nnz, double qmax /* largest fixed-point payload of the index */,
     const int32_t *__restrict__ tile_off, int n_tab, int tshift, int n_tiles, int64_t N,
@@ -1216,7 +1340,7 @@ __global__ __launch_bounds__(C::NT) void bm25_ascan_kernel(
     double *__restrict__ part_scores, int32_t *__restrict__ part_ids, int32_t *__restrict__ part_len,
     uint32_t *__restrict__ redo, int abl /* measurement builds: 1 no adds, 2 no posting loads, 4 no clear, 8 one descriptor set */,
     unsigned long long *__restrict__ dbg) {
-    constexpr int NT = C::NT, TILE = C::TILE, NW = C::NW, CAP = C::CAP;
+    constexpr int NT = C::NT, TILE = C::TILE, NW = C::NW, CAP = C::CAP, WORDS = C::WORDS, U = C::U;
 #ifdef ERH_MEASURE
 #define ERH_ABL(B) (abl & (B))
     long long t_sec[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // [8] the final shrink, [9] exact re-score + rank + output
@@ -1251,17 +1375,19 @@ __global__ __launch_bounds__(C::NT) void bm25_ascan_kernel(
     t_end = t_end < n_tiles ? t_end : n_tiles;
     const int64_t out_base = ((int64_t)q * segs + seg) * k;
     const double keep_frac = 1.0 - 3.0 * 1.01 * (double)(nq + 2) * 5.9604644775390625e-08;   // 1 - 3 eps
+    const int n_err = C::PACK ? 2 * nq : nq;                              // units a sum can exceed the real one by (as_drop_threshold)
+    const int sh = C::PACK ? as_pack_shift(nq, qmax) : 0;                 // packed sums: right shift of the stored payloads
 
     if (tid == 0) {
         hdr->ncand = 0; hdr->total = 0; hdr->tau_idx = 0x7fffffff; hdr->tau_s = 0.0;
         hdr->full[0] = hdr->full[1] = hdr->full[2] = 0;
         hdr->want[0] = hdr->want[1] = hdr->want[2] = 0;
         h2->thetaq = 0u; h2->thq = 1u; h2->keep = 0;
-        h2->redo = ((double)nq * qmax >= 4294967296.0) ? 1 : 0;           // the sums could overflow: leave it to the exact scan
+        h2->redo = (C::PACK ? sh >= 32 : (double)nq * qmax >= 4294967296.0) ? 1 : 0;   // the sums could overflow: leave it to the exact scan
     }
     if (tid < 2 * (NW + 1)) xzb[tid] = 0;
     if (tid < 64) dummy[tid] = 0u;
-    for (int i = tid; i < TILE; i += NT) accu[i] = 0u;
+    for (int i = tid; i < WORDS; i += NT) accu[i] = 0u;
     __syncthreads();
 
     int ph = 0;                                                           // sweep pass counter (workgroup-uniform)
@@ -1276,7 +1402,7 @@ __global__ __launch_bounds__(C::NT) void bm25_ascan_kernel(
         if (tid < NW + 1) xzb[(par ^ 1) * (NW + 1) + tid] = 0;                      // the next tile's counters (idle until the next barrier)
         bool by_list = thq > 1u && xmax <= kAsXW;                         // workgroup-uniform
         if (by_list && nc0 + NW * xmax > CAP) {                  // make room first (rare)
-            as_shrink<CAP>(hdr, h2, ca, ci, hist, k, keep_frac, nq, C::RESERVE);
+            as_shrink<CAP>(hdr, h2, ca, ci, hist, k, keep_frac, n_err, C::RESERVE);
             if (h2->redo) return true;
             by_list = hdr->ncand + NW * xmax <= CAP;             // (stable: read behind as_shrink's last barrier)
         }
@@ -1287,7 +1413,7 @@ __global__ __launch_bounds__(C::NT) void bm25_ascan_kernel(
                 const uint32_t thn = h2->thq;
                 for (int i = lane; i < cnt; i += 64) {
                     const int sl = xl[wave * kAsXW + i];
-                    const uint32_t av = accu[sl];
+                    const uint32_t av = C::PACK ? (accu[sl & (WORDS - 1)] >> ((sl >> 14) << 4)) & 0xffffu : accu[sl];
                     const int64_t doc = (int64_t)base_doc + sl;
                     bool pass = av >= thn;
                     if (pass && (doc >= N || (fd >= 0 && (int)dir_id[doc] != fd))) pass = false;
@@ -1309,18 +1435,18 @@ __global__ __launch_bounds__(C::NT) void bm25_ascan_kernel(
             __syncthreads();
             ERH_SEC(4);
             if (hdr->ncand > k + NT / 2) {                        // uniform: keep the list short, the threshold current
-                as_shrink<CAP>(hdr, h2, ca, ci, hist, k, keep_frac, nq, C::RESERVE);
+                as_shrink<CAP>(hdr, h2, ca, ci, hist, k, keep_frac, n_err, C::RESERVE);
                 ERH_SEC(5);
                 if (h2->redo) return true;
             }
             return false;
         }
-        return as_sweep_tile<C>(hdr, h2, accu, ca, ci, hist, tile == t_begin, base_doc, N, fd, dir_id, k, keep_frac, nq, ph);
+        return as_sweep_tile<C>(hdr, h2, accu, ca, ci, hist, tile == t_begin, base_doc, N, fd, dir_id, k, keep_frac, n_err, ph);
     };
 
     bool stop = h2->redo != 0;
     if (nq > 0 && t_begin < t_end && !stop) {
-        AsSet S;
+        AsSet<U> S;
         auto pieces_of = [&](int pt, int nd) __attribute__((always_inline)) -> int {   // this wave's share of a tile's pt pieces, dealt to waves 0 .. nd - 1
             return (wave < nd && pt > wave) ? (pt - wave + nd - 1) / nd : 0;
         };
@@ -1380,13 +1506,13 @@ __global__ __launch_bounds__(C::NT) void bm25_ascan_kernel(
                 if (dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); ERH_SEC(6); }   // (measurement: load wait on its own, booked under [6])
 #endif
                 const uint32_t thx = thq > 1u ? thq : 0u;
-                if (!ERH_ABL(1)) as_apply<NW>(S, dc_c, 0, np_c, lane, accu, dummy, base_doc, thx, xl, xz);   // (requested a tile ago)
+                if (!ERH_ABL(1)) as_apply<NW, U, C::PACK>(S, dc_c, 0, np_c, lane, accu, dummy, base_doc, thx, xl, xz, sh);   // (requested a tile ago)
 #ifdef ERH_MEASURE
                 if (dbg) ERH_SEC(7);                                      // (measurement: the adds on their own, booked under [7])
 #endif
-                for (int r0 = kAsU; r0 < np_c; r0 += kAsU) {              // more pieces than the register slots hold (long posting lists)
+                for (int r0 = U; r0 < np_c; r0 += U) {              // more pieces than the register slots hold (long posting lists)
                     as_fill(S, ds_c, dc_c, r0, np_c, post, lane, nnz);
-                    as_apply<NW>(S, dc_c, r0, np_c, lane, accu, dummy, base_doc, thx, xl, xz);
+                    as_apply<NW, U, C::PACK>(S, dc_c, r0, np_c, lane, accu, dummy, base_doc, thx, xl, xz, sh);
                 }
                 if (wave == PW) {                                          // ranges of tile + 2 -> LDS, skip-table entries of tile + 3
                     publish(r_nn, ra, rb);
@@ -1434,9 +1560,9 @@ __global__ __launch_bounds__(C::NT) void bm25_ascan_kernel(
                     int dc;
                     as_describe<NW>(rng, nullptr, nqc, lane, wave, ds, dc);
                     const int np = pieces_of(__builtin_amdgcn_readfirstlane(rng[0][3]), NW);
-                    for (int r0 = 0; r0 < np; r0 += kAsU) {
+                    for (int r0 = 0; r0 < np; r0 += U) {
                         as_fill(S, ds, dc, r0, np, post, lane, nnz);
-                        as_apply<NW>(S, dc, r0, np, lane, accu, dummy, base_doc, thx, xl, xz);
+                        as_apply<NW, U, C::PACK>(S, dc, r0, np, lane, accu, dummy, base_doc, thx, xl, xz, sh);
                     }
                     __syncthreads();                                      // (the ranges are overwritten by the next chunk)
                 }
@@ -1445,7 +1571,7 @@ __global__ __launch_bounds__(C::NT) void bm25_ascan_kernel(
             }
         }
     }
-    if (!stop) as_shrink<CAP>(hdr, h2, ca, ci, hist, k, keep_frac, nq, 0);     // final list: k entries + the near ties of the k-th
+    if (!stop) as_shrink<CAP>(hdr, h2, ca, ci, hist, k, keep_frac, n_err, 0);     // final list: k entries + the near ties of the k-th
     if (h2->redo) {                                                       // workgroup-uniform
         if (tid == 0) { redo[(int64_t)q * segs + seg] = 1u; part_len[(int64_t)q * segs + seg] = 0; }
         return;
@@ -1583,6 +1709,10 @@ hipError_t bm25_init() {
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void *)bm25_ascan_kernel<double, AsSmall>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AsSmall::BYTES);
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void *)bm25_ascan_kernel<float, AsPack>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AsPack::BYTES);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void *)bm25_ascan_kernel<double, AsPack>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AsPack::BYTES);
+    if (e != hipSuccess) return e;
     return hipFuncSetAttribute((const void *)bm25_merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                8192 * 12 + 64);
 }
@@ -1630,7 +1760,7 @@ hipError_t launch_bm25_scan(int variant, const int64_t *indptr, const int32_t *d
     return hipGetLastError();
 }
 
-int bm25_ascan_tile_docs(int small) { return small ? AsSmall::TILE : AsBig::TILE; }
+int bm25_ascan_tile_docs(int shape) { return shape == 1 ? AsSmall::TILE : AsBig::TILE; }   // (shape 2, packed: AsBig's tiles)
 int bm25_ascan_small_max_k() { return AsSmall::CAP - AsSmall::NT / 2 - 3 * AsSmall::RESERVE; }   // 384: the shrink trigger (k + 256) leaves room for the notes of a tile
 
 hipError_t launch_bm25_ascan(int variant, int small, const int64_t *indptr, const int32_t *doc_ids, const void *payload,
@@ -1641,15 +1771,15 @@ hipError_t launch_bm25_ascan(int variant, int small, const int64_t *indptr, cons
                              unsigned long long *dbg, hipStream_t st) {
     if (B <= 0) return hipSuccess;
     if (cut_mul < 1) cut_mul = 1;
-    const int tile = small ? AsSmall::TILE : AsBig::TILE;
+    const int tile = bm25_ascan_tile_docs(small);
     const int n_tiles = (int)((N + tile - 1) / tile);
     dim3 grid(segs, B);
 #define ERH_AS_LAUNCH(ST, CFG)                                                                                       \
     hipLaunchKernelGGL((bm25_ascan_kernel<ST, CFG>), grid, dim3(CFG::NT), CFG::BYTES, st, indptr, doc_ids,           \
                        (const ST *)payload, (const as_uint2 *)post, nnz, qmax, tile_off, n_tab, tshift, n_tiles, N, q_indptr, \
                        q_tok, q_order, k, segs, cut_mul, filter_dir, dir_id, part_scores, part_ids, part_len, redo, ablate, dbg)
-    if (variant == 0) { if (small) ERH_AS_LAUNCH(double, AsSmall); else ERH_AS_LAUNCH(double, AsBig); }
-    else { if (small) ERH_AS_LAUNCH(float, AsSmall); else ERH_AS_LAUNCH(float, AsBig); }
+    if (variant == 0) { if (small == 2) ERH_AS_LAUNCH(double, AsPack); else if (small) ERH_AS_LAUNCH(double, AsSmall); else ERH_AS_LAUNCH(double, AsBig); }
+    else { if (small == 2) ERH_AS_LAUNCH(float, AsPack); else if (small) ERH_AS_LAUNCH(float, AsSmall); else ERH_AS_LAUNCH(float, AsBig); }
 #undef ERH_AS_LAUNCH
     return hipGetLastError();
 }

@@ -303,8 +303,10 @@ int erh_reset_kernel_time(erh_handle *h);
  *                         -1 = by batch size: 1 up to 256 queries, where neither scan fills the chip (one query: 0.59 -> 0.54
  *                         ms per call, 64: 0.85 -> 0.77), 0 above (1024 queries: 3.25 / 3.31 against 2.95 ms -- the scans need
  *                         a whole CU's LDS each, so they time-slice instead of sharing)
- *   bm25_small (1)        fixed-point scan in its 512-thread shape (16384-document tiles, 80 KiB of LDS: two workgroups = two
- *                         queries per CU) for batches of >= 8 queries and k <= 384; 0 = always 1024 threads, 32768-document tiles
+ *   bm25_small (2)        shape of the fixed-point scan for batches of >= 8 queries and k <= 384: 2 = 512 threads, 32768-document
+ *                         tiles, two documents per accumulator word (16-bit sums, payloads shifted per query); 1 = 512 threads,
+ *                         16384-document tiles, 32-bit sums (both: 80 KiB of LDS, two workgroups = two queries per CU);
+ *                         0 = always 1024 threads, 32768-document tiles.  Same results, bit for bit
  *   bm25_crossing (1)     wave-owned scan: survivors from threshold crossings noted in the token loop instead of a sweep
  *                         over the accumulators (1 = fp32 sums only, 2 = fp64 too, 0 = always sweep); indices with a
  *                         non-positive payload always sweep

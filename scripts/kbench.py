@@ -314,12 +314,12 @@ def main():
             queries = synth.token_queries(flat, lens, vocab, 1024, seed=9)
             eng.set_bm25(idx, payload_on_device=True)
             for rep in "ab":
-                for small in (1, 0):
+                for small in (2, 1, 0):
                     eng.set_option("bm25_small", small)
                     for Bq, k in ((1024, 192), (256, 100), (16, 192), (1, 192)):
                         qi, qt = queries_to_csr(queries[:Bq])
                         res[f"{name} ascan small={small} B={Bq} k={k} (run {rep})"] = timed(eng, lambda: eng.bm25_topk(qi, qt, k, device_out=True), 3)
-            eng.set_option("bm25_small", 1)
+            eng.set_option("bm25_small", 2)
             qi, qt = queries_to_csr(queries)
             if name == "bm25s":
                 for abl in (0, 1):                # 1 no adds, 4 no clear, 8 one descriptor set (cached loads, adds out of range)

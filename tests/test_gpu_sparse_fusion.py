@@ -13,18 +13,21 @@ from oracle.retrievers import Item
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[(1, 0, 1), (0, 1, 2), (0, 1, 0), (0, 0, 0)],
-                ids=["approx-scan-rescore", "wave-owned-crossings", "wave-owned-sweep", "block-scan"])
+@pytest.fixture(params=[(1, 0, 1, 2), (1, 0, 1, 1), (1, 0, 1, 0), (0, 1, 2, 2), (0, 1, 0, 2), (0, 0, 0, 2)],
+                ids=["approx-scan-packed", "approx-scan-small", "approx-scan-big", "wave-owned-crossings", "wave-owned-sweep",
+                     "block-scan"])
 def bm25_kernel(request, engine):
     """Every BM25 scan kernel / survivor-selection path must satisfy every parity test (bm25_ascan / bm25_wscan take
     effect at the next set_bm25)."""
     engine.set_option("bm25_ascan", request.param[0])
     engine.set_option("bm25_wscan", request.param[1])
     engine.set_option("bm25_crossing", request.param[2])
+    engine.set_option("bm25_small", request.param[3])       # shape of the approximate scan for batches of >= 8 queries
     yield request.param
     engine.set_option("bm25_ascan", 1)
     engine.set_option("bm25_wscan", 0)
     engine.set_option("bm25_crossing", 1)
+    engine.set_option("bm25_small", 2)
 
 
 def _oracle_for(variant, docs):
