@@ -521,7 +521,10 @@ int bm25_topk_dev(erh_handle *h, const int32_t *qptr_dev, const int32_t *qtok_de
     const bool small = shape != 0;                                        // two workgroups per CU
     const int as_docs = erh::bm25_ascan_tile_docs(shape);
     const int tiles = ascan ? (int)((S.Nb + as_docs - 1) / as_docs) : S.n_tiles;
-    int segs = h->opt_bm25_segs > 0 ? h->opt_bm25_segs : ((small ? 1024 : 512) + B - 1) / B;
+    // segments per query: one resident round of workgroups -- 512 slots with two 512-thread workgroups per CU.  (The packed shape
+    // walks half as many tiles per query as the 16384-document shape, whose best was two rounds: every segment pays a first
+    // tile without a threshold and a re-score of its own list.  profiles/r04r_kbench_bm25_segs.log)
+    int segs = h->opt_bm25_segs > 0 ? h->opt_bm25_segs : ((shape == 1 ? 1024 : 512) + B - 1) / B;
     segs = std::max(1, std::min(segs, ascan ? std::min(tiles, std::max(S.n_tiles, 1)) : tiles));
     // the merge sorts pow2(segs * k) padded slots in one workgroup: beyond 2048 it costs more than the extra segments save
     // (profiles/r03c_small_batch.log: one query, k = 192: 31 segments 0.038 + 0.106 ms, 10 segments 0.052 + 0.027 ms)

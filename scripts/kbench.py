@@ -302,6 +302,19 @@ def main():
             tot = c[:6].sum()
             res[f"{name} wscan sections (% of thread-0 cycles, k=192)"] = {n_: round(100 * v / tot, 1) for n_, v in zip(names, c[:6])}
             res[f"{name} wscan cycles per query (thread 0)"] = {"total": round(tot / 1024)}
+    if what == "bm25segs":                                   # segments per query of the fixed-point scan (packed shape), both bench batch sizes
+        indptr, doc, tf, lens, flat = synth.token_csr_torch(n, vocab, seed=3, device=dev)
+        idx = build_bm25_index_from_postings(indptr, doc, tf, lens, BM25S, compute_payload=False)
+        queries = synth.token_queries(flat, lens, vocab, 1024, seed=9)
+        eng.set_bm25(idx, payload_on_device=True)
+        for Bq, k, sweep in ((1024, 192, (0, 1, 2)), (256, 100, (0, 2, 3, 4, 6, 8)), (64, 100, (0, 4, 8, 16))):
+            qi, qt = queries_to_csr(queries[:Bq])
+            for rep in "ab":
+                for sg in sweep:
+                    eng.set_option("bm25_segs", sg)
+                    r = timed(eng, lambda: eng.bm25_topk(qi, qt, k, device_out=True), 10)
+                    print(f"bm25s B={Bq} k={k} segs={sg} (run {rep})  {json.dumps(r)}", flush=True)
+        eng.set_option("bm25_segs", 0)
     if what == "bm25a":                                      # fixed-point scan + exact re-score: times, ablations, section clocks
         class _Live(dict):
             def __setitem__(self, k_, v_):
@@ -322,7 +335,7 @@ def main():
             eng.set_option("bm25_small", 2)
             qi, qt = queries_to_csr(queries)
             if name == "bm25s":
-                for abl in (0, 1):                # 1 no adds, 4 no clear, 8 one descriptor set (cached loads, adds out of range)
+                for abl in (0, 1, 2, 3, 4, 8):    # 1 no adds, 4 no clear, 8 one descriptor set (cached loads, adds out of range)
                     eng.set_option("bm25_ablate", abl)
                     res[f"{name} ascan B=1024 k=192 ablate={abl}"] = timed(eng, lambda: eng.bm25_topk(qi, qt, 192, device_out=True), 3)
                 eng.set_option("bm25_ablate", 0)
