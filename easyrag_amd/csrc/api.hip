@@ -78,6 +78,7 @@ struct erh_handle {
     DevBuf scan_sync;                        // one counter per chunk-tile stream of the ping-pong scan (dense_sync)
     DevBuf Xt;                               // tiled copy of X for the ping-pong scan (option dense_tiled), valid iff xt_valid
     DevBuf Qt;                               // tiled copy of the query block of the current call (dense_pp = 4)
+    DevBuf seed_top;                         // sample pass of the ping-pong scan: the cells' two best scores (kernels.h: ErhSeedIo)
     bool xt_valid = false;
     bool qt_valid = false;                   // Qt holds the tiled copy of the CURRENT call's Q16
     int64_t N = 0;
@@ -142,6 +143,7 @@ struct erh_handle {
     int opt_dense_gemv = 1;                // batches of <= 16 queries: skinny-GEMM stream instead of the padded 256-query scan
     int opt_n0_auto = 0;                   // seed prefix snapped down to a whole number of scan rounds (less seed work, more candidates: a wash at 1M chunks)
     int opt_dense_sync = 0;                // the query-tile workgroups of a stream meet at a counter every four tiles (measured: no gain)
+    int opt_dense_selfseed = 1;            // the ping-pong scan draws its own threshold sample (sample pass + cell maxima) instead of store kernel + S0 + seed select
     int opt_dense_tiled = 0;               // keep a tiled, pre-swizzled copy of the chunk matrix for the ping-pong scan (+ N * d * 2 bytes; no measurable gain: off)
     int opt_dense_speculate = 1;           // speculative (verified) first threshold + a single scan stage; 0: guaranteed bounds, refined in stages
     int opt_dense_var = 0;                 // dense_scan_pp2_kernel VAR (bit 0: two barriers per stage, bit 1: static priority)
@@ -289,7 +291,7 @@ hipError_t scan_append(erh_handle *h, const _Float16 *X, int64_t N, int d, int64
                                                  h->opt_debug_counters ? h->dbg.as<unsigned long long>() : nullptr,
                                                  (h->opt_dense_pp >= 2 && own)
                                                      ? (1 | (var << 1) | (h->opt_dense_pp >= 3 ? 8 : 0) | (dense_rot_stages(h, d, Bpad) << 8)) : 0,
-                                                 sync, st);
+                                                 sync, nullptr, st);
         if (e != hipErrorInvalidValue) return e;
         (void)hipGetLastError();
     }
@@ -370,9 +372,72 @@ int dense_topk_dev(erh_handle *h, const void *q_dev, int q_dtype, int normalize_
         *flops = 2.0 * (double)rows * (double)Bpad * (double)d;
     };
     double wb, wf;
+    const bool small = h->opt_dense_gemv && h->opt_dense_ablate == 0 && B <= erh::dense_gemv_max_queries();
+    // ---- the ping-pong scan draws its own threshold sample (round 4) ----------------------------------------------------
+    // Sample pass = the scan kernel over the first tile(s) of every chunk stream, without thresholds: the two best scores of
+    // every 64-row cell are all that leaves the registers, and the speculative threshold is the rank-th largest of them
+    // (seed_cells_select_kernel: 4 KiB per query instead of a 128 KiB row of S0 read twice).  The main launch then scans ALL
+    // rows -- the sampled ones again -- so there is no store kernel, no S0 and no candidate hand-over: what the sampled rows
+    // cost twice (1.6 % of the scan at 1024 queries) is less than storing and selecting from their scores.
+    // Not with a dir filter (the sample would have to be filtered per query), not for the skinny-GEMM batches, not when the
+    // rank is so deep that cells with three or more of the sample's best would be the rule (the threshold would still be
+    // valid, only loose): those take the stages below.
+    {
+        const int n_streams = erh::dense_scan_pp_streams(h->n_cus, Bpad);
+        // one tile per chunk stream, more only if that samples fewer than 16384 rows (1024 queries: 64 streams -> 16384 rows, 512
+        // queries: 128 streams -> 32768; the pass takes a tile time whatever the number of streams)
+        const int seed_tiles = n_streams > 0 ? (int)std::max<int64_t>(1, std::min<int64_t>(h->opt_n0, 16384) / ((int64_t)n_streams * QT)) : 0;
+        const int64_t rows_seed = (int64_t)seed_tiles * n_streams * QT;
+        const bool tiled_run = h->opt_dense_tiled && h->xt_valid;
+        const int n_cells = seed_tiles * n_streams * 4;
+        const int rank = (rows_seed > 0 && rows_seed <= N) ? erh_dense_seed_rank(k, rows_seed, N) : k;
+        // From 512 queries on: below, the sampled rows scanned twice (one tile per stream = 65536 rows at 256 queries) cost more
+        // than the store kernel and the select they replace (profiles/r04s_kbench_sample_pass.log).
+        const bool ok = h->opt_dense_selfseed && Bpad >= 2 * QT && h->opt_dense_speculate && h->opt_dense_pp == 3 && h->opt_dense_var == 0 &&
+                        h->opt_dense_ablate == 0 && !h->opt_dense_sync && !tiled_run && !small && !filter_dev && n_streams > 0 &&
+                        d % 64 == 0 && d / 32 >= 8 && rows_seed > 0 && N >= 2 * rows_seed && rank < k && 4 * rank <= n_cells;
+        if (ok) {
+            erh::ErhSeedIo sio{};
+            sio.seed_tiles = seed_tiles;
+            sio.n_cells = n_cells;
+            sio.mode = 1;
+            const int n_vals = n_cells * 2;
+            HIPCHK(h, h->seed_top.ensure((size_t)Bpad * n_vals * 4));
+            sio.seed_top = h->seed_top.as<float>();
+            const int lean = 1 | 8 | (dense_rot_stages(h, d, Bpad) << 8);
+            // (the pass books no work: the sampled rows are scanned again below, and N rows are what the algorithm needs)
+            { ProfScope ps(h, st, ERH_K_DENSE_SCAN, 0, 0);
+              HIPCHK(h, erh::launch_dense_scan_pp(X, N, d, 0, rows_seed, Q16, Bpad, B, h->tau.as<float>(), nullptr, nullptr,
+                                                  h->cand.as<ErhCand>(), h->cand_cnt.as<uint32_t>(), cap, flags, h->n_cus, 0,
+                                                  nullptr, lean, nullptr, &sio, st)); }
+            { ProfScope ps(h, st, ERH_K_DENSE_SELECT, 0, 0);
+              HIPCHK(h, erh::launch_seed_cells_select(sio.seed_top, n_vals, B, rank, h->qnorm.as<float>(), h->xnorm_max, d,
+                                                      h->tau.as<float>(), h->cand_cnt.as<uint32_t>(), st)); }
+            scan_work(N, &wb, &wf);
+            int rc_scan = ERH_OK;
+            { ProfScope ps(h, st, ERH_K_DENSE_SCAN, wb, wf);
+              hipError_t e = scan_append(h, X, N, d, 0, N, Q16, Bpad, B, h->tau.as<float>(), nullptr, nullptr,
+                                         h->cand.as<ErhCand>(), h->cand_cnt.as<uint32_t>(), cap, flags, st);
+              if (e != hipSuccess) rc_scan = h->fail(ERH_ERR_HIP, "dense scan behind the sample pass", e); }
+            if (rc_scan != ERH_OK) return rc_scan;
+            if (h->fork_after_scan) HIPCHK(h, hipEventRecord(h->ev_fork, st));
+            { ProfScope ps(h, st, ERH_K_DENSE_SELECT, 0, 0);
+              HIPCHK(h, erh::launch_dense_finalize(B, k, mode, h->qnorm.as<float>(), h->xnorm_max, d, X, Q16,
+                                                   h->cand.as<ErhCand>(), h->cand_cnt.as<uint32_t>(), cap, d_ids, d_sc, d_len,
+                                                   reinterpret_cast<float *>(flags + 1), flags + 2, bad, N, h->pos_mul, h->pos_inv,
+                                                   h->tau.as<float>(), st));
+              HIPCHK(h, erh::launch_dense_exhaustive(bad, B, 0, k, X, N, d, Q16, filter_dev,
+                                                     h->has_dir ? h->dir_id.as<int16_t>() : nullptr, h->pos_inv, h->ex_ws.p,
+                                                     flags, h->n_cus, d_ids, d_sc, d_len, st)); }
+            h->last = erh_handle::LastDense();
+            h->last.valid = true;
+            h->last.B = B; h->last.k = k; h->last.filter_dev = filter_dev;
+            h->last.d_ids = d_ids; h->last.d_sc = d_sc; h->last.d_len = d_len;
+            return ERH_OK;
+        }
+    }
     // stage A: score the seed prefix densely, k-th best -> pruning threshold
     scan_work(n0, &wb, &wf);
-    const bool small = h->opt_dense_gemv && h->opt_dense_ablate == 0 && B <= erh::dense_gemv_max_queries();
     { ProfScope ps(h, st, ERH_K_DENSE_SCAN, wb, wf);
       hipError_t e = hipErrorInvalidValue;
       if (small) e = erh::launch_dense_gemv_store(X, N, d, 0, (int)n0, Q16, B, h->S0.as<float>(), ld, h->n_cus,
@@ -677,7 +742,7 @@ int erh_destroy(erh_handle *h) {
     drain_events(h);
     for (auto &ev : h->pool) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
     if (h->side) { (void)hipStreamDestroy(h->side); (void)hipEventDestroy(h->ev_fork); (void)hipEventDestroy(h->ev_join); }
-    DevBuf *bufs[] = {&h->X, &h->Xt, &h->Qt, &h->scan_sync, &h->qorder, &h->content_id, &h->dir_id,
+    DevBuf *bufs[] = {&h->X, &h->Xt, &h->Qt, &h->seed_top, &h->scan_sync, &h->qorder, &h->content_id, &h->dir_id,
                       &h->qin, &h->Q16, &h->qnorm, &h->tau, &h->S0, &h->cand, &h->cand_cnt, &h->flags, &h->filt, &h->filt2,
                       &h->o_ids, &h->o_sc, &h->o_len, &h->qptr, &h->qtok, &h->part_sc, &h->part_ids, &h->part_len,
                       &h->hy_sids, &h->hy_ssc, &h->hy_slen, &h->hy_dids, &h->hy_dsc, &h->hy_dlen,
@@ -712,6 +777,7 @@ int erh_set_option(erh_handle *h, const char *name, int64_t value) {
     if (!strcmp(name, "dense_pp")) { if (value < 0 || value > 4) return h->fail(ERH_ERR_INVALID, "dense_pp"); h->opt_dense_pp = (int)value; return ERH_OK; }
     if (!strcmp(name, "dense_n0_auto")) { h->opt_n0_auto = value != 0; return ERH_OK; }
     if (!strcmp(name, "dense_sync")) { h->opt_dense_sync = value != 0; return ERH_OK; }
+    if (!strcmp(name, "dense_selfseed")) { h->opt_dense_selfseed = value != 0; return ERH_OK; }
     if (!strcmp(name, "dense_tiled")) { h->opt_dense_tiled = value != 0; return ERH_OK; }   // building the copy: at the next erh_set_dense
     if (!strcmp(name, "dense_speculate")) { h->opt_dense_speculate = value != 0; return ERH_OK; }
     if (!strcmp(name, "dense_var")) { if (value < 0 || value > 3) return h->fail(ERH_ERR_INVALID, "dense_var"); h->opt_dense_var = (int)value; return ERH_OK; }

@@ -1380,7 +1380,8 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp3_kernel(
     const float *__restrict__ tau, const int16_t *__restrict__ filter_dir, const int16_t *__restrict__ dir_id,
     ErhCand *__restrict__ cand, uint32_t *__restrict__ cand_cnt, int cap, uint32_t *__restrict__ overflow,
     unsigned long long *__restrict__ dbg /* kPpClocks only */, int rot_stages,
-    uint32_t *__restrict__ stream_sync /* one zeroed word per stream, or null: see ERH_PP3_STREAM_SYNC */) {
+    uint32_t *__restrict__ stream_sync /* one zeroed word per stream, or null: see ERH_PP3_STREAM_SYNC */,
+    const erh::ErhSeedIo sio /* VAR bit 4: this launch is the sample pass (kernels.h) */) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1389,6 +1390,7 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp3_kernel(
     long long t_mark = (PABL & kPpClocks) ? clock64() : 0;
 #define ERH_PH(I) do { if (PABL & kPpClocks) { const long long n_ = clock64(); tph[I] += n_ - t_mark; t_mark = n_; } } while (0)
     const int nk = d / pp::BK;
+    constexpr bool SEED = (VAR & 16) != 0;                             // sample pass: score the tiles, keep the two best of every cell, no thresholds
 
     const int n_qt = Bpad / pp::BN;
     const int64_t n_ct = (c1 - c0 + pp::BM - 1) / pp::BM;
@@ -1415,7 +1417,7 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp3_kernel(
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const int q = (int)q_row0 + nt * 128 + wave_n * 32 + l31;
-        t_q[nt] = (nt < NTL && q < B && !(PABL & kPpTauInf)) ? tau[q] : INFINITY;
+        t_q[nt] = (!SEED && nt < NTL && q < B && !(PABL & kPpTauInf)) ? tau[q] : INFINITY;
     }
     asm volatile("" ::"v"(t_q[0]), "v"(t_q[1]));                      // loaded before the DMA stream starts (keeps vmcnt countable)
 
@@ -1626,6 +1628,38 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp3_kernel(
     } while (0)
     constexpr int kSyncTiles = 4;
 
+// Sample pass (VAR bit 4): of the tile's scores only the two best of every cell -- this lane's 64 rows of one query column --
+// leave the registers.  Three VALU instructions per score, written as inline asm: left to the compiler the chain is
+// re-associated across the 64 accumulators and spills into the main loop.
+#define ERH_PP3_SEED_EPILOGUE()                                                                       \
+    do {                                                                                              \
+        _Pragma("unroll") for (int nt = 0; nt < NTL; ++nt) {                                          \
+            float t0_ = -INFINITY, t1_ = -INFINITY;                                                   \
+            _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                        \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                      \
+                    float a_;                                                                         \
+                    asm volatile("v_min_f32 %2, %0, %3\n\tv_max_f32 %0, %0, %3\n\tv_max_f32 %1, %1, %2" \
+                                 : "+v"(t0_), "+v"(t1_), "=&v"(a_)                                    \
+                                 : "v"(acc[mt][nt][r]));                                              \
+                }                                                                                     \
+            }                                                                                         \
+            const int q_ = (int)q_row0 + nt * 128 + wave_n * 32 + l31;                                \
+            const int cell_ = (i * n_streams + stream) * 4 + grp * 2 + hh;                            \
+            if (q_ < B) {                                                                             \
+                float2 top_;                                                                          \
+                top_.x = t0_;                                                                         \
+                top_.y = t1_;                                                                         \
+                *reinterpret_cast<float2 *>(sio.seed_top + ((int64_t)q_ * sio.n_cells + cell_) * 2) = top_; \
+            }                                                                                         \
+        }                                                                                             \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     /* stores and loads retire out of order: none outstanding when the counted waits resume */ \
+    } while (0)
+#define ERH_PP3_EPILOGUE()                                                                            \
+    do {                                                                                              \
+        if constexpr (SEED) { ERH_PP3_SEED_EPILOGUE(); }                                              \
+        else { ERH_PP_EPILOGUE_V(true, 1, NTL); }     /* mask-first group tests: profiles/r04k_kbench_epi2.log */ \
+    } while (0)
+
     // prologue: A(0,1) B(0,1) A(2,3) B(2,3); stages 0 and 1 complete = the last 8 instructions may stay in flight
     ERH_PP3_ISSUE_A();
     ERH_PP3_ISSUE_B();
@@ -1662,7 +1696,7 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp3_kernel(
                 ERH_PP_BARRIER();                                                                     \
                 ERH_PH(2);                                                                            \
             }                                                                                         \
-            ERH_PP_EPILOGUE_V(true, 1, NTL);     /* mask-first group tests: profiles/r04k_kbench_epi2.log */                                                                        \
+            ERH_PP3_EPILOGUE();                                                                        \
             ERH_PH(4);                                                                                \
             ERH_PP_BARRIER();                                                                         \
             ERH_PH(5);                                                                                \
@@ -1697,7 +1731,7 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp3_kernel(
                 ERH_PP_BARRIER();
                 ERH_PH(2);
             }
-            ERH_PP_EPILOGUE_V(true, 1, NTL);     /* mask-first group tests: profiles/r04k_kbench_epi2.log */
+            ERH_PP3_EPILOGUE();
             ERH_PH(4);
             ERH_PP_BARRIER();
             ERH_PH(5);
@@ -1730,7 +1764,7 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp3_kernel(
                 ERH_PP_BARRIER();
                 ERH_PH(2);
             }
-            ERH_PP_EPILOGUE_V(true, 1, NTL);     /* mask-first group tests: profiles/r04k_kbench_epi2.log */
+            ERH_PP3_EPILOGUE();
             ERH_PH(4);
             ERH_PP_BARRIER();
             ERH_PH(5);
@@ -1748,6 +1782,8 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp3_kernel(
 #undef ERH_PP3_STREAM_SYNC
 #undef ERH_PP3_ISSUE_A
 #undef ERH_PP3_ISSUE_AT
+#undef ERH_PP3_SEED_EPILOGUE
+#undef ERH_PP3_EPILOGUE
 #undef ERH_PP3_ISSUE_B
 #undef ERH_PP3_PART_A
 #undef ERH_PP3_PART_B
@@ -2139,10 +2175,14 @@ constexpr int pp3_halfq_mask(int mask) { return pp3_halfq_ok(mask) ? mask : 0; }
 hipError_t launch_pp(const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1, const _Float16 *Q, int Bpad, int B,
                      const float *tau, const int16_t *filter_dir, const int16_t *dir_id, ErhCand *cand,
                      uint32_t *cand_cnt, int cap, uint32_t *overflow, int ctas, int pabl, unsigned long long *dbg,
-                     int lean, uint32_t *stream_sync, hipStream_t st) {
+                     int lean, uint32_t *stream_sync, const erh::ErhSeedIo *sio, hipStream_t st) {
     const int n_qt = Bpad / pp::BN;
     const int grid_n = ctas / (8 * n_qt) * (8 * n_qt);
     if (grid_n <= 0) return hipErrorInvalidValue;
+    erh::ErhSeedIo sio_v{};
+    if (sio) sio_v = *sio;
+    const bool seed = sio_v.mode == 1;
+    if (sio_v.mode != 0 && !(lean & 8)) return hipErrorInvalidValue;    // the sample pass exists for the strict ping-pong kernel only
     const int64_t n_ct = (c1 - c0 + pp::BM - 1) / pp::BM;
     if (n_ct / (grid_n / n_qt) + 1 >= (1ll << pp::TILE_BITS)) return hipErrorInvalidValue;   // tile index must fit the record
     dim3 grid((unsigned)grid_n), block(pp::NT);
@@ -2154,20 +2194,22 @@ hipError_t launch_pp(const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1
                        tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow, dbg, rot)
 #define ERH_LAUNCH_PP3V(A, V)                                                                              \
     hipLaunchKernelGGL((dense_scan_pp3_kernel<A, V>), grid, block, pp::LDS_BYTES, st, X, N, d, c0, c1, Q, Bpad, B, tau, \
-                       filter_dir, dir_id, cand, cand_cnt, cap, overflow, dbg, rot, stream_sync)
+                       filter_dir, dir_id, cand, cand_cnt, cap, overflow, dbg, rot, stream_sync, sio_v)
 #define ERH_LAUNCH_PP3(A)                                                                                  \
     do {                                                                                                   \
-        if (halfq && pp3_halfq_ok(A)) {                    /* 65 ... 128 queries: the nt = 1 half of the tile is not computed */ \
+        if (seed) {                                        /* the sample pass: row-major operands, full kernel only */ \
+            if (halfq) ERH_LAUNCH_PP3V(0, 24); else ERH_LAUNCH_PP3V(0, 16);                                \
+        } else if (halfq && pp3_halfq_ok(A)) {             /* 65 ... 128 queries: the nt = 1 half of the tile is not computed */ \
             if (var & 2) ERH_LAUNCH_PP3V(pp3_halfq_mask(A), 10); else ERH_LAUNCH_PP3V(pp3_halfq_mask(A), 8); \
         } else if (var & 2)                                                                                \
             hipLaunchKernelGGL((dense_scan_pp3_kernel<A, 2>), grid, block, pp::LDS_BYTES, st, X, N, d, c0, c1, Q, Bpad, \
-                               B, tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow, dbg, rot, stream_sync); \
+                               B, tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow, dbg, rot, stream_sync, sio_v); \
         else if ((var & 1) && kPp3LockStep)                                                                \
             hipLaunchKernelGGL((dense_scan_pp3_kernel<A, kPp3LockStep>), grid, block, pp::LDS_BYTES, st, X, N, d, c0, c1, Q, \
-                               Bpad, B, tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow, dbg, rot, stream_sync); \
+                               Bpad, B, tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow, dbg, rot, stream_sync, sio_v); \
         else                                                                                               \
             hipLaunchKernelGGL((dense_scan_pp3_kernel<A, 0>), grid, block, pp::LDS_BYTES, st, X, N, d, c0, c1, Q, Bpad, \
-                               B, tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow, dbg, rot, stream_sync); \
+                               B, tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow, dbg, rot, stream_sync, sio_v); \
     } while (0)
 #ifdef ERH_MEASURE
 #define ERH_LAUNCH_PP(A)                                                                                   \
@@ -2239,7 +2281,7 @@ hipError_t dense_scan_init() {
     if (e != hipSuccess) return e;
 #define ERH_SET_PP(A) ERH_SET_PP3(A, 0) ERH_SET_PP3(A, 2)
     ERH_SET_PP(0)
-    ERH_SET_PP3(0, 8) ERH_SET_PP3(0, 10)
+    ERH_SET_PP3(0, 8) ERH_SET_PP3(0, 10) ERH_SET_PP3(0, 16) ERH_SET_PP3(0, 24)
 #ifdef ERH_MEASURE
     e = hipFuncSetAttribute((const void *)dense_scan_pp_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             pp::LDS_BYTES);
@@ -2273,11 +2315,19 @@ hipError_t dense_scan_init() {
 hipError_t launch_dense_scan_pp(const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1, const _Float16 *Q,
                                 int Bpad, int B, const float *tau, const int16_t *filter_dir, const int16_t *dir_id,
                                 ErhCand *cand, uint32_t *cand_cnt, int cap, uint32_t *overflow, int n_cus, int pabl,
-                                unsigned long long *dbg, int lean, uint32_t *stream_sync, hipStream_t st) {
+                                unsigned long long *dbg, int lean, uint32_t *stream_sync, const ErhSeedIo *sio,
+                                hipStream_t st) {
     if (c1 <= c0) return hipSuccess;
     if (d % (2 * pp::BK) != 0 || d / pp::BK < 8) return hipErrorInvalidValue;   // stage pairs never straddle a tile
     return launch_pp(X, N, d, c0, c1, Q, Bpad, B, tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow, n_cus, pabl,
-                     dbg, lean, stream_sync, st);
+                     dbg, lean, stream_sync, sio, st);
+}
+
+int dense_scan_pp_streams(int n_cus, int Bpad) {
+    const int n_qt = Bpad / pp::BN;
+    if (n_qt < 1 || Bpad % pp::BN != 0) return 0;
+    const int grid_n = n_cus / (8 * n_qt) * (8 * n_qt);
+    return grid_n > 0 ? (grid_n / (8 * n_qt)) * 8 : 0;
 }
 
 // The tiled-operand ping-pong scan (dense_scan_pp4_kernel): Xt / Qt are the tiled copies (launch_dense_tile_rows) of the

@@ -8,6 +8,18 @@ namespace erh {
 
 // ---- dense_scan.hip --------------------------------------------------------------------------
 int dense_scan_q_tile();   // queries are padded to a multiple of this
+// Sample pass of the strict ping-pong scan (round 4: the scan kernel draws the sample its pruning threshold is selected from).
+// The first `seed_tiles` tiles of every chunk stream are scored WITHOUT a threshold and nothing but the two best scores of
+// every "cell" -- the 64 chunk rows one lane holds of one query column -- leaves the registers: `seed_top`, the sample of
+// seed_cells_select_kernel.  The main launch then scans ALL rows, the sampled ones included, against that threshold.
+struct ErhSeedIo {
+    float *seed_top;       // [Bpad][n_cells][2]
+    int seed_tiles;        // tiles per chunk stream in the sample pass
+    int n_cells;           // seed_tiles * streams * 4
+    int mode;              // 0 none, 1 sample pass (no thresholds, no candidates)
+};
+// chunk streams (co-resident workgroups per query tile) of the ping-pong scan on n_cus CUs, 0 if the shape does not qualify
+int dense_scan_pp_streams(int n_cus, int Bpad);
 hipError_t dense_scan_init();
 hipError_t launch_dense_scan_store(int cfg, const _Float16 *Q, int Bpad, const _Float16 *X, int64_t N, int d,
                                    int64_t c0, int nc, float *S0, int ld_s0, hipStream_t st);
@@ -21,6 +33,7 @@ hipError_t launch_dense_scan_pp(const _Float16 *X, int64_t N, int d, int64_t c0,
                                 ErhCand *cand, uint32_t *cand_cnt, int cap, uint32_t *overflow, int n_cus, int pabl,
                                 unsigned long long *dbg, int lean /* the lean-issue kernel: X must be padded by kDensePadRows zero rows */,
                                 uint32_t *stream_sync /* dense_pp 3: 256 zeroed words (one per stream) or null */,
+                                const ErhSeedIo *sio /* null, or the sample pass (dense_pp 3 only) */,
                                 hipStream_t st);
 // tiled copy of the chunk matrix for the ping-pong scan: ceil(N / 256) * 256 * d halves (see dense_tile_rows_kernel)
 hipError_t launch_dense_tile_rows(const _Float16 *X, int64_t N, int d, void *Xt, hipStream_t st);
@@ -69,6 +82,8 @@ hipError_t launch_row_norm_max(const _Float16 *x, int64_t n, int d, float *out, 
 // are written to cand[q] and cand_cnt[q] is (re)initialised.
 // rank <= k: position in the prefix that seeds the threshold (k: guaranteed bound, < k: speculative, verified by
 // launch_dense_finalize when it is given tau_verify)
+hipError_t launch_seed_cells_select(const float *seed_top, int n_vals, int B, int rank, const float *qnorm, float xnorm_max, int d,
+                                    float *tau, uint32_t *cand_cnt, hipStream_t st);
 hipError_t launch_seed_select(const float *S0, int ld_s0, int n0, int64_t c0, int B, int k, int rank,
                               const float *qnorm, float xnorm_max, int d,
                               const int16_t *filter_dir, const int16_t *dir_id,

@@ -310,6 +310,35 @@ __global__ __launch_bounds__(kSelThreads) void seed_select_full_kernel(
     seed_emit(row, n0, c0, fd, dir_id, prune, q, tau, cand, cand_cnt, cap, bad, &s_cnt);
 }
 
+// Threshold from the sample pass of the ping-pong scan (round 4; kernels.h: ErhSeedIo): per query n_vals scores -- the two
+// best of every cell (64 sampled chunk rows) -- of which the rank-th largest, minus the margin, is the speculative pruning
+// threshold.  The rank-th largest of the cells' two best never exceeds the rank-th largest of the whole sample (a cell with
+// more than two of the sample's best hides the others), so the threshold errs on the safe side; dense_finalize_kernel verifies
+// it as it verifies seed_select_kernel's.  The candidate lists start empty: the main launch scans the sampled rows again.
+// grid = B, block = 256, dynamic LDS = np2 * 4 bytes.
+__global__ __launch_bounds__(256) void seed_cells_select_kernel(
+    const float *__restrict__ seed_top, int n_vals, int np2, int rank, const float *__restrict__ qnorm, float xnorm_max, int d,
+    float *__restrict__ tau, uint32_t *__restrict__ cand_cnt) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint32_t *keys = reinterpret_cast<uint32_t *>(smem);
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const float *row = seed_top + (int64_t)q * n_vals;
+    for (int i = tid; i < np2; i += 256) {
+        uint32_t key = 0u;
+        if (i < n_vals) {
+            const float v = row[i];
+            if (v > -INFINITY) key = erh_f2ord(v);
+        }
+        keys[i] = key;
+    }
+    erh_bitonic_desc<uint32_t>(keys, np2);                           // begins and ends with a barrier
+    if (tid == 0) {
+        const uint32_t v = (rank >= 1 && rank <= n_vals) ? keys[rank - 1] : 0u;
+        tau[q] = v ? erh_ord2f(v) - margin_of(qnorm[q], xnorm_max, d) : -INFINITY;
+        cand_cnt[q] = 0u;
+    }
+}
+
 // ---- refine: tighten tau from the candidates gathered so far --------------------------------------
 // grid = B, block = 1024, dynamic LDS = cp2 * 8 bytes.
 // Launched twice: with LDS for kRefineLight entries (two workgroups per CU; the usual few thousand candidates)
@@ -819,6 +848,16 @@ hipError_t launch_seed_select(const float *S0, int ld_s0, int n0, int64_t c0, in
     hipLaunchKernelGGL(seed_select_full_kernel, dim3(B), dim3(kSelThreads), (size_t)np2 * 4 + 64, st,
                        S0, ld_s0, n0, np2, c0, k, rank, qnorm, xnorm_max, d, filter_dir, dir_id, tau, cand, cand_cnt, cap,
                        bad, need_full);
+    return hipGetLastError();
+}
+
+hipError_t launch_seed_cells_select(const float *seed_top, int n_vals, int B, int rank, const float *qnorm, float xnorm_max, int d,
+                                    float *tau, uint32_t *cand_cnt, hipStream_t st) {
+    if (B <= 0) return hipSuccess;
+    const int np2 = pow2_ge(n_vals < 2 ? 2 : n_vals);
+    if ((size_t)np2 * 4 > 48 * 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(seed_cells_select_kernel, dim3(B), dim3(256), (size_t)np2 * 4, st, seed_top, n_vals, np2, rank, qnorm,
+                       xnorm_max, d, tau, cand_cnt);
     return hipGetLastError();
 }
 

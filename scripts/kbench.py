@@ -248,6 +248,20 @@ def main():
                     n_: round(v / stages, 1) for n_, v in zip(names, c[g * 8:g * 8 + 6])} if stages else {}
         eng.set_option("dense_ablate", 0)
         del x
+    if what == "selfseed":                                   # sample pass inside the scan kernel (dense_selfseed) against store kernel + S0 + seed select
+        x = synth.dense_corpus_torch(n, d, seed=2, device=dev)
+        eng.set_dense(x)
+        for B, k in ((1024, 288), (256, 100), (512, 100), (129, 100), (65, 10)):
+            q = synth.dense_queries_torch(x, B, seed=7)
+            for ss, n0 in ((1, 32768), (0, 32768), (1, 16384), (1, 32768), (0, 32768), (1, 16384)):
+                eng.set_option("dense_selfseed", ss)
+                eng.set_option("dense_n0", n0)
+                r = timed(eng, lambda: eng.dense_topk(q, k, device_out=True), 20)
+                r["sum"] = round(sum(r.values()), 4)
+                res[f"dense B={B} k={k} selfseed={ss} n0={n0} #{len(res)}"] = r
+        eng.set_option("dense_selfseed", 1)
+        eng.set_option("dense_n0", 32768)
+        del x
     if what == "p3":                                         # strict-alternation ping-pong (dense_pp=3) vs the lean one (2)
         x = synth.dense_corpus_torch(n, d, seed=2, device=dev)
         eng.set_dense(x)

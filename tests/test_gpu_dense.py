@@ -273,6 +273,64 @@ def test_dense_speculation_failure_is_caught(engine):
         engine.set_option("dense_gemv", 1)
 
 
+@pytest.mark.parametrize("b,k", [(300, 100), (512, 100), (700, 288), (1024, 10), (1024, 288)])
+def test_dense_sample_pass_matches_oracle(engine, b, k):
+    """Round 4, batches padded to 512 queries and more: the ping-pong scan draws its own threshold sample -- a pass without thresholds over the first tile(s) of every
+    chunk stream whose only output is the two best scores of every 64-row cell, a select over those, then the scan of ALL
+    rows (no store kernel, no S0).  Same ids and fp64 scores as the oracle, and as the store-kernel / S0 / seed-select path
+    (dense_selfseed = 0) bit for bit."""
+    n, d = 200_000, 256
+    x = synth.dense_corpus(n, d, seed=401)
+    q16 = to_f16_unit(synth.dense_queries(x, b, seed=402 + b))
+    engine.set_option("dense_gemv", 0)
+    try:
+        engine.set_dense(x)
+        ids, sc, ln = engine.dense_topk(q16, k)
+        diag = engine.dense_diag()
+        assert diag["uncertified"] == 0 and diag["max_abs_err"] <= diag["margin"] and diag["exhaustive"] == 0
+        engine.set_option("dense_selfseed", 0)
+        ids0, sc0, ln0 = engine.dense_topk(q16, k)
+    finally:
+        engine.set_option("dense_selfseed", 1)
+        engine.set_option("dense_gemv", 1)
+    assert np.array_equal(ids, ids0) and np.array_equal(sc.view(np.uint64), sc0.view(np.uint64)) and np.array_equal(ln, ln0)
+    assert np.all(ln == k)
+    for i in sorted(set([0, 1, b // 3, b // 2, b - 2, b - 1, min(b - 1, 127), min(b - 1, 128)])):
+        oid, osc = dense_exact_topk(x, q16[i], k)
+        assert np.array_equal(ids[i], oid), f"query {i}: ids differ"
+        assert np.array_equal(sc[i].view(np.uint64), osc.view(np.uint64)), f"query {i}: fp64 scores differ"
+
+
+def test_dense_sample_pass_with_a_cell_full_of_copies(engine):
+    """Eight copies of the chunk a query asks for, planted in ONE cell of the sampled rows (stored rows 0-3 and 8-11 of tile 0:
+    one lane of one wave holds them; dense_shuffle = 0 keeps the caller's order).  The cell shows the sample only two of them
+    (a looser threshold, never a wrong one) and the main launch scans the sampled rows like all others: all eight come back,
+    in index order, on the pruned path."""
+    rng = np.random.default_rng(9)
+    n, d, b, k = 200_000, 256, 300, 100                            # (300 queries: padded to 512, the sample pass runs; k large enough for a speculative rank)
+    x32 = rng.standard_normal((n, d))
+    hot = rng.standard_normal(d)
+    for r in (0, 1, 2, 3, 8, 9, 10, 11):
+        x32[r] = hot
+    x = to_f16_unit(x32)
+    q32 = rng.standard_normal((b, d))
+    q32[3] = hot + 0.05 * rng.standard_normal(d)
+    q16 = to_f16_unit(q32)
+    engine.set_option("dense_gemv", 0)
+    engine.set_option("dense_shuffle", 0)
+    try:
+        engine.set_dense(x)
+        ids, sc, ln = engine.dense_topk(q16, k)
+        assert engine.dense_diag()["exhaustive"] == 0
+        for i in (0, 1, 2, 3, 4, 150, 299):
+            oid, osc = dense_exact_topk(x, q16[i], k)
+            assert np.array_equal(ids[i], oid) and np.array_equal(sc[i].view(np.uint64), osc.view(np.uint64))
+        assert list(ids[3, :8]) == [0, 1, 2, 3, 8, 9, 10, 11]
+    finally:
+        engine.set_option("dense_shuffle", 1)
+        engine.set_option("dense_gemv", 1)
+
+
 def test_dense_budgets_exhausted_still_answers(engine):
     """Corpora that exhaust the pruned pipeline's budgets (boilerplate-heavy manuals are exactly EasyRAG's
     data): 20000 exact copies of the chunk a query asks for (the 16384-entry candidate list cannot hold the tie
