@@ -150,7 +150,8 @@ struct erh_handle {
     int opt_dense_rot = 0;                 // K-rotation between the query tiles of a stream, in stages per query tile (-1: nk / n_qt)
     int opt_dense_pp = 3;                  // ping-pong persistent append scan (falls back to the kernels below when it does not apply)
     int opt_dense_persist = 1;             // persistent append scan (falls back to the plain launch when it does not apply)
-    int n_cus = 0;                         // compute units of the device (persistent grids = one workgroup per CU)
+    int n_cus = 0;                         // compute units persistent grids are sized for (one workgroup per CU): the device's, or option n_cus
+    int n_cus_dev = 0;                     // compute units of the device
     // profiling
     bool prof = false;
     std::vector<EvPair> pending;
@@ -723,7 +724,7 @@ int erh_create(int device, erh_handle **out) {
     erh_handle *h = new (std::nothrow) erh_handle();
     if (!h) return ERH_ERR_NOMEM;
     h->device = device;
-    h->n_cus = prop.multiProcessorCount;
+    h->n_cus = h->n_cus_dev = prop.multiProcessorCount;
     if (erh::dense_scan_init() != hipSuccess || erh::select_init() != hipSuccess || erh::bm25_init() != hipSuccess ||
         erh::fuse_init() != hipSuccess || erh::dense_gemv_init() != hipSuccess) {   // (function attributes are per device)
         delete h;
@@ -778,6 +779,11 @@ int erh_set_option(erh_handle *h, const char *name, int64_t value) {
     if (!strcmp(name, "dense_n0_auto")) { h->opt_n0_auto = value != 0; return ERH_OK; }
     if (!strcmp(name, "dense_sync")) { h->opt_dense_sync = value != 0; return ERH_OK; }
     if (!strcmp(name, "dense_selfseed")) { h->opt_dense_selfseed = value != 0; return ERH_OK; }
+    if (!strcmp(name, "n_cus")) {          // persistent grids: the CUs the caller's stream may use (a CU-masked stream); 0 = all of the device
+        if (value < 0 || value > h->n_cus_dev) return h->fail(ERH_ERR_INVALID, "n_cus");
+        h->n_cus = value == 0 ? h->n_cus_dev : (int)value;
+        return ERH_OK;
+    }
     if (!strcmp(name, "dense_tiled")) { h->opt_dense_tiled = value != 0; return ERH_OK; }   // building the copy: at the next erh_set_dense
     if (!strcmp(name, "dense_speculate")) { h->opt_dense_speculate = value != 0; return ERH_OK; }
     if (!strcmp(name, "dense_var")) { if (value < 0 || value > 3) return h->fail(ERH_ERR_INVALID, "dense_var"); h->opt_dense_var = (int)value; return ERH_OK; }
