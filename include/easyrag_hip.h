@@ -282,6 +282,11 @@ int erh_reset_kernel_time(erh_handle *h);
  *   dense_n1 (131072)     dense_speculate 0: first refinement boundary; 0 = never refine.  Further boundaries follow x4 while 8x fits.
  *   dense_n1_auto (1)     snap the boundaries to whole rounds of the persistent scan
  *   dense_n0_auto (0)     shrink the seed prefix to where the rest is a whole number of scan rounds
+ *   dense_selfseed (1)    batches padded to >= 512 queries: the scan kernel draws the threshold sample itself (a pass without
+ *                         thresholds over one tile per chunk stream, the two best scores of every 64-row cell) and then scans
+ *                         all rows; 0 = store kernel + S0 + seed select for every batch size
+ *   n_cus (0)             CUs the persistent grids are sized for; set it when the caller's stream is CU-masked
+ *                         (hipExtStreamCreateWithCUMask), 0 = all CUs of the device
  *   dense_shuffle (1)     golden-ratio row placement of the chunk matrix (takes effect at the next erh_set_dense);
  *                         keep it on for corpora sorted by document or topic
  *   dense_pp (3)          ping-pong persistent append scan: 3 = strict alternation (fragment reads inside the matrix segment),
