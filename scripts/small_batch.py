@@ -19,7 +19,8 @@ def main():
     eng = RetrievalEngine(0)
     x = synth.dense_corpus_torch(n, d, seed=2, device=dev)
     eng.set_dense(x)
-    for pipe in (-1, 0, 1):
+    only_overlap = len(sys.argv) > 1 and sys.argv[1] == "overlap"      # just the side-stream sweep from 256 queries up
+    for pipe in (() if only_overlap else (-1, 0, 1)):
         eng.set_option("dense_gemv_pipe", pipe)
         for B, k in ((1, 288), (1, 10), (4, 288), (16, 288), (17, 288), (32, 288), (48, 288), (64, 288), (65, 288), (128, 288), (256, 288)):
             if pipe >= 0 and (B > 64 or k == 10):
@@ -52,7 +53,7 @@ def main():
     eng.set_bm25(idx, payload_on_device=True)
     eng.set_doc_meta(n, None, None)
     queries = synth.token_queries(flat, lens, vocab, 16, seed=9)
-    for B in (1, 16):
+    for B in (() if only_overlap else (1, 16)):
         q = synth.dense_queries_torch(x, B, seed=7)
         qi, qt = queries_to_csr(queries[:B])
         for segs in (0, 5, 10, 21, 31):
@@ -76,9 +77,11 @@ def main():
     eng.set_option("bm25_segs", 0)
     # the two routes are independent until the fusion: sparse route on a side stream (hybrid_overlap 1) or forked behind
     # the dense scan (2) -- at these batch sizes neither scan fills the chip
-    for B in (1, 4, 16, 64, 128, 256, 512):
+    for B in (1, 4, 16, 64, 128, 256, 384, 512, 768, 1024):
+        if only_overlap and B < 256:
+            continue
         q = synth.dense_queries_torch(x, B, seed=7)
-        qi, qt = queries_to_csr(synth.token_queries(flat, lens, vocab, 512, seed=9)[:B])
+        qi, qt = queries_to_csr(synth.token_queries(flat, lens, vocab, 1024, seed=9)[:B])
         for ov in (0, 1, 2):
             eng.set_option("hybrid_overlap", ov)
             fn = lambda: eng.hybrid_topk(q, qi, qt, k_dense=288, k_sparse=192, K=60, topk=10, device_out=True)
