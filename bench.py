@@ -443,6 +443,11 @@ def main(argv=None, platform=None):
         roof = roofline_of(kd, dom)
         if roof is not None:
             roof.update(pmc_traffic(args, dom, roof["algorithmic_bytes_per_launch"]))
+            roof["launches_per_step"] = roof["launches"] / args.steps
+            if dom == "dense_scan" and roof["launches"] > args.steps:
+                roof["launch_mix"] = ("the dense-scan class has two launches per step -- the threshold stage (sample pass of the scan "
+                                      "kernel from 512 queries on, the seed-prefix store kernel below) and the main scan; per-launch "
+                                      "figures are class totals / launches, rocprofv3 lists the two kernels separately")
         cpu = None
         if world == 1 and args.cpu_queries > 0:
             payload = payload_check = None
