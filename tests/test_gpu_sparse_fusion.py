@@ -83,9 +83,10 @@ def test_bm25_ties_and_filter(engine, bm25_kernel, variant):
     engine.set_bm25(idx)
     dir_id = (np.arange(640) // 100).astype(np.int16)
     engine.set_doc_meta(640, None, dir_id)
-    queries = [[0, 1, 2], [5], [3, 3, 7, 11], [2, 9]]
+    # (every query twice: batches of >= 8 queries take the two-workgroups-per-CU shapes of the approximate scan)
+    queries = [[0, 1, 2], [5], [3, 3, 7, 11], [2, 9]] * 2
     qi, qt = queries_to_csr([idx.tokens_to_ids(q) for q in queries])
-    filt = np.array([-1, 2, 6, 0], np.int16)
+    filt = np.tile(np.array([-1, 2, 6, 0], np.int16), 2)
     for k in (7, 100):
         ids, sc, ln = engine.bm25_topk(qi, qt, k, filter_dir=filt)
         for b, q in enumerate(queries):
@@ -109,9 +110,9 @@ def test_bm25_near_tie_flood(engine, bm25_kernel, variant):
     dir_id = (np.arange(n) % 3).astype(np.int16)
     engine.set_doc_meta(n, None, dir_id)
     present = sorted({t for d in base for t in d})
-    queries = [[present[0]], present[:2], present[:4] + [present[1]], list(present), [present[-1]] * 3 + present[:3]]
+    queries = [[present[0]], present[:2], present[:4] + [present[1]], list(present), [present[-1]] * 3 + present[:3]] * 2
     qi, qt = queries_to_csr([idx.tokens_to_ids(q) for q in queries])
-    for filt in (None, np.array([0, -1, 2, 1, 0], np.int16)):
+    for filt in (None, np.tile(np.array([0, -1, 2, 1, 0], np.int16), 2)):
         for k in (3, 192, 1000):
             ids, sc, ln = engine.bm25_topk(qi, qt, k, filter_dir=filt)
             for b, q in enumerate(queries):
@@ -196,10 +197,11 @@ def test_bm25_long_queries_frequent_terms_and_list_flood(engine, bm25_kernel, va
     engine.set_doc_meta(n_docs, None, dir_id)
     queries = [[0, 1, 2, 3, 7], [3, 3, 0, 9, 11, 12, 200], list(range(4, 80)) + [1, 1],        # 78 tokens
                [int(t) for t in rng.integers(0, vocab, size=40)], [5], [0] * 20 + list(range(30, 70))]
+    osc = [_oracle_scores(ora, variant, q) for q in queries] * 2
+    queries = queries * 2                                              # (>= 8 queries per batch: the packed shape runs them too)
     qi, qt = queries_to_csr([idx.tokens_to_ids(q) for q in queries])
-    osc = [_oracle_scores(ora, variant, q) for q in queries]
     short = [b for b, q in enumerate(queries) if len(q) <= 64]
-    for filt in (None, np.array([1, 0, 1, -1, 0, 1], np.int16)):
+    for filt in (None, np.tile(np.array([1, 0, 1, -1, 0, 1], np.int16), 2)):
         for k in (5, 192, 1024):
             for sel in (list(range(len(queries))), short):                    # mixed batch / all-short batch
                 qi2, qt2 = queries_to_csr([idx.tokens_to_ids(queries[b]) for b in sel])
