@@ -49,6 +49,8 @@ struct Bm25State {
     DevBuf tile_off16;                    // bm25s: skip table at 16384 documents for the two-workgroups-per-CU scan (Okapi: tile_off is that)
     int n_tiles16 = 0;
     DevBuf post;                          // fixed-point scan: interleaved {document, fixed-point payload} postings + one sentinel
+    DevBuf post16;                        // ... and the 4-byte postings of its packed shape {document & 32767, (q >> g16) + 1}
+    int g16 = 0;
     double qmax = 0;                      // largest fixed-point payload
     DevBuf tf;                            // kept by erh_build_bm25_index (what erh_get_bm25_csr returns)
     std::vector<double> idf_host;         // idem (float32 values widened exactly for the bm25s variant)
@@ -59,7 +61,7 @@ struct Bm25State {
     std::vector<int64_t> host_indptr;     // host copy: query validation + algorithmic-byte accounting
     int n_tiles = 0, tile_docs = 0;
     int n_fine = 0;                       // sub-ranges of the fine skip table (0 = not built: block scan only)
-    void release() { indptr.release(); doc_ids.release(); payload.release(); tile_off.release(); fine_off.release(); tf.release(); post.release(); tile_off16.release(); }
+    void release() { indptr.release(); doc_ids.release(); payload.release(); tile_off.release(); fine_off.release(); tf.release(); post.release(); post16.release(); tile_off16.release(); }
 };
 
 }  // namespace
@@ -107,6 +109,7 @@ struct erh_handle {
     bool fork_after_scan = false;         // dense_topk_dev records ev_fork behind its last scan launch (hybrid_overlap 2)
     int opt_bm25_small = 2;               // fixed-point scan, when k allows: 2 the 512-thread shape with packed 16-bit sums over 32768-document
                                           // tiles (two workgroups per CU), 1 the 512-thread shape over 16384-document tiles, 0 always 1024 threads
+    int opt_bm25_post16 = 1;              // packed shape: read the 4-byte postings (built when an index is set; 0: the 8-byte ones)
     int opt_bm25_ascan = 1;               // approximate-order scan + exact re-score when the index qualifies (positive payloads)
     int opt_bm25_wscan = 0;               // otherwise: wave-owned scan when the batch qualifies (needs the fine skip table, built at the
                                           // next erh_set_bm25_*), else the block scan
@@ -610,7 +613,8 @@ int bm25_topk_dev(erh_handle *h, const int32_t *qptr_dev, const int32_t *qtok_de
             const int tshift = (use16 || S.tile_docs == as_docs) ? 0 : 1;
             const int cut_mul = S.tile_docs > as_docs ? 2 : 1;                 // segment cuts on the exact scan's (larger) tiles
             hipError_t e = erh::launch_bm25_ascan(S.variant, shape, S.indptr.as<int64_t>(), S.doc_ids.as<int32_t>(), S.payload.p,
-                                                  S.post.p, (uint32_t)S.nnz, S.qmax,
+                                                  S.post.p, (h->opt_bm25_post16 && S.post16.p) ? S.post16.p : nullptr, S.g16,
+                                                  (uint32_t)S.nnz, S.qmax,
                                                   tab, n_tab, tshift, S.Nb, qptr_dev, qtok_dev, q_order,
                                                   B, k, segs, cut_mul, filter_dev, dir, p_sc, p_ids, p_len, h->bm_redo.as<uint32_t>(),
                                                   h->opt_bm25_ablate, dbg, st);
@@ -806,6 +810,7 @@ int erh_set_option(erh_handle *h, const char *name, int64_t value) {
     if (!strcmp(name, "bm25_segs")) { if (value < 0 || value > 64) return h->fail(ERH_ERR_INVALID, "bm25_segs"); h->opt_bm25_segs = (int)value; return ERH_OK; }
     if (!strcmp(name, "bm25_crossing")) { if (value < 0 || value > 2) return h->fail(ERH_ERR_INVALID, "bm25_crossing"); h->opt_bm25_crossing = (int)value; return ERH_OK; }
     if (!strcmp(name, "bm25_ascan")) { h->opt_bm25_ascan = value != 0; return ERH_OK; }
+    if (!strcmp(name, "bm25_post16")) { h->opt_bm25_post16 = value != 0; return ERH_OK; }
     if (!strcmp(name, "bm25_small")) { h->opt_bm25_small = value < 0 ? 0 : value > 2 ? 2 : (int)value; return ERH_OK; }
     if (!strcmp(name, "hybrid_overlap")) { if (value < -1 || value > 2) return h->fail(ERH_ERR_INVALID, "hybrid_overlap"); h->opt_hybrid_overlap = (int)value; return ERH_OK; }
     if (!strcmp(name, "bm25_wscan")) { h->opt_bm25_wscan = value != 0; return ERH_OK; }   // the fine table is built at the next erh_set_bm25_*
@@ -1013,6 +1018,7 @@ static int bm25_check_payload_sign(erh_handle *h, hipStream_t st) {
     // 1.2e-38 would round to a subnormal or to zero).  8 bytes per posting on top of the index.
     S.ascan_ok = false;
     S.post.release();
+    S.post16.release();
     // (a throw-away index of a handful of sentences -- BM25Retriever.get_scores(query, docs) -- is scanned by the block scan:
     // building the fixed-point copy would cost an allocation and three stream synchronisations per call)
     if (S.payload_positive && h->opt_bm25_ascan && S.nnz >= 2048 && S.nnz < (1LL << 28)) {         // (32-bit byte offsets into post[])
@@ -1049,12 +1055,19 @@ static int bm25_check_payload_sign(erh_handle *h, hipStream_t st) {
                 if (e == hipSuccess) e = hipStreamSynchronize(st);
                 S.qmax = std::floor((double)pmax * (double)scale) + 1.0;
                 ok = e == hipSuccess;
+                if (ok && h->opt_bm25_small == 2 && h->opt_bm25_post16) {         // the packed shape's 4-byte postings
+                    S.g16 = erh::bm25_post16_shift(S.qmax);
+                    e = S.post16.ensure((size_t)(S.nnz + 8) * 4);
+                    if (e == hipSuccess) e = erh::launch_bm25_post16(S.post.p, S.nnz, S.g16, S.post16.p, st);
+                    if (e == hipSuccess) e = hipStreamSynchronize(st);
+                    ok = e == hipSuccess;
+                }
             }
         }
         p32buf.release();
-        if (e != hipSuccess) { S.post.release(); return h->fail(e == hipErrorOutOfMemory ? ERH_ERR_NOMEM : ERH_ERR_HIP, "bm25 fixed-point postings", e); }
+        if (e != hipSuccess) { S.post.release(); S.post16.release(); return h->fail(e == hipErrorOutOfMemory ? ERH_ERR_NOMEM : ERH_ERR_HIP, "bm25 fixed-point postings", e); }
         S.ascan_ok = ok;
-        if (!ok) S.post.release();
+        if (!ok) { S.post.release(); S.post16.release(); }
     }
     return ERH_OK;
 }

@@ -811,12 +811,17 @@ static_assert(kAsOffRng + 3 * 64 * 16 <= kAsOffAcc, "range tables overlap the ac
 // lives in half sl >> 14 of word sl & 16383), sums of 16 bits.  The stored fixed-point payloads are shifted right per query
 // (as_pack_shift) until nq of them fit 16 bits, so a low half never carries into the high one.  The work per tile that
 // does not depend on the postings (ranges, descriptors, barriers, list, clear) is paid once per 32768 documents.
-template <int NT_, int TILE_, bool PACK_ = false>
+//   AsPack16: the packed shape reading a 4-BYTE posting -- {document & 32767, ((q >> G) + 1) as 16 bits}: a piece's tile is known, so
+// fifteen bits of the document suffice, and sixteen bits of payload are more than a query's sums can use anyway -- four
+// postings per lane and 16-byte load, pieces of 256: half the load instructions, half the bytes in flight per CU.
+template <int NT_, int TILE_, bool PACK_ = false, bool P16_ = false>
 struct AsCfg {
     static constexpr int NT = NT_, TILE = TILE_, NW = NT_ / 64, CAP = 2 * NT_, RESERVE = NT_ / 4;
-    static constexpr bool PACK = PACK_;
+    static constexpr bool PACK = PACK_, P16 = P16_;
+    static constexpr int PIECE = P16_ ? 256 : 128;                   // postings per piece: one 16-byte load per lane
+    static_assert(!P16_ || (PACK_ && TILE_ == 32768), "the 4-byte postings carry 15 document bits and feed the packed sums");
     static constexpr int WORDS = PACK_ ? TILE_ / 2 : TILE_;          // 32-bit accumulator words of a tile
-    static constexpr int U = PACK_ ? 2 * kAsU : kAsU;                // posting pieces per wave and tile held in registers
+    static constexpr int U = (PACK_ && !P16_) ? 2 * kAsU : kAsU;     // posting pieces per wave and tile held in registers (768 postings when packed)
     static_assert(WORDS / (NT_ / 64) == kAsRegion, "a wave owns 2048 accumulator words");
     static_assert(!PACK_ || WORDS == 16384, "the packed slot -> (word, half) split is written for 16384 words");
     static constexpr size_t OFF_CA = kAsOffAcc + (size_t)WORDS * 4;
@@ -830,6 +835,7 @@ struct AsCfg {
 using AsBig = AsCfg<1024, 32768>;
 using AsSmall = AsCfg<512, 16384>;
 using AsPack = AsCfg<512, 32768, true>;
+using AsPack16 = AsCfg<512, 32768, true, true>;
 static_assert(AsBig::BYTES <= 160 * 1024 && 2 * AsSmall::BYTES <= 160 * 1024 && 2 * AsPack::BYTES <= 160 * 1024, "fixed-point scan LDS layouts");
 
 struct AsHdr {
@@ -844,7 +850,7 @@ static_assert(sizeof(AsHdr) <= 64, "AsHdr must fit its 64-byte slot");
 typedef int as_int4 __attribute__((ext_vector_type(4)));
 typedef uint32_t as_uint2 __attribute__((ext_vector_type(2)));
 typedef uint32_t as_uint4 __attribute__((ext_vector_type(4)));
-constexpr int kAsPiece = 128;                            // postings per piece: two consecutive ones per lane, one 16-byte load
+constexpr int kAsPiece = 128;                            // postings per piece of the 8-byte format: two consecutive ones per lane, one 16-byte load
 template <int U>
 struct AsSet { as_uint4 p[U]; };     // two postings per lane: .x/.z document, .y/.w fixed-point payload
 
@@ -869,9 +875,10 @@ __device__ __forceinline__ int as_wave_scan(int x) {
 
 // lane j: raw skip-table entries a, b of token j (0, 0 for lanes without a token) -> ranges of one tile:
 // {pieces of the tokens before this one (0x7fffffff: no such token), postings, index of the first one, pieces of the tile}
+template <int PIECE = kAsPiece>
 __device__ __forceinline__ as_int4 as_make_ranges(uint32_t ip, int a, int b, int nq, int lane) {
     const int n = b - a;
-    const int c = (n + kAsPiece - 1) / kAsPiece;
+    const int c = (n + PIECE - 1) / PIECE;
     const int incl = as_wave_scan(c);
     as_int4 r;
     r[0] = lane < nq ? incl - c : 0x7fffffff;
@@ -885,7 +892,7 @@ __device__ __forceinline__ as_int4 as_make_ranges(uint32_t ip, int a, int b, int
 // lie in LDS at `rt` (64 x the vector above): first posting index and how many postings the piece holds (<= 0: none --
 // past the token's range or past the tile's last piece; > 128: the token goes on in its next piece).  Every lane scans
 // the tokens' piece offsets with broadcast reads; no wave-uniform control flow, no scalar work.
-template <int NW>
+template <int NW, int PIECE = kAsPiece>
 __device__ __forceinline__ void as_describe(const as_int4 *rt, const as_int4 *px16, int nq, int lane, int wave, uint32_t &dstart,
                                             int &dcnt) {
     const int p = wave + lane * NW;                                      // (NW = the number of waves the pieces are dealt to)
@@ -900,22 +907,27 @@ __device__ __forceinline__ void as_describe(const as_int4 *rt, const as_int4 *px
         for (int i = 0; i < nq; ++i) j += (rt[i][0] <= p) ? 1 : 0;        // non-decreasing: last token with offset <= p
     }
     const as_int4 r = rt[j < 0 ? 0 : j];
-    const int o = (p - r[0]) * kAsPiece;
+    const int o = (p - r[0]) * PIECE;
     dstart = (uint32_t)r[2] + (uint32_t)o;
     dcnt = r[1] - o;
 }
 
 // pieces [r0, r0 + kAsU) of this wave (np of them exist) -> registers; lanes without a posting read the sentinel pair
-template <int U>
-__device__ __forceinline__ void as_fill(AsSet<U> &S, uint32_t dstart, int dcnt, int r0, int np, const as_uint2 *__restrict__ post,
+template <int U, bool P16 = false>
+__device__ __forceinline__ void as_fill(AsSet<U> &S, uint32_t dstart, int dcnt, int r0, int np, const void *__restrict__ post,
                                         int lane, uint32_t sentinel) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         if (r0 + u < np) {                                                // wave-uniform
             const uint32_t st = (uint32_t)__builtin_amdgcn_readlane((int)dstart, r0 + u);
             const int cn = __builtin_amdgcn_readlane(dcnt, r0 + u);
-            const uint32_t idx = 2 * lane < cn ? st + 2u * (uint32_t)lane : sentinel;
-            S.p[u] = *reinterpret_cast<const as_uint4 *>(post + idx);
+            if constexpr (P16) {                                          // four 4-byte postings per lane
+                const uint32_t idx = 4 * lane < cn ? st + 4u * (uint32_t)lane : sentinel;
+                S.p[u] = *reinterpret_cast<const as_uint4 *>(reinterpret_cast<const uint32_t *>(post) + idx);
+            } else {
+                const uint32_t idx = 2 * lane < cn ? st + 2u * (uint32_t)lane : sentinel;
+                S.p[u] = *reinterpret_cast<const as_uint4 *>(reinterpret_cast<const as_uint2 *>(post) + idx);
+            }
         }
     }
 }
@@ -971,6 +983,42 @@ __device__ __forceinline__ void as_apply(const AsSet<U> &S, int dcnt, int r0, in
                 as_note<NW>(thx - 1u - o0[u] < q0[u], (int)S.p[u].x - base_doc, xl, xz);
                 as_note<NW>(thx - 1u - o1[u] < q1[u], (int)S.p[u].z - base_doc, xl, xz);
             }
+        }
+    }
+}
+
+// the 4-byte postings onto the packed sums: word w of a piece = {slot of the tile in bits 0-14, 16-bit payload in bits 16-31};
+// four per lane.  Same shape as as_apply: all adds of the round issued back to back, returns collected afterwards.
+template <int NW, int U>
+__device__ __forceinline__ void as_apply16(const AsSet<U> &S, int dcnt, int r0, int np, int lane, uint32_t *accu, uint32_t *dummy,
+                                           uint32_t thx, int32_t *xl, int *xz, int sh) {
+    uint32_t o[U][4], q[U][4];
+    uint32_t *mine = dummy + lane;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        int cn = __builtin_amdgcn_readlane(dcnt, r0 + u < 64 ? r0 + u : 63);
+        cn = r0 + u < np ? cn : 0;                                        // scalar select
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t w = S.p[u][e];
+            const bool v = 4 * lane + e < cn;
+            const uint32_t hb = (w >> 10) & 16u;                          // slot bit 14 -> the half's bit offset
+            q[u][e] = v ? ((w >> 16) >> sh) + 1u : 0u;
+            o[u][e] = atomicAdd(v ? &accu[w & 16383u] : mine, q[u][e] << hb);
+            o[u][e] = (o[u][e] >> hb) & 0xffffu;
+        }
+    }
+    if (thx) {
+        bool any = false;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) any |= thx - 1u - o[u][e] < q[u][e];   // old < thx <= old + q
+        if (__builtin_amdgcn_ballot_w64(any)) {                           // wave-uniform, rare once the threshold has settled
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) as_note<NW>(thx - 1u - o[u][e] < q[u][e], (int)(S.p[u][e] & 32767u), xl, xz);
         }
     }
 }
@@ -1332,7 +1380,8 @@ __device__ __forceinline__ void as_finish_query(char *smem, BmHdr *hdr, uint32_t
 template <typename ST, class C>
 __global__ __launch_bounds__(C::NT, 4 /* waves per SIMD: two 512-thread workgroups per CU */) void bm25_ascan_kernel(
     const int64_t *__restrict__ indptr, const int32_t *__restrict__ doc_ids, const ST *__restrict__ payload,
-    const as_uint2 *__restrict__ post, uint32_t nnz, double qmax /* largest fixed-point payload of the index */,
+    const void *__restrict__ post /* as_uint2 {document, q}, or for C::P16 the 4-byte postings */, uint32_t nnz,
+    double qmax /* largest fixed-point payload of the index */, int g16 /* C::P16: the 4-byte postings hold (q >> g16) + 1 */,
     const int32_t *__restrict__ tile_off, int n_tab, int tshift, int n_tiles, int64_t N,
     const int32_t *__restrict__ q_indptr, const int32_t *__restrict__ q_tok, const int32_t *__restrict__ q_order, int k,
     int segs, int cut_mul /* segment boundaries fall on multiples of cut_mul tiles (the exact scan's tile may be larger) */,
@@ -1375,8 +1424,10 @@ __global__ __launch_bounds__(C::NT, 4 /* waves per SIMD: two 512-thread workgrou
     t_end = t_end < n_tiles ? t_end : n_tiles;
     const int64_t out_base = ((int64_t)q * segs + seg) * k;
     const double keep_frac = 1.0 - 3.0 * 1.01 * (double)(nq + 2) * 5.9604644775390625e-08;   // 1 - 3 eps
-    const int n_err = C::PACK ? 2 * nq : nq;                              // units a sum can exceed the real one by (as_drop_threshold)
-    const int sh = C::PACK ? as_pack_shift(nq, qmax) : 0;                 // packed sums: right shift of the stored payloads
+    // units a sum can exceed the real one by (as_drop_threshold): one per truncation + 1 the payload has gone through
+    const int n_err = C::P16 ? 3 * nq : C::PACK ? 2 * nq : nq;
+    const double qm_eff = C::P16 ? (double)((uint64_t)qmax >> g16) + 1.0 : qmax;
+    const int sh = C::PACK ? as_pack_shift(nq, qm_eff) : 0;               // packed sums: right shift of the stored payloads
 
     if (tid == 0) {
         hdr->ncand = 0; hdr->total = 0; hdr->tau_idx = 0x7fffffff; hdr->tau_s = 0.0;
@@ -1447,6 +1498,10 @@ __global__ __launch_bounds__(C::NT, 4 /* waves per SIMD: two 512-thread workgrou
     bool stop = h2->redo != 0;
     if (nq > 0 && t_begin < t_end && !stop) {
         AsSet<U> S;
+        auto apply = [&](int dc, int r0, int np, int base_doc, uint32_t thx, int *xz) __attribute__((always_inline)) {
+            if constexpr (C::P16) as_apply16<NW, U>(S, dc, r0, np, lane, accu, dummy, thx, xl, xz, sh);
+            else as_apply<NW, U, C::PACK>(S, dc, r0, np, lane, accu, dummy, base_doc, thx, xl, xz, sh);
+        };
         auto pieces_of = [&](int pt, int nd) __attribute__((always_inline)) -> int {   // this wave's share of a tile's pt pieces, dealt to waves 0 .. nd - 1
             return (wave < nd && pt > wave) ? (pt - wave + nd - 1) / nd : 0;
         };
@@ -1471,7 +1526,7 @@ __global__ __launch_bounds__(C::NT, 4 /* waves per SIMD: two 512-thread workgrou
                 b = tokl ? fo[i1] : 0;
             };
             auto publish = [&](int slot, int a, int b) __attribute__((always_inline)) {   // publishing wave only
-                const as_int4 r = as_make_ranges(ip, a, b, nq, lane);
+                const as_int4 r = as_make_ranges<C::PIECE>(ip, a, b, nq, lane);
                 rng[slot * 64 + lane] = r;
                 if (lane < 16) pxs[slot * 16 + lane] = r[0];
                 if (lane == 0 && r[3] > 64 * ND) h2->redo = 1;      // more pieces than the waves' lanes can describe
@@ -1487,9 +1542,9 @@ __global__ __launch_bounds__(C::NT, 4 /* waves per SIMD: two 512-thread workgrou
             __syncthreads();
             uint32_t ds_c, ds_n = 0u;                                     // this tile's / the next tile's piece descriptors
             int dc_c, dc_n = 0;
-            as_describe<ND>(rng, reinterpret_cast<const as_int4 *>(pxs), nq, lane, wave, ds_c, dc_c);
+            as_describe<ND, C::PIECE>(rng, reinterpret_cast<const as_int4 *>(pxs), nq, lane, wave, ds_c, dc_c);
             int np_c = pieces_of(__builtin_amdgcn_readfirstlane(rng[0][3]), ND), np_n = 0;
-            as_fill(S, ds_c, dc_c, 0, np_c, post, lane, nnz);
+            as_fill<U, C::P16>(S, ds_c, dc_c, 0, np_c, post, lane, nnz);
             int r3 = 0;                                                   // (tile - t_begin) % 3: slot of the current tile's ranges
             for (int tile = t_begin; tile < t_end && !stop; ++tile) {
                 const int base_doc = tile * TILE;
@@ -1498,7 +1553,7 @@ __global__ __launch_bounds__(C::NT, 4 /* waves per SIMD: two 512-thread workgrou
                 int *xz = xzb + (tile & 1) * (NW + 1);
                 const int r_n = r3 == 2 ? 0 : r3 + 1, r_nn = r_n == 2 ? 0 : r_n + 1;
                 if (!ERH_ABL(8)) {                                        // next tile (clamped past the end)
-                    as_describe<ND>(rng + r_n * 64, reinterpret_cast<const as_int4 *>(pxs + r_n * 16), nq, lane, wave, ds_n, dc_n);
+                    as_describe<ND, C::PIECE>(rng + r_n * 64, reinterpret_cast<const as_int4 *>(pxs + r_n * 16), nq, lane, wave, ds_n, dc_n);
                     np_n = pieces_of(__builtin_amdgcn_readfirstlane(rng[r_n * 64][3]), ND);
                 }
                 ERH_SEC(0);
@@ -1506,13 +1561,13 @@ __global__ __launch_bounds__(C::NT, 4 /* waves per SIMD: two 512-thread workgrou
                 if (dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); ERH_SEC(6); }   // (measurement: load wait on its own, booked under [6])
 #endif
                 const uint32_t thx = thq > 1u ? thq : 0u;
-                if (!ERH_ABL(1)) as_apply<NW, U, C::PACK>(S, dc_c, 0, np_c, lane, accu, dummy, base_doc, thx, xl, xz, sh);   // (requested a tile ago)
+                if (!ERH_ABL(1)) apply(dc_c, 0, np_c, base_doc, thx, xz);   // (requested a tile ago)
 #ifdef ERH_MEASURE
                 if (dbg) ERH_SEC(7);                                      // (measurement: the adds on their own, booked under [7])
 #endif
                 for (int r0 = U; r0 < np_c; r0 += U) {              // more pieces than the register slots hold (long posting lists)
-                    as_fill(S, ds_c, dc_c, r0, np_c, post, lane, nnz);
-                    as_apply<NW, U, C::PACK>(S, dc_c, r0, np_c, lane, accu, dummy, base_doc, thx, xl, xz, sh);
+                    as_fill<U, C::P16>(S, ds_c, dc_c, r0, np_c, post, lane, nnz);
+                    apply(dc_c, r0, np_c, base_doc, thx, xz);
                 }
                 if (wave == PW) {                                          // ranges of tile + 2 -> LDS, skip-table entries of tile + 3
                     publish(r_nn, ra, rb);
@@ -1520,7 +1575,7 @@ __global__ __launch_bounds__(C::NT, 4 /* waves per SIMD: two 512-thread workgrou
                 }
                 // (the next tile's postings are requested LAST: the publishing wave's wait for its two table entries would otherwise
                 // -- the counter is in order -- also wait for them)
-                if (!ERH_ABL(2)) as_fill(S, ds_n, dc_n, 0, np_n, post, lane, nnz);   // lands during the bookkeeping below
+                if (!ERH_ABL(2)) as_fill<U, C::P16>(S, ds_n, dc_n, 0, np_n, post, lane, nnz);   // lands during the bookkeeping below
                 ERH_SEC(1);
                 __syncthreads();                                          // every posting of the tile is in its sum
                 ERH_SEC(2);
@@ -1551,18 +1606,18 @@ __global__ __launch_bounds__(C::NT, 4 /* waves per SIMD: two 512-thread workgrou
                             a = foc[i0];
                             b = foc[i1];
                         }
-                        const as_int4 r = as_make_ranges(ipc, a, b, nqc, lane);
+                        const as_int4 r = as_make_ranges<C::PIECE>(ipc, a, b, nqc, lane);
                         rng[lane] = r;
                         if (lane == 0 && r[3] > 64 * NW) h2->redo = 1;
                     }
                     __syncthreads();
                     uint32_t ds;
                     int dc;
-                    as_describe<NW>(rng, nullptr, nqc, lane, wave, ds, dc);
+                    as_describe<NW, C::PIECE>(rng, nullptr, nqc, lane, wave, ds, dc);
                     const int np = pieces_of(__builtin_amdgcn_readfirstlane(rng[0][3]), NW);
                     for (int r0 = 0; r0 < np; r0 += U) {
-                        as_fill(S, ds, dc, r0, np, post, lane, nnz);
-                        as_apply<NW, U, C::PACK>(S, dc, r0, np, lane, accu, dummy, base_doc, thx, xl, xz, sh);
+                        as_fill<U, C::P16>(S, ds, dc, r0, np, post, lane, nnz);
+                        apply(dc, r0, np, base_doc, thx, xz);
                     }
                     __syncthreads();                                      // (the ranges are overwritten by the next chunk)
                 }
@@ -1599,6 +1654,15 @@ __global__ void bm25_post_kernel(const int32_t *__restrict__ doc_ids, const floa
         if (i < nnz) { v.x = (uint32_t)doc_ids[i]; v.y = (uint32_t)(pay32[i] * scale) + 1u; }
         else { v.x = 0xffffffffu; v.y = 0u; }
         post[i] = v;
+    }
+}
+
+// 4-byte postings of the packed scan: post16[i] = (document & 32767) | (((q >> g) + 1) << 16), zeros from index nnz on
+__global__ void bm25_post16_kernel(const as_uint2 *__restrict__ post, int64_t nnz, int g, uint32_t *__restrict__ post16) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nnz + 8; i += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t v = 0u;
+        if (i < nnz) { const as_uint2 p = post[i]; v = (p.x & 32767u) | (((p.y >> g) + 1u) << 16); }
+        post16[i] = v;
     }
 }
 
@@ -1713,6 +1777,10 @@ hipError_t bm25_init() {
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void *)bm25_ascan_kernel<double, AsPack>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AsPack::BYTES);
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void *)bm25_ascan_kernel<float, AsPack16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AsPack16::BYTES);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void *)bm25_ascan_kernel<double, AsPack16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AsPack16::BYTES);
+    if (e != hipSuccess) return e;
     return hipFuncSetAttribute((const void *)bm25_merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                8192 * 12 + 64);
 }
@@ -1764,23 +1832,44 @@ int bm25_ascan_tile_docs(int shape) { return shape == 1 ? AsSmall::TILE : AsBig:
 int bm25_ascan_small_max_k() { return AsSmall::CAP - AsSmall::NT / 2 - 3 * AsSmall::RESERVE; }   // 384: the shrink trigger (k + 256) leaves room for the notes of a tile
 
 hipError_t launch_bm25_ascan(int variant, int small, const int64_t *indptr, const int32_t *doc_ids, const void *payload,
-                             const void *post, uint32_t nnz, double qmax, const int32_t *tile_off, int n_tab, int tshift,
-                             int64_t N, const int32_t *q_indptr, const int32_t *q_tok, const int32_t *q_order, int B, int k,
-                             int segs, int cut_mul, const int16_t *filter_dir, const int16_t *dir_id,
-                             double *part_scores, int32_t *part_ids, int32_t *part_len, uint32_t *redo, int ablate,
-                             unsigned long long *dbg, hipStream_t st) {
+                             const void *post, const void *post16, int g16, uint32_t nnz, double qmax, const int32_t *tile_off,
+                             int n_tab, int tshift, int64_t N, const int32_t *q_indptr, const int32_t *q_tok,
+                             const int32_t *q_order, int B, int k, int segs, int cut_mul, const int16_t *filter_dir,
+                             const int16_t *dir_id, double *part_scores, int32_t *part_ids, int32_t *part_len, uint32_t *redo,
+                             int ablate, unsigned long long *dbg, hipStream_t st) {
     if (B <= 0) return hipSuccess;
     if (cut_mul < 1) cut_mul = 1;
     const int tile = bm25_ascan_tile_docs(small);
     const int n_tiles = (int)((N + tile - 1) / tile);
     dim3 grid(segs, B);
-#define ERH_AS_LAUNCH(ST, CFG)                                                                                       \
+#define ERH_AS_LAUNCH(ST, CFG, POST)                                                                                 \
     hipLaunchKernelGGL((bm25_ascan_kernel<ST, CFG>), grid, dim3(CFG::NT), CFG::BYTES, st, indptr, doc_ids,           \
-                       (const ST *)payload, (const as_uint2 *)post, nnz, qmax, tile_off, n_tab, tshift, n_tiles, N, q_indptr, \
+                       (const ST *)payload, POST, nnz, qmax, g16, tile_off, n_tab, tshift, n_tiles, N, q_indptr,      \
                        q_tok, q_order, k, segs, cut_mul, filter_dir, dir_id, part_scores, part_ids, part_len, redo, ablate, dbg)
-    if (variant == 0) { if (small == 2) ERH_AS_LAUNCH(double, AsPack); else if (small) ERH_AS_LAUNCH(double, AsSmall); else ERH_AS_LAUNCH(double, AsBig); }
-    else { if (small == 2) ERH_AS_LAUNCH(float, AsPack); else if (small) ERH_AS_LAUNCH(float, AsSmall); else ERH_AS_LAUNCH(float, AsBig); }
+#define ERH_AS_SHAPES(ST)                                                                                            \
+    do {                                                                                                             \
+        if (small == 2 && post16) ERH_AS_LAUNCH(ST, AsPack16, post16);                                               \
+        else if (small == 2) ERH_AS_LAUNCH(ST, AsPack, post);                                                        \
+        else if (small) ERH_AS_LAUNCH(ST, AsSmall, post);                                                            \
+        else ERH_AS_LAUNCH(ST, AsBig, post);                                                                         \
+    } while (0)
+    if (variant == 0) ERH_AS_SHAPES(double); else ERH_AS_SHAPES(float);
+#undef ERH_AS_SHAPES
 #undef ERH_AS_LAUNCH
+    return hipGetLastError();
+}
+
+// 4-byte postings: the smallest shift g with (qmax >> g) + 1 <= 65535
+int bm25_post16_shift(double qmax) {
+    const uint64_t qm = (uint64_t)qmax;
+    int g = 0;
+    while (((qm >> g) + 1ull) > 65535ull) ++g;
+    return g;
+}
+
+hipError_t launch_bm25_post16(const void *post, int64_t nnz, int g, void *post16, hipStream_t st) {
+    const unsigned grid = (unsigned)std::min<int64_t>((nnz + 8 + 255) / 256, 8192);
+    hipLaunchKernelGGL(bm25_post16_kernel, dim3(grid), dim3(256), 0, st, (const as_uint2 *)post, nnz, g, (uint32_t *)post16);
     return hipGetLastError();
 }
 

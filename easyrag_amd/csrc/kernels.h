@@ -135,13 +135,18 @@ int bm25_ascan_tile_docs(int small);   // 32768, or 16384 for the two-workgroups
 int bm25_ascan_small_max_k();
 float bm25_post_scale(float pmax);
 hipError_t launch_bm25_post(const int32_t *doc_ids, const float *pay32, int64_t nnz, float scale, void *post, hipStream_t st);
-hipError_t launch_bm25_ascan(int variant, int small /* 512 threads, 16384-document tiles, two workgroups per CU */, const int64_t *indptr, const int32_t *doc_ids, const void *payload,
-                             const void *post, uint32_t nnz, double qmax, const int32_t *tile_off, int n_tab, int tshift,
+hipError_t launch_bm25_ascan(int variant, int small /* 0: 1024 threads; 1: 512 threads, 16384-document tiles; 2: packed 16-bit sums */,
+                             const int64_t *indptr, const int32_t *doc_ids, const void *payload,
+                             const void *post, const void *post16 /* shape 2: the 4-byte postings (launch_bm25_post16), or null */, int g16,
+                             uint32_t nnz, double qmax, const int32_t *tile_off, int n_tab, int tshift,
                              int64_t N, const int32_t *q_indptr, const int32_t *q_tok, const int32_t *q_order, int B, int k,
                              int segs, int cut_mul /* segment cuts on multiples of this many tiles */,
                              const int16_t *filter_dir, const int16_t *dir_id,
                              double *part_scores, int32_t *part_ids, int32_t *part_len, uint32_t *redo,
                              int ablate /* measurement builds only */, unsigned long long *dbg, hipStream_t st);
+// 4-byte postings of the packed scan {document & 32767, (q >> g) + 1 in 16 bits}: nnz + 8 words (zeros behind the postings)
+int bm25_post16_shift(double qmax);
+hipError_t launch_bm25_post16(const void *post, int64_t nnz, int g, void *post16, hipStream_t st);
 hipError_t launch_narrow_f64(const double *in, int64_t n, float *out, hipStream_t st);
 hipError_t launch_bm25_payload_max(const float *pay32, int64_t nnz, uint32_t *bits, hipStream_t st);
 // wave-owned scan (bm25.hip: bm25_wscan_kernel): fine_off = skip table at bm25_wscan_sub_docs() granularity

@@ -312,6 +312,8 @@ int erh_reset_kernel_time(erh_handle *h);
  *                         tiles, two documents per accumulator word (16-bit sums, payloads shifted per query); 1 = 512 threads,
  *                         16384-document tiles, 32-bit sums (both: 80 KiB of LDS, two workgroups = two queries per CU);
  *                         0 = always 1024 threads, 32768-document tiles.  Same results, bit for bit
+ *   bm25_post16 (1)       packed shape: read 4-byte postings {15-bit document offset in the tile, 16-bit payload} (built when an
+ *                         index is set while bm25_small = 2; + 4 bytes per posting); 0 = the 8-byte fixed-point postings
  *   bm25_crossing (1)     wave-owned scan: survivors from threshold crossings noted in the token loop instead of a sweep
  *                         over the accumulators (1 = fp32 sums only, 2 = fp64 too, 0 = always sweep); indices with a
  *                         non-positive payload always sweep

@@ -329,6 +329,19 @@ def main():
                     r = timed(eng, lambda: eng.bm25_topk(qi, qt, k, device_out=True), 10)
                     print(f"bm25s B={Bq} k={k} segs={sg} (run {rep})  {json.dumps(r)}", flush=True)
         eng.set_option("bm25_segs", 0)
+    if what == "bm25p16":                                    # packed shape: 4-byte postings (bm25_post16) against the 8-byte ones
+        indptr, doc, tf, lens, flat = synth.token_csr_torch(n, vocab, seed=3, device=dev)
+        for variant, name in ((BM25S, "bm25s"), (OKAPI, "okapi")):
+            idx = build_bm25_index_from_postings(indptr, doc, tf, lens, variant, compute_payload=False)
+            queries = synth.token_queries(flat, lens, vocab, 1024, seed=9)
+            eng.set_bm25(idx, payload_on_device=True)
+            for Bq, k in ((1024, 192), (256, 100), (64, 100)):
+                qi, qt = queries_to_csr(queries[:Bq])
+                for p16 in (1, 0, 1, 0):
+                    eng.set_option("bm25_post16", p16)
+                    r = timed(eng, lambda: eng.bm25_topk(qi, qt, k, device_out=True), 10)
+                    print(f"{name} B={Bq} k={k} post16={p16}  {json.dumps(r)}", flush=True)
+            eng.set_option("bm25_post16", 1)
     if what == "bm25a":                                      # fixed-point scan + exact re-score: times, ablations, section clocks
         class _Live(dict):
             def __setitem__(self, k_, v_):
