@@ -70,7 +70,8 @@ def main():
                 for o, v in (("dense_pp", 3), ("dense_persist", 1), ("dense_cfg", 0), ("dense_speculate", 1), ("dense_sync", 0), ("dense_rot", 0)):
                     eng.set_option(o, v)
         if name == "bm25":                                    # every BM25 scan kernel must give the same exact result
-            for label, opts in (("fixed-point scan, 1024-thread shape", {"bm25_small": 0}),
+            for label, opts in (("fixed-point scan, packed shape on 8-byte postings", {"bm25_post16": 0}),
+                                ("fixed-point scan, 1024-thread shape", {"bm25_small": 0}),
                                 ("fixed-point scan, 512-thread shape, 32-bit sums", {"bm25_small": 1}),
                                 ("block scan (library summation order during the scan)", {"bm25_ascan": 0})):
                 for o, v in opts.items():
@@ -82,8 +83,9 @@ def main():
                     bad += 1
                     print(f"{name}: {label} differs from the default kernel")
                 eng.set_option("bm25_small", 2)
+                eng.set_option("bm25_post16", 1)
                 eng.set_option("bm25_ascan", 1)
-        extra = " (+ three other scan kernels)" if name == "bm25" else " (+ six other scan kernels / pruning schemes)"
+        extra = " (+ four other scan kernels)" if name == "bm25" else " (+ six other scan kernels / pruning schemes)"
         print(f"{name}: {reps} repeats{extra}, B={B}: {'identical' if not bad else 'DIFFERENCES'}")
     eng.close()
     sys.exit(1 if bad else 0)

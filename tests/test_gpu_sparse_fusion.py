@@ -13,9 +13,10 @@ from oracle.retrievers import Item
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[(1, 0, 1, 2), (1, 0, 1, 1), (1, 0, 1, 0), (0, 1, 2, 2), (0, 1, 0, 2), (0, 0, 0, 2)],
-                ids=["approx-scan-packed", "approx-scan-small", "approx-scan-big", "wave-owned-crossings", "wave-owned-sweep",
-                     "block-scan"])
+@pytest.fixture(params=[(1, 0, 1, 2, 1), (1, 0, 1, 2, 0), (1, 0, 1, 1, 1), (1, 0, 1, 0, 1), (0, 1, 2, 2, 1), (0, 1, 0, 2, 1),
+                        (0, 0, 0, 2, 1)],
+                ids=["approx-scan-packed-4byte", "approx-scan-packed-8byte", "approx-scan-small", "approx-scan-big",
+                     "wave-owned-crossings", "wave-owned-sweep", "block-scan"])
 def bm25_kernel(request, engine):
     """Every BM25 scan kernel / survivor-selection path must satisfy every parity test (bm25_ascan / bm25_wscan take
     effect at the next set_bm25)."""
@@ -23,11 +24,13 @@ def bm25_kernel(request, engine):
     engine.set_option("bm25_wscan", request.param[1])
     engine.set_option("bm25_crossing", request.param[2])
     engine.set_option("bm25_small", request.param[3])       # shape of the approximate scan for batches of >= 8 queries
+    engine.set_option("bm25_post16", request.param[4])      # packed shape: 4-byte or 8-byte postings
     yield request.param
     engine.set_option("bm25_ascan", 1)
     engine.set_option("bm25_wscan", 0)
     engine.set_option("bm25_crossing", 1)
     engine.set_option("bm25_small", 2)
+    engine.set_option("bm25_post16", 1)
 
 
 def _oracle_for(variant, docs):
