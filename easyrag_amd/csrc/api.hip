@@ -82,6 +82,9 @@ struct erh_handle {
     DevBuf Qt;                               // tiled copy of the query block of the current call (dense_pp = 4)
     DevBuf seed_top;                         // sample pass of the ping-pong scan: the cells' two best scores (kernels.h: ErhSeedIo)
     bool xt_valid = false;
+    DevBuf Xt384;                            // 384-row tiled copy of X for the 384 x 256 scan (dense_scan_pp5_kernel), built on first use
+    bool xt384_valid = false;
+    bool qt5_valid = false;                  // Qt holds the tiled copy of the CURRENT call's Q16 for that scan
     bool qt_valid = false;                   // Qt holds the tiled copy of the CURRENT call's Q16
     int64_t N = 0;
     int d = 0;
@@ -147,6 +150,7 @@ struct erh_handle {
     int opt_n0_auto = 0;                   // seed prefix snapped down to a whole number of scan rounds (less seed work, more candidates: a wash at 1M chunks)
     int opt_dense_sync = 0;                // the query-tile workgroups of a stream meet at a counter every four tiles (measured: no gain)
     int opt_dense_selfseed = 1;            // the ping-pong scan draws its own threshold sample (sample pass + cell maxima) instead of store kernel + S0 + seed select
+    int opt_dense_tile384 = 1;             // batches padded to >= 512 queries scan on a 384 x 256 tile over tiled operands (+ N * d * 2 bytes on first use)
     int opt_dense_tiled = 0;               // keep a tiled, pre-swizzled copy of the chunk matrix for the ping-pong scan (+ N * d * 2 bytes; no measurable gain: off)
     int opt_dense_speculate = 1;           // speculative (verified) first threshold + a single scan stage; 0: guaranteed bounds, refined in stages
     int opt_dense_var = 0;                 // dense_scan_pp2_kernel VAR (bit 0: two barriers per stage, bit 1: static priority)
@@ -268,6 +272,14 @@ hipError_t scan_append(erh_handle *h, const _Float16 *X, int64_t N, int d, int64
     }
     const int abl = h->opt_dense_ablate;
     const bool pp_code = abl == 0 || abl == 7 || abl == 8 || (abl >= 11 && abl <= 18) || (abl >= 20 && abl <= 24);
+    if (h->qt5_valid && h->xt384_valid && abl == 0 && X == h->X.as<_Float16>()) {
+        // 384 x 256 tile over the tiled copies (the caller checked the options and built the copies)
+        hipError_t e = erh::launch_dense_scan_pp5(h->Xt384.as<_Float16>(), N, d, c0, c1, h->Qt.as<_Float16>(), Bpad, B, tau, filt,
+                                                  dir, cand, cnt, cap, flags, h->n_cus,
+                                                  h->opt_dense_rot >= 0 ? h->opt_dense_rot : 0 /* the workgroups of a stream on the same stage: measured best here (profiles/r04w_kbench_tile384.log) */, st);
+        if (e != hipErrorInvalidValue) return e;
+        (void)hipGetLastError();
+    }
     if (h->opt_dense_pp >= 4 && pp_code && X == h->X.as<_Float16>() && h->xt_valid && h->qt_valid) {
         // both operands from their tiled copies (dense_scan_pp4_kernel)
         hipError_t e = erh::launch_dense_scan_pp4(h->Xt.as<_Float16>(), N, d, c0, c1, h->Qt.as<_Float16>(), Bpad, B, tau, filt,
@@ -347,6 +359,7 @@ int dense_topk_dev(erh_handle *h, const void *q_dev, int q_dtype, int normalize_
     HIPCHK(h, hipMemsetAsync(flags, 0, 64, st));
 
     h->qt_valid = false;
+    h->qt5_valid = false;
     { ProfScope ps(h, st, ERH_K_DENSE_SELECT, 0, 0);
       HIPCHK(h, erh::launch_prep_queries(q_dev, q_dtype, normalize_q, B, Bpad, d, h->Q16.as<_Float16>(),
                                          h->qnorm.as<float>(), st));
@@ -355,6 +368,23 @@ int dense_topk_dev(erh_handle *h, const void *q_dev, int q_dtype, int normalize_
           HIPCHK(h, h->Qt.ensure((size_t)Bpad * d * 2));
           HIPCHK(h, erh::launch_dense_tile_rows(h->Q16.as<_Float16>(), Bpad, d, h->Qt.p, st));
           h->qt_valid = true;
+      }
+      // the 384 x 256 scan of batches padded to >= 512 queries: the chunk matrix' 384-row tiled copy (once per erh_set_dense, here
+      // on first use) and the query block as stage images (512 KiB per 256 queries, per call)
+      if (h->opt_dense_tile384 && Bpad >= 2 * QT && h->opt_dense_pp == 3 && h->opt_dense_var == 0 && h->opt_dense_ablate == 0 &&
+          !h->opt_dense_sync && d % 64 == 0 && d / 32 >= 8 && N >= 2 * erh::dense_scan_pp5_rows()) {
+          if (!h->xt384_valid) {
+              const int rows = erh::dense_scan_pp5_rows();
+              const int64_t n_tiles = (N + rows - 1) / rows;
+              HIPCHK(h, h->Xt384.ensure((size_t)n_tiles * rows * (size_t)d * 2));
+              HIPCHK(h, erh::launch_dense_tile_rows_n(h->X.as<_Float16>(), N, d, rows, h->Xt384.p, st));
+              h->xt384_valid = true;
+          }
+          if (!h->qt_valid) {
+              HIPCHK(h, h->Qt.ensure((size_t)Bpad * d * 2));
+              HIPCHK(h, erh::launch_dense_tile_rows(h->Q16.as<_Float16>(), Bpad, d, h->Qt.p, st));
+          }
+          h->qt5_valid = true;
       } }
     const _Float16 *X = h->X.as<_Float16>();
     const _Float16 *Q16 = h->Q16.as<_Float16>();
@@ -747,7 +777,7 @@ int erh_destroy(erh_handle *h) {
     drain_events(h);
     for (auto &ev : h->pool) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
     if (h->side) { (void)hipStreamDestroy(h->side); (void)hipEventDestroy(h->ev_fork); (void)hipEventDestroy(h->ev_join); }
-    DevBuf *bufs[] = {&h->X, &h->Xt, &h->Qt, &h->seed_top, &h->scan_sync, &h->qorder, &h->content_id, &h->dir_id,
+    DevBuf *bufs[] = {&h->X, &h->Xt, &h->Xt384, &h->Qt, &h->seed_top, &h->scan_sync, &h->qorder, &h->content_id, &h->dir_id,
                       &h->qin, &h->Q16, &h->qnorm, &h->tau, &h->S0, &h->cand, &h->cand_cnt, &h->flags, &h->filt, &h->filt2,
                       &h->o_ids, &h->o_sc, &h->o_len, &h->qptr, &h->qtok, &h->part_sc, &h->part_ids, &h->part_len,
                       &h->hy_sids, &h->hy_ssc, &h->hy_slen, &h->hy_dids, &h->hy_dsc, &h->hy_dlen,
@@ -788,6 +818,7 @@ int erh_set_option(erh_handle *h, const char *name, int64_t value) {
         h->n_cus = value == 0 ? h->n_cus_dev : (int)value;
         return ERH_OK;
     }
+    if (!strcmp(name, "dense_tile384")) { h->opt_dense_tile384 = value != 0; return ERH_OK; }
     if (!strcmp(name, "dense_tiled")) { h->opt_dense_tiled = value != 0; return ERH_OK; }   // building the copy: at the next erh_set_dense
     if (!strcmp(name, "dense_speculate")) { h->opt_dense_speculate = value != 0; return ERH_OK; }
     if (!strcmp(name, "dense_var")) { if (value < 0 || value > 3) return h->fail(ERH_ERR_INVALID, "dense_var"); h->opt_dense_var = (int)value; return ERH_OK; }
@@ -953,6 +984,7 @@ int erh_set_dense(erh_handle *h, const void *x, int64_t n, int d, int dtype, int
     h->N = n;
     h->d = d;
     // tiled copy for the ping-pong scan (dense_scan.hip: dense_tile_rows_kernel); d / 32 >= 8 stages as the kernel wants
+    h->xt384_valid = false;                // (the 384-row copy is rebuilt on first use)
     h->xt_valid = false;
     if (h->opt_dense_tiled && d % 64 == 0 && d >= 256) {
         const int64_t n_tiles = (n + 255) / 256;

@@ -2034,6 +2034,340 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp4_kernel(
 
 #endif  // ERH_MEASURE
 
+// ---------------------------------------------------------------------------------------------
+// Ping-pong scan on a 384 x 256 tile over TILED operands (batches padded to >= 512 queries; round 4).  The loop of
+// scripts/ubench/scan_tile384.hip as a product kernel: same waves, strict alternation (two barriers per 32-half stage),
+// epilogue, records and results as dense_scan_pp3_kernel, but a workgroup holds 384 chunk rows against its 256 queries --
+// 17 % fewer LDS fill bytes per MAC -- which is worth 7-8 % of the bare loop where the chunk side hits in L2, i.e. where two
+// or more query-tile workgroups share a chunk stream (profiles/r04v_ubench_scan_tile384.log; at one query tile per stream
+// the shallower rings lose 6 %, so 256-query batches stay on pp3).  What it takes to fit 256 VGPRs and 160 KiB:
+//   - 6 x 2 accumulator tiles per wave (192 VGPRs) and fragment registers for HALF a stage (32): each is re-loaded behind its
+//     last MFMA with the next half-stage's contents (the second K sub-step of the same stage, then the first of the next);
+//   - rings of 4 x 24 KiB (chunk side, three stages ahead) + 3 x 16 KiB (query side, two ahead) -- the record area and the
+//     flush flags stay where the 256-row kernels have them; the query side of stage g + 2 is issued FIRST in memory segment g
+//     and waited for there (vmcnt(3): only the three chunk-side instructions of stage g + 3 stay in flight), because the
+//     next matrix segment re-loads from stage g + 2;
+//   - both operands from tiled copies (one LDS stage image per tile and stage, swizzle included: launch_dense_tile_rows_n
+//     with 384 rows for the chunk matrix -- built once per erh_set_dense, on first use -- and 256 rows for the query block
+//     of the call): every DMA instruction moves 1 KiB of consecutive bytes, addresses are a wave-uniform pointer + lane * 16;
+//   - a record carries nine row bits (tile index: 17 bits).
+namespace pp5 {
+constexpr int BM = 384, MT = 6, GROWS = 192, ROW_BITS = 9, AST = 4, BST = 3;
+constexpr int A_BYTES = BM * pp::RB;
+constexpr int B_BASE = AST * A_BYTES;
+constexpr int TILE_BITS = 32 - 6 - ROW_BITS;
+static_assert(B_BASE + BST * pp::B_BYTES == pp::REC_BASE, "records and flush flags sit where the 256-row kernels have them");
+}  // namespace pp5
+
+__global__ __launch_bounds__(pp::NT) void dense_scan_pp5_kernel(
+    const _Float16 *__restrict__ Xt, int64_t N, int d, int64_t c0, int64_t c1,
+    const _Float16 *__restrict__ Qt, int Bpad, int B,
+    const float *__restrict__ tau, const int16_t *__restrict__ filter_dir, const int16_t *__restrict__ dir_id,
+    ErhCand *__restrict__ cand, uint32_t *__restrict__ cand_cnt, int cap, uint32_t *__restrict__ overflow, int rot_stages) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp = wave >> 2, wave_n = wave & 3;
+    const int nk = d / pp::BK;
+    const int n_qt = Bpad / pp::BN;
+    const int64_t n_ct = (c1 - c0 + pp5::BM - 1) / pp5::BM;
+    const int xcd = blockIdx.x & 7;
+    const int jx = blockIdx.x >> 3;
+    const int qt = jx % n_qt;
+    const int stream = (jx / n_qt) * 8 + xcd;
+    const int n_streams = (gridDim.x / (8 * n_qt)) * 8;
+    if (stream >= n_ct) return;                                        // whole workgroup, before any barrier
+    const int n_tiles = (int)((n_ct - stream + n_streams - 1) / n_streams);
+    const int total = n_tiles * nk;                                    // flattened (tile, stage) sequence
+    const int64_t q_row0 = (int64_t)qt * pp::BN;
+    const int64_t lim = (c1 < N) ? c1 : N;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int k0 = (qt * rot_stages) % nk;
+    float t_q[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int q = (int)q_row0 + wave_n * 64 + nt * 32 + l31;
+        t_q[nt] = q < B ? tau[q] : INFINITY;
+    }
+    asm volatile("" ::"v"(t_q[0]), "v"(t_q[1]));                      // loaded before the DMA stream starts (keeps vmcnt countable)
+
+    // wave-uniform byte pointers (this wave's 1 KiB slice of a stage image; the lane's 16 bytes are lane_off) -- the loads take
+    // the scalar-base form, no 64-bit address registers
+    const int64_t tile_bytes_a = (int64_t)nk * pp5::A_BYTES, tile_bytes_b = (int64_t)nk * pp::B_BYTES;
+    const char *xa = reinterpret_cast<const char *>(Xt) + ((c0 / pp5::BM + stream) * (int64_t)nk + k0) * pp5::A_BYTES + wave * 1024;
+    const char *const qb = reinterpret_cast<const char *>(Qt) + (int64_t)qt * tile_bytes_b + wave * 1024;
+    const int64_t a_jump = (int64_t)n_streams * tile_bytes_a;         // a stage -> the same stage of the stream's next tile
+    // fragment read addresses of the first K sub-step; the second one's 16-byte slot has bit 1 flipped: address ^ 32,
+    // re-computed where it is needed (by an asm statement the compiler cannot hoist) instead of held in registers
+    // ONE per-lane address (row l31 of a 32-row block, this lane's slot); what distinguishes the operands and the waves is
+    // wave-uniform and rides on the scalar ring offsets (multiples of 64, so the ^ 32 commutes with them)
+    // ... and even that one is re-derived from the lane index in every matrix segment (eight VALU instructions beside 24 MFMAs)
+    // instead of held: row (lane & 31) * 64 + ((lane >> 5) ^ ((lane >> 2) & 3)) * 16
+    static_assert(pp::PR == 4 && pp::RB == 64, "ERH_PP5_FADR spells out the swizzle of 64-byte rows");
+#define ERH_PP5_FADR(F)                                                                               \
+    do {                                                                                              \
+        int t_, u_;                                                                                   \
+        asm volatile("v_mbcnt_lo_u32_b32 %1, -1, 0\n\tv_mbcnt_hi_u32_b32 %1, -1, %1\n\tv_and_b32 %0, 31, %1\n\t"   \
+                     "v_lshrrev_b32 %1, 5, %1\n\tv_bfe_u32 %2, %0, 2, 2\n\tv_xor_b32 %1, %1, %2\n\t"                \
+                     "v_lshlrev_b32 %0, 6, %0\n\tv_lshl_or_b32 %0, %1, 4, %0"                                       \
+                     : "=&v"(F), "=&v"(t_), "=&v"(u_));                                               \
+    } while (0)
+    const int a_wave = __builtin_amdgcn_readfirstlane(grp * pp5::GROWS * pp::RB);
+    const int b_wave = __builtin_amdgcn_readfirstlane(pp5::B_BASE + wave_n * 64 * pp::RB);
+    char *const rec = lds + pp::REC_BASE + wave * pp::REC_BYTES;
+    if (threadIdx.x == 0) { ERH_PP_FLAG(0) = 0; ERH_PP_FLAG(1) = 0; }
+
+    constexpr int kABytes = pp5::AST * pp5::A_BYTES, kBBytes = pp5::BST * pp::B_BYTES;
+    int a_dst = 0, b_dst = 0, ka = k0, kb = k0;
+    int a_left = total, b_left = total;
+    int fa_off = 0, fb_off = 0;                                        // ring offsets of the stage whose FIRST half is read next
+    int cur_a = 0, cur_b = 0;                                          // ... of the stage whose SECOND half is read next
+    half8 fa[pp5::MT], fb[2];
+    // LDS-DMA by inline assembly in the scalar-base form: wave-uniform 64-bit source in SGPRs + this lane's 32-bit byte offset,
+    // destination = M0 (wave-uniform LDS byte address; lane i lands at + 16 i).  Through the builtin the compiler keeps a 64-bit
+    // per-lane pointer per operand, which this kernel has no registers for.
+    const uint32_t lds0 = (uint32_t)(uintptr_t)ERH_LDS_PTR(lds);       // (0: the kernel has no static LDS)
+    const uint32_t my_dst = lds0 + (uint32_t)wave * 1024u;
+#define ERH_PP5_GLDS(SRC, DST)                                                                        \
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"                    \
+                 :: "s"((uint32_t)(DST)), "v"(lo_), "s"((const char *)(SRC)) : "memory", "m0")
+// this lane's byte offset inside its wave's 1 KiB slice, re-derived from the lane index (two VALU instructions per issue
+// instead of a register held across the main loop)
+#define ERH_PP5_LANE_OFF(V) asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0\n\tv_lshlrev_b32 %0, 4, %0" : "=v"(V))
+#define ERH_PP5_ISSUE_A()                                                                             \
+    do {                                                                                              \
+        if (a_left > 0) {                                                                             \
+            int lo_;                                                                                  \
+            ERH_PP5_LANE_OFF(lo_);                                                                    \
+            ERH_PP5_GLDS(xa, my_dst + a_dst);                                                         \
+            ERH_PP5_GLDS(xa + 8192, my_dst + a_dst + 8192);                                           \
+            ERH_PP5_GLDS(xa + 16384, my_dst + a_dst + 16384);                                         \
+            xa += pp5::A_BYTES;                                                                       \
+            if (++ka == nk) { ka = 0; xa -= tile_bytes_a; }                /* wrap to stage 0 of the same tile */ \
+            if (ka == k0) xa += a_jump;                                    /* tile complete: the stream's next tile */ \
+            a_dst += pp5::A_BYTES;                                                                    \
+            if (a_dst == kABytes) a_dst = 0;                                                          \
+            --a_left;                                                                                 \
+        }                                                                                             \
+    } while (0)
+#define ERH_PP5_ISSUE_B()                                                                             \
+    do {                                                                                              \
+        if (b_left > 0) {                                                                             \
+            int lo_;                                                                                  \
+            ERH_PP5_LANE_OFF(lo_);                                                                    \
+            const char *q_ = qb + (int64_t)kb * pp::B_BYTES;                                          \
+            ERH_PP5_GLDS(q_, my_dst + pp5::B_BASE + b_dst);                                           \
+            ERH_PP5_GLDS(q_ + 8192, my_dst + pp5::B_BASE + b_dst + 8192);                             \
+            if (++kb == nk) kb = 0;                                                                   \
+            b_dst += pp::B_BYTES;                                                                     \
+            if (b_dst == kBBytes) b_dst = 0;                                                          \
+            --b_left;                                                                                 \
+        }                                                                                             \
+    } while (0)
+// one K sub-step: 6 x 2 MFMAs; every fragment register is re-loaded from LDS address PA_ / PB_ (VGPR byte address + immediate
+// offset) right behind the last MFMA that reads it.  The re-loads are inline assembly so that they land IN the register they
+// replace (left to the compiler the loaded values get registers of their own until the old ones die: sixteen more than this
+// kernel has); whatever the previous sub-step re-loaded is complete behind the lgkmcnt(0) at the top.  (Past the end of the
+// stream the reads fetch stale ring bytes that nothing uses.)
+#define ERH_PP5_LD(DST, ADR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "+v"(DST) : "v"(ADR), "n"(OFF) : "memory")   /* "+": the register it replaces */
+#define ERH_PP5_HALF(PA_, PB_, FIRST)                                                                 \
+    do {                                                                                              \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        _Pragma("unroll") for (int mt = 0; mt < pp5::MT; ++mt) {                                      \
+            if (FIRST) {                                                                              \
+                const f32x16 z_ = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; \
+                acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mt], fb[0], z_, 0, 0, 0);      \
+                acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mt], fb[1], z_, 0, 0, 0);      \
+            } else {                                                                                  \
+                acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mt], fb[0], acc[mt][0], 0, 0, 0); \
+                acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mt], fb[1], acc[mt][1], 0, 0, 0); \
+            }                                                                                         \
+            __builtin_amdgcn_sched_barrier(0);                                                        \
+            ERH_PP5_LD(fa[mt], PA_, mt * 32 * pp::RB);                                                \
+            __builtin_amdgcn_sched_barrier(0);                                                        \
+        }                                                                                             \
+        ERH_PP5_LD(fb[0], PB_, 0);                                                                    \
+        ERH_PP5_LD(fb[1], PB_, 32 * pp::RB);                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+    } while (0)
+// matrix segment of stage g: the first sub-step re-loads with the second half of stage g (cur_*), the second one with the
+// first half of stage g + 1 (f*_off)
+#define ERH_PP5_COMPUTE(FIRST)                                                                        \
+    do {                                                                                              \
+        /* LDS byte addresses (the dynamic LDS block starts at 0: this kernel has no static __shared__) */ \
+        { int pa_, pb_, f_;                                                                           \
+          ERH_PP5_FADR(f_);                                                                           \
+          asm volatile("v_xor_b32 %0, 32, %2\n\tv_add_u32 %1, %4, %0\n\tv_add_u32 %0, %3, %0"         \
+                       : "=&v"(pa_), "=&v"(pb_) : "v"(f_), "s"(a_wave + cur_a), "s"(b_wave + cur_b)); \
+          ERH_PP5_HALF(pa_, pb_, FIRST); }                                                            \
+        { int pa_, pb_, f_;                                                                           \
+          ERH_PP5_FADR(f_);                                                                           \
+          asm volatile("v_add_u32 %0, %3, %2\n\tv_add_u32 %1, %4, %2"                                 \
+                       : "=&v"(pa_), "=&v"(pb_) : "v"(f_), "s"(a_wave + fa_off), "s"(b_wave + fb_off)); \
+          ERH_PP5_HALF(pa_, pb_, false); }                                                            \
+        cur_a = __builtin_amdgcn_readfirstlane(fa_off);                                               \
+        cur_b = __builtin_amdgcn_readfirstlane(fb_off);                                               \
+        fa_off += pp5::A_BYTES;                                                                       \
+        if (fa_off == kABytes) fa_off = 0;                                                            \
+        fb_off += pp::B_BYTES;                                                                        \
+        if (fb_off == kBBytes) fb_off = 0;                                                            \
+    } while (0)
+// after M_g (query stage g+2, then chunk stage g+3 issued): everything but the three chunk-side instructions has landed, i.e.
+// stage g+2; the fragment reads of this wave's last matrix segment have retired (ring slots may be overwritten after the barrier)
+#define ERH_PP5_WAIT(G)                                                                               \
+    do {                                                                                              \
+        if ((G) + 4 >= total) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");             \
+        else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");                              \
+    } while (0)
+// Epilogue of tile i for this wave: ERH_PP_EPILOGUE's group tests over six block rows, nine row bits in the record
+#define ERH_PP5_EPILOGUE()                                                                            \
+    do {                                                                                              \
+        int lane, l31, hh;      /* re-derived here (opaque to the compiler): not held in registers across the main loop */ \
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0\n\tv_and_b32 %1, 31, %0\n\tv_lshrrev_b32 %2, 5, %0" \
+                     : "=&v"(lane), "=&v"(l31), "=&v"(hh));                                           \
+        if (wave == 0 && lane == 0) ERH_PP_FLAG((i + 1) & 1) = 0;                                     \
+        const bool last_ = (i + 1 == n_tiles);                                                        \
+        const int fill0_ = fill;                                                                      \
+        for (int shift_ = 0;; shift_ += pp::CAPW) {                                                   \
+            int cnt_ = fill0_;                                                                        \
+            float tt_[2] = {t_q[0], t_q[1]};                                                          \
+            asm volatile("" : "+v"(tt_[0]), "+v"(tt_[1]));   /* opaque per pass: nothing of the pass is hoisted out of the loop */ \
+            _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                                        \
+                const float t_ = tt_[nt];                                                             \
+                uint32_t pk_l_ = (uint32_t)(nt * 32 + l31) | ((uint32_t)(grp * pp5::GROWS + 4 * hh) << 6) | \
+                                 ((uint32_t)i << (6 + pp5::ROW_BITS));                                \
+                asm volatile("" : "+v"(pk_l_));                                                       \
+                _Pragma("unroll") for (int mt = 0; mt < pp5::MT; ++mt) {                              \
+                    _Pragma("unroll") for (int r4 = 0; r4 < 16; r4 += 4) {                            \
+                        const bool any_ = erh_max4(acc[mt][nt][r4], acc[mt][nt][r4 + 1], acc[mt][nt][r4 + 2],   \
+                                                   acc[mt][nt][r4 + 3]) >= t_;                                 \
+                        if (__builtin_amdgcn_ballot_w64(any_)) ERH_PP_EPI_QUAD(mt, nt, r4);           \
+                        __builtin_amdgcn_sched_barrier(0);                                            \
+                    }                                                                                 \
+                }                                                                                     \
+            }                                                                                         \
+            const int avail_ = cnt_ - shift_;                                                         \
+            const bool over_ = avail_ > pp::CAPW;                                                     \
+            const int nrec_ = over_ ? pp::CAPW : avail_;                                              \
+            if (over_ || flush_now || last_) {                                                        \
+                for (int base_ = 0; base_ < nrec_; base_ += 64) {                                     \
+                    const int j_ = base_ + lane;                                                      \
+                    if (j_ < nrec_) {                                                                 \
+                        uint2 rc_;                                                                    \
+                        rc_.x = *reinterpret_cast<const uint32_t *>(rec + j_ * 4);                    \
+                        rc_.y = *reinterpret_cast<const uint32_t *>(rec + 1024 + j_ * 4);             \
+                        const int q_ = (int)q_row0 + wave_n * 64 + (int)(rc_.y & 63u);                \
+                        const int64_t chunk_ = c0 + ((int64_t)stream + (int64_t)(rc_.y >> (6 + pp5::ROW_BITS)) * n_streams) * pp5::BM + \
+                                               (int64_t)((rc_.y >> 6) & ((1u << pp5::ROW_BITS) - 1u)); \
+                        bool ok_ = chunk_ < lim;                                                      \
+                        if (ok_ && filter_dir) {                                                      \
+                            const int fd_ = (int)filter_dir[q_];                                      \
+                            ok_ = fd_ < 0 || (int)dir_id[chunk_] == fd_;                              \
+                        }                                                                             \
+                        if (ok_) {                                                                    \
+                            const uint32_t p_ = atomicAdd(&cand_cnt[q_], 1u);                         \
+                            if (p_ < (uint32_t)cap) {                                                 \
+                                ErhCand c_;                                                           \
+                                c_.s = __uint_as_float(rc_.x);                                        \
+                                c_.idx = (int32_t)chunk_;                                             \
+                                cand[(int64_t)q_ * cap + p_] = c_;                                    \
+                            } else {                                                                  \
+                                atomicOr(overflow, 1u);                                               \
+                            }                                                                         \
+                        }                                                                             \
+                    }                                                                                 \
+                }                                                                                     \
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                      \
+                fill = 0;                                                                             \
+            } else {                                                                                  \
+                fill = nrec_;                                                                         \
+            }                                                                                         \
+            if (!over_) break;                                                                        \
+        }                                                                                             \
+        if (fill > pp::CAPW / 2 && lane == 0) ERH_PP_FLAG(i & 1) = 1;                                 \
+    } while (0)
+
+    // prologue: A0 B0 A1 B1 A2; stages 0 and 1 complete = the last 3 instructions may stay in flight
+    ERH_PP5_ISSUE_A(); ERH_PP5_ISSUE_B(); ERH_PP5_ISSUE_A(); ERH_PP5_ISSUE_B(); ERH_PP5_ISSUE_A();
+    if (total >= 4) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ERH_PP_BARRIER();
+    {
+        int f_adr0;
+        ERH_PP5_FADR(f_adr0);
+#pragma unroll
+        for (int mt = 0; mt < pp5::MT; ++mt) fa[mt] = *reinterpret_cast<const half8 *>(lds + f_adr0 + a_wave + mt * 32 * pp::RB);
+        fb[0] = *reinterpret_cast<const half8 *>(lds + f_adr0 + b_wave);
+        fb[1] = *reinterpret_cast<const half8 *>(lds + f_adr0 + b_wave + 32 * pp::RB);
+    }
+    fa_off = pp5::A_BYTES;                                             // (stage 0's first half is in registers, its second half is cur_* = 0)
+    fb_off = pp::B_BYTES;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    ERH_PP_BARRIER();
+
+    f32x16 acc[pp5::MT][2];
+    int fill = 0;                                                      // records buffered in this wave's area
+    int flush_now = 0;                                                 // workgroup-uniform, decided one tile ahead
+    int g = 0;
+    if (grp == 0) {
+        for (int i = 0; i < n_tiles; ++i) {
+            for (int kt = 0; kt < nk; ++kt, ++g) {
+                ERH_PP5_COMPUTE(kt == 0);                              // C(g)
+                ERH_PP_BARRIER();                                      // |A|
+                ERH_PP5_ISSUE_B();                                     // M_g: the query side first (it is waited for)
+                ERH_PP5_ISSUE_A();
+                __builtin_amdgcn_sched_barrier(0);
+                ERH_PP5_WAIT(g);
+                ERH_PP_BARRIER();                                      // |B|
+            }
+            ERH_PP5_EPILOGUE();
+            ERH_PP_BARRIER();
+            flush_now = __builtin_amdgcn_readfirstlane(ERH_PP_FLAG(i & 1));
+        }
+    } else {
+        for (int i = 0; i < n_tiles; ++i) {
+            for (int kt = 0; kt < nk; ++kt, ++g) {
+                ERH_PP5_ISSUE_B();                                     // M_g
+                ERH_PP5_ISSUE_A();
+                __builtin_amdgcn_sched_barrier(0);
+                ERH_PP_BARRIER();                                      // |A|
+                ERH_PP5_COMPUTE(kt == 0);                              // C(g)
+                ERH_PP5_WAIT(g);
+                ERH_PP_BARRIER();                                      // |B|
+            }
+            ERH_PP5_EPILOGUE();
+            ERH_PP_BARRIER();
+            flush_now = __builtin_amdgcn_readfirstlane(ERH_PP_FLAG(i & 1));
+        }
+    }
+#undef ERH_PP5_GLDS
+#undef ERH_PP5_ISSUE_A
+#undef ERH_PP5_ISSUE_B
+#undef ERH_PP5_HALF
+#undef ERH_PP5_LD
+#undef ERH_PP5_FADR
+#undef ERH_PP5_LANE_OFF
+#undef ERH_PP5_COMPUTE
+#undef ERH_PP5_WAIT
+#undef ERH_PP5_EPILOGUE
+}
+
+// tiled copy with `rows` rows per tile (384: the chunk matrix for dense_scan_pp5_kernel): per tile and 32-half stage one block
+// of rows * 64 bytes that IS the LDS stage image -- piece p (16 bytes) = row p >> 2 of the tile, logical slot (p & 3) ^ swizzle
+__global__ __launch_bounds__(256) void dense_tile_rows_n_kernel(const _Float16 *__restrict__ X, int d, int rows, int64_t n_tiles,
+                                                                int4 *__restrict__ Xt) {
+    const int nk = d / 32, per = rows * 4;
+    const int64_t total = n_tiles * nk * per;
+    for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
+        const int p = (int)(o % per);
+        const int64_t blk = o / per;
+        const int s = (int)(blk % nk);
+        const int64_t T = blk / nk;
+        const int r = p >> 2, ls = (p & 3) ^ row_swizzle<pp::PR>(r);
+        Xt[o] = *reinterpret_cast<const int4 *>(X + (T * rows + r) * (int64_t)d + s * 32 + ls * 8);
+    }
+}
+
 using Cfg0 = ScanCfg<256, 256, 2, 4, 64, 3, 2>;   // one 8-wave workgroup per CU, 160 KiB LDS
 using Cfg1 = ScanCfg<128, 256, 1, 4, 32, 4, 3>;   // two 4-wave workgroups per CU, 80 KiB LDS each
 using Cfg2 = ScanCfg<256, 256, 2, 4, 32, 5, 5>;   // one workgroup per CU, BK 32, both operands 4 half-steps ahead
@@ -2282,6 +2616,8 @@ hipError_t dense_scan_init() {
 #define ERH_SET_PP(A) ERH_SET_PP3(A, 0) ERH_SET_PP3(A, 2)
     ERH_SET_PP(0)
     ERH_SET_PP3(0, 8) ERH_SET_PP3(0, 10) ERH_SET_PP3(0, 16) ERH_SET_PP3(0, 24)
+    e = hipFuncSetAttribute((const void *)dense_scan_pp5_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, pp::LDS_BYTES);
+    if (e != hipSuccess) return e;
 #ifdef ERH_MEASURE
     e = hipFuncSetAttribute((const void *)dense_scan_pp_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             pp::LDS_BYTES);
@@ -2367,6 +2703,35 @@ hipError_t launch_dense_tile_rows(const _Float16 *X, int64_t N, int d, void *Xt,
     const int64_t pieces = n_tiles * (d / 64) * 2048;                 // 16-byte pieces to move
     const unsigned blocks = (unsigned)std::min<int64_t>(8192, (pieces + 255) / 256);
     hipLaunchKernelGGL(dense_tile_rows_kernel, dim3(blocks), dim3(256), 0, st, X, d, n_tiles, reinterpret_cast<int4 *>(Xt));
+    return hipGetLastError();
+}
+
+int dense_scan_pp5_rows() { return pp5::BM; }
+
+hipError_t launch_dense_tile_rows_n(const _Float16 *X, int64_t N, int d, int rows, void *Xt, hipStream_t st) {
+    if (d % 32 != 0 || rows % 32 != 0 || rows <= 0) return hipErrorInvalidValue;
+    const int64_t n_tiles = (N + rows - 1) / rows;
+    const int64_t pieces = n_tiles * (d / 32) * rows * 4;             // 16-byte pieces to move
+    const unsigned blocks = (unsigned)std::min<int64_t>(8192, (pieces + 255) / 256);
+    hipLaunchKernelGGL(dense_tile_rows_n_kernel, dim3(blocks), dim3(256), 0, st, X, d, rows, n_tiles, reinterpret_cast<int4 *>(Xt));
+    return hipGetLastError();
+}
+
+// The 384 x 256 ping-pong scan (dense_scan_pp5_kernel): Xt = launch_dense_tile_rows_n(X, N, d, 384), Qt = launch_dense_tile_rows of the
+// query block; c0 must be a multiple of 384, Bpad >= 512.  hipErrorInvalidValue when the shape does not qualify.
+hipError_t launch_dense_scan_pp5(const _Float16 *Xt, int64_t N, int d, int64_t c0, int64_t c1, const _Float16 *Qt,
+                                 int Bpad, int B, const float *tau, const int16_t *filter_dir, const int16_t *dir_id,
+                                 ErhCand *cand, uint32_t *cand_cnt, int cap, uint32_t *overflow, int n_cus, int rot_stages,
+                                 hipStream_t st) {
+    if (c1 <= c0) return hipSuccess;
+    if (d % 64 != 0 || d / pp::BK < 8 || c0 % pp5::BM != 0 || Bpad % pp::BN != 0 || Bpad < 2 * pp::BN) return hipErrorInvalidValue;
+    const int n_qt = Bpad / pp::BN;
+    const int grid_n = n_cus / (8 * n_qt) * (8 * n_qt);
+    if (grid_n <= 0) return hipErrorInvalidValue;
+    const int64_t n_ct = (c1 - c0 + pp5::BM - 1) / pp5::BM;
+    if (n_ct / (grid_n / n_qt) + 1 >= (1ll << pp5::TILE_BITS)) return hipErrorInvalidValue;   // tile index must fit the record
+    hipLaunchKernelGGL(dense_scan_pp5_kernel, dim3((unsigned)grid_n), dim3(pp::NT), pp::LDS_BYTES, st, Xt, N, d, c0, c1, Qt,
+                       Bpad, B, tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow, rot_stages);
     return hipGetLastError();
 }
 

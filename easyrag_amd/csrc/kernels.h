@@ -35,13 +35,22 @@ hipError_t launch_dense_scan_pp(const _Float16 *X, int64_t N, int d, int64_t c0,
                                 uint32_t *stream_sync /* dense_pp 3: 256 zeroed words (one per stream) or null */,
                                 const ErhSeedIo *sio /* null, or the sample pass (dense_pp 3 only) */,
                                 hipStream_t st);
+// 384 x 256 ping-pong scan over tiled operands (dense_scan_pp5_kernel; batches padded to >= 512 queries): Xt from
+// launch_dense_tile_rows_n(X, N, d, dense_scan_pp5_rows(), ...) -- ceil(N / 384) * 384 * d halves --, Qt from launch_dense_tile_rows of
+// the query block; c0 a multiple of 384.  hipErrorInvalidValue when the shape does not qualify (the caller falls through).
+int dense_scan_pp5_rows();
+hipError_t launch_dense_tile_rows_n(const _Float16 *X, int64_t N, int d, int rows, void *Xt, hipStream_t st);
+hipError_t launch_dense_scan_pp5(const _Float16 *Xt, int64_t N, int d, int64_t c0, int64_t c1, const _Float16 *Qt,
+                                 int Bpad, int B, const float *tau, const int16_t *filter_dir, const int16_t *dir_id,
+                                 ErhCand *cand, uint32_t *cand_cnt, int cap, uint32_t *overflow, int n_cus, int rot_stages,
+                                 hipStream_t st);
 // tiled copy of the chunk matrix for the ping-pong scan: ceil(N / 256) * 256 * d halves (see dense_tile_rows_kernel)
 hipError_t launch_dense_tile_rows(const _Float16 *X, int64_t N, int d, void *Xt, hipStream_t st);
 hipError_t launch_dense_scan_pp4(const _Float16 *Xt, int64_t N, int d, int64_t c0, int64_t c1, const _Float16 *Qt,
                                  int Bpad, int B, const float *tau, const int16_t *filter_dir, const int16_t *dir_id,
                                  ErhCand *cand, uint32_t *cand_cnt, int cap, uint32_t *overflow, int n_cus, int pabl,
                                  unsigned long long *dbg, int rot_stages, hipStream_t st);
-constexpr int kDensePadRows = 256;   // zero rows erh_set_dense keeps behind the matrix (tiles past N read them)
+constexpr int kDensePadRows = 384;   // zero rows erh_set_dense keeps behind the matrix (tiles past N read them: up to 383 for the 384-row tile)
 hipError_t launch_dense_scan_persist(int cfg, const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1,
                                      const _Float16 *Q, int Bpad, int B, const float *tau,
                                      const int16_t *filter_dir, const int16_t *dir_id,

@@ -282,6 +282,9 @@ int erh_reset_kernel_time(erh_handle *h);
  *   dense_n1 (131072)     dense_speculate 0: first refinement boundary; 0 = never refine.  Further boundaries follow x4 while 8x fits.
  *   dense_n1_auto (1)     snap the boundaries to whole rounds of the persistent scan
  *   dense_n0_auto (0)     shrink the seed prefix to where the rest is a whole number of scan rounds
+ *   dense_tile384 (1)     batches padded to >= 512 queries: scan on a 384 x 256 tile over tiled copies of both operands
+ *                         (dense_scan_pp5_kernel; the 384-row copy of the chunk matrix, + N * d * 2 bytes, is built on first use);
+ *                         0 = the 256 x 256 tile for every batch size
  *   dense_selfseed (1)    batches padded to >= 512 queries: the scan kernel draws the threshold sample itself (a pass without
  *                         thresholds over one tile per chunk stream, the two best scores of every 64-row cell) and then scans
  *                         all rows; 0 = store kernel + S0 + seed select for every batch size

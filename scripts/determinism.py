@@ -49,7 +49,9 @@ def main():
         if name != "bm25":                                    # every other scan kernel / pruning scheme must give the same exact result
             # (the product library carries the strict ping-pong scan and the per-tile fallbacks; the superseded kernels are
             # measurement-build arms of scripts/kbench.py)
-            variants = (("lock-step per tile 256x256x64", {"dense_pp": 0, "dense_persist": 0}),
+            variants = (("strict ping-pong on the 256 x 256 tile for every batch size", {"dense_tile384": 0}),
+                        ("store kernel + S0 + seed select instead of the sample pass", {"dense_selfseed": 0}),
+                        ("lock-step per tile 256x256x64", {"dense_pp": 0, "dense_persist": 0}),
                         ("per tile 128x256x32, two workgroups per CU", {"dense_pp": 0, "dense_persist": 0, "dense_cfg": 1}),
                         ("per tile 256x256x32", {"dense_pp": 0, "dense_persist": 0, "dense_cfg": 2}),
                         ("strict ping-pong, guaranteed bounds", {"dense_speculate": 0}),
@@ -67,7 +69,8 @@ def main():
                 if not all(np.array_equal(a.view(np.uint8), b.view(np.uint8)) for a, b in zip(ref, cur)):
                     bad += 1
                     print(f"{name}: {label} differs from the default kernel")
-                for o, v in (("dense_pp", 3), ("dense_persist", 1), ("dense_cfg", 0), ("dense_speculate", 1), ("dense_sync", 0), ("dense_rot", 0)):
+                for o, v in (("dense_pp", 3), ("dense_persist", 1), ("dense_cfg", 0), ("dense_speculate", 1), ("dense_sync", 0), ("dense_rot", -1),
+                             ("dense_tile384", 1), ("dense_selfseed", 1)):
                     eng.set_option(o, v)
         if name == "bm25":                                    # every BM25 scan kernel must give the same exact result
             for label, opts in (("fixed-point scan, packed shape on 8-byte postings", {"bm25_post16": 0}),
@@ -85,7 +88,7 @@ def main():
                 eng.set_option("bm25_small", 2)
                 eng.set_option("bm25_post16", 1)
                 eng.set_option("bm25_ascan", 1)
-        extra = " (+ four other scan kernels)" if name == "bm25" else " (+ six other scan kernels / pruning schemes)"
+        extra = " (+ four other scan kernels)" if name == "bm25" else " (+ seven other scan kernels / pruning schemes)"
         print(f"{name}: {reps} repeats{extra}, B={B}: {'identical' if not bad else 'DIFFERENCES'}")
     eng.close()
     sys.exit(1 if bad else 0)

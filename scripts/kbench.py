@@ -262,6 +262,24 @@ def main():
         eng.set_option("dense_selfseed", 1)
         eng.set_option("dense_n0", 32768)
         del x
+    if what == "tile384":                                    # 384 x 256 scan tile (dense_tile384) against the 256 x 256 one, >= 512 queries
+        x = synth.dense_corpus_torch(n, d, seed=2, device=dev)
+        eng.set_dense(x)
+        for B, k in ((1024, 288), (512, 100), (768, 100)):
+            q = synth.dense_queries_torch(x, B, seed=7)
+            for t in (1, 0, 1, 0):
+                eng.set_option("dense_tile384", t)
+                r = timed(eng, lambda: eng.dense_topk(q, k, device_out=True), 20)
+                r["sum"] = round(sum(r.values()), 4)
+                res[f"dense B={B} k={k} tile384={t} #{len(res)}"] = r
+        eng.set_option("dense_tile384", 1)
+        q = synth.dense_queries_torch(x, 1024, seed=7)
+        for rot in (-1, 0, 2, 8, -1, 0, 2, 8):                     # K rotation per query tile of the 384 x 256 scan (-1: the default, 0)
+            eng.set_option("dense_rot", rot)
+            r = timed(eng, lambda: eng.dense_topk(q, 288, device_out=True), 20)
+            res[f"dense B=1024 k=288 tile384=1 rot={rot} #{len(res)}"] = r
+        eng.set_option("dense_rot", -1)
+        del x
     if what == "p3":                                         # strict-alternation ping-pong (dense_pp=3) vs the lean one (2)
         x = synth.dense_corpus_torch(n, d, seed=2, device=dev)
         eng.set_dense(x)
