@@ -69,7 +69,7 @@ def main():
                 if not all(np.array_equal(a.view(np.uint8), b.view(np.uint8)) for a, b in zip(ref, cur)):
                     bad += 1
                     print(f"{name}: {label} differs from the default kernel")
-                for o, v in (("dense_pp", 3), ("dense_persist", 1), ("dense_cfg", 0), ("dense_speculate", 1), ("dense_sync", 0), ("dense_rot", -1),
+                for o, v in (("dense_pp", 3), ("dense_persist", 1), ("dense_cfg", 0), ("dense_speculate", 1), ("dense_sync", 0), ("dense_rot", 0),
                              ("dense_tile384", 1), ("dense_selfseed", 1)):
                     eng.set_option(o, v)
         if name == "bm25":                                    # every BM25 scan kernel must give the same exact result

@@ -274,11 +274,11 @@ def main():
                 res[f"dense B={B} k={k} tile384={t} #{len(res)}"] = r
         eng.set_option("dense_tile384", 1)
         q = synth.dense_queries_torch(x, 1024, seed=7)
-        for rot in (-1, 0, 2, 8, -1, 0, 2, 8):                     # K rotation per query tile of the 384 x 256 scan (-1: the default, 0)
+        for rot in (0, 1, 2, 8, 0, 1, 2, 8):                       # K rotation per query tile of the 384 x 256 scan (default 0)
             eng.set_option("dense_rot", rot)
             r = timed(eng, lambda: eng.dense_topk(q, 288, device_out=True), 20)
             res[f"dense B=1024 k=288 tile384=1 rot={rot} #{len(res)}"] = r
-        eng.set_option("dense_rot", -1)
+        eng.set_option("dense_rot", 0)
         del x
     if what == "p3":                                         # strict-alternation ping-pong (dense_pp=3) vs the lean one (2)
         x = synth.dense_corpus_torch(n, d, seed=2, device=dev)
