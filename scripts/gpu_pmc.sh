@@ -40,7 +40,7 @@ pat = re.compile(r"bm25_[wa]?scan" if wl == "bm25" else r"dense_(scan|gemv)")
 def klass(name):
     if wl == "bm25":
         return "ascan" if "ascan" in name else ("wscan" if "wscan" in name else "scan")
-    for key in ("pp3", "pp2", "_pp_", "persist", "append", "store", "gemv"):
+    for key in ("pp5", "pp3", "pp2", "_pp_", "persist", "append", "store", "gemv"):
         if key in name:
             return key.strip("_")
     return "other"
