@@ -71,6 +71,8 @@ SIGNATURES = {
     "erh_debug_counters": (_i32, [_vp, _vp]),
     "erh_dense_diag": (_i32, [_vp, C.POINTER(_dbl), C.POINTER(_dbl), C.POINTER(_i32)]),
     "erh_dense_exhaustive_count": (_i32, [_vp, C.POINTER(_i32)]),
+    "erh_get_stat": (_i32, [_vp, C.c_char_p, C.POINTER(_i64)]),
+    "erh_reset_stats": (_i32, [_vp]),
     "erh_dense_seed_rank": (_i32, [_i32, _i64, _i64]),
     "erh_debug_dense_scores": (_i32, [_vp, _vp, _i32, _i64, _i32, _i32, _vp]),
     "erh_vocab_create": (_i32, [C.POINTER(_vp)]),

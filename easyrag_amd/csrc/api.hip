@@ -84,6 +84,8 @@ struct erh_handle {
     bool xt_valid = false;
     DevBuf Xt384;                            // 384-row tiled copy of X for the 384 x 256 scan (dense_scan_pp5_kernel), built on first use
     bool xt384_valid = false;
+    bool xt384_nomem = false;                // the copy did not fit beside X: the 256 x 256 scan serves every batch until the next erh_set_dense
+    int64_t opt_tile384_max_mb = -1;         // test hook: refuse a 384-row copy above this many MiB as if the allocation had failed (-1: no limit)
     bool qt5_valid = false;                  // Qt holds the tiled copy of the CURRENT call's Q16 for that scan
     bool qt_valid = false;                   // Qt holds the tiled copy of the CURRENT call's Q16
     int64_t N = 0;
@@ -131,6 +133,14 @@ struct erh_handle {
     DevBuf scores_tmp, scores_wide;
     DevBuf dbg;                              // 16 x u64 section counters (measurement only)
     int opt_debug_counters = 0;
+    // erh_get_stat: which kernels answered the calls since erh_create / erh_reset_stats.  Host counters (launch decisions are
+    // made on the host) + two device counters the kernels bump themselves, so that device-output pipelines need no round trip:
+    // dstats[0] queries answered by the dense exhaustive path, dstats[1] BM25 (query, segment) pairs handed to the exact scan
+    DevBuf dstats;
+    struct Stats {
+        int64_t dense_calls = 0, dense_scan_pp5 = 0, dense_scan_pp3 = 0, dense_scan_gemv = 0, dense_scan_tile = 0,
+                dense_sample_passes = 0, dense_tile384_nomem = 0, bm25_calls = 0, hybrid_calls = 0;
+    } stats;
     // multi-GPU exchange (erh_comm_* / erh_allgather_topk): RCCL communicator + packed send / receive rows
     void *comm = nullptr;
     int comm_rank = 0, comm_world = 1;
@@ -267,7 +277,7 @@ hipError_t scan_append(erh_handle *h, const _Float16 *X, int64_t N, int d, int64
     if (h->opt_dense_gemv && h->opt_dense_ablate == 0 && B <= erh::dense_gemv_max_queries()) {
         hipError_t e = erh::launch_dense_gemv_append(X, N, d, c0, c1, Q16, B, tau, filt, dir, cand, cnt, cap, flags,
                                                      h->n_cus, h->opt_gemv_kb, h->opt_gemv_wgs, h->opt_gemv_pipe, st);
-        if (e != hipErrorInvalidValue) return e;
+        if (e != hipErrorInvalidValue) { h->stats.dense_scan_gemv += (c1 > c0); return e; }
         (void)hipGetLastError();
     }
     const int abl = h->opt_dense_ablate;
@@ -277,7 +287,7 @@ hipError_t scan_append(erh_handle *h, const _Float16 *X, int64_t N, int d, int64
         hipError_t e = erh::launch_dense_scan_pp5(h->Xt384.as<_Float16>(), N, d, c0, c1, h->Qt.as<_Float16>(), Bpad, B, tau, filt,
                                                   dir, cand, cnt, cap, flags, h->n_cus,
                                                   h->opt_dense_rot >= 0 ? h->opt_dense_rot : 0 /* the workgroups of a stream on the same stage: measured best here (profiles/r04w_kbench_tile384.log) */, st);
-        if (e != hipErrorInvalidValue) return e;
+        if (e != hipErrorInvalidValue) { h->stats.dense_scan_pp5 += (c1 > c0); return e; }
         (void)hipGetLastError();
     }
     if (h->opt_dense_pp >= 4 && pp_code && X == h->X.as<_Float16>() && h->xt_valid && h->qt_valid) {
@@ -308,15 +318,16 @@ hipError_t scan_append(erh_handle *h, const _Float16 *X, int64_t N, int d, int64
                                                  (h->opt_dense_pp >= 2 && own)
                                                      ? (1 | (var << 1) | (h->opt_dense_pp >= 3 ? 8 : 0) | (dense_rot_stages(h, d, Bpad) << 8)) : 0,
                                                  sync, nullptr, st);
-        if (e != hipErrorInvalidValue) return e;
+        if (e != hipErrorInvalidValue) { h->stats.dense_scan_pp3 += (c1 > c0); return e; }
         (void)hipGetLastError();
     }
     if (h->opt_dense_persist && (h->opt_dense_ablate == 0 || h->opt_dense_ablate >= 6)) {
         hipError_t e = erh::launch_dense_scan_persist(h->opt_dense_cfg, X, N, d, c0, c1, Q16, Bpad, B, tau, filt, dir, cand,
                                                       cnt, cap, flags, h->n_cus, h->opt_dense_ablate, h->opt_dense_readahead, st);
-        if (e != hipErrorInvalidValue) return e;
+        if (e != hipErrorInvalidValue) { h->stats.dense_scan_tile += (c1 > c0); return e; }
         (void)hipGetLastError();
     }
+    h->stats.dense_scan_tile += (c1 > c0);
     return erh::launch_dense_scan_append(h->opt_dense_cfg, X, N, d, c0, c1, Q16, Bpad, B, tau, filt, dir, cand, cnt, cap,
                                          flags, h->opt_dense_ablate,
                                          h->opt_debug_counters ? h->dbg.as<unsigned long long>() : nullptr, st);
@@ -373,18 +384,32 @@ int dense_topk_dev(erh_handle *h, const void *q_dev, int q_dtype, int normalize_
       // on first use) and the query block as stage images (512 KiB per 256 queries, per call)
       if (h->opt_dense_tile384 && Bpad >= 2 * QT && h->opt_dense_pp == 3 && h->opt_dense_var == 0 && h->opt_dense_ablate == 0 &&
           !h->opt_dense_sync && d % 64 == 0 && d / 32 >= 8 && N >= 2 * erh::dense_scan_pp5_rows()) {
-          if (!h->xt384_valid) {
+          if (!h->xt384_valid && !h->xt384_nomem) {
               const int rows = erh::dense_scan_pp5_rows();
               const int64_t n_tiles = (N + rows - 1) / rows;
-              HIPCHK(h, h->Xt384.ensure((size_t)n_tiles * rows * (size_t)d * 2));
-              HIPCHK(h, erh::launch_dense_tile_rows_n(h->X.as<_Float16>(), N, d, rows, h->Xt384.p, st));
-              h->xt384_valid = true;
+              // The copy doubles the matrix.  A corpus that leaves no room for it (X above about half of HBM) keeps the 256 x 256
+              // scan, which needs no copy: out-of-memory here is a fall-through, not an error, and is not retried until the
+              // next erh_set_dense.
+              const size_t want = (size_t)n_tiles * rows * (size_t)d * 2;
+              const hipError_t ea = (h->opt_tile384_max_mb >= 0 && want > ((size_t)h->opt_tile384_max_mb << 20))
+                                        ? hipErrorOutOfMemory : h->Xt384.ensure(want);
+              if (ea == hipErrorOutOfMemory) {
+                  (void)hipGetLastError();
+                  h->xt384_nomem = true;
+                  h->stats.dense_tile384_nomem += 1;
+              } else {
+                  HIPCHK(h, ea);
+                  HIPCHK(h, erh::launch_dense_tile_rows_n(h->X.as<_Float16>(), N, d, rows, h->Xt384.p, st));
+                  h->xt384_valid = true;
+              }
           }
-          if (!h->qt_valid) {
-              HIPCHK(h, h->Qt.ensure((size_t)Bpad * d * 2));
-              HIPCHK(h, erh::launch_dense_tile_rows(h->Q16.as<_Float16>(), Bpad, d, h->Qt.p, st));
+          if (h->xt384_valid) {
+              if (!h->qt_valid) {
+                  HIPCHK(h, h->Qt.ensure((size_t)Bpad * d * 2));
+                  HIPCHK(h, erh::launch_dense_tile_rows(h->Q16.as<_Float16>(), Bpad, d, h->Qt.p, st));
+              }
+              h->qt5_valid = true;
           }
-          h->qt5_valid = true;
       } }
     const _Float16 *X = h->X.as<_Float16>();
     const _Float16 *Q16 = h->Q16.as<_Float16>();
@@ -429,7 +454,8 @@ int dense_topk_dev(erh_handle *h, const void *q_dev, int q_dtype, int normalize_
         // than the store kernel and the select they replace (profiles/r04s_kbench_sample_pass.log).
         const bool ok = h->opt_dense_selfseed && Bpad >= 2 * QT && h->opt_dense_speculate && h->opt_dense_pp == 3 && h->opt_dense_var == 0 &&
                         h->opt_dense_ablate == 0 && !h->opt_dense_sync && !tiled_run && !small && !filter_dev && n_streams > 0 &&
-                        d % 64 == 0 && d / 32 >= 8 && rows_seed > 0 && N >= 2 * rows_seed && rank < k && 4 * rank <= n_cells;
+                        d % 64 == 0 && d / 32 >= 8 && rows_seed > 0 && N >= 2 * rows_seed && rank < k && 4 * rank <= n_cells &&
+                        erh::seed_cells_select_fits(n_cells * 2);   // (its LDS sort: out of reach with the device's CU count, checked anyway)
         if (ok) {
             erh::ErhSeedIo sio{};
             sio.seed_tiles = seed_tiles;
@@ -438,6 +464,7 @@ int dense_topk_dev(erh_handle *h, const void *q_dev, int q_dtype, int normalize_
             const int n_vals = n_cells * 2;
             HIPCHK(h, h->seed_top.ensure((size_t)Bpad * n_vals * 4));
             sio.seed_top = h->seed_top.as<float>();
+            h->stats.dense_sample_passes += 1;
             const int lean = 1 | 8 | (dense_rot_stages(h, d, Bpad) << 8);
             // (the pass books no work: the sampled rows are scanned again below, and N rows are what the algorithm needs)
             { ProfScope ps(h, st, ERH_K_DENSE_SCAN, 0, 0);
@@ -462,7 +489,7 @@ int dense_topk_dev(erh_handle *h, const void *q_dev, int q_dtype, int normalize_
                                                    h->tau.as<float>(), st));
               HIPCHK(h, erh::launch_dense_exhaustive(bad, B, 0, k, X, N, d, Q16, filter_dev,
                                                      h->has_dir ? h->dir_id.as<int16_t>() : nullptr, h->pos_inv, h->ex_ws.p,
-                                                     flags, h->n_cus, d_ids, d_sc, d_len, st)); }
+                                                     flags, h->n_cus, d_ids, d_sc, d_len, h->dstats.as<unsigned long long>(), st)); }
             h->last = erh_handle::LastDense();
             h->last.valid = true;
             h->last.B = B; h->last.k = k; h->last.filter_dev = filter_dev;
@@ -558,7 +585,7 @@ int dense_topk_dev(erh_handle *h, const void *q_dev, int q_dtype, int normalize_
       // dense_exhaustive_max() queries were flagged, in which case dense_check_flags runs further rounds
       HIPCHK(h, erh::launch_dense_exhaustive(bad, B, 0, k, X, N, d, Q16, filter_dev,
                                              h->has_dir ? h->dir_id.as<int16_t>() : nullptr, h->pos_inv, h->ex_ws.p,
-                                             flags, h->n_cus, d_ids, d_sc, d_len, st)); }
+                                             flags, h->n_cus, d_ids, d_sc, d_len, h->dstats.as<unsigned long long>(), st)); }
     h->last = erh_handle::LastDense();
     h->last.valid = true;
     h->last.B = B; h->last.k = k; h->last.filter_dev = filter_dev;
@@ -581,7 +608,7 @@ int dense_check_flags(erh_handle *h, hipStream_t st) {
                                                    h->Q16.as<_Float16>(), L.filter_dev,
                                                    h->has_dir ? h->dir_id.as<int16_t>() : nullptr, h->pos_inv,
                                                    h->ex_ws.p, h->flags.as<uint32_t>(), h->n_cus, L.d_ids, L.d_sc,
-                                                   L.d_len, st));
+                                                   L.d_len, h->dstats.as<unsigned long long>(), st));
         if (L.hybrid) {
             const int32_t *cid = h->has_content ? h->content_id.as<int32_t>() : nullptr;
             HIPCHK(h, erh::launch_rrf(h->hy_sids.as<int32_t>(), h->hy_slen.as<int32_t>(), L.k_sparse, L.d_ids, L.d_len,
@@ -647,7 +674,7 @@ int bm25_topk_dev(erh_handle *h, const int32_t *qptr_dev, const int32_t *qtok_de
                                                   (uint32_t)S.nnz, S.qmax,
                                                   tab, n_tab, tshift, S.Nb, qptr_dev, qtok_dev, q_order,
                                                   B, k, segs, cut_mul, filter_dev, dir, p_sc, p_ids, p_len, h->bm_redo.as<uint32_t>(),
-                                                  h->opt_bm25_ablate, dbg, st);
+                                                  h->dstats.as<unsigned long long>(), h->opt_bm25_ablate, dbg, st);
             if (e != hipSuccess) return e;
             // near-tie floods (rare): those workgroups are scanned again by the exact block scan (same document ranges per
             // segment: the cuts are expressed in the block scan's own tiles), the others exit at once
@@ -764,6 +791,11 @@ int erh_create(int device, erh_handle **out) {
         delete h;
         return ERH_ERR_HIP;
     }
+    if (h->dstats.ensure(64) != hipSuccess || hipMemset(h->dstats.p, 0, 64) != hipSuccess) {
+        h->dstats.release();
+        delete h;
+        return ERH_ERR_NOMEM;
+    }
     *out = h;
     return ERH_OK;
 }
@@ -782,7 +814,7 @@ int erh_destroy(erh_handle *h) {
                       &h->o_ids, &h->o_sc, &h->o_len, &h->qptr, &h->qtok, &h->part_sc, &h->part_ids, &h->part_len,
                       &h->hy_sids, &h->hy_ssc, &h->hy_slen, &h->hy_dids, &h->hy_dsc, &h->hy_dlen,
                       &h->fa_ids, &h->fa_sc, &h->fa_len, &h->fb_ids, &h->fb_sc, &h->fb_len,
-                      &h->scores_tmp, &h->scores_wide, &h->dbg, &h->dir_pos, &h->seed_need, &h->bad, &h->ex_ws, &h->bm_redo};
+                      &h->scores_tmp, &h->scores_wide, &h->dbg, &h->dstats, &h->dir_pos, &h->seed_need, &h->bad, &h->ex_ws, &h->bm_redo};
     for (DevBuf *b : bufs) b->release();
     for (auto &b : h->bm) b.release();
     if (h->comm || h->comm_pending) (void)erh_comm_destroy(h);
@@ -819,6 +851,7 @@ int erh_set_option(erh_handle *h, const char *name, int64_t value) {
         return ERH_OK;
     }
     if (!strcmp(name, "dense_tile384")) { h->opt_dense_tile384 = value != 0; return ERH_OK; }
+    if (!strcmp(name, "dense_tile384_max_mb")) { h->opt_tile384_max_mb = value; h->xt384_nomem = false; return ERH_OK; }
     if (!strcmp(name, "dense_tiled")) { h->opt_dense_tiled = value != 0; return ERH_OK; }   // building the copy: at the next erh_set_dense
     if (!strcmp(name, "dense_speculate")) { h->opt_dense_speculate = value != 0; return ERH_OK; }
     if (!strcmp(name, "dense_var")) { if (value < 0 || value > 3) return h->fail(ERH_ERR_INVALID, "dense_var"); h->opt_dense_var = (int)value; return ERH_OK; }
@@ -921,6 +954,35 @@ int erh_dense_seed_rank(int k, int64_t n0, int64_t n) {
     return r < (double)k ? (int)r : k;
 }
 
+int erh_get_stat(erh_handle *h, const char *name, int64_t *value) {
+    if (!h || !name || !value) return ERH_ERR_INVALID;
+    const erh_handle::Stats &T = h->stats;
+    const struct { const char *n; int64_t v; } host[] = {
+        {"dense_calls", T.dense_calls}, {"dense_scan_pp5_launches", T.dense_scan_pp5}, {"dense_scan_pp3_launches", T.dense_scan_pp3},
+        {"dense_scan_gemv_launches", T.dense_scan_gemv}, {"dense_scan_tile_launches", T.dense_scan_tile},
+        {"dense_sample_passes", T.dense_sample_passes}, {"dense_tile384_nomem", T.dense_tile384_nomem},
+        {"bm25_calls", T.bm25_calls}, {"hybrid_calls", T.hybrid_calls}};
+    for (const auto &e : host)
+        if (!strcmp(name, e.n)) { *value = e.v; return ERH_OK; }
+    const int di = !strcmp(name, "dense_exhaustive_queries") ? 0 : !strcmp(name, "bm25_redo_segments") ? 1 : -1;
+    if (di < 0) return h->fail(ERH_ERR_INVALID, "erh_get_stat: unknown counter");
+    unsigned long long v[2] = {0, 0};
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipDeviceSynchronize());                       // the counters of everything enqueued so far
+    HIPCHK(h, hipMemcpy(v, h->dstats.p, sizeof v, hipMemcpyDeviceToHost));
+    *value = (int64_t)v[di];
+    return ERH_OK;
+}
+
+int erh_reset_stats(erh_handle *h) {
+    if (!h) return ERH_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipDeviceSynchronize());
+    HIPCHK(h, hipMemset(h->dstats.p, 0, 64));
+    h->stats = erh_handle::Stats();
+    return ERH_OK;
+}
+
 int erh_dense_exhaustive_count(erh_handle *h, int32_t *count) {
     if (!h || !count) return ERH_ERR_INVALID;
     *count = h->diag_exhaustive;
@@ -940,6 +1002,10 @@ int erh_set_dense(erh_handle *h, const void *x, int64_t n, int d, int dtype, int
     HIPCHK(h, hipSetDevice(h->device));
     hipStream_t st = nullptr;
     hipStream_t st_pad = nullptr;
+    // the 384-row copy of the OLD matrix goes first (it is rebuilt on first use): it must not sit beside the old and the new X
+    h->xt384_valid = false;
+    h->xt384_nomem = false;
+    h->Xt384.release();
     HIPCHK(h, h->X.ensure((size_t)(n + erh::kDensePadRows) * d * 2));   // zero rows behind the matrix: tiles may run past N
     HIPCHK(h, hipMemsetAsync(h->X.as<char>() + (size_t)n * d * 2, 0, (size_t)erh::kDensePadRows * d * 2, st_pad));
     const hipMemcpyKind kind = is_device_ptr ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
@@ -1445,6 +1511,7 @@ int erh_dense_topk(erh_handle *h, const void *q, int q_dtype, int q_is_device, i
         HIPCHK(h, h->o_len.ensure((size_t)B * 4));
         d_ids = h->o_ids.as<int32_t>(); d_sc = h->o_sc.as<double>(); d_len = h->o_len.as<int32_t>();
     }
+    h->stats.dense_calls += 1;
     rc = dense_topk_dev(h, qd, q_dtype, normalize_q, B, k, filt, mode, d_ids, d_sc, d_len, st);
     if (rc != ERH_OK) return rc;
     if (!out_is_device) {
@@ -1479,6 +1546,7 @@ int erh_bm25_topk(erh_handle *h, const int32_t *q_indptr, const int32_t *q_tok, 
         HIPCHK(h, h->o_len.ensure((size_t)B * 4));
         d_ids = h->o_ids.as<int32_t>(); d_sc = h->o_sc.as<double>(); d_len = h->o_len.as<int32_t>();
     }
+    h->stats.bm25_calls += 1;
     rc = bm25_topk_dev(h, h->qptr.as<int32_t>(), h->qtok.as<int32_t>(), B, k, filt, d_ids, d_sc, d_len, bytes, max_qlen, st);
     if (rc != ERH_OK) return rc;
     if (!out_is_device) return copy_out(h, B, k, d_ids, d_sc, d_len, out_ids, out_scores, out_len, st);
@@ -1612,6 +1680,7 @@ int erh_hybrid_topk(erh_handle *h, const void *q, int q_dtype, int q_is_device, 
     // other: with hybrid_overlap the sparse route is enqueued on a side stream that forks from the caller's stream (its
     // inputs were staged there) and joins it again in front of the fusion; whatever the dense pipeline leaves idle --
     // the under-filled seed grid, the selection kernels, the tail of the persistent scan -- the other route can use.
+    h->stats.hybrid_calls += 1;
     hipStream_t st_sparse = st;
     const int ov = h->opt_hybrid_overlap >= 0 ? h->opt_hybrid_overlap : (B <= 256 ? 1 : 0);
     if (ov) {

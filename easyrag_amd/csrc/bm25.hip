@@ -1387,7 +1387,8 @@ __global__ __launch_bounds__(C::NT, 4 /* waves per SIMD: two 512-thread workgrou
     int segs, int cut_mul /* segment boundaries fall on multiples of cut_mul tiles (the exact scan's tile may be larger) */,
     const int16_t *__restrict__ filter_dir, const int16_t *__restrict__ dir_id,
     double *__restrict__ part_scores, int32_t *__restrict__ part_ids, int32_t *__restrict__ part_len,
-    uint32_t *__restrict__ redo, int abl /* measurement builds: 1 no adds, 2 no posting loads, 4 no clear, 8 one descriptor set */,
+    uint32_t *__restrict__ redo, unsigned long long *__restrict__ stats /* null, or erh_get_stat's device counters */,
+    int abl /* measurement builds: 1 no adds, 2 no posting loads, 4 no clear, 8 one descriptor set */,
     unsigned long long *__restrict__ dbg) {
     constexpr int NT = C::NT, TILE = C::TILE, NW = C::NW, CAP = C::CAP, WORDS = C::WORDS, U = C::U;
 #ifdef ERH_MEASURE
@@ -1628,7 +1629,11 @@ __global__ __launch_bounds__(C::NT, 4 /* waves per SIMD: two 512-thread workgrou
     }
     if (!stop) as_shrink<CAP>(hdr, h2, ca, ci, hist, k, keep_frac, n_err, 0);     // final list: k entries + the near ties of the k-th
     if (h2->redo) {                                                       // workgroup-uniform
-        if (tid == 0) { redo[(int64_t)q * segs + seg] = 1u; part_len[(int64_t)q * segs + seg] = 0; }
+        if (tid == 0) {
+            redo[(int64_t)q * segs + seg] = 1u;
+            part_len[(int64_t)q * segs + seg] = 0;
+            if (stats) atomicAdd(&stats[1], 1ull);
+        }
         return;
     }
     if (ERH_ABL(0xff)) { if (tid == 0) part_len[(int64_t)q * segs + seg] = 0; return; }   // (ablations: the list is garbage)
@@ -1836,7 +1841,7 @@ hipError_t launch_bm25_ascan(int variant, int small, const int64_t *indptr, cons
                              int n_tab, int tshift, int64_t N, const int32_t *q_indptr, const int32_t *q_tok,
                              const int32_t *q_order, int B, int k, int segs, int cut_mul, const int16_t *filter_dir,
                              const int16_t *dir_id, double *part_scores, int32_t *part_ids, int32_t *part_len, uint32_t *redo,
-                             int ablate, unsigned long long *dbg, hipStream_t st) {
+                             unsigned long long *stats, int ablate, unsigned long long *dbg, hipStream_t st) {
     if (B <= 0) return hipSuccess;
     if (cut_mul < 1) cut_mul = 1;
     const int tile = bm25_ascan_tile_docs(small);
@@ -1845,7 +1850,7 @@ hipError_t launch_bm25_ascan(int variant, int small, const int64_t *indptr, cons
 #define ERH_AS_LAUNCH(ST, CFG, POST)                                                                                 \
     hipLaunchKernelGGL((bm25_ascan_kernel<ST, CFG>), grid, dim3(CFG::NT), CFG::BYTES, st, indptr, doc_ids,           \
                        (const ST *)payload, POST, nnz, qmax, g16, tile_off, n_tab, tshift, n_tiles, N, q_indptr,      \
-                       q_tok, q_order, k, segs, cut_mul, filter_dir, dir_id, part_scores, part_ids, part_len, redo, ablate, dbg)
+                       q_tok, q_order, k, segs, cut_mul, filter_dir, dir_id, part_scores, part_ids, part_len, redo, stats, ablate, dbg)
 #define ERH_AS_SHAPES(ST)                                                                                            \
     do {                                                                                                             \
         if (small == 2 && post16) ERH_AS_LAUNCH(ST, AsPack16, post16);                                               \

@@ -91,6 +91,7 @@ hipError_t launch_row_norm_max(const _Float16 *x, int64_t n, int d, float *out, 
 // are written to cand[q] and cand_cnt[q] is (re)initialised.
 // rank <= k: position in the prefix that seeds the threshold (k: guaranteed bound, < k: speculative, verified by
 // launch_dense_finalize when it is given tau_verify)
+bool seed_cells_select_fits(int n_vals);   // the select sorts pow2(n_vals) floats in 48 KiB of LDS
 hipError_t launch_seed_cells_select(const float *seed_top, int n_vals, int B, int rank, const float *qnorm, float xnorm_max, int d,
                                     float *tau, uint32_t *cand_cnt, hipStream_t st);
 hipError_t launch_seed_select(const float *S0, int ld_s0, int n0, int64_t c0, int B, int k, int rank,
@@ -114,7 +115,9 @@ size_t dense_exhaustive_bytes(int64_t N);
 hipError_t launch_dense_exhaustive(const uint32_t *bad, int B, int skip, int k, const _Float16 *X, int64_t N, int d,
                                    const _Float16 *Q16, const int16_t *filter_dir, const int16_t *dir_id,
                                    int64_t pos_inv, void *ws, uint32_t *flags, int n_cus,
-                                   int32_t *out_ids, double *out_scores, int32_t *out_len, hipStream_t st);
+                                   int32_t *out_ids, double *out_scores, int32_t *out_len,
+                                   unsigned long long *stats /* null, or the handle's device counters: [0] += flagged queries */,
+                                   hipStream_t st);
 
 // ---- bm25.hip --------------------------------------------------------------------------------
 constexpr int kBm25TileF32 = 32768;   // documents per LDS accumulator tile (fp32 sums)
@@ -152,6 +155,7 @@ hipError_t launch_bm25_ascan(int variant, int small /* 0: 1024 threads; 1: 512 t
                              int segs, int cut_mul /* segment cuts on multiples of this many tiles */,
                              const int16_t *filter_dir, const int16_t *dir_id,
                              double *part_scores, int32_t *part_ids, int32_t *part_len, uint32_t *redo,
+                             unsigned long long *stats /* null, or the handle's device counters: [1] += (query, segment) pairs handed to the exact scan */,
                              int ablate /* measurement builds only */, unsigned long long *dbg, hipStream_t st);
 // 4-byte postings of the packed scan {document & 32767, (q >> g) + 1 in 16 bits}: nnz + 8 words (zeros behind the postings)
 int bm25_post16_shift(double qmax);

@@ -633,7 +633,8 @@ constexpr int kExCap = 2048;
 // list[0 .. kExMax) = flagged queries of rank skip .. skip + kExMax - 1 (ascending), count[0] = how many, count[1] = all flagged
 __global__ __launch_bounds__(1024) void dense_bad_collect_kernel(const uint32_t *__restrict__ bad, int B, int skip,
                                                                 int32_t *__restrict__ list, int32_t *__restrict__ count,
-                                                                uint32_t *__restrict__ flags) {
+                                                                uint32_t *__restrict__ flags,
+                                                                unsigned long long *__restrict__ stats /* erh_get_stat: [0] += flagged queries (first round only) */) {
     __shared__ int s_base, s_taken;
     const int tid = threadIdx.x;
     if (tid == 0) { s_base = 0; s_taken = 0; }
@@ -664,6 +665,7 @@ __global__ __launch_bounds__(1024) void dense_bad_collect_kernel(const uint32_t 
         flags[0] = (s_base > skip + kExMax) ? 1u : 0u;                   // still unanswered after this round
         flags[3] = (uint32_t)s_base;
         if (s_base <= skip + kExMax) flags[2] = 0u;                      // every flagged query gets its exact answer
+        if (stats && skip == 0 && s_base) atomicAdd(&stats[0], (unsigned long long)s_base);
     }
 }
 
@@ -851,11 +853,13 @@ hipError_t launch_seed_select(const float *S0, int ld_s0, int n0, int64_t c0, in
     return hipGetLastError();
 }
 
+bool seed_cells_select_fits(int n_vals) { return (size_t)pow2_ge(n_vals < 2 ? 2 : n_vals) * 4 <= 48 * 1024; }
+
 hipError_t launch_seed_cells_select(const float *seed_top, int n_vals, int B, int rank, const float *qnorm, float xnorm_max, int d,
                                     float *tau, uint32_t *cand_cnt, hipStream_t st) {
     if (B <= 0) return hipSuccess;
     const int np2 = pow2_ge(n_vals < 2 ? 2 : n_vals);
-    if ((size_t)np2 * 4 > 48 * 1024) return hipErrorInvalidValue;
+    if (!seed_cells_select_fits(n_vals)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(seed_cells_select_kernel, dim3(B), dim3(256), (size_t)np2 * 4, st, seed_top, n_vals, np2, rank, qnorm,
                        xnorm_max, d, tau, cand_cnt);
     return hipGetLastError();
@@ -897,11 +901,12 @@ size_t dense_exhaustive_bytes(int64_t N) { return (size_t)kExMax * (size_t)N * 8
 hipError_t launch_dense_exhaustive(const uint32_t *bad, int B, int skip, int k, const _Float16 *X, int64_t N, int d,
                                    const _Float16 *Q16, const int16_t *filter_dir, const int16_t *dir_id,
                                    int64_t pos_inv, void *ws, uint32_t *flags, int n_cus,
-                                   int32_t *out_ids, double *out_scores, int32_t *out_len, hipStream_t st) {
+                                   int32_t *out_ids, double *out_scores, int32_t *out_len, unsigned long long *stats,
+                                   hipStream_t st) {
     double *S64 = reinterpret_cast<double *>(ws);
     int32_t *list = reinterpret_cast<int32_t *>(S64 + (size_t)kExMax * (size_t)N);
     int32_t *count = list + kExMax;
-    hipLaunchKernelGGL(dense_bad_collect_kernel, dim3(1), dim3(1024), 0, st, bad, B, skip, list, count, flags);
+    hipLaunchKernelGGL(dense_bad_collect_kernel, dim3(1), dim3(1024), 0, st, bad, B, skip, list, count, flags, stats);
     const size_t lds = (size_t)kExGroup * d * 2;
     hipError_t e = hipFuncSetAttribute((const void *)dense_exact_all_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);

@@ -63,8 +63,9 @@ class RetrievalEngine:
 
     @property
     def bm25(self) -> Optional[BM25Index]:
-        """The BM25 index of the selected slot."""
-        return self._bm25_slots[self._bm25_cur]
+        """The BM25 index of the selected slot (None while the slot is empty or only reserved)."""
+        v = self._bm25_slots[self._bm25_cur]
+        return None if v is self._RESERVED else v
 
     # -- lifetime ---------------------------------------------------------------------------
     def close(self):
@@ -113,26 +114,41 @@ class RetrievalEngine:
 
     # A handle holds ERH_BM25_SLOTS independent BM25 indices (content route + know_path route of the reference
     # pipeline share one engine); every BM25 call names its slot, default 0.
+    _RESERVED = "reserved"                  # a slot handed out by alloc_bm25_slot that has no index yet
+
     def alloc_bm25_slot(self) -> int:
+        """Reserve a free slot (it counts as taken from here on, index or not; free_bm25_slot gives it back)."""
         for i, v in enumerate(self._bm25_slots):
             if v is None:
+                self._bm25_slots[i] = self._RESERVED
                 return i
-        raise RuntimeError(f"all {_lib.ERH_BM25_SLOTS} BM25 index slots of this engine are in use")
+        hint = (" (one of them is the scratch slot of BM25Retriever.get_scores(query, docs): release_scratch() frees it)"
+                if getattr(self, "_scratch_slot", None) is not None else "")
+        raise RuntimeError(f"all {_lib.ERH_BM25_SLOTS} BM25 index slots of this engine are in use{hint}")
 
     def scratch_bm25_slot(self) -> int:
         """The engine's scratch slot for throw-away indices (BM25Retriever.get_scores(query, docs): a handful of sentences per
         call on the compressor's per-query path).  Allocated on first use and kept: re-setting an index re-uses the slot's
-        device buffers, whereas alloc / free per call costs device allocations, frees and a full synchronisation each time."""
+        device buffers, whereas alloc / free per call costs device allocations, frees and a full synchronisation each time.
+        It occupies one of the ERH_BM25_SLOTS slots until release_scratch() (or close())."""
         if getattr(self, "_scratch_slot", None) is None:
             self._scratch_slot = self.alloc_bm25_slot()
-            self._bm25_slots[self._scratch_slot] = "scratch"            # reserved even while no index is set
         return self._scratch_slot
+
+    def release_scratch(self):
+        """Give the scratch slot (and its device buffers) back; the next get_scores(query, docs) allocates it again."""
+        slot = getattr(self, "_scratch_slot", None)
+        if slot is not None:
+            self._scratch_slot = None
+            self.free_bm25_slot(slot)
 
     def free_bm25_slot(self, slot: int):
         """Empty a slot: the device copies of its index are freed as well (erh_bm25_release)."""
-        if self._bm25_slots[slot] is not None and getattr(self, "_h", None):
+        if self._bm25_slots[slot] is not None and self._bm25_slots[slot] is not self._RESERVED and getattr(self, "_h", None):
             self._check(self._lib.erh_bm25_release(self._h, int(slot)))
         self._bm25_slots[slot] = None
+        if getattr(self, "_scratch_slot", None) == slot:
+            self._scratch_slot = None
 
     def _select(self, slot: Optional[int]) -> int:
         slot = 0 if slot is None else int(slot)              # every BM25 call names its slot; None = slot 0, as documented
@@ -447,6 +463,22 @@ class RetrievalEngine:
         x = C.c_int()
         self._check(self._lib.erh_dense_exhaustive_count(self._h, C.byref(x)))
         return {"max_abs_err": e.value, "margin": m.value, "uncertified": u.value, "exhaustive": x.value}
+
+    STAT_NAMES = ("dense_calls", "bm25_calls", "hybrid_calls", "dense_scan_pp5_launches", "dense_scan_pp3_launches",
+                  "dense_scan_gemv_launches", "dense_scan_tile_launches", "dense_sample_passes", "dense_tile384_nomem",
+                  "dense_exhaustive_queries", "bm25_redo_segments")
+
+    def stat(self, name: str) -> int:
+        """One counter of erh_get_stat (which kernels answered the calls since the last reset_stats)."""
+        v = C.c_int64()
+        self._check(self._lib.erh_get_stat(self._h, name.encode(), C.byref(v)))
+        return int(v.value)
+
+    def stats(self) -> dict:
+        return {n: self.stat(n) for n in self.STAT_NAMES}
+
+    def reset_stats(self):
+        self._check(self._lib.erh_reset_stats(self._h))
 
     def debug_dense_scores(self, q16: np.ndarray, row0: int, rows: int, use_mfma: bool) -> np.ndarray:
         q16 = np.ascontiguousarray(q16, dtype=np.float16)

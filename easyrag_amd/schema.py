@@ -19,10 +19,18 @@ except Exception:
     HAVE_LLAMA_INDEX = False
 
     @dataclass
+    class RelatedNodeInfo:
+        """What llama_index stores per relationship; the hot path reads only ``node_id``."""
+        node_id: str
+        metadata: Dict[str, Any] = field(default_factory=dict)
+
+    @dataclass
     class TextNode:
         text: str = ""
         metadata: Dict[str, Any] = field(default_factory=dict)
         id_: Optional[str] = None
+        # embed_type 6 walks the PREVIOUS link (ref ingestion.py:36-57); keys: "PREVIOUS", "2" or 2 (llama_index's enum value)
+        relationships: Dict[Any, Any] = field(default_factory=dict)
 
         def __post_init__(self):
             if self.id_ is None:

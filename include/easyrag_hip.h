@@ -285,6 +285,8 @@ int erh_reset_kernel_time(erh_handle *h);
  *   dense_tile384 (1)     batches padded to >= 512 queries: scan on a 384 x 256 tile over tiled copies of both operands
  *                         (dense_scan_pp5_kernel; the 384-row copy of the chunk matrix, + N * d * 2 bytes, is built on first use);
  *                         0 = the 256 x 256 tile for every batch size
+ *   dense_tile384_max_mb (-1)  test hook: a 384-row copy larger than this many MiB is refused as if its allocation had failed
+ *                         (the 256 x 256 scan then serves every batch; -1 = no limit)
  *   dense_selfseed (1)    batches padded to >= 512 queries: the scan kernel draws the threshold sample itself (a pass without
  *                         thresholds over one tile per chunk stream, the two best scores of every 64-row cell) and then scans
  *                         all rows; 0 = store kernel + S0 + seed select for every batch size
@@ -352,6 +354,20 @@ int erh_dense_diag(erh_handle *h, double *max_abs_err, double *margin, int32_t *
  * near-duplicate chunks around the k-th score -- and that were answered by the exhaustive path instead (exact fp64
  * score of every chunk, streaming top-k; same results contract).  Normally 0. */
 int erh_dense_exhaustive_count(erh_handle *h, int32_t *count);
+
+/* Which kernels answered the calls since erh_create / erh_reset_stats (a record that proves its own path: tests assert that
+ * the kernel under test ran, bench.py reports that no query of the timed steps left the pruned pipeline).  Counters:
+ *   dense_calls / bm25_calls / hybrid_calls           entry-point calls
+ *   dense_scan_pp5_launches                            dense scan launches on the 384 x 256 tile (dense_scan_pp5_kernel)
+ *   dense_scan_pp3_launches                            ... on the 256 x 256 ping-pong tile (main scans; sample passes are counted apart)
+ *   dense_scan_gemv_launches / dense_scan_tile_launches  ... on the skinny-GEMM stream / the per-tile fallback kernels
+ *   dense_sample_passes                                threshold samples drawn by the scan kernel itself (dense_selfseed)
+ *   dense_tile384_nomem                                times the 384-row copy of the chunk matrix did not fit and the 256 x 256 scan took over
+ *   dense_exhaustive_queries                           queries answered by the exhaustive path (device counter; summed over calls)
+ *   bm25_redo_segments                                 (query, segment) pairs the fixed-point scan handed to the exact block scan (device counter)
+ * Reading a device counter synchronises the device.  Unknown name: ERH_ERR_INVALID. */
+int erh_get_stat(erh_handle *h, const char *name, int64_t *value);
+int erh_reset_stats(erh_handle *h);
 
 /* Pure function (no handle, no device): the rank of the seed-prefix score that erh_dense_topk takes as its first pruning
  * threshold for top-k over n chunks with a prefix of n0 -- k itself (a guaranteed bound) or, with option dense_speculate,

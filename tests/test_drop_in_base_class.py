@@ -141,3 +141,46 @@ def test_embed_type_6_merges_the_table_header():
     # a bare TextNode with a table-like text: the reference dereferences node.node and raises; so does this
     with pytest.raises(AttributeError):
         get_node_content(body, 6, nodes, nid)
+
+
+def test_embed_type_6_with_the_stand_in_node_types_only():
+    """without llama_index the package's OWN TextNode must carry `relationships` (embed_type 6 reads
+    node.node.relationships) and offer a RelatedNodeInfo with node_id -- no attribute patched on from outside."""
+    from easyrag_amd import schema
+    from easyrag_amd.retrievers import get_node_content
+    if schema.HAVE_LLAMA_INDEX:
+        pytest.skip("llama_index is installed here")
+    head = schema.TextNode(text="t\nname | port | role | x | y\n--- | --- | --- | --- | ---\na | 1 | x | p | q", id_="h")
+    assert head.relationships == {}
+    for key in ("PREVIOUS", "2", 2):
+        body = schema.TextNode(text="a | 1 | x | p | q\nb | 2 | y | p | q", id_="b",
+                               relationships={key: schema.RelatedNodeInfo(node_id="h")})
+        got = get_node_content(schema.NodeWithScore(node=body, score=0.5), 6, [head, body], {"h": 0, "b": 1})
+        assert got == "name | port | role | x | y--- | --- | --- | --- | ---\na | 1 | x | p | q\nb | 2 | y | p | q"
+    # a table-like chunk WITHOUT a predecessor link: the reference raises KeyError on relationships[PREVIOUS]; so does this
+    lone = schema.TextNode(text="a | 1 | x | p | q\nb | 2 | y | p | q", id_="l")
+    with pytest.raises(KeyError):
+        get_node_content(schema.NodeWithScore(node=lone, score=0.5), 6, [lone], {"l": 0})
+
+
+def test_engine_slot_bookkeeping_without_a_device():
+    """alloc_bm25_slot reserves (two allocations without a set in between must differ), the scratch slot is
+    given back by release_scratch, and the 'all slots in use' error says where the fourth slot went."""
+    from easyrag_amd import _lib
+    from easyrag_amd.engine import RetrievalEngine
+    eng = RetrievalEngine.__new__(RetrievalEngine)          # bookkeeping only: no handle, no device
+    eng._h = None
+    eng._bm25_slots = [None] * _lib.ERH_BM25_SLOTS
+    eng._bm25_cur = 0
+    a, b = eng.alloc_bm25_slot(), eng.alloc_bm25_slot()
+    assert a != b and eng.bm25 is None
+    s = eng.scratch_bm25_slot()
+    assert s not in (a, b) and eng.scratch_bm25_slot() == s
+    last = eng.alloc_bm25_slot()
+    assert len({a, b, s, last}) == _lib.ERH_BM25_SLOTS
+    with pytest.raises(RuntimeError, match="release_scratch"):
+        eng.alloc_bm25_slot()
+    eng.release_scratch()
+    assert eng.alloc_bm25_slot() == s                        # the freed scratch slot is handed out again
+    eng.free_bm25_slot(a)
+    assert eng.scratch_bm25_slot() == a
