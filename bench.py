@@ -43,6 +43,11 @@ def parse_args(argv=None):
     ap.add_argument("--batch", type=int, default=0, help="queries per GPU per step (default: hybrid 1024 = configs[3]; dense / bm25 256 = configs[1] / configs[2])")
     ap.add_argument("--pool", type=int, default=4, help="distinct query batches rotated through the steps")
     ap.add_argument("--gather", default=None, choices=["torch", "native"], help="multi-GPU gather: torch.distributed around the library's pack/unpack kernels (default) or erh_allgather_topk (RCCL inside the library)")
+    ap.add_argument("--backend", default=None, choices=["nccl", "gloo"], help="process-group backend for --gpus > 1 (default nccl = RCCL; gloo with "
+                                                                            "--share-device is the one-GPU dry run of the multi-process path)")
+    ap.add_argument("--share-device", action="store_true", help="all ranks use GPU 0 (dry run of the N-process path on a one-GPU box: needs "
+                                                                "--backend gloo; the numbers it prints are not a scaling measurement)")
+    ap.add_argument("--dump-out", default=None, help="every rank saves the last step's (global) result as <path>.rank<r>.npz (tests)")
     ap.add_argument("--variant", default="bm25s", choices=["bm25s", "okapi"])
     ap.add_argument("--cpu-queries", type=int, default=96, help="queries in the bounded CPU-baseline sample, ~15 s of host work (0 = skip)")
     ap.add_argument("--option", action="append", default=[], help="library option name=value (e.g. dense_n1=131072)")
@@ -315,7 +320,7 @@ def spawn_ranks(args, argv) -> int:
     import subprocess
     import torch
     have = torch.cuda.device_count()
-    if have < args.gpus:
+    if have < args.gpus and not args.share_device:
         print(f"bench.py: --gpus {args.gpus} needs {args.gpus} GPUs on this node, found {have} "
               f"(one rank per GPU; RCCL does not share a device between ranks)", file=sys.stderr)
         return 2
@@ -343,10 +348,13 @@ def main(argv=None, platform=None):
     plat = platform if platform is not None else GpuPlatform()
     synth, queries_to_csr, build_bm25_index_from_postings = plat.synth, plat.queries_to_csr, plat.build_index
 
-    rank, world = erd.init_from_env()
+    t_setup = time.perf_counter()
+    if args.share_device and args.backend != "gloo" and args.gpus > 1:
+        raise SystemExit("--share-device needs --backend gloo (RCCL does not share a device between ranks)")
+    local = 0 if args.share_device else int(os.environ.get("LOCAL_RANK", "0"))
+    rank, world = erd.init_from_env(device_index=local, backend=args.backend)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    local = int(os.environ.get("LOCAL_RANK", "0"))
     dev = plat.set_device(local)
     n, d, vocab = args.chunks, args.dim, args.vocab
     B = args.batch or (1024 if args.workload == "hybrid" else 256)
@@ -413,6 +421,7 @@ def main(argv=None, platform=None):
     for _ in range(args.warmup):
         step()
     plat.synchronize()
+    setup_s = time.perf_counter() - t_setup                   # process start -> ready for the timed region (corpus, index, warm-up)
     if args.workload != "bm25":
         eng.dense_check()                                     # raises on candidate overflow
     eng.set_profiling(True)
@@ -428,10 +437,14 @@ def main(argv=None, platform=None):
     if world > 1:
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
+    setup_all = [setup_s]
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        host_side = torch.distributed.get_backend() == "gloo"       # (gloo reduces host tensors)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if host_side else dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
+        setup_all = [None] * world
+        torch.distributed.all_gather_object(setup_all, setup_s)
     eng.set_profiling(False)
     if args.workload != "bm25":
         eng.dense_check()
@@ -504,6 +517,8 @@ def main(argv=None, platform=None):
             "multi_gpu": None if world == 1 else {
                 "rccl_ranks": int(torch.distributed.get_world_size()), "backend": torch.distributed.get_backend(),
                 "gather_mode": shards.mode, "gather_fallback_reason": shards.fallback_reason,
+                "transport": getattr(shards, "transport", None), "shared_device": bool(args.share_device),
+                "setup_s_per_rank": [round(float(v), 3) for v in setup_all],
                 "allgather_ms_per_step": (sum(a.elapsed_time(b) for a, b in gather_events) / max(len(gather_events), 1)),
                 "allgather_what": "rank 0: dense_check + pack kernel + all_gather_into_tensor + unpack kernel (CUDA events)"},
             "roofline": roof,
@@ -516,6 +531,10 @@ def main(argv=None, platform=None):
             rec["sub_benchmarks"] = sub_benchmarks(eng, synth, queries_to_csr, build_bm25_index_from_postings, OKAPI,
                                                    q16_pool, tok_pool, csr_pool, (indptr, doc, tf, lens), pool)
         print(json.dumps(rec), flush=True)
+    if args.dump_out and out is not None:
+        plat.synchronize()
+        np.savez(f"{args.dump_out}.rank{rank}.npz", **{name: (t.cpu().numpy() if hasattr(t, "cpu") else np.asarray(t))
+                                                       for name, t in zip(("ids", "scores", "len"), out)})
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

@@ -40,6 +40,7 @@ SIGNATURES = {
     "erh_last_error": (C.c_char_p, [_vp]),
     "erh_sync": (_i32, [_vp, _vp]),
     "erh_set_dense": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i32]),
+    "erh_get_dense_rows": (_i32, [_vp, _i64, _i64, _vp, _i32]),
     "erh_set_bm25_csr": (_i32, [_vp, _i32, _i64, _i64, _i64, _vp, _vp, _vp]),
     "erh_set_bm25_tf": (_i32, [_vp, _i32, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl]),
     "erh_build_bm25_index": (_i32, [_vp, _i32, _i64, _i64, _i64, _vp, _vp, _i32, _dbl, _dbl, _dbl, C.POINTER(_i64)]),

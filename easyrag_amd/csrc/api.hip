@@ -1064,6 +1064,25 @@ int erh_set_dense(erh_handle *h, const void *x, int64_t n, int d, int dtype, int
     return ERH_OK;
 }
 
+int erh_get_dense_rows(erh_handle *h, int64_t row0, int64_t rows, void *out_f16, int out_is_device) {
+    if (!h) return ERH_ERR_INVALID;
+    if (!h->X.p || h->N <= 0) return h->fail(ERH_ERR_STATE, "erh_get_dense_rows before erh_set_dense");
+    if (!out_f16 || rows <= 0 || row0 < 0 || row0 + rows > h->N) return h->fail(ERH_ERR_INVALID, "erh_get_dense_rows: bad range");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t st = nullptr;
+    const int d = h->d;
+    // the caller's rows live at their golden-ratio positions: gather them back into the caller's order
+    _Float16 *dst = reinterpret_cast<_Float16 *>(out_f16);
+    if (!out_is_device) {
+        HIPCHK(h, h->scores_tmp.ensure((size_t)rows * d * 2));
+        dst = h->scores_tmp.as<_Float16>();
+    }
+    HIPCHK(h, erh::launch_gather_rows(h->X.as<_Float16>(), row0, rows, d, h->pos_mul, h->N, dst, st));
+    if (!out_is_device) HIPCHK(h, hipMemcpyAsync(out_f16, dst, (size_t)rows * d * 2, hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    return ERH_OK;
+}
+
 // Skip tables over device-resident CSR postings (indptr / doc_ids of the selected slot): the 32768 / 16384-document
 // tile table of the block scan and the fine table of the wave-owned scan.
 static int bm25_finish_tables(erh_handle *h, int variant, int64_t V, int64_t N, hipStream_t st) {

@@ -37,9 +37,11 @@ def max_shard(n_queries: int, world: int) -> int:
     return (n_queries + world - 1) // world
 
 
-def init_from_env(device_index: Optional[int] = None) -> Tuple[int, int]:
+def init_from_env(device_index: Optional[int] = None, backend: Optional[str] = None) -> Tuple[int, int]:
     """Initialise the default process group from RANK / WORLD_SIZE / MASTER_* (torchrun sets them).
-    Returns (rank, world).  Single-process runs skip the group entirely."""
+    Returns (rank, world).  Single-process runs skip the group entirely.  `backend` (or ERH_DIST_BACKEND): "nccl" (= RCCL, the
+    default on GPUs) or "gloo" -- the dry-run transport for several ranks on ONE GPU (RCCL does not share a device between
+    ranks): QueryShards then stages the packed rows through the host, everything else is the same code."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     if world == 1:
@@ -52,7 +54,8 @@ def init_from_env(device_index: Optional[int] = None) -> Tuple[int, int]:
             if device_index is None:
                 device_index = int(os.environ.get("LOCAL_RANK", "0"))
             torch.cuda.set_device(device_index)
-        dist.init_process_group(backend="nccl" if use_gpu else "gloo", rank=rank, world_size=world)
+        backend = backend or os.environ.get("ERH_DIST_BACKEND") or ("nccl" if use_gpu else "gloo")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world
 
 
@@ -115,7 +118,9 @@ class QueryShards:
         self.mode = mode
         self._k = None
         self._send = self._recv = self._out = None
+        self._send_host = self._recv_host = None
         self.fallback_reason = None
+        self.transport = None                     # set by the first gather: "rccl", "gloo", "gloo-staged" (device rows through pinned host memory) or "local"
         if mode == "native" and world > 1:
             self._init_native()
 
@@ -185,9 +190,23 @@ class QueryShards:
             return self.engine.allgather_topk(ids, sc, ln, self.n, out=out)
         self.engine.pack_topk(ids, sc, ln, send)
         if self.world > 1:
-            dist.all_gather_into_tensor(recv, send, group=self.group)
+            staged = send.is_cuda and dist.get_backend(self.group) == "gloo"
+            if staged:
+                # several ranks on ONE GPU (dry run of the multi-process path: RCCL does not share a device between ranks):
+                # the packed rows cross the process boundary through pinned host memory; pack and unpack stay on the device
+                if self._send_host is None or self._send_host.shape != send.shape:
+                    self._send_host = torch.empty(send.shape, dtype=send.dtype, pin_memory=True)
+                    self._recv_host = torch.empty(recv.shape, dtype=recv.dtype, pin_memory=True)
+                self._send_host.copy_(send)                # (synchronises: the pack kernel has finished)
+                dist.all_gather_into_tensor(self._recv_host, self._send_host, group=self.group)
+                recv.copy_(self._recv_host)
+                self.transport = "gloo-staged"
+            else:
+                dist.all_gather_into_tensor(recv, send, group=self.group)
+                self.transport = "rccl" if send.is_cuda else "gloo"
         else:
             recv.copy_(send)
+            self.transport = "local"
         self.engine.unpack_topk(recv, self.n, self.world, k, out)
         return out
 

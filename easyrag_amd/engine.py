@@ -112,6 +112,15 @@ class RetrievalEngine:
         self._check(self._lib.erh_set_dense(self._h, _ptr(x), n, d, dt, is_dev, 1 if normalize else 0))
         self.n_dense, self.d = int(n), int(d)
 
+    def get_dense_rows(self, row0: int, rows: int, out: Optional[np.ndarray] = None) -> np.ndarray:
+        """Rows [row0, row0 + rows) of the stored fp16 matrix in the caller's order (erh_get_dense_rows)."""
+        if out is None:
+            out = np.empty((int(rows), self.d), np.float16)
+        if out.dtype != np.float16 or not out.flags["C_CONTIGUOUS"] or out.shape != (int(rows), self.d):
+            raise ValueError("out must be a C-contiguous float16 array of shape (rows, d)")
+        self._check(self._lib.erh_get_dense_rows(self._h, int(row0), int(rows), _ptr(out), 0))
+        return out
+
     # A handle holds ERH_BM25_SLOTS independent BM25 indices (content route + know_path route of the reference
     # pipeline share one engine); every BM25 call names its slot, default 0.
     _RESERVED = "reserved"                  # a slot handed out by alloc_bm25_slot that has no index yet

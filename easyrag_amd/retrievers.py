@@ -38,7 +38,7 @@ import numpy as np
 from . import _lib
 from .engine import RetrievalEngine, queries_to_csr
 from .index import BM25Index, build_bm25_index, vocab_ids
-from .schema import NodeWithScore, QueryBundle
+from .schema import NodeWithScore, QueryBundle, TextNode
 
 logger = logging.getLogger(__name__)
 
@@ -246,6 +246,173 @@ class HipVectorStore:
     @property
     def nodes(self):
         return self.corpus.nodes
+
+    # -- restart path ---------------------------------------------------------------------------------------------------
+    # The reference embeds the corpus ONCE: when the Qdrant collection is already populated it skips ingestion
+    # (ref pipeline.py:138-141, `collection_info.points_count == 0`), so after a restart the embeddings exist only in
+    # Qdrant.  Two ways to come back without re-embedding: read them out of that collection (from_qdrant / afrom_qdrant),
+    # or keep the fp16 matrix this store scores with in a file of its own (save / load).  These are loaders, not a storage
+    # engine: one pass, then everything is resident in HBM as before.
+    @staticmethod
+    def _point_fields(point):
+        """(id, vector, text, metadata) of one scrolled Qdrant point as llama-index-vector-stores-qdrant==0.2.0 writes it
+        (ref requirements.txt:49; UNPINNED offline: point id = node_id, payload = flat metadata + `_node_content`, the
+        node's JSON).  Named-vector collections hand back {name: vector}: the single entry is taken."""
+        import json
+        payload = getattr(point, "payload", None) or {}
+        vec = getattr(point, "vector", None)
+        if isinstance(vec, dict):
+            if len(vec) != 1:
+                raise ValueError("point carries several named vectors; pass vectors through a client wrapper that selects one")
+            vec = next(iter(vec.values()))
+        text, meta = payload.get("text"), None
+        content = payload.get("_node_content")
+        if content:
+            node_json = json.loads(content) if isinstance(content, str) else dict(content)
+            text = node_json.get("text", text)
+            meta = node_json.get("metadata")
+        if meta is None:
+            meta = {k: v for k, v in payload.items() if not k.startswith("_") and k not in ("text", "document_id", "doc_id", "ref_doc_id")}
+        return getattr(point, "id", None), vec, text, meta
+
+    @classmethod
+    def _assemble(cls, points, nodes, engine, normalize):
+        """Scrolled points -> (nodes, [N, d] float32 rows aligned with them).  With `nodes` given every node must find its
+        vector: by point id == node_id when all ids match, otherwise by text content -- the key the reference itself joins
+        the two routes on (RRF / fusion key = get_content(), ref retrievers.py:245,263): its sparse-route nodes come from a
+        second run of the splitter (pipeline.py:160-167) and share no ids with the ingested points.  Among nodes with equal
+        text a point with equal `file_path` is preferred, then first come first served.  Without `nodes` the node list is
+        rebuilt from the payloads in scroll order (what the reference's QdrantRetriever returns)."""
+        fields = [cls._point_fields(p) for p in points]
+        if not fields:
+            raise ValueError("the collection is empty (points_count == 0): run the ingestion first, as the reference does")
+        for pid, vec, _, _ in fields:
+            if vec is None:
+                raise ValueError(f"point {pid!r} came back without its vector (scroll with with_vectors=True)")
+        d = len(fields[0][1])
+        if nodes is None:
+            nodes = [TextNode(text=t or "", metadata=dict(m or {}), id_=str(pid)) for pid, _, t, m in fields]
+            order = list(range(len(fields)))
+        else:
+            nodes = list(nodes)
+            by_id = {str(pid): j for j, (pid, _, _, _) in enumerate(fields)}
+            if len(by_id) == len(fields) and all(str(n.node_id) in by_id for n in nodes):
+                order = [by_id[str(n.node_id)] for n in nodes]
+            else:
+                by_text: Dict[Any, List[int]] = {}
+                for j, (_, _, t, _) in enumerate(fields):
+                    by_text.setdefault(t, []).append(j)
+                order, missing = [], 0
+                for n in nodes:
+                    bucket = by_text.get(n.get_content())
+                    if not bucket:
+                        missing += 1
+                        order.append(-1)
+                        continue
+                    fp = n.metadata.get("file_path")
+                    pick = next((j for j in bucket if (fields[j][3] or {}).get("file_path") == fp), bucket[0])
+                    bucket.remove(pick)
+                    order.append(pick)
+                if missing:
+                    raise ValueError(f"{missing} of {len(nodes)} nodes have no point with their text in the collection "
+                                     f"({len(fields)} points): the collection was built from a different corpus / splitter")
+        emb = np.empty((len(nodes), d), np.float32)
+        for i, j in enumerate(order):
+            v = fields[j][1]
+            if len(v) != d:
+                raise ValueError("points of different vector sizes in one collection")
+            emb[i] = v
+        return cls(nodes, emb, engine=engine, normalize=normalize)
+
+    @classmethod
+    def from_qdrant(cls, client, collection_name: str, nodes=None, engine: Optional[RetrievalEngine] = None,
+                    batch_size: int = 1024, normalize: bool = True) -> "HipVectorStore":
+        """The chunk matrix out of an already populated Qdrant collection (a synchronous `QdrantClient`, or anything with its
+        `scroll(collection_name=, limit=, offset=, with_payload=, with_vectors=) -> (points, next_offset)`)."""
+        points, offset = [], None
+        while True:
+            res = client.scroll(collection_name=collection_name, limit=batch_size, offset=offset, with_payload=True,
+                                with_vectors=True)
+            if hasattr(res, "__await__"):
+                if hasattr(res, "close"):
+                    res.close()
+                raise TypeError("this client's scroll() is a coroutine (AsyncQdrantClient): use `await HipVectorStore.afrom_qdrant(...)`")
+            batch, offset = res
+            points.extend(batch)
+            if offset is None or not batch:
+                break
+        return cls._assemble(points, nodes, engine, normalize)
+
+    @classmethod
+    async def afrom_qdrant(cls, client, collection_name: str, nodes=None, engine: Optional[RetrievalEngine] = None,
+                           batch_size: int = 1024, normalize: bool = True) -> "HipVectorStore":
+        """from_qdrant for the `AsyncQdrantClient` the reference's pipeline holds (ref ingestion.py:163-169)."""
+        points, offset = [], None
+        while True:
+            batch, offset = await client.scroll(collection_name=collection_name, limit=batch_size, offset=offset,
+                                                with_payload=True, with_vectors=True)
+            points.extend(batch)
+            if offset is None or not batch:
+                break
+        return cls._assemble(points, nodes, engine, normalize)
+
+    @staticmethod
+    def _fingerprint(nodes) -> str:
+        import hashlib
+        h = hashlib.sha256()
+        for n in nodes:
+            t = n.get_content().encode("utf-8", "surrogatepass")
+            h.update(len(t).to_bytes(8, "little"))
+            h.update(t)
+        return h.hexdigest()
+
+    @staticmethod
+    def _paths(path):
+        path = str(path)
+        if not path.endswith(".npy"):
+            path += ".npy"
+        return path, path + ".meta.json"
+
+    def save(self, path) -> str:
+        """Write the resident matrix -- the unit-norm fp16 rows the kernels score, in node order -- as `<path>.npy` plus a
+        small `<path>.npy.meta.json` (shape and a fingerprint of the node texts, checked by load).  2 bytes per element."""
+        import json
+        npy, meta = self._paths(path)
+        eng = self.engine
+        n, d = int(eng.n_dense), int(eng.d)
+        if n != len(self.corpus.nodes):
+            raise ValueError("the engine's chunk matrix does not belong to this store's nodes")
+        mm = np.lib.format.open_memmap(npy, mode="w+", dtype=np.float16, shape=(n, d))
+        slab = max(1, (64 << 20) // (2 * d))
+        for r0 in range(0, n, slab):
+            rows = min(slab, n - r0)
+            eng.get_dense_rows(r0, rows, out=mm[r0:r0 + rows])
+        mm.flush()
+        del mm
+        with open(meta, "w") as f:
+            json.dump({"format": "easyrag_amd.HipVectorStore/1", "n": n, "d": d, "dtype": "float16", "unit_norm": True,
+                       "nodes_sha256": self._fingerprint(self.corpus.nodes)}, f)
+        return npy
+
+    @classmethod
+    def load(cls, path, nodes, engine: Optional[RetrievalEngine] = None, check: bool = True) -> "HipVectorStore":
+        """The store of a previous process over the same nodes: rows go to the device as they were saved (no re-normalisation,
+        no re-rounding), so every result is bit-identical to the process that saved them."""
+        import json
+        npy, meta = cls._paths(path)
+        with open(meta) as f:
+            info = json.load(f)
+        nodes = list(nodes)
+        if info.get("format") != "easyrag_amd.HipVectorStore/1" or info.get("dtype") != "float16":
+            raise ValueError(f"{meta}: not a HipVectorStore file")
+        if int(info["n"]) != len(nodes):
+            raise ValueError(f"{npy} holds {info['n']} rows, the node list has {len(nodes)}")
+        if check and info.get("nodes_sha256") != cls._fingerprint(nodes):
+            raise ValueError(f"{npy} was saved for different node texts (fingerprint mismatch); pass check=False to override")
+        x = np.load(npy, mmap_mode="r")
+        if x.dtype != np.float16 or x.shape != (int(info["n"]), int(info["d"])):
+            raise ValueError(f"{npy}: shape / dtype differ from its meta file")
+        return cls(nodes, x, engine=engine, normalize=False)
 
     def query_batch(self, query_embeddings, similarity_top_k: int, filters=None, mode: int = _lib.ERH_DENSE_EXACT):
         fd = _filter_to_dict(filters)

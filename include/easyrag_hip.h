@@ -85,6 +85,11 @@ int         erh_sync(erh_handle *h, void *stream);
  * The handle keeps its own device copy. */
 int erh_set_dense(erh_handle *h, const void *x, int64_t n, int d, int dtype, int is_device_ptr, int normalize);
 
+/* Read rows [row0, row0 + rows) of the stored chunk matrix back in the CALLER's order (fp16, as stored): what
+ * HipVectorStore.save() writes, so that a restarted process reloads the matrix instead of re-embedding the corpus -- the
+ * reference skips ingestion when its Qdrant collection is already populated (src/easyrag/pipeline/pipeline.py:138-141). */
+int erh_get_dense_rows(erh_handle *h, int64_t row0, int64_t rows, void *out_f16, int out_is_device);
+
 /* Inverted postings with precomputed ("eager") per-posting scores, CSR by term:
  *   indptr  int64[V+1]; doc_ids int32[nnz] strictly ascending inside each term;
  *   payload float32[nnz] (ERH_BM25_BM25S) or float64[nnz] (ERH_BM25_OKAPI).

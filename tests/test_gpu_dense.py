@@ -75,11 +75,34 @@ CASES = [
     (12000, 1024, 5, 288, 512, 0),
     (9000, 192, 2, 20, 256, 0),             # d = 6 steps of 32
     (40000, 1280, 1, 50, 2048, 8192),       # one query, d > 1024: two blocks of K
+    # d = 3584: the reference's own vector_size (ref:src/configs/easyrag.yaml:16, gte-Qwen2-7B) -- 112 K-stages, the finalize
+    # kernel's d > 2048 tail straight from memory, and in the gemv arm the fallback of 17 ... 64 queries to the padded scan
+    # (2 / 4 column groups x 3584 x 32 bytes of query fragments exceed the 128 KiB the skinny-GEMM stream keeps in LDS)
+    (4000, 3584, 1, 288, 1024, 0),          # one query: the skinny-GEMM stream at 112 KiB of query fragments
+    (4000, 3584, 16, 100, 1024, 0),         # one full column group
+    (4000, 3584, 17, 100, 1024, 0),         # gemv arm: falls back to the half-tile ping-pong scan
+    (4000, 3584, 64, 100, 512, 2048),       # ... likewise, with a refinement boundary
+    (4000, 3584, 100, 288, 1024, 0),        # half-tile mode of the ping-pong scan
+    (4000, 3584, 256, 100, 1024, 0),        # one full query tile
+    (4000, 3584, 600, 10, 768, 0),          # three query tiles; seed prefix = 2 x 384 rows: the 384 x 256 kernel in the ping-pong arms
 ]
+
+
+_ORACLE_CACHE = {}
+
+
+def _oracle_cached(kind, case, i, fn):
+    """The oracle's answer for query i of a CASES entry: the inputs are a pure function of the entry (seeded generators), so
+    the eight kernel arms share one oracle evaluation (at d = 3584 it is 0.4 s per query on the host)."""
+    key = (kind, case, i)
+    if key not in _ORACLE_CACHE:
+        _ORACLE_CACHE[key] = fn()
+    return _ORACLE_CACHE[key]
 
 
 @pytest.mark.parametrize("n,d,b,k,n0,n1", CASES)
 def test_dense_topk_exact_matches_oracle(engine, scan_cfg, n, d, b, k, n0, n1):
+    case = (n, d, b, k)
     x = synth.dense_corpus(n, d, seed=n + d)
     q32 = synth.dense_queries(x, b, seed=b + k)
     q16 = to_f16_unit(q32)
@@ -98,7 +121,7 @@ def test_dense_topk_exact_matches_oracle(engine, scan_cfg, n, d, b, k, n0, n1):
     assert np.all(ln == kk) and np.all(fln == kk)
     check = sorted(set(list(range(min(b, 6))) + list(range(0, b, max(1, b // 10))) + [b - 1, min(b - 1, 256)]))
     for i in check:                                   # the oracle is O(n*d) fp64 per query: sample large batches
-        oid, osc = dense_exact_topk(x, q16[i], k)
+        oid, osc = _oracle_cached("exact", case, i, lambda: dense_exact_topk(x, q16[i], k))
         assert ln[i] == kk and fln[i] == kk
         assert np.array_equal(ids[i, :kk], oid), f"query {i}: ids differ"
         assert np.array_equal(sc[i, :kk].view(np.uint64), osc.view(np.uint64)), f"query {i}: fp64 scores differ"
@@ -109,7 +132,7 @@ def test_dense_topk_exact_matches_oracle(engine, scan_cfg, n, d, b, k, n0, n1):
         assert np.all(np.diff(fsc[i, :kk]) <= 0)
     # against the qdrant-local style fp32 search (reference semantics): cosine within 1e-3, same id set
     for i in range(min(b, 4)):
-        qi, qs = qdrant_cosine_search(x.astype(np.float32), q32[i], k)
+        qi, qs = _oracle_cached("qdrant", case, i, lambda: qdrant_cosine_search(x.astype(np.float32), q32[i], k))
         assert np.max(np.abs(np.sort(qs)[::-1] - sc[i, :kk])) < 1e-3
         assert len(set(qi) & set(ids[i, :kk])) >= kk - 2            # only near-ties at the cut may differ
 
@@ -391,6 +414,36 @@ def test_dense_budgets_exhausted_still_answers(engine):
         want = reciprocal_rank_fusion([[Item(a, a, s) for a, s in sp],
                                        [Item(int(a), int(a), float(s)) for a, s in zip(oid, osc)]], K=60, topk=10)
         assert list(fid[i, :fln[i]]) == [w.idx for w in want] and list(fsc[i, :fln[i]]) == [w.score for w in want], i
+
+
+def test_dense_d3584_exhaustive_path_and_rescore_tail(engine):
+    """The reference's vector_size (3584) through the budget-exhausted cases: 17000 exact copies of the chunk a query asks for
+    (candidate list overflow -> dense_exact_all_kernel with 28 KiB of query rows in LDS, seven rounds of 512 elements per lane),
+    1500 near-copies inside the pruning margin (the fp64 re-score of more than 1024 rows: flagged as well), and plain queries
+    whose 100 re-scored rows take the finalize kernel's d > 2048 tail.  ids and fp64 scores equal the oracle's."""
+    rng = np.random.default_rng(59)
+    n, d, k = 20000, 3584, 100
+    x = to_f16_unit(rng.standard_normal((n, d), dtype=np.float32))
+    hot = to_f16_unit(rng.standard_normal((1, d)))[0]
+    copies = np.sort(rng.choice(n, size=17000, replace=False))
+    x[copies] = hot
+    near = to_f16_unit(rng.standard_normal((1, d)))[0]
+    near_rows = np.setdiff1d(np.arange(n), copies)[:1500]
+    x[near_rows] = near
+    col = int(np.argmax(np.abs(near.astype(np.float32))))
+    x[near_rows[::2], col] = np.nextafter(x[near_rows[::2], col], np.float16(0))
+    engine.set_dense(x)
+    q16 = np.stack([hot, near] + [to_f16_unit(rng.standard_normal((1, d)))[0] for _ in range(3)])
+    for qb in (q16, np.concatenate([q16] * 4)):                       # 5 queries (skinny-GEMM stream) and 20 (padded scan)
+        engine.reset_stats()
+        ids, sc, ln = engine.dense_topk(qb, k)
+        diag = engine.dense_diag()
+        assert diag["exhaustive"] == 2 * (qb.shape[0] // 5) and engine.stat("dense_exhaustive_queries") == diag["exhaustive"]
+        assert np.array_equal(ids[0], copies[:k])
+        for i in range(5):
+            oid, osc = dense_exact_topk(x, qb[i], k)
+            assert np.array_equal(ids[i], oid) and np.array_equal(sc[i].view(np.uint64), osc.view(np.uint64)), i
+        assert np.array_equal(ids[-1], ids[4]) and np.array_equal(sc[-2].view(np.uint64), sc[3].view(np.uint64))
 
 
 def test_dense_fp32_inputs_normalised_on_device(engine):

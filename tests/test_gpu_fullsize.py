@@ -271,3 +271,45 @@ def test_hybrid_configs3_filters_and_duplicate_contents(engine, dense_data, spar
             assert list(s_ids[r, :s_ln[r]]) == [i for i, _ in sp] and list(s_sc[r, :s_ln[r]]) == [s for _, s in sp]
     finally:
         engine.set_doc_meta(N, None, None)
+
+
+# ---- the reference's own vector size: d = 3584 (ref:src/configs/easyrag.yaml:15-16, gte-Qwen2-7B-instruct) ------------------------
+N3584, D3584 = 285_696, 3584          # 744 x 384 rows x 3584 halves = 2.05 GB: the byte volume of the 1M x 1024 configurations
+
+
+@pytest.fixture(scope="module")
+def dense_3584():
+    import torch
+    dev = torch.device("cuda", 0)
+    x = synth.dense_corpus_torch(N3584, D3584, seed=12, device=dev)
+    q = synth.dense_queries_torch(x, 1024, seed=1012)
+    return x, q
+
+
+@pytest.mark.parametrize("b,k", [(256, 100), (1024, 288), (1, 288), (40, 100)])
+def test_dense_d3584_full_size_exact(engine, dense_3584, b, k):
+    """2.05 GB of 3584-d chunks (the reference's vector_size) through every batch regime -- one query (skinny-GEMM stream, 112 KiB of
+    query fragments), 40 (two column groups do not fit LDS at this row length: the padded scan), 256 (one query tile, store
+    kernel + seed select), 1024 (sample pass + 384 x 256 scan, 112 K-stages per tile) -- against the oracle: an independent
+    fp32 GEMM proposes every row within 2e-3 of the k-th best (|fp32 - exact| <= d 2^-23 |x||q| = 4.3e-4 here), the pinned-order
+    float64 scores of those rows decide; ids and scores bit for bit."""
+    x, q = dense_3584
+    engine.set_dense(x)
+    engine.reset_stats()
+    ids, sc, ln = engine.dense_topk(q[:b].contiguous(), k)
+    diag, st = engine.dense_diag(), engine.stats()
+    assert diag["uncertified"] == 0 and diag["max_abs_err"] <= diag["margin"] and diag["exhaustive"] == 0
+    assert np.all(ln == k)
+    if b == 1024:
+        assert st["dense_scan_pp5_launches"] == 1 and st["dense_sample_passes"] == 1, st
+    elif b == 1:
+        assert st["dense_scan_gemv_launches"] == 1, st
+    else:
+        assert st["dense_scan_pp3_launches"] == 1, st
+    sample = sorted(set([0, 1, b // 3, b // 2, b - 2, b - 1, min(b - 1, 255), min(b - 1, 256), min(b - 1, 700)]) & set(range(b)))
+    want = dense_oracle_topk(x, q[sample], k)
+    for (oid, osc), i in zip(want, sample):
+        assert np.array_equal(ids[i], oid), f"query {i}: ids differ"
+        assert np.array_equal(sc[i].view(np.uint64), osc.view(np.uint64)), f"query {i}: fp64 scores differ"
+    for i in range(b):
+        assert len(set(ids[i])) == k and np.all(np.diff(sc[i]) <= 0)

@@ -262,3 +262,53 @@ def test_bm25_retriever_with_the_native_cutter(bm25_type):
             assert [g.score for g in got] == [s for _, s in want]
     r_py.close()
     r_nat.close()
+
+
+def test_vector_store_restart_round_trip(corpus, tmp_path):
+    """The restart path on the device (ref pipeline.py:138-141: ingestion is skipped when the collection is populated): a store
+    built from embeddings, one rebuilt by scrolling a Qdrant-shaped client (points in another order, other ids: joined on the
+    text), and one loaded from the file the first one saved must answer every query with the same nodes and the same scores, bit
+    for bit -- the saved rows are the fp16 rows the kernels score, read back through erh_get_dense_rows (the golden-ratio row
+    placement undone) and uploaded as they are."""
+    import json
+    from easyrag_amd.engine import RetrievalEngine
+    nodes, vecs, emb = corpus
+    first = HipVectorStore(nodes, vecs, engine=RetrievalEngine(0))
+    assert np.array_equal(first.engine.get_dense_rows(0, len(nodes)), to_f16_unit(vecs))         # rows come back in the caller's order
+    assert np.array_equal(first.engine.get_dense_rows(1000, 200), to_f16_unit(vecs)[1000:])
+    path = first.save(tmp_path / "store")
+
+    class Point:
+        def __init__(self, id, vector, payload): self.id, self.vector, self.payload = id, vector, payload
+
+    class Client:
+        def __init__(self, pts): self.pts = pts
+        def scroll(self, collection_name, limit, offset, with_payload, with_vectors):
+            s = int(offset or 0)
+            return self.pts[s:s + limit], (s + limit if s + limit < len(self.pts) else None)
+
+    order = np.random.default_rng(3).permutation(len(nodes))
+    # (texts 7 / 100 / 900 are equal and carry no file_path: equal texts are handed out first come first served, so the scroll
+    # keeps those three in node order -- any other order is an equally valid join, with the three vectors permuted)
+    where = sorted(int(np.nonzero(order == j)[0][0]) for j in (7, 100, 900))
+    order[where] = (7, 100, 900)
+    pts = [Point(f"uuid-{j}", vecs[j].tolist(), {"dir": nodes[j].metadata["dir"],
+                                                "_node_content": json.dumps({"text": nodes[j].text, "metadata": nodes[j].metadata})})
+           for j in order]
+    second = HipVectorStore.from_qdrant(Client(pts), "aiops24", nodes, engine=RetrievalEngine(0), batch_size=500)
+    third = HipVectorStore.load(path, nodes, engine=RetrievalEngine(0))
+    try:
+        qs = np.asarray([emb.get_query_embedding(f"question {i}") for i in range(9)], np.float32)
+        for filters in (None, {"dir": "rcp"}):
+            want = first.query_batch(qs, 50, filters)
+            for other in (second, third):
+                got = other.query_batch(qs, 50, filters)
+                assert np.array_equal(got[0], want[0]) and np.array_equal(got[2], want[2])
+                assert np.array_equal(got[1].view(np.uint64), want[1].view(np.uint64))
+        x16 = to_f16_unit(vecs)
+        oid, osc = dense_exact_topk(x16, to_f16_unit(qs[:1])[0], 50)
+        got = third.query(qs[0], 50)
+        assert [n.node_id for n in got[0]] == [nodes[i].node_id for i in oid] and got[1] == [float(s) for s in osc]
+    finally:
+        for s in (first, second, third):
+            s.engine.close()

@@ -330,8 +330,9 @@ def test_rrf_and_fusion_match_oracle(engine):
 
 @pytest.mark.parametrize("variant", [OKAPI, BM25S])
 def test_hybrid_dual_route_matches_oracle_composition(engine, variant):
-    """Config 1 shape scaled to the GPU test budget: dense(288) + BM25(192) + RRF(60) -> top-10."""
-    n, d, vocab, B = 10000, 768, 4096, 24
+    """BASELINE.json configs[0] at its own size: 10k chunks x 768-d, 100 queries, dense(288) + BM25(192) + RRF(60) -> top-10
+    (and top-256, the yaml default), every query against the oracle composition; 1 % duplicated contents."""
+    n, d, vocab, B = 10000, 768, 4096, 100
     x = synth.dense_corpus(n, d, seed=1)
     q16 = to_f16_unit(synth.dense_queries(x, B, seed=2))
     flat, lens = synth.token_corpus(n, vocab, seed=3)
