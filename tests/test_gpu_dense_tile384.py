@@ -116,7 +116,8 @@ def test_tile384_budgets_exhausted_hand_over_to_the_exhaustive_path(engine):
         engine.set_option("dense_gemv", 1)
     (ids, sc, ln), diag, st = runs[0]
     assert st["dense_sample_passes"] == 1
-    assert 40 <= diag["exhaustive"] <= 48 and st["dense_exhaustive_queries"] == diag["exhaustive"]
+    # (the 48, plus the odd random query for which the 20000 copies happen to score above its threshold: they flood its list too)
+    assert 48 <= diag["exhaustive"] <= 64 and st["dense_exhaustive_queries"] == diag["exhaustive"]
     assert np.array_equal(ids[special[0]], copies[:k])             # the tie block: lowest indices first
     _check(x, q16, ids, sc, ln, k, [0, 1, 2, special[0], special[1], special[2], special[-1], special[-2], 255, 256, b - 1])
     assert np.all(ln == k)
