@@ -713,7 +713,8 @@ __device__ __forceinline__ float erh_max4(float a, float b, float c, float d) {
 // Epilogue of tile i for this wave (acc final); shared by both ping-pong kernels (it uses their local names).  See the
 // header comment of the ping-pong scan above.
 // the survivors of four accumulator registers (one 32 x 32 block row group): ballot + mbcnt compaction into the wave's records
-#define ERH_PP_EPI_QUAD(MT, NT, R4)                                                                   \
+#define ERH_PP_EPI_QUAD(MT, NT, R4) ERH_PP_EPI_QUAD_C(MT, NT, R4, pp::CAPW)
+#define ERH_PP_EPI_QUAD_C(MT, NT, R4, CAPW_)                                                          \
     do {                                                                                              \
         _Pragma("unroll") for (int r = (R4); r < (R4) + 4; ++r) {                                     \
             const float sc_ = acc[MT][NT][r];                                                         \
@@ -723,7 +724,7 @@ __device__ __forceinline__ float erh_max4(float a, float b, float c, float d) {
                 const int pos_ = cnt_ - shift_ +                                                      \
                     (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m_ >> 32),                              \
                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)m_, 0u));      \
-                if (hit_ && (unsigned)pos_ < (unsigned)pp::CAPW) {                                    \
+                if (hit_ && (unsigned)pos_ < (unsigned)(CAPW_)) {                                     \
                     *reinterpret_cast<float *>(rec + pos_ * 4) = sc_;                                 \
                     *reinterpret_cast<uint32_t *>(rec + 1024 + pos_ * 4) =                            \
                         pk_l_ + ((uint32_t)((MT) * 32 + (r & 3) + 8 * (r >> 2)) << 6);                \
@@ -2056,6 +2057,13 @@ constexpr int BM = 384, MT = 6, GROWS = 192, ROW_BITS = 9, AST = 4, BST = 3;
 constexpr int A_BYTES = BM * pp::RB;
 constexpr int B_BASE = AST * A_BYTES;
 constexpr int TILE_BITS = 32 - 6 - ROW_BITS;
+// Records per wave: 190 of the 256 slots; the last 64 words of the wave's LOCATION array hold its 64 pruning thresholds (round 5).
+// Kept in registers across the main loop they were spilled to scratch and re-loaded at the top of every epilogue -- a scratch
+// load counts on vmcnt, so each tile waited for the three LDS-DMA instructions in flight (the NEXT tile's first chunk stages)
+// before its first compare.  From LDS the wait is lgkmcnt only.  (The flush flags stay in wave 0's score words 254 / 255.)
+constexpr int CAPW = 190;
+constexpr int TAU_OFF = 1024 + 192 * 4;          // byte offset in the wave's record area
+static_assert(CAPW <= 192 && TAU_OFF + 64 * 4 == pp::REC_BYTES && pp::CAPW >= CAPW, "pp5 record area layout");
 static_assert(B_BASE + BST * pp::B_BYTES == pp::REC_BASE, "records and flush flags sit where the 256-row kernels have them");
 }  // namespace pp5
 
@@ -2083,13 +2091,18 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp5_kernel(
     const int64_t lim = (c1 < N) ? c1 : N;
     const int l31 = lane & 31, hh = lane >> 5;
     const int k0 = (qt * rot_stages) % nk;
-    float t_q[2];
+    {   // this wave's 64 thresholds -> LDS (loaded and parked before the DMA stream starts: vmcnt stays countable)
+        float t_q[2];
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int q = (int)q_row0 + wave_n * 64 + nt * 32 + l31;
-        t_q[nt] = q < B ? tau[q] : INFINITY;
+        for (int nt = 0; nt < 2; ++nt) {
+            const int q = (int)q_row0 + wave_n * 64 + nt * 32 + l31;
+            t_q[nt] = q < B ? tau[q] : INFINITY;
+        }
+        char *const tq = lds + pp::REC_BASE + wave * pp::REC_BYTES + pp5::TAU_OFF + l31 * 4;   // (both halves of the wave write the same values)
+        *reinterpret_cast<float *>(tq) = t_q[0];
+        *reinterpret_cast<float *>(tq + 128) = t_q[1];
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     }
-    asm volatile("" ::"v"(t_q[0]), "v"(t_q[1]));                      // loaded before the DMA stream starts (keeps vmcnt countable)
 
     // wave-uniform byte pointers (this wave's 1 KiB slice of a stage image; the lane's 16 bytes are lane_off) -- the loads take
     // the scalar-base form, no 64-bit address registers
@@ -2220,7 +2233,10 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp5_kernel(
         if ((G) + 4 >= total) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");             \
         else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");                              \
     } while (0)
-// Epilogue of tile i for this wave: ERH_PP_EPILOGUE's group tests over six block rows, nine row bits in the record
+// Epilogue of tile i for this wave: ERH_PP_EPILOGUE's group tests over six block rows, nine row bits in the record.  The thresholds
+// come from the wave's LDS slots (pp5::TAU_OFF), not from registers held -- i.e. spilled -- across the main loop: -0.7 % scan time,
+// no scratch access inside the tile loop.  (Measured and NOT kept: pp3's mask-first group tests in two halves of three block rows,
+// +-0 here; with no epilogue at all the scan class is 5.6 % faster -- profiles/r05e_ab_pp5_epilogue.log.)
 #define ERH_PP5_EPILOGUE()                                                                            \
     do {                                                                                              \
         int lane, l31, hh;      /* re-derived here (opaque to the compiler): not held in registers across the main loop */ \
@@ -2229,10 +2245,15 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp5_kernel(
         if (wave == 0 && lane == 0) ERH_PP_FLAG((i + 1) & 1) = 0;                                     \
         const bool last_ = (i + 1 == n_tiles);                                                        \
         const int fill0_ = fill;                                                                      \
-        for (int shift_ = 0;; shift_ += pp::CAPW) {                                                   \
+        for (int shift_ = 0;; shift_ += pp5::CAPW) {                                                   \
             int cnt_ = fill0_;                                                                        \
-            float tt_[2] = {t_q[0], t_q[1]};                                                          \
-            asm volatile("" : "+v"(tt_[0]), "+v"(tt_[1]));   /* opaque per pass: nothing of the pass is hoisted out of the loop */ \
+            float tt_[2];                                                                             \
+            {                                                                                         \
+                const uint32_t ta_ = lds0 + (uint32_t)(pp::REC_BASE + pp5::TAU_OFF) + (uint32_t)wave * (uint32_t)pp::REC_BYTES + \
+                                     (uint32_t)l31 * 4u;                                              \
+                asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:128\n\ts_waitcnt lgkmcnt(0)"   \
+                             : "=&v"(tt_[0]), "=&v"(tt_[1]) : "v"(ta_) : "memory");                  \
+            }                                                                                         \
             _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                                        \
                 const float t_ = tt_[nt];                                                             \
                 uint32_t pk_l_ = (uint32_t)(nt * 32 + l31) | ((uint32_t)(grp * pp5::GROWS + 4 * hh) << 6) | \
@@ -2242,14 +2263,14 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp5_kernel(
                     _Pragma("unroll") for (int r4 = 0; r4 < 16; r4 += 4) {                            \
                         const bool any_ = erh_max4(acc[mt][nt][r4], acc[mt][nt][r4 + 1], acc[mt][nt][r4 + 2],   \
                                                    acc[mt][nt][r4 + 3]) >= t_;                                 \
-                        if (__builtin_amdgcn_ballot_w64(any_)) ERH_PP_EPI_QUAD(mt, nt, r4);           \
+                        if (__builtin_amdgcn_ballot_w64(any_)) ERH_PP_EPI_QUAD_C(mt, nt, r4, pp5::CAPW);           \
                         __builtin_amdgcn_sched_barrier(0);                                            \
                     }                                                                                 \
                 }                                                                                     \
             }                                                                                         \
             const int avail_ = cnt_ - shift_;                                                         \
-            const bool over_ = avail_ > pp::CAPW;                                                     \
-            const int nrec_ = over_ ? pp::CAPW : avail_;                                              \
+            const bool over_ = avail_ > pp5::CAPW;                                                     \
+            const int nrec_ = over_ ? pp5::CAPW : avail_;                                              \
             if (over_ || flush_now || last_) {                                                        \
                 for (int base_ = 0; base_ < nrec_; base_ += 64) {                                     \
                     const int j_ = base_ + lane;                                                      \
@@ -2285,7 +2306,7 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp5_kernel(
             }                                                                                         \
             if (!over_) break;                                                                        \
         }                                                                                             \
-        if (fill > pp::CAPW / 2 && lane == 0) ERH_PP_FLAG(i & 1) = 1;                                 \
+        if (fill > pp5::CAPW / 2 && lane == 0) ERH_PP_FLAG(i & 1) = 1;                                 \
     } while (0)
 
     // prologue: A0 B0 A1 B1 A2; stages 0 and 1 complete = the last 3 instructions may stay in flight
