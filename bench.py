@@ -211,6 +211,37 @@ def pmc_traffic(args, kernel_class, algorithmic_bytes):
             "traffic_source": "profiles/pmc_traffic.json (" + rec["command"] + "; " + rec["correction"] + ")"}
 
 
+def pmc_counters(args, key, main_class, class_ms_per_step):
+    """MFMA-busy, L2 hit rate, LDS-fill (TD) path and effective shader clock of the dominant kernel from the committed PMC passes
+    (scripts/gpu_pmc.sh -> scripts/pmc_summary.py -> profiles/pmc_counters.json), attached under the same guard as the FETCH_SIZE
+    traffic: default sizes only, and only when the kernel sources of this run are the profiled ones (digest).  north_star:
+    "rocprof HBM GB/s and MFMA-busy counters reported against gfx950 peak"."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_counters.json")
+    default_shape = (args.chunks == 1_000_000 and args.dim == 1024 and args.vocab == 262_144 and args.batch == 0
+                     and not args.option and args.variant == "bm25s" and args.gpus == 1)
+    try:
+        table = json.load(open(path))
+        entry = table[key]
+    except (OSError, KeyError, ValueError):
+        return None
+    from easyrag_amd import _build
+    if table.get("_kernel_digest") != _build._kernel_digest():
+        return {"note": "profiles/pmc_counters.json was collected on different kernel sources (stale): not attached"}
+    if not default_shape or main_class not in entry.get("classes", {}):
+        return None
+    d = entry["classes"][main_class]["derived"]
+    out = {"kernel_class": main_class, "mfma_busy": d.get("mfma_busy"), "mfma_busy_what": "SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs): share of the kernel's cycles the matrix pipe is busy (peak = 1.0)",
+           "l2_hit": d.get("l2_hit"), "td_busy": d.get("td_busy"), "td_busy_what": "TD_TD_BUSY_sum / 256 CUs / cycles: the data-return path that carries the L1 -> LDS fills",
+           "lds_bank_conflict_share": d.get("lds_bank_conflict_share"), "waves_waiting": d.get("waves_waiting"),
+           "source": "profiles/pmc_counters.json <- " + entry.get("source", "?") + " (separate rocprofv3 --pmc passes, --kernel-trace only)"}
+    cyc = sum(c["derived"].get("gui_cycles_per_xcd", 0.0) for c in entry["classes"].values())
+    if cyc and class_ms_per_step:
+        out["effective_clock_ghz"] = cyc / (class_ms_per_step * 1e-3) / 1e9
+        out["effective_clock_what"] = ("GRBM_GUI_ACTIVE / 8 of the class's launches per step (PMC pass) / this run's HIP-event time of the class per step; "
+                                       "the fp16 MFMA peak of 2.5 PF assumes 2.4 GHz")
+    return out
+
+
 def roofline_of(kd, dom):
     """Roofline block of one kernel class from the library's HIP-event time and the algorithmic work it booked."""
     if not kd["launches"]:
@@ -265,6 +296,12 @@ def run_sub(eng, classes, fn, n_queries, dom, min_seconds=0.3, sync_each=False, 
            "kernel_ms_per_step": {k_: v["ms"] / steps for k_, v in kt.items()}}
     if dom is not None:
         rec["roofline"] = roofline_of(kt[dom], dom)
+        if rec["roofline"] is not None:
+            lps = rec["roofline"]["launches"] / steps
+            rec["roofline"]["launches_per_step"] = lps
+            if lps > 1.01:
+                rec["roofline"]["launch_mix"] = (f"{lps:g} launches of the class per step (threshold stage -- sample pass or seed-prefix store kernel -- + main scan): "
+                                                 "avg_launch_ms / *_per_launch are class totals / launches; kernel_ms_per_step holds the per-step class time")
     return rec
 
 
@@ -310,6 +347,20 @@ def sub_benchmarks(eng, synth, queries_to_csr, build_index, OKAPI, q16_pool, tok
     finally:
         eng.free_bm25_slot(1)
         eng._select(0)
+    # the reference's own vector size (ref src/configs/easyrag.yaml:15-16: gte-Qwen2-7B, vector_size 3584): the same 2.05 GB of chunk
+    # matrix as 285 696 x 3584 fp16, dense top-100, batch 256 -- LAST, because it replaces the resident 1M x 1024 matrix
+    import torch
+    n35, d35 = 285_696, 3584
+    x35 = synth.dense_corpus_torch(n35, d35, seed=12, device=q16_pool[0].device)
+    q35 = [synth.dense_queries_torch(x35, 256, seed=3000 + p) for p in range(pool)]
+    eng.set_dense(x35)
+    out["dense_d3584_b256"] = run_sub(
+        eng, classes, lambda i: eng.dense_topk(q35[i % pool], 100, device_out=True), 256, "dense_scan",
+        what=f"the reference's vector_size: {n35} chunks x {d35}-d fp16 (2.05 GB, as configs[1]), dense cosine top-100, batch 256")
+    eng.dense_check()
+    out["dense_d3584_b256"]["dense_exhaustive_queries_last_call"] = eng.dense_diag()["exhaustive"]
+    del x35, q35
+    torch.cuda.empty_cache()
     return out
 
 
@@ -426,6 +477,8 @@ def main(argv=None, platform=None):
         eng.dense_check()                                     # raises on candidate overflow
     eng.set_profiling(True)
     eng.reset_kernel_time()
+    if hasattr(eng, "reset_stats"):
+        eng.reset_stats()                                     # the counters below cover exactly the timed steps
     gather_events.clear()
     if world > 1:
         torch.distributed.barrier()
@@ -448,6 +501,7 @@ def main(argv=None, platform=None):
     eng.set_profiling(False)
     if args.workload != "bm25":
         eng.dense_check()
+    path_stats = eng.stats() if hasattr(eng, "stats") else None    # (reads the device counters: synchronises, outside the timed region)
 
     rec = None
     if rank == 0:
@@ -461,6 +515,9 @@ def main(argv=None, platform=None):
         if roof is not None:
             roof.update(pmc_traffic(args, dom, roof["algorithmic_bytes_per_launch"]))
             roof["launches_per_step"] = roof["launches"] / args.steps
+            if args.workload != "bm25":
+                key, main = ("dense_b1024", "pp5") if args.workload == "hybrid" else ("dense_b256", "pp3")
+                roof["counters"] = pmc_counters(args, key, main, per_step["dense_scan"])
             if dom == "dense_scan" and roof["launches"] > args.steps:
                 roof["launch_mix"] = ("the dense-scan class has two launches per step -- the threshold stage (sample pass of the scan "
                                       "kernel from 512 queries on, the seed-prefix store kernel below) and the main scan; per-launch "
@@ -524,6 +581,10 @@ def main(argv=None, platform=None):
             "roofline": roof,
             "cpu_baseline": cpu,
             "kernel_ms_per_step": per_step,
+            # which kernels answered the TIMED steps (erh_get_stat; rank 0): the record proves its own path -- every query of every
+            # timed step stayed on the pruned dense pipeline iff dense_exhaustive_queries == 0 (the exhaustive path's later rounds
+            # would run in the un-timed erh_dense_check), and no BM25 (query, segment) fell back to the exact block scan
+            "path": path_stats,
         }
         default_shape = (args.chunks == 1_000_000 and args.dim == 1024 and args.vocab == 262_144 and args.batch == 0
                          and not args.option and args.variant == "bm25s")

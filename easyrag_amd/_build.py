@@ -18,6 +18,8 @@ STAMP = PKG_DIR / (".libeasyrag_hip_measure.stamp" if MEASURE else ".libeasyrag_
 
 SOURCES = ["api.hip", "dense_scan.hip", "dense_gemv.hip", "select.hip", "bm25.hip", "fuse.hip", "index_build.hip", "text.hip"]
 HEADERS = ["common.h", "kernels.h"]
+# kernel generations that compile only into the measurement build (scripts/kbench.py): part of ITS digest, not of the product's
+MEASURE_ONLY = ["measure/dense_scan_persist.inc", "measure/dense_scan_pp12.inc", "measure/dense_scan_pp4.inc"]
 
 HIPCC_FLAGS = [
     "--offload-arch=gfx950",
@@ -46,7 +48,7 @@ def _hipcc() -> str:
 
 def _digest() -> str:
     h = hashlib.sha256()
-    for name in SOURCES + HEADERS:
+    for name in SOURCES + HEADERS + (MEASURE_ONLY if MEASURE else []):
         h.update((CSRC / name).read_bytes())
     h.update((INCLUDE / "easyrag_hip.h").read_bytes())
     h.update(" ".join(_flags()).encode())
@@ -58,7 +60,7 @@ def _kernel_digest() -> str:
     the flags): what profiles/pmc_traffic.json is keyed by, so that a change to the text ABI or to the public header does
     not orphan the PMC figures of unchanged kernels."""
     h = hashlib.sha256()
-    for name in [n for n in SOURCES if n != "text.hip"] + HEADERS:
+    for name in [n for n in SOURCES if n != "text.hip"] + HEADERS + (MEASURE_ONLY if MEASURE else []):
         h.update((CSRC / name).read_bytes())
     h.update(" ".join(_flags()).encode())
     return h.hexdigest()

@@ -387,259 +387,8 @@ __global__ __launch_bounds__(C::NT) void dense_scan_append_kernel(
     }
 }
 
-#ifdef ERH_MEASURE   // superseded by the ping-pong scan: measurement builds only (comparison arm of scripts/kbench.py)
-// ---------------------------------------------------------------------------------------------
-// Persistent APPEND scan.  One workgroup per CU walks a strided list of chunk tiles against ONE fixed query
-// tile, and the LDS-DMA pipeline runs continuously over the flattened (tile, K-step) sequence: while the
-// epilogue of tile i inspects the accumulators, the first two K-steps of tile i+1 are already in flight, so HBM
-// never idles between tiles and the pipeline is filled once per workgroup instead of once per tile.
-//   - thresholds tau[q] of the (fixed) query columns are loaded once;
-//   - survivors are staged in registers (a lane rarely has more than a couple per tile), their slot-reserving
-//     global atomics are issued together, and the records are written afterwards;
-//   - ring slots are numbered by the global step g = i*nk + kt (A: g % A_STAGES, B: g % B_STAGES), which keeps
-//     the write-after-read argument of gemm_tile valid across tile boundaries.
-// Block b -> XCD b % 8 (observed dispatch); the n_qt workgroups that share a chunk-tile stream sit on one XCD.
-// PABL (measurement only): 0 full, 6 no global atomics (records land at slot 0), 7 no epilogue at all,
-// 8 thresholds forced to +inf (scan runs, nothing survives)
-template <class C, int PABL, bool RA>
-__global__ __launch_bounds__(C::NT) void dense_scan_persist_kernel(
-    const _Float16 *__restrict__ X, int64_t N, int d, int64_t c0, int64_t c1,
-    const _Float16 *__restrict__ Q, int Bpad, int B,
-    const float *__restrict__ tau, const int16_t *__restrict__ filter_dir, const int16_t *__restrict__ dir_id,
-    ErhCand *__restrict__ cand, uint32_t *__restrict__ cand_cnt, int cap, uint32_t *__restrict__ overflow) {
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    constexpr int kSlots = 6;                                          // staged survivors per lane (across tiles)
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wave_m = wave / C::WGN, wave_n = wave % C::WGN;
-    const int nk = d / C::BK;
-
-    const int n_qt = Bpad / C::BN;
-    const int64_t n_ct = (c1 - c0 + C::BM - 1) / C::BM;
-    const int xcd = blockIdx.x & 7;
-    const int jx = blockIdx.x >> 3;
-    const int qt = jx % n_qt;
-    const int stream = (jx / n_qt) * 8 + xcd;
-    const int n_streams = (gridDim.x / (8 * n_qt)) * 8;
-    if (stream >= n_ct) return;                                        // whole workgroup: no barrier was executed yet
-    const int n_tiles = (int)((n_ct - stream + n_streams - 1) / n_streams);
-    const int64_t q_row0 = (int64_t)qt * C::BN;
-    const int64_t lim = (c1 < N) ? c1 : N;
-
-    // fixed per workgroup: query-side source pointers, thresholds, filters
-    TileSrc<C::BN, C::NW, C::PR> tb;
-    tb.init(Q, q_row0, Bpad, d, wave, lane);
-    float t_q[C::NTL];
-    int fd_q[C::NTL], q_col[C::NTL];
-#pragma unroll
-    for (int nt = 0; nt < C::NTL; ++nt) {
-        const int q = (int)q_row0 + wave_n * C::WN + nt * 32 + (lane & 31);
-        q_col[nt] = q;
-        t_q[nt] = (q < B && PABL != 8) ? tau[q] : INFINITY;
-        fd_q[nt] = (filter_dir && q < B) ? (int)filter_dir[q] : -1;
-    }
-    const int l31 = lane & 31, h = lane >> 5;
-    const int sw = row_swizzle<C::PR>(l31);
-    int soff[C::KS];
-#pragma unroll
-    for (int j = 0; j < C::KS; ++j) soff[j] = (((2 * j + h) ^ sw) << 4);
-    const int a_lane_off = (wave_m * C::WM + l31) * C::RB;
-    const int b_lane_off = C::B_BASE + (wave_n * C::WN + l31) * C::RB;
-
-    // chunk-side source pointers: re-pointed at the next tile as soon as the current tile's last load is issued
-    TileSrc<C::BM, C::NW, C::PR> ta_cur;
-    ta_cur.init(X, c0 + (int64_t)stream * C::BM, N, d, wave, lane);
-
-    const int total = n_tiles * nk;                                   // length of the flattened (tile, K-step) sequence
-
-    // prologue: virtual steps -DA .. -1 of the flattened sequence (all inside tile 0: nk > DA is checked on the host)
-#pragma unroll
-    for (int s_ = -C::DA; s_ < 0; ++s_) {
-        if (s_ + C::DB >= 0 && s_ + C::DB < total)
-            tb.issue((s_ + C::DB) % nk, C::BK, lds + C::B_BASE + ((s_ + C::DB) % C::B_STAGES) * C::B_BYTES, wave);
-        if (s_ + C::DA < total)
-            ta_cur.issue((s_ + C::DA) % nk, C::BK, lds + ((s_ + C::DA) % C::A_STAGES) * C::A_BYTES, wave);
-    }
-
-    // survivors staged in registers ACROSS tiles: a global write (atomic or store) forces the next tile's first
-    // wait to drain the queue, so records are flushed only when some lane's buffer is nearly full
-    float rs[kSlots];
-    uint32_t rd[kSlots];                                               // chunk index | (query-tile index nt << 31)
-    int n_mine = 0;
-    static_assert(C::NTL <= 2, "one bit encodes the query tile");
-
-    int a_slot = 0, b_slot = 0, g = 0;
-    bool wrote = false;                                                // wave-uniform: vm writes issued since the last drain
-    half8 fa_next[C::MT], fb_next[C::NTL];                             // RA: first fragments of the next K-step
-    for (int i = 0; i < n_tiles; ++i) {
-        const int64_t c_row0 = c0 + ((int64_t)stream + (int64_t)i * n_streams) * C::BM;
-        f32x16 acc[C::MT][C::NTL];
-#pragma unroll
-        for (int mt = 0; mt < C::MT; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < C::NTL; ++nt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
-
-        for (int kt = 0; kt < nk; ++kt, ++g) {
-            // Counted wait: everything issued after B(g) may stay in flight.  Exceptions: the first step after an
-            // epilogue that wrote to memory (loads and stores/atomics retire out of order with respect to each other,
-            // so with both kinds outstanding only vmcnt(0) is meaningful) and the tail of the whole sequence.
-            if ((kt == 0 && wrote) || g + C::DA > total) {
-                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-                wrote = false;
-            }
-            else
-                asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(RA ? C::WAIT_RA : C::WAIT_N) : "memory");
-            const char *cur_a = lds + a_slot * C::A_BYTES;
-            const char *cur_b = lds + b_slot * C::B_BYTES;
-            // targets of this step's prefetches (B first, then A: the order the wait count assumes)
-            const bool do_b = g + C::DB < total, do_a = g + C::DA < total;
-            int sb = b_slot + C::DB;
-            if (sb >= C::B_STAGES) sb -= C::B_STAGES;
-            int kb = kt + C::DB;
-            if (kb >= nk) kb -= nk;                                   // wraps into the next tile: same query rows
-            int sa = a_slot + C::DA;
-            if (sa >= C::A_STAGES) sa -= C::A_STAGES;
-            int ka = kt + C::DA;
-            if (do_a && ka == nk)                                     // first load of the next tile (it exists: g + DA < total)
-                ta_cur.init(X, c0 + ((int64_t)stream + (int64_t)(i + 1) * n_streams) * C::BM, N, d, wave, lane);
-            if (ka >= nk) ka -= nk;
-            char *dst_b = lds + C::B_BASE + sb * C::B_BYTES;
-            char *dst_a = lds + sa * C::A_BYTES;
-            constexpr bool kSpread = (PABL != 10);                    // DMA issue spread behind the MFMA groups (10 = all at once)
-            if (!kSpread) {
-                if (do_b) tb.issue(kb, C::BK, dst_b, wave);
-                if (do_a) ta_cur.issue(ka, C::BK, dst_a, wave);
-            }
-#pragma unroll
-            for (int j = 0; j < C::KS; ++j) {
-                half8 af[C::MT], bf[C::NTL];
-                if (RA && j == 0 && kt > 0) {                         // read before the barrier, at the end of step kt-1
-#pragma unroll
-                    for (int mt = 0; mt < C::MT; ++mt) af[mt] = fa_next[mt];
-#pragma unroll
-                    for (int nt = 0; nt < C::NTL; ++nt) bf[nt] = fb_next[nt];
-                } else {
-#pragma unroll
-                    for (int mt = 0; mt < C::MT; ++mt)
-                        af[mt] = *reinterpret_cast<const half8 *>(cur_a + a_lane_off + mt * 32 * C::RB + soff[j]);
-#pragma unroll
-                    for (int nt = 0; nt < C::NTL; ++nt)
-                        bf[nt] = *reinterpret_cast<const half8 *>(cur_b + b_lane_off + nt * 32 * C::RB + soff[j]);
-                }
-                if (RA && j == C::KS - 1 && kt + 1 < nk) {
-                    // Read-ahead: stage g+1 has been complete since this step's barrier (the wait above covers it), so
-                    // its first fragments are fetched now and the MFMAs of step kt+1 can start right after its barrier.
-                    const char *nx_a = lds + ((a_slot + 1 == C::A_STAGES) ? 0 : a_slot + 1) * C::A_BYTES;
-                    const char *nx_b = lds + ((b_slot + 1 == C::B_STAGES) ? 0 : b_slot + 1) * C::B_BYTES;
-#pragma unroll
-                    for (int mt = 0; mt < C::MT; ++mt)
-                        fa_next[mt] = *reinterpret_cast<const half8 *>(nx_a + a_lane_off + mt * 32 * C::RB + soff[0]);
-#pragma unroll
-                    for (int nt = 0; nt < C::NTL; ++nt)
-                        fb_next[nt] = *reinterpret_cast<const half8 *>(nx_b + b_lane_off + nt * 32 * C::RB + soff[0]);
-                }
-#pragma unroll
-                for (int mt = 0; mt < C::MT; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < C::NTL; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mt], bf[nt], acc[mt][nt], 0, 0, 0);
-                if (kSpread) {
-                    // all B instructions go out before any A instruction (first half of the sub-steps / second half)
-                    constexpr int HB = (C::KS + 1) / 2;
-                    constexpr int PB = (C::B_ITERS + HB - 1) / HB, PA = (C::A_ITERS + (C::KS - HB) - 1) / (C::KS - HB);
-                    if (j < HB) { if (do_b) tb.issue_part(kb, C::BK, dst_b, wave, j * PB, (j + 1) * PB); }
-                    else        { if (do_a) ta_cur.issue_part(ka, C::BK, dst_a, wave, (j - HB) * PA, (j - HB + 1) * PA); }
-                }
-            }
-            a_slot = (a_slot + 1 == C::A_STAGES) ? 0 : a_slot + 1;
-            b_slot = (b_slot + 1 == C::B_STAGES) ? 0 : b_slot + 1;
-        }
-
-        // ---- epilogue of tile i (the loads of tile i+1, steps 0 .. DA-1, are in flight) ------------------------
-        if (PABL == 7) {
-            float keep = 0.f;
-#pragma unroll
-            for (int mt = 0; mt < C::MT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < C::NTL; ++nt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) keep += acc[mt][nt][r];
-            if (keep == 1.2345e-30f) *overflow = 7u;
-            continue;
-        }
-        const int64_t row_base = c_row0 + wave_m * C::WM + 4 * (lane >> 5);
-        bool direct = false;                                           // a lane had to append past its staging slots
-#pragma unroll
-        for (int nt = 0; nt < C::NTL; ++nt) {
-            const float t = t_q[nt];
-#pragma unroll
-            for (int mt = 0; mt < C::MT; ++mt) {
-                float m = acc[mt][nt][0];
-#pragma unroll
-                for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[mt][nt][r]);
-                if (__builtin_amdgcn_ballot_w64(m >= t) == 0) continue;   // wave-uniform: nothing in this 32x32 tile
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float sc = acc[mt][nt][r];
-                    const bool hit = sc >= t;
-                    if (__builtin_amdgcn_ballot_w64(hit)) {              // wave-uniform
-                        if (hit) {
-                            const int64_t chunk = row_base + mt * 32 + (r & 3) + 8 * (r >> 2);
-                            if (chunk < lim && (fd_q[nt] < 0 || (int)dir_id[chunk] == fd_q[nt])) {
-                                if (n_mine < kSlots) {
-#pragma unroll
-                                    for (int j = 0; j < kSlots; ++j)
-                                        if (n_mine == j) { rs[j] = sc; rd[j] = (uint32_t)chunk | ((uint32_t)nt << 31); }
-                                    ++n_mine;
-                                } else {                                 // staging full in this lane: append now
-                                    direct = true;
-                                    const uint32_t pos = atomicAdd(&cand_cnt[q_col[nt]], 1u);
-                                    if (pos < (uint32_t)cap) {
-                                        ErhCand c;
-                                        c.s = sc;
-                                        c.idx = (int32_t)chunk;
-                                        cand[(int64_t)q_col[nt] * cap + pos] = c;
-                                    } else {
-                                        atomicOr(overflow, 1u);
-                                    }
-                                }
-                            }
-                        }
-                    }
-                }
-            }
-        }
-        if (__builtin_amdgcn_ballot_w64(direct)) wrote = true;
-        const bool last_tile = (i + 1 == n_tiles);
-        if (__builtin_amdgcn_ballot_w64(n_mine >= kSlots - 1) || (last_tile && __builtin_amdgcn_ballot_w64(n_mine > 0))) {
-            wrote = true;
-            uint32_t pos[kSlots];
-#pragma unroll
-            for (int j = 0; j < kSlots; ++j) {                           // all atomics in flight before any is consumed
-                const int qj = (C::NTL > 1 && (rd[j] >> 31)) ? q_col[C::NTL - 1] : q_col[0];
-                pos[j] = (j < n_mine) ? atomicAdd(&cand_cnt[qj], 1u) : 0u;
-            }
-#pragma unroll
-            for (int j = 0; j < kSlots; ++j) {
-                if (j < n_mine) {
-                    const int qj = (C::NTL > 1 && (rd[j] >> 31)) ? q_col[C::NTL - 1] : q_col[0];
-                    if (pos[j] < (uint32_t)cap) {
-                        ErhCand c;
-                        c.s = rs[j];
-                        c.idx = (int32_t)(rd[j] & 0x7fffffffu);
-                        cand[(int64_t)qj * cap + pos[j]] = c;
-                    } else {
-                        atomicOr(overflow, 1u);
-                    }
-                }
-            }
-            n_mine = 0;
-        }
-    }
-}
-
+#ifdef ERH_MEASURE   // the lock-step persistent scan (round 1; superseded by the ping-pong scan): csrc/measure/dense_scan_persist.inc
+#include "measure/dense_scan_persist.inc"
 #endif  // ERH_MEASURE
 
 // ---------------------------------------------------------------------------------------------
@@ -883,452 +632,8 @@ constexpr int kPp3LockStep = 1;    // VAR bit 0 of dense_scan_pp3_kernel (DMA in
 constexpr int kPp3LockStep = 0;    // ... a measured dead end: not in the product build
 #endif
 constexpr int kPpNoEpi = 1, kPpTauInf = 2, kPpNoMfma = 4, kPpNoDmaA = 8, kPpNoDmaB = 16, kPpNoFrag = 32, kPpClocks = 64;
-#ifdef ERH_MEASURE   // the first two generations of the ping-pong scan: measurement builds only
-template <int PABL>
-__global__ __launch_bounds__(pp::NT) void dense_scan_pp_kernel(
-    const _Float16 *__restrict__ X, int64_t N, int d, int64_t c0, int64_t c1,
-    const _Float16 *__restrict__ Q, int Bpad, int B,
-    const float *__restrict__ tau, const int16_t *__restrict__ filter_dir, const int16_t *__restrict__ dir_id,
-    ErhCand *__restrict__ cand, uint32_t *__restrict__ cand_cnt, int cap, uint32_t *__restrict__ overflow,
-    unsigned long long *__restrict__ dbg /* kPpClocks only: phase clock sums of waves 0 and 4 */) {
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int grp = wave >> 2, wave_n = wave & 3;
-    // kPpClocks (measurement): shader-clock sums per phase kind -- 0 matrix segment, 1 counted wait, 2 barrier,
-    // 3 memory segment, 4 epilogue, 5 epilogue barrier
-    long long tph[6] = {0, 0, 0, 0, 0, 0};
-    long long t_mark = (PABL & kPpClocks) ? clock64() : 0;
-#define ERH_PH(I) do { if (PABL & kPpClocks) { const long long n_ = clock64(); tph[I] += n_ - t_mark; t_mark = n_; } } while (0)
-    const int nk = d / pp::BK;
-
-    const int n_qt = Bpad / pp::BN;
-    const int64_t n_ct = (c1 - c0 + pp::BM - 1) / pp::BM;
-    const int xcd = blockIdx.x & 7;
-    const int jx = blockIdx.x >> 3;
-    const int qt = jx % n_qt;
-    const int stream = (jx / n_qt) * 8 + xcd;
-    const int n_streams = (gridDim.x / (8 * n_qt)) * 8;
-    if (stream >= n_ct) return;                                        // whole workgroup, before any barrier
-    const int n_tiles = (int)((n_ct - stream + n_streams - 1) / n_streams);
-    const int total = n_tiles * nk;                                    // flattened (tile, stage) sequence
-    const int64_t q_row0 = (int64_t)qt * pp::BN;
-    const int64_t lim = (c1 < N) ? c1 : N;
-
-    const int l31 = lane & 31, hh = lane >> 5;
-    float t_q[2];
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int q = (int)q_row0 + wave_n * 64 + nt * 32 + l31;
-        t_q[nt] = (q < B && !(PABL & kPpTauInf)) ? tau[q] : INFINITY;
-    }
-    asm volatile("" ::"v"(t_q[0]), "v"(t_q[1]));                      // loaded before the DMA stream starts (keeps vmcnt countable)
-
-    TileSrc<pp::BN, pp::NW, pp::PR> tb;
-    TileSrc<pp::BM, pp::NW, pp::PR> ta;
-    tb.init(Q, q_row0, Bpad, d, wave, lane);
-    ta.init(X, c0 + (int64_t)stream * pp::BM, N, d, wave, lane);
-    const int sw = row_swizzle<pp::PR>(l31);
-    const int soff0 = ((hh ^ sw) << 4), soff1 = (((2 + hh) ^ sw) << 4);
-    const int a_lane_off = (grp * 128 + l31) * pp::RB;
-    const int b_lane_off = pp::B_BASE + (wave_n * 64 + l31) * pp::RB;
-    char *const rec = lds + pp::REC_BASE + wave * pp::REC_BYTES;
-    if (threadIdx.x == 0) { ERH_PP_FLAG(0) = 0; ERH_PP_FLAG(1) = 0; }
-
-    // issue state: next B stage pair (gb even, kb = gb % nk, sb = gb % BST), next A stage pair (ga, ka, sa, tile of ga);
-    // m_odd = parity of the next memory phase M(h): even h issues the A pair (h+4, h+5), odd h the B pair (h+3, h+4)
-    int gb = 0, kb = 0, sb = 0, ga = 0, ka = 0, sa = 0, ta_tile = 0, m_odd = 0;
-    // fragment-read state: next stage to read (gf) and its ring slots
-    int gf = 0, fa_slot = 0, fb_slot = 0;
-    half8 fa[4][2], fb[2][2];
-
-// Both 64-byte halves of the same 128-byte lines go out back to back (first halves -> slot s, second halves ->
-// slot s+1): the second request hits in L1 / merges, so L2 sees each line once (scripts/ubench/ldsdma.hip: 129 vs
-// 70 GB/s per CU when the halves are a stage apart).
-#define ERH_PP_ISSUE_B()                                                                              \
-    do {                                                                                              \
-        if (gb < total && !(PABL & kPpNoDmaB)) {                                                 \
-            char *d0_ = lds + pp::B_BASE + sb * pp::B_BYTES;                                          \
-            char *d1_ = lds + pp::B_BASE + ((sb + 1) & (pp::BST - 1)) * pp::B_BYTES;                  \
-            tb.issue_part(kb, pp::BK, d0_, wave, 0, 1);                                               \
-            tb.issue_part(kb + 1, pp::BK, d1_, wave, 0, 1);                                           \
-            tb.issue_part(kb, pp::BK, d0_, wave, 1, 2);                                               \
-            tb.issue_part(kb + 1, pp::BK, d1_, wave, 1, 2);                                           \
-        }                                                                                             \
-        gb += 2; kb = (kb + 2 == nk) ? 0 : kb + 2; sb = (sb + 2) & (pp::BST - 1);                     \
-    } while (0)
-#define ERH_PP_ISSUE_A()                                                                              \
-    do {                                                                                              \
-        if (ga < total && !(PABL & kPpNoDmaA)) {                                                 \
-            if (ka == 0 && ga > 0) {                                                                  \
-                ++ta_tile;                                                                            \
-                ta.init(X, c0 + ((int64_t)stream + (int64_t)ta_tile * n_streams) * pp::BM, N, d, wave, lane); \
-            }                                                                                         \
-            char *d0_ = lds + sa * pp::A_BYTES;                                                       \
-            char *d1_ = lds + ((sa + 1 == pp::AST) ? 0 : sa + 1) * pp::A_BYTES;                       \
-            ta.issue_part(ka, pp::BK, d0_, wave, 0, 1);                                               \
-            ta.issue_part(ka + 1, pp::BK, d1_, wave, 0, 1);                                           \
-            ta.issue_part(ka, pp::BK, d0_, wave, 1, 2);                                               \
-            ta.issue_part(ka + 1, pp::BK, d1_, wave, 1, 2);                                           \
-        }                                                                                             \
-        ga += 2; ka = (ka + 2 == nk) ? 0 : ka + 2; sa += 2; if (sa >= pp::AST) sa -= pp::AST;         \
-    } while (0)
-// memory phase M(h): the fragments of stage h+1, then the A pair (h+4, h+5) for even h / the B pair (h+3, h+4) for odd h
-#define ERH_PP_MEM()                                                                                  \
-    do {                                                                                              \
-        if (gf < total && (!(PABL & kPpNoFrag) || gf == 0)) {                                                  \
-            const char *pa_ = lds + fa_slot * pp::A_BYTES + a_lane_off;                               \
-            const char *pb_ = lds + fb_slot * pp::B_BYTES + b_lane_off;                               \
-            _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                        \
-                fa[mt][0] = *reinterpret_cast<const half8 *>(pa_ + mt * 32 * pp::RB + soff0);         \
-                fa[mt][1] = *reinterpret_cast<const half8 *>(pa_ + mt * 32 * pp::RB + soff1);         \
-            }                                                                                         \
-            _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                                        \
-                fb[nt][0] = *reinterpret_cast<const half8 *>(pb_ + nt * 32 * pp::RB + soff0);         \
-                fb[nt][1] = *reinterpret_cast<const half8 *>(pb_ + nt * 32 * pp::RB + soff1);         \
-            }                                                                                         \
-        }                                                                                             \
-        ++gf; fa_slot = (fa_slot + 1 == pp::AST) ? 0 : fa_slot + 1; fb_slot = (fb_slot + 1) & (pp::BST - 1); \
-        __builtin_amdgcn_sched_barrier(0);   /* reads first: the DMA issue below covers their latency */ \
-        if (m_odd) ERH_PP_ISSUE_B(); else ERH_PP_ISSUE_A();                                           \
-        m_odd ^= 1;                                                                                   \
-        __builtin_amdgcn_sched_barrier(0);                                                            \
-    } while (0)
-#define ERH_PP_COMPUTE()                                                                              \
-    do {                                                                                              \
-        if (PABL & kPpNoMfma) {                                                                       \
-            _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) asm volatile("" ::"v"(fa[mt][0]), "v"(fa[mt][1])); \
-            _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) asm volatile("" ::"v"(fb[nt][0]), "v"(fb[nt][1])); \
-            if (kt == 0) { _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) \
-                _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f; }                \
-            break;                                                                                    \
-        }                                                                                             \
-        if (kt == 0) {                                                                                \
-            const f32x16 z_ = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; \
-            _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                          \
-                _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                      \
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mt][0], fb[nt][0], z_, 0, 0, 0); \
-        } else {                                                                                      \
-            _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                          \
-                _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                      \
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mt][0], fb[nt][0], acc[mt][nt], 0, 0, 0); \
-        }                                                                                             \
-        _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                              \
-            _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                          \
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mt][1], fb[nt][1], acc[mt][nt], 0, 0, 0); \
-        __builtin_amdgcn_sched_barrier(0);                                                            \
-    } while (0)
-// end of P_a(g): stage g+1 complete for this wave's pieces (see the header comment), then publish
-#define ERH_PP_WAIT()                                                                                 \
-    do {                                                                                              \
-        if (g + 4 >= total) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                          \
-        else if (g & 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                              \
-        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                         \
-    } while (0)
-
-    // prologue: the issue halves of M(-4) M(-3) M(-2) = A(0,1) B(0,1) A(2,3); stage 0 complete = the last 4 in flight
-    ERH_PP_ISSUE_A();
-    ERH_PP_ISSUE_B();
-    ERH_PP_ISSUE_A();
-    m_odd = 1;                                                         // next: M(-1)
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    ERH_PP_BARRIER();
-
-    f32x16 acc[4][2];
-    int fill = 0;                                                      // records buffered in this wave's area
-    int flush_now = 0;                                                 // workgroup-uniform, decided one tile ahead
-    int g = 0;
-
-    // One barrier per stage: between barrier g and barrier g+1 group 0 runs M(g) then C(g+1), group 1 runs C(g) then
-    // M(g) -- opposite order, so on every SIMD one wave is in its matrix segment while its partner does the memory
-    // segment.  (The barrier is only needed where a stage changes hands: before it every read of stage g is done
-    // and every piece of stage g+1 has landed.)
-    if (grp == 0) {
-        ERH_PP_MEM();                                                  // M(-1): B(2,3), fragments of stage 0
-        for (int i = 0; i < n_tiles; ++i) {
-            for (int kt = 0; kt < nk; ++kt, ++g) {
-                ERH_PP_COMPUTE();
-                ERH_PH(0);
-                ERH_PP_WAIT();
-                ERH_PH(1);
-                ERH_PP_BARRIER();                                      // barrier g
-                ERH_PH(2);
-                ERH_PP_MEM();                                          // M(g)
-                ERH_PH(3);
-            }
-            ERH_PP_EPILOGUE();
-            ERH_PH(4);
-            ERH_PP_BARRIER();
-            ERH_PH(5);
-            if (!(PABL & kPpNoEpi)) flush_now = __builtin_amdgcn_readfirstlane(ERH_PP_FLAG(i & 1));
-        }
-    } else {
-        for (int i = 0; i < n_tiles; ++i) {
-            for (int kt = 0; kt < nk; ++kt, ++g) {
-                ERH_PP_MEM();                                          // M(g-1)
-                ERH_PH(3);
-                ERH_PP_WAIT();
-                ERH_PH(1);
-                ERH_PP_BARRIER();                                      // barrier g
-                ERH_PH(2);
-                ERH_PP_COMPUTE();
-                ERH_PH(0);
-            }
-            ERH_PP_EPILOGUE();
-            ERH_PH(4);
-            ERH_PP_BARRIER();
-            ERH_PH(5);
-            if (!(PABL & kPpNoEpi)) flush_now = __builtin_amdgcn_readfirstlane(ERH_PP_FLAG(i & 1));
-        }
-    }
-    if ((PABL & kPpClocks) && dbg && lane == 0 && (wave == 0 || wave == 4)) {
-#pragma unroll
-        for (int i = 0; i < 6; ++i) atomicAdd(&dbg[grp * 8 + i], (unsigned long long)tph[i]);
-        atomicAdd(&dbg[grp * 8 + 6], (unsigned long long)total);
-    }
-#undef ERH_PH
-#undef ERH_PP_ISSUE_A
-#undef ERH_PP_ISSUE_B
-#undef ERH_PP_MEM
-#undef ERH_PP_COMPUTE
-#undef ERH_PP_WAIT
-}
-
-// ---------------------------------------------------------------------------------------------
-// Ping-pong scan, lean issue stream (option "dense_pp" = 2, the default).  Same tiles, rings, schedule, epilogue and
-// results as dense_scan_pp_kernel.  What changed is the instruction count of the memory segment: a wave issues at
-// most one instruction every ~4 cycles, and the phase clocks showed M(h) at 760-1130 cycles against 515-650 for the 16
-// MFMAs it is supposed to hide behind (profiles/r02a_kbench_pp_ablations.log) -- with ~140 instructions in it, most
-// of them bookkeeping (64-bit address arithmetic per DMA instruction, stage -> ring-slot arithmetic, the A/B parity
-// and tail tests).  Here
-//   - the per-lane source pointers ADVANCE (128 bytes per stage pair; one uniform-increment add per pointer, the jump
-//     to the stream's next tile folded into the same add) instead of being recomputed from (tile, stage);
-//     rows past N are read from the zero padding erh_set_dense allocates behind the matrix, so nothing is clamped;
-//   - ring positions are byte offsets that wrap by compare-and-subtract; the stage loop is unrolled by two, so the
-//     A-pair / B-pair alternation and the vmcnt(8) / vmcnt(4) alternation are compile-time;
-//   - fragment addresses are one VGPR add per operand and stage plus immediate offsets.
-//   - VAR bit 0: a second barrier per stage between the two halves of an interval, so that the groups alternate strictly
-//     (one group in its matrix segment, the other in its memory segment, never both in the same kind);
-//     bit 1: static s_setprio 1 for the later-dispatched group (waves 4-7);
-//   - rot_stages: query tile qt walks K starting at stage qt * rot_stages (wrapping), so the workgroups that share a
-//     chunk-tile stream miss on DIFFERENT lines at any moment (scripts/ubench/stream: the shared stream runs 20-25 %
-//     faster); fp32 sums in another order are within the pruning margin by construction, the final scores are re-scored.
-template <int PABL, int VAR>
-__global__ __launch_bounds__(pp::NT) void dense_scan_pp2_kernel(
-    const _Float16 *__restrict__ X, int64_t N, int d, int64_t c0, int64_t c1,
-    const _Float16 *__restrict__ Q, int Bpad, int B,
-    const float *__restrict__ tau, const int16_t *__restrict__ filter_dir, const int16_t *__restrict__ dir_id,
-    ErhCand *__restrict__ cand, uint32_t *__restrict__ cand_cnt, int cap, uint32_t *__restrict__ overflow,
-    unsigned long long *__restrict__ dbg /* kPpClocks only */, int rot_stages) {
-    constexpr bool SYNC2 = (VAR & 1) != 0, PRIO = (VAR & 2) != 0;
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int grp = wave >> 2, wave_n = wave & 3;
-    long long tph[6] = {0, 0, 0, 0, 0, 0};
-    long long t_mark = (PABL & kPpClocks) ? clock64() : 0;
-#define ERH_PH(I) do { if (PABL & kPpClocks) { const long long n_ = clock64(); tph[I] += n_ - t_mark; t_mark = n_; } } while (0)
-    const int nk = d / pp::BK;
-
-    const int n_qt = Bpad / pp::BN;
-    const int64_t n_ct = (c1 - c0 + pp::BM - 1) / pp::BM;
-    const int xcd = blockIdx.x & 7;
-    const int jx = blockIdx.x >> 3;
-    const int qt = jx % n_qt;
-    const int stream = (jx / n_qt) * 8 + xcd;
-    const int n_streams = (gridDim.x / (8 * n_qt)) * 8;
-    if (stream >= n_ct) return;                                        // whole workgroup, before any barrier
-    const int n_tiles = (int)((n_ct - stream + n_streams - 1) / n_streams);
-    const int total = n_tiles * nk;                                    // flattened (tile, stage) sequence
-    const int64_t q_row0 = (int64_t)qt * pp::BN;
-    const int64_t lim = (c1 < N) ? c1 : N;
-
-    const int l31 = lane & 31, hh = lane >> 5;
-    const int k0 = ((qt * rot_stages) % nk) & ~1;                      // first K stage of every tile for this query tile
-    float t_q[2];
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int q = (int)q_row0 + wave_n * 64 + nt * 32 + l31;
-        t_q[nt] = (q < B && !(PABL & kPpTauInf)) ? tau[q] : INFINITY;
-    }
-    asm volatile("" ::"v"(t_q[0]), "v"(t_q[1]));                      // loaded before the DMA stream starts (keeps vmcnt countable)
-
-    // per-lane source pointers of this wave's two 1-KiB DMA instructions per operand and stage: piece = 16-byte unit,
-    // 4 per row; instruction `it` of wave w moves pieces [(it * 8 + w) * 64, +64) of the 256-row stage image
-    const _Float16 *pa[2], *pb[2];
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const int piece = (it * pp::NW + wave) * 64 + lane;
-        const int r = piece >> 2, p4 = piece & 3;
-        const int ls = p4 ^ row_swizzle<pp::PR>(r);                    // logical 16-byte slot stored at physical slot p4
-        pa[it] = X + (c0 + (int64_t)stream * pp::BM + r) * (int64_t)d + ls * 8 + k0 * pp::BK;
-        pb[it] = Q + (q_row0 + r) * (int64_t)d + ls * 8 + k0 * pp::BK;
-    }
-    const int64_t a_jump = (int64_t)n_streams * pp::BM * (int64_t)d;   // a row -> the same row of the stream's next tile
-    const int sw = row_swizzle<pp::PR>(l31);
-    const int a_rd0 = (grp * 128 + l31) * pp::RB + ((hh ^ sw) << 4);
-    const int a_rd1 = (grp * 128 + l31) * pp::RB + (((2 + hh) ^ sw) << 4);
-    const int b_rd0 = pp::B_BASE + (wave_n * 64 + l31) * pp::RB + ((hh ^ sw) << 4);
-    const int b_rd1 = pp::B_BASE + (wave_n * 64 + l31) * pp::RB + (((2 + hh) ^ sw) << 4);
-    char *const rec = lds + pp::REC_BASE + wave * pp::REC_BYTES;
-    if (threadIdx.x == 0) { ERH_PP_FLAG(0) = 0; ERH_PP_FLAG(1) = 0; }
-
-    // issue state: ring byte offsets of the next pair's first slot, stage-in-tile counters, pair issues left
-    constexpr int kABytes = pp::AST * pp::A_BYTES, kBBytes = pp::BST * pp::B_BYTES;
-    int a_dst = 0, b_dst = 0, ka = k0, kb = k0;
-    int a_left = total >> 1, b_left = total >> 1;                      // (nk is even: pairs never straddle a tile)
-    // fragment-read state
-    int fa_off = 0, fb_off = 0, f_left = total;
-    half8 fa[4][2], fb[2][2];
-    char *const my_dst = lds + wave * 1024;                            // + it * 8192 + ring offset
-
-// fragments of the next stage to read (the stage after the one the matrix segment is working on)
-#define ERH_PP2_READ()                                                                                \
-    do {                                                                                              \
-        if (f_left > 0) {                                                                             \
-            if (!(PABL & kPpNoFrag) || f_left == total) {                                             \
-                const char *pa0_ = lds + (a_rd0 + fa_off), *pa1_ = lds + (a_rd1 + fa_off);            \
-                const char *pb0_ = lds + (b_rd0 + fb_off), *pb1_ = lds + (b_rd1 + fb_off);            \
-                _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                    \
-                    fa[mt][0] = *reinterpret_cast<const half8 *>(pa0_ + mt * 32 * pp::RB);            \
-                    fa[mt][1] = *reinterpret_cast<const half8 *>(pa1_ + mt * 32 * pp::RB);            \
-                }                                                                                     \
-                _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                                    \
-                    fb[nt][0] = *reinterpret_cast<const half8 *>(pb0_ + nt * 32 * pp::RB);            \
-                    fb[nt][1] = *reinterpret_cast<const half8 *>(pb1_ + nt * 32 * pp::RB);            \
-                }                                                                                     \
-            }                                                                                         \
-            fa_off += pp::A_BYTES;                                                                    \
-            if (fa_off == kABytes) fa_off = 0;                                                        \
-            fb_off = (fb_off + pp::B_BYTES) & (kBBytes - 1);                                          \
-            --f_left;                                                                                 \
-        }                                                                                             \
-        __builtin_amdgcn_sched_barrier(0);   /* reads first: the DMA issue below covers their latency */ \
-    } while (0)
-#define ERH_PP2_COMPUTE(FIRST)                                                                        \
-    do {                                                                                              \
-        if (PABL & kPpNoMfma) {                                                                       \
-            _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) asm volatile("" ::"v"(fa[mt][0]), "v"(fa[mt][1])); \
-            _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) asm volatile("" ::"v"(fb[nt][0]), "v"(fb[nt][1])); \
-            if (FIRST) { _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) \
-                _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f; }                \
-            break;                                                                                    \
-        }                                                                                             \
-        if (FIRST) {                                                                                  \
-            const f32x16 z_ = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; \
-            _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                          \
-                _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                      \
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mt][0], fb[nt][0], z_, 0, 0, 0); \
-        } else {                                                                                      \
-            _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                          \
-                _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                      \
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mt][0], fb[nt][0], acc[mt][nt], 0, 0, 0); \
-        }                                                                                             \
-        _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                              \
-            _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                          \
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mt][1], fb[nt][1], acc[mt][nt], 0, 0, 0); \
-        __builtin_amdgcn_sched_barrier(0);                                                            \
-    } while (0)
-// before barrier g: everything this wave issued up to B(g+1) has landed (see the header of the ping-pong scan)
-#define ERH_PP2_WAIT(G, ODD)                                                                          \
-    do {                                                                                              \
-        if ((G) + 4 >= total) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        \
-        else if (ODD) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                \
-        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                         \
-    } while (0)
-
-    // prologue: A(0,1) B(0,1) A(2,3); stage 0 complete = the last 4 instructions may stay in flight
-    ERH_PP2_ISSUE_A();
-    ERH_PP2_ISSUE_B();
-    ERH_PP2_ISSUE_A();
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    ERH_PP_BARRIER();
-
-    f32x16 acc[4][2];
-    int fill = 0;                                                      // records buffered in this wave's area
-    int flush_now = 0;                                                 // workgroup-uniform, decided one tile ahead
-    int g = 0;
-
-    if (PRIO && grp == 1) __builtin_amdgcn_s_setprio(1);
-    if (grp == 0) {
-        ERH_PP2_READ();                                                // M(-1): fragments of stage 0, B(2,3)
-        ERH_PP2_ISSUE_B();
-        __builtin_amdgcn_sched_barrier(0);
-        for (int i = 0; i < n_tiles; ++i) {
-            for (int kt = 0; kt < nk; kt += 2, g += 2) {
-                ERH_PP2_COMPUTE(kt == 0);                              // C(g), g even
-                ERH_PH(0);
-                ERH_PP2_WAIT(g, false);
-                ERH_PH(1);
-                ERH_PP_BARRIER();                                      // barrier g
-                ERH_PH(2);
-                ERH_PP2_READ();                                        // M(g): fragments of g+1, A(g+4, g+5)
-                ERH_PP2_ISSUE_A();
-                __builtin_amdgcn_sched_barrier(0);
-                ERH_PH(3);
-                if (SYNC2) ERH_PP_BARRIER();
-                ERH_PP2_COMPUTE(false);                                // C(g), g odd
-                ERH_PH(0);
-                ERH_PP2_WAIT(g + 1, true);
-                ERH_PH(1);
-                ERH_PP_BARRIER();
-                ERH_PH(2);
-                ERH_PP2_READ();                                        // M(g): fragments of g+1, B(g+3, g+4)
-                ERH_PP2_ISSUE_B();
-                __builtin_amdgcn_sched_barrier(0);
-                ERH_PH(3);
-                if (SYNC2) ERH_PP_BARRIER();
-            }
-            ERH_PP_EPILOGUE();
-            ERH_PH(4);
-            ERH_PP_BARRIER();
-            ERH_PH(5);
-            if (!(PABL & kPpNoEpi)) flush_now = __builtin_amdgcn_readfirstlane(ERH_PP_FLAG(i & 1));
-        }
-    } else {
-        for (int i = 0; i < n_tiles; ++i) {
-            for (int kt = 0; kt < nk; kt += 2, g += 2) {
-                ERH_PP2_READ();                                        // M(g-1), g even: fragments of g, B(g+2, g+3)
-                ERH_PP2_ISSUE_B();
-                __builtin_amdgcn_sched_barrier(0);
-                ERH_PH(3);
-                ERH_PP2_WAIT(g, false);
-                ERH_PH(1);
-                ERH_PP_BARRIER();                                      // barrier g
-                ERH_PH(2);
-                ERH_PP2_COMPUTE(kt == 0);
-                ERH_PH(0);
-                if (SYNC2) ERH_PP_BARRIER();
-                ERH_PP2_READ();                                        // M(g-1), g odd: fragments of g, A(g+3, g+4)
-                ERH_PP2_ISSUE_A();
-                __builtin_amdgcn_sched_barrier(0);
-                ERH_PH(3);
-                ERH_PP2_WAIT(g + 1, true);
-                ERH_PH(1);
-                ERH_PP_BARRIER();
-                ERH_PH(2);
-                ERH_PP2_COMPUTE(false);
-                ERH_PH(0);
-                if (SYNC2) ERH_PP_BARRIER();
-            }
-            ERH_PP_EPILOGUE();
-            ERH_PH(4);
-            ERH_PP_BARRIER();
-            ERH_PH(5);
-            if (!(PABL & kPpNoEpi)) flush_now = __builtin_amdgcn_readfirstlane(ERH_PP_FLAG(i & 1));
-        }
-    }
-    if ((PABL & kPpClocks) && dbg && lane == 0 && (wave == 0 || wave == 4)) {
-#pragma unroll
-        for (int i = 0; i < 6; ++i) atomicAdd(&dbg[grp * 8 + i], (unsigned long long)tph[i]);
-        atomicAdd(&dbg[grp * 8 + 6], (unsigned long long)total);
-    }
-#undef ERH_PH
-#undef ERH_PP2_READ
-#undef ERH_PP2_COMPUTE
-#undef ERH_PP2_WAIT
-}
-
+#ifdef ERH_MEASURE   // the first two generations of the ping-pong scan (dense_scan_pp_kernel, dense_scan_pp2_kernel): csrc/measure/dense_scan_pp12.inc
+#include "measure/dense_scan_pp12.inc"
 #endif  // ERH_MEASURE
 
 // ---------------------------------------------------------------------------------------------
@@ -1796,243 +1101,8 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp3_kernel(
 #undef ERH_PP2_ISSUE_A
 #undef ERH_PP2_ISSUE_B
 
-#ifdef ERH_MEASURE   // measured equal to pp3 (profiles/r04e_kbench_pp4.log): measurement builds only
-// ---------------------------------------------------------------------------------------------
-// Ping-pong scan over TILED operands (option "dense_pp" = 4).  Same tile, waves, strict alternation (two barriers per
-// stage), fragment-read placement and epilogue as dense_scan_pp3_kernel; what changes is the memory side, rebuilt from the
-// mainloop of scripts/ubench/scan_sync.hip (SYNC 0), which on the same box runs ~10 % faster than pp3 without its epilogue:
-//   - BOTH operands come from tiled copies -- per 256-row tile and 32-half stage one 16 KiB block that IS the LDS stage
-//     image (swizzle included): the chunk matrix' copy Xt (dense_tile_rows_kernel at erh_set_dense) and a copy Qt of the
-//     query block made per call by the same kernel (512 KiB per query tile).  Every DMA instruction moves 1 KiB of
-//     consecutive bytes; stages are issued one at a time, so nothing relies on an L1 hit of a line's second half;
-//   - every memory segment issues the same four instructions: two of chunk stage g+4 (ring 5), two of query stage g+3 (ring
-//     4); before the barrier that ends stage g all but those four have landed (vmcnt(4)), i.e. stage g+2 is complete one
-//     whole stage before its fragments are read;
-//   - the bookkeeping is two running byte pointers and two ring offsets: ~100 VGPRs fewer than pp3, nothing spills.
-// K-rotation (rot_stages): query tile qt starts every chunk tile at stage k0 = qt * rot_stages mod nk (any stage, not only
-// even ones), so the workgroups of a stream miss on different lines.
-template <int PABL>
-__global__ __launch_bounds__(pp::NT) void dense_scan_pp4_kernel(
-    const _Float16 *__restrict__ Xt, int64_t N, int d, int64_t c0, int64_t c1,
-    const _Float16 *__restrict__ Qt, int Bpad, int B,
-    const float *__restrict__ tau, const int16_t *__restrict__ filter_dir, const int16_t *__restrict__ dir_id,
-    ErhCand *__restrict__ cand, uint32_t *__restrict__ cand_cnt, int cap, uint32_t *__restrict__ overflow,
-    unsigned long long *__restrict__ dbg /* kPpClocks only */, int rot_stages) {
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int grp = wave >> 2, wave_n = wave & 3;
-    long long tph[6] = {0, 0, 0, 0, 0, 0};
-    long long t_mark = (PABL & kPpClocks) ? clock64() : 0;
-#define ERH_PH(I) do { if (PABL & kPpClocks) { const long long n_ = clock64(); tph[I] += n_ - t_mark; t_mark = n_; } } while (0)
-    const int nk = d / pp::BK;
-    const int n_qt = Bpad / pp::BN;
-    const int64_t n_ct = (c1 - c0 + pp::BM - 1) / pp::BM;
-    const int xcd = blockIdx.x & 7;
-    const int jx = blockIdx.x >> 3;
-    const int qt = jx % n_qt;
-    const int stream = (jx / n_qt) * 8 + xcd;
-    const int n_streams = (gridDim.x / (8 * n_qt)) * 8;
-    if (stream >= n_ct) return;                                        // whole workgroup, before any barrier
-    const int n_tiles = (int)((n_ct - stream + n_streams - 1) / n_streams);
-    const int total = n_tiles * nk;                                    // flattened (tile, stage) sequence
-    const int64_t q_row0 = (int64_t)qt * pp::BN;
-    const int64_t lim = (c1 < N) ? c1 : N;
-    const int l31 = lane & 31, hh = lane >> 5;
-    const int k0 = (qt * rot_stages) % nk;
-    float t_q[2];
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int q = (int)q_row0 + wave_n * 64 + nt * 32 + l31;
-        t_q[nt] = (q < B && !(PABL & kPpTauInf)) ? tau[q] : INFINITY;
-    }
-    asm volatile("" ::"v"(t_q[0]), "v"(t_q[1]));                      // loaded before the DMA stream starts (keeps vmcnt countable)
-
-    // this lane's 16 bytes of a stage image: instruction 0 moves bytes [wave * 1024, +1024), instruction 1 the same + 8 KiB
-    const int64_t tile_bytes = (int64_t)nk * pp::A_BYTES;
-    const char *xa = reinterpret_cast<const char *>(Xt) + ((c0 / pp::BM + stream) * (int64_t)nk + k0) * pp::A_BYTES + wave * 1024 + lane * 16;
-    const char *const qb = reinterpret_cast<const char *>(Qt) + (int64_t)qt * tile_bytes + wave * 1024 + lane * 16;
-    const int64_t a_jump = (int64_t)n_streams * tile_bytes;           // a stage -> the same stage of the stream's next tile
-    const int sw = row_swizzle<pp::PR>(l31);
-    const int a_rd0 = (grp * 128 + l31) * pp::RB + ((hh ^ sw) << 4);
-    const int a_rd1 = (grp * 128 + l31) * pp::RB + (((2 + hh) ^ sw) << 4);
-    const int b_rd0 = pp::B_BASE + (wave_n * 64 + l31) * pp::RB + ((hh ^ sw) << 4);
-    const int b_rd1 = pp::B_BASE + (wave_n * 64 + l31) * pp::RB + (((2 + hh) ^ sw) << 4);
-    char *const rec = lds + pp::REC_BASE + wave * pp::REC_BYTES;
-    if (threadIdx.x == 0) { ERH_PP_FLAG(0) = 0; ERH_PP_FLAG(1) = 0; }
-
-    constexpr int kABytes = pp::AST * pp::A_BYTES, kBBytes = pp::BST * pp::B_BYTES;
-    int a_dst = 0, b_dst = 0, ka = k0, kb = k0;
-    int a_left = total, b_left = total;
-    int fa_off = 0, fb_off = 0;                                        // ring offsets of the next stage to read
-    half8 fa[4][2], fb[2][2];
-    char *const my_dst = lds + wave * 1024;
-#define ERH_PP4_GLDS(SRC, DST) __builtin_amdgcn_global_load_lds((const void *)(SRC), ERH_LDS_PTR(DST), 16, 0, 0)
-#define ERH_PP4_ISSUE_A()                                                                             \
-    do {                                                                                              \
-        if (a_left > 0) {                                                                             \
-            if (!(PABL & kPpNoDmaA)) {                                                                \
-                ERH_PP4_GLDS(xa, my_dst + a_dst);                                                     \
-                ERH_PP4_GLDS(xa + 8192, my_dst + a_dst + 8192);                                       \
-            }                                                                                         \
-            xa += pp::A_BYTES;                                                                        \
-            if (++ka == nk) { ka = 0; xa -= tile_bytes; }                  /* wrap to stage 0 of the same tile */ \
-            if (ka == k0) xa += a_jump;                                    /* tile complete: the stream's next tile */ \
-            a_dst += pp::A_BYTES;                                                                     \
-            if (a_dst == kABytes) a_dst = 0;                                                          \
-            --a_left;                                                                                 \
-        }                                                                                             \
-    } while (0)
-#define ERH_PP4_ISSUE_B()                                                                             \
-    do {                                                                                              \
-        if (b_left > 0) {                                                                             \
-            if (!(PABL & kPpNoDmaB)) {                                                                \
-                const char *q_ = qb + (int64_t)kb * pp::B_BYTES;                                      \
-                ERH_PP4_GLDS(q_, my_dst + pp::B_BASE + b_dst);                                        \
-                ERH_PP4_GLDS(q_ + 8192, my_dst + pp::B_BASE + b_dst + 8192);                          \
-            }                                                                                         \
-            if (++kb == nk) kb = 0;                                                                   \
-            b_dst = (b_dst + pp::B_BYTES) & (kBBytes - 1);                                            \
-            --b_left;                                                                                 \
-        }                                                                                             \
-    } while (0)
-#define ERH_PP4_ADVANCE_READ()                                                                        \
-    do {                                                                                              \
-        fa_off += pp::A_BYTES;                                                                        \
-        if (fa_off == kABytes) fa_off = 0;                                                            \
-        fb_off = (fb_off + pp::B_BYTES) & (kBBytes - 1);                                              \
-    } while (0)
-#define ERH_PP4_READ_ALL()                                                                            \
-    do {                                                                                              \
-        const char *pa0_ = lds + (a_rd0 + fa_off), *pa1_ = lds + (a_rd1 + fa_off);                    \
-        const char *pb0_ = lds + (b_rd0 + fb_off), *pb1_ = lds + (b_rd1 + fb_off);                    \
-        _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                            \
-            fa[mt][0] = *reinterpret_cast<const half8 *>(pa0_ + mt * 32 * pp::RB);                    \
-            fa[mt][1] = *reinterpret_cast<const half8 *>(pa1_ + mt * 32 * pp::RB);                    \
-        }                                                                                             \
-        _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                                            \
-            fb[nt][0] = *reinterpret_cast<const half8 *>(pb0_ + nt * 32 * pp::RB);                    \
-            fb[nt][1] = *reinterpret_cast<const half8 *>(pb1_ + nt * 32 * pp::RB);                    \
-        }                                                                                             \
-        ERH_PP4_ADVANCE_READ();                                                                       \
-    } while (0)
-// one K sub-step of the matrix segment; each fragment register is re-loaded with the NEXT stage's contents right behind the
-// last MFMA that reads it (past the end of the stream the reads fetch stale ring bytes that nothing uses)
-#define ERH_PP4_HALF(J, PA_, PB_, FIRST)                                                              \
-    do {                                                                                              \
-        _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                            \
-            if (!(PABL & kPpNoMfma)) {                                                                \
-                if (FIRST) {                                                                          \
-                    const f32x16 z_ = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; \
-                    acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mt][J], fb[0][J], z_, 0, 0, 0);  \
-                    acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mt][J], fb[1][J], z_, 0, 0, 0);  \
-                } else {                                                                              \
-                    acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mt][J], fb[0][J], acc[mt][0], 0, 0, 0); \
-                    acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mt][J], fb[1][J], acc[mt][1], 0, 0, 0); \
-                }                                                                                     \
-            } else {                                                                                  \
-                asm volatile("" ::"v"(fa[mt][J]), "v"(fb[0][J]), "v"(fb[1][J]));                      \
-                if (FIRST) { _Pragma("unroll") for (int r = 0; r < 16; ++r) { acc[mt][0][r] = 0.f; acc[mt][1][r] = 0.f; } } \
-            }                                                                                         \
-            if (!(PABL & kPpNoFrag)) fa[mt][J] = *reinterpret_cast<const half8 *>(PA_ + mt * 32 * pp::RB); \
-            __builtin_amdgcn_sched_barrier(0);                                                        \
-        }                                                                                             \
-        if (!(PABL & kPpNoFrag)) {                                                                    \
-            fb[0][J] = *reinterpret_cast<const half8 *>(PB_);                                         \
-            fb[1][J] = *reinterpret_cast<const half8 *>(PB_ + 32 * pp::RB);                           \
-        }                                                                                             \
-        __builtin_amdgcn_sched_barrier(0);                                                            \
-    } while (0)
-#define ERH_PP4_COMPUTE(FIRST)                                                                        \
-    do {                                                                                              \
-        const char *pa0_ = lds + (a_rd0 + fa_off), *pa1_ = lds + (a_rd1 + fa_off);                    \
-        const char *pb0_ = lds + (b_rd0 + fb_off), *pb1_ = lds + (b_rd1 + fb_off);                    \
-        ERH_PP4_HALF(0, pa0_, pb0_, FIRST);                                                           \
-        ERH_PP4_HALF(1, pa1_, pb1_, false);                                                           \
-        ERH_PP4_ADVANCE_READ();                                                                       \
-    } while (0)
-// after M_g (chunk stage g+4, query stage g+3 issued): everything but those four instructions has landed, i.e. stage g+2;
-// the fragment reads of this wave's last matrix segment have retired (ring slots may be overwritten after the barrier)
-#define ERH_PP4_WAIT(G)                                                                               \
-    do {                                                                                              \
-        if ((G) + 4 >= total) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");             \
-        else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");                              \
-    } while (0)
-
-    // prologue: A0 B0 A1 B1 A2 B2 A3; stages 0 and 1 complete = the last 6 instructions may stay in flight
-    ERH_PP4_ISSUE_A(); ERH_PP4_ISSUE_B(); ERH_PP4_ISSUE_A(); ERH_PP4_ISSUE_B(); ERH_PP4_ISSUE_A(); ERH_PP4_ISSUE_B();
-    ERH_PP4_ISSUE_A();
-    if (total >= 4) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    ERH_PP_BARRIER();
-    ERH_PP4_READ_ALL();                                                // stage 0
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    ERH_PP_BARRIER();
-
-    f32x16 acc[4][2];
-    int fill = 0;                                                      // records buffered in this wave's area
-    int flush_now = 0;                                                 // workgroup-uniform, decided one tile ahead
-    int g = 0;
-    if (grp == 0) {
-        for (int i = 0; i < n_tiles; ++i) {
-            for (int kt = 0; kt < nk; ++kt, ++g) {
-                ERH_PP4_COMPUTE(kt == 0);                              // C(g)
-                ERH_PH(0);
-                ERH_PP_BARRIER();                                      // |A|
-                ERH_PH(2);
-                ERH_PP4_ISSUE_A();                                     // M_g
-                ERH_PP4_ISSUE_B();
-                __builtin_amdgcn_sched_barrier(0);
-                ERH_PH(3);
-                ERH_PP4_WAIT(g);
-                ERH_PH(1);
-                ERH_PP_BARRIER();                                      // |B|
-                ERH_PH(2);
-            }
-            ERH_PP_EPILOGUE();
-            ERH_PH(4);
-            ERH_PP_BARRIER();
-            ERH_PH(5);
-            if (!(PABL & kPpNoEpi)) flush_now = __builtin_amdgcn_readfirstlane(ERH_PP_FLAG(i & 1));
-        }
-    } else {
-        for (int i = 0; i < n_tiles; ++i) {
-            for (int kt = 0; kt < nk; ++kt, ++g) {
-                ERH_PP4_ISSUE_A();                                     // M_g
-                ERH_PP4_ISSUE_B();
-                __builtin_amdgcn_sched_barrier(0);
-                ERH_PH(3);
-                ERH_PP_BARRIER();                                      // |A|
-                ERH_PH(2);
-                ERH_PP4_COMPUTE(kt == 0);                              // C(g)
-                ERH_PH(0);
-                ERH_PP4_WAIT(g);
-                ERH_PH(1);
-                ERH_PP_BARRIER();                                      // |B|
-                ERH_PH(2);
-            }
-            ERH_PP_EPILOGUE();
-            ERH_PH(4);
-            ERH_PP_BARRIER();
-            ERH_PH(5);
-            if (!(PABL & kPpNoEpi)) flush_now = __builtin_amdgcn_readfirstlane(ERH_PP_FLAG(i & 1));
-        }
-    }
-    if ((PABL & kPpClocks) && dbg && lane == 0 && (wave == 0 || wave == 4)) {
-#pragma unroll
-        for (int i = 0; i < 6; ++i) atomicAdd(&dbg[grp * 8 + i], (unsigned long long)tph[i]);
-        atomicAdd(&dbg[grp * 8 + 6], (unsigned long long)total);
-    }
-#undef ERH_PH
-#undef ERH_PP4_GLDS
-#undef ERH_PP4_ISSUE_A
-#undef ERH_PP4_ISSUE_B
-#undef ERH_PP4_ADVANCE_READ
-#undef ERH_PP4_READ_ALL
-#undef ERH_PP4_HALF
-#undef ERH_PP4_COMPUTE
-#undef ERH_PP4_WAIT
-}
-
+#ifdef ERH_MEASURE   // the tiled-operand ping-pong scan of round 4 (dense_scan_pp4_kernel; measured equal to pp3: profiles/r04e_kbench_pp4.log): csrc/measure/dense_scan_pp4.inc
+#include "measure/dense_scan_pp4.inc"
 #endif  // ERH_MEASURE
 
 // ---------------------------------------------------------------------------------------------
