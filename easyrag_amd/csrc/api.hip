@@ -350,8 +350,7 @@ int dense_topk_dev(erh_handle *h, const void *q_dev, int q_dtype, int normalize_
     HIPCHK(h, h->seed_need.ensure((size_t)B * 4));
     HIPCHK(h, h->bad.ensure((size_t)B * 4));
     HIPCHK(h, h->ex_ws.ensure(erh::dense_exhaustive_bytes(N)));
-    HIPCHK(h, hipMemsetAsync(h->bad.p, 0, (size_t)B * 4, st));
-    uint32_t *bad = h->bad.as<uint32_t>();
+    uint32_t *bad = h->bad.as<uint32_t>();                       // (cleared by the query-prep kernel, like the flag words)
     int64_t n0 = std::min<int64_t>(std::min<int64_t>(h->opt_n0, erh::kDenseN0Max), N);
     if (n0 < 1) n0 = 1;
     // The persistent scan walks ceil(tiles / streams) rounds of 256-chunk tiles.  With dense_n0_auto the seed prefix shrinks
@@ -367,13 +366,12 @@ int dense_topk_dev(erh_handle *h, const void *q_dev, int q_dtype, int normalize_
     const int ld = round_up((int)n0, 256);
     HIPCHK(h, h->S0.ensure((size_t)Bpad * ld * 4));
     uint32_t *flags = h->flags.as<uint32_t>();   // [0] overflow, [1] maxerr (float bits), [2] uncertified
-    HIPCHK(h, hipMemsetAsync(flags, 0, 64, st));
 
     h->qt_valid = false;
     h->qt5_valid = false;
     { ProfScope ps(h, st, ERH_K_DENSE_SELECT, 0, 0);
       HIPCHK(h, erh::launch_prep_queries(q_dev, q_dtype, normalize_q, B, Bpad, d, h->Q16.as<_Float16>(),
-                                         h->qnorm.as<float>(), st));
+                                         h->qnorm.as<float>(), bad, flags, st));
       // the tiled-operand scan reads the query block as stage images too (512 KiB per 256 queries, once per call)
       if (h->opt_dense_pp >= 4 && h->xt_valid && d % 64 == 0 && B > erh::dense_gemv_max_queries()) {
           HIPCHK(h, h->Qt.ensure((size_t)Bpad * d * 2));
@@ -411,6 +409,7 @@ int dense_topk_dev(erh_handle *h, const void *q_dev, int q_dtype, int normalize_
               h->qt5_valid = true;
           }
       } }
+
     const _Float16 *X = h->X.as<_Float16>();
     const _Float16 *Q16 = h->Q16.as<_Float16>();
     const int16_t *dir = nullptr;                 // dir id by stored position, only needed when a filter is present
@@ -1778,7 +1777,7 @@ int erh_debug_dense_scores(erh_handle *h, const void *q_f16_host, int B, int64_t
     HIPCHK(h, hipMemcpyAsync(h->qin.p, q_f16_host, (size_t)B * d * 2, hipMemcpyHostToDevice, st));
     HIPCHK(h, h->Q16.ensure((size_t)Bpad * d * 2));
     HIPCHK(h, h->qnorm.ensure((size_t)Bpad * 4));
-    HIPCHK(h, erh::launch_prep_queries(h->qin.p, ERH_F16, 0, B, Bpad, d, h->Q16.as<_Float16>(), h->qnorm.as<float>(), st));
+    HIPCHK(h, erh::launch_prep_queries(h->qin.p, ERH_F16, 0, B, Bpad, d, h->Q16.as<_Float16>(), h->qnorm.as<float>(), nullptr, nullptr, st));
     // the requested ORIGINAL rows, gathered into a contiguous block
     HIPCHK(h, h->scores_tmp.ensure((size_t)rows * d * 2));
     HIPCHK(h, erh::launch_gather_rows(h->X.as<_Float16>(), row0, rows, d, h->pos_mul, h->N, h->scores_tmp.as<_Float16>(), st));

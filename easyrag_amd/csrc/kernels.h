@@ -76,7 +76,8 @@ constexpr int kDenseRescoreMax = 1024;
 hipError_t select_init();
 // fp32/fp16 -> fp16 query block [Bpad x d] (+ fp32 norm of the fp16 row); rows >= B are zeroed.
 hipError_t launch_prep_queries(const void *q, int q_dtype, int normalize, int B, int Bpad, int d,
-                               _Float16 *Q16, float *qnorm, hipStream_t st);
+                               _Float16 *Q16, float *qnorm, uint32_t *zero_bad /* null, or B words cleared by the kernel */,
+                               uint32_t *zero_flags /* null, or 16 words cleared by the kernel */, hipStream_t st);
 // rows fp32 -> fp16 (optionally L2-normalised) for erh_set_dense
 hipError_t launch_convert_rows(const float *x, int64_t n, int d, int normalize, _Float16 *out_base, int64_t r0,
                                int64_t mul, int64_t N, hipStream_t st);

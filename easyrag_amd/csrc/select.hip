@@ -33,9 +33,14 @@ __device__ __forceinline__ float margin_of(float qn, float xn, int d) {
 // ---- query block preparation -----------------------------------------------------------------
 template <typename TIN>
 __global__ __launch_bounds__(256) void prep_queries_kernel(const TIN *__restrict__ q, int normalize, int B, int d,
-                                                          _Float16 *__restrict__ Q16, float *__restrict__ qnorm) {
+                                                          _Float16 *__restrict__ Q16, float *__restrict__ qnorm,
+                                                          uint32_t *__restrict__ zero_bad /* null, or B words to clear */,
+                                                          uint32_t *__restrict__ zero_flags /* null, or the call's 16 flag words */) {
     __shared__ float red[4];
     const int row = blockIdx.x;
+    // the call's per-query "uncertified" marks and its flag words start at zero: cleared here instead of by two memset launches
+    if (zero_bad && row < B && threadIdx.x == 0) zero_bad[row] = 0u;
+    if (zero_flags && row == 0 && threadIdx.x < 16) zero_flags[threadIdx.x] = 0u;
     _Float16 *out = Q16 + (int64_t)row * d;
     if (row >= B) {
         for (int i = threadIdx.x; i < d; i += 256) out[i] = (_Float16)0.f;
@@ -789,13 +794,13 @@ hipError_t select_init() {
 }
 
 hipError_t launch_prep_queries(const void *q, int q_dtype, int normalize, int B, int Bpad, int d,
-                               _Float16 *Q16, float *qnorm, hipStream_t st) {
+                               _Float16 *Q16, float *qnorm, uint32_t *zero_bad, uint32_t *zero_flags, hipStream_t st) {
     if (q_dtype == 0)
         hipLaunchKernelGGL(prep_queries_kernel<_Float16>, dim3(Bpad), dim3(256), 0, st,
-                           (const _Float16 *)q, normalize, B, d, Q16, qnorm);
+                           (const _Float16 *)q, normalize, B, d, Q16, qnorm, zero_bad, zero_flags);
     else
         hipLaunchKernelGGL(prep_queries_kernel<float>, dim3(Bpad), dim3(256), 0, st,
-                           (const float *)q, normalize, B, d, Q16, qnorm);
+                           (const float *)q, normalize, B, d, Q16, qnorm, zero_bad, zero_flags);
     return hipGetLastError();
 }
 
