@@ -211,7 +211,7 @@ def pmc_traffic(args, kernel_class, algorithmic_bytes):
             "traffic_source": "profiles/pmc_traffic.json (" + rec["command"] + "; " + rec["correction"] + ")"}
 
 
-def pmc_counters(args, key, main_class, class_ms_per_step):
+def pmc_counters(args, key, main_class, class_ms_per_step, timed_classes=None):
     """MFMA-busy, L2 hit rate, LDS-fill (TD) path and effective shader clock of the dominant kernel from the committed PMC passes
     (scripts/gpu_pmc.sh -> scripts/pmc_summary.py -> profiles/pmc_counters.json), attached under the same guard as the FETCH_SIZE
     traffic: default sizes only, and only when the kernel sources of this run are the profiled ones (digest).  north_star:
@@ -234,7 +234,9 @@ def pmc_counters(args, key, main_class, class_ms_per_step):
            "l2_hit": d.get("l2_hit"), "td_busy": d.get("td_busy"), "td_busy_what": "TD_TD_BUSY_sum / 256 CUs / cycles: the data-return path that carries the L1 -> LDS fills",
            "lds_bank_conflict_share": d.get("lds_bank_conflict_share"), "waves_waiting": d.get("waves_waiting"),
            "source": "profiles/pmc_counters.json <- " + entry.get("source", "?") + " (separate rocprofv3 --pmc passes, --kernel-trace only)"}
-    cyc = sum(c["derived"].get("gui_cycles_per_xcd", 0.0) for c in entry["classes"].values())
+    # cycles of the kernels that the HIP-event class time covers (the sample pass has a timing class of its own)
+    cyc = sum(c["derived"].get("gui_cycles_per_xcd", 0.0) for name, c in entry["classes"].items()
+              if timed_classes is None or name in timed_classes)
     if cyc and class_ms_per_step:
         out["effective_clock_ghz"] = cyc / (class_ms_per_step * 1e-3) / 1e9
         out["effective_clock_what"] = ("GRBM_GUI_ACTIVE / 8 of the class's launches per step (PMC pass) / this run's HIP-event time of the class per step; "
@@ -300,7 +302,7 @@ def run_sub(eng, classes, fn, n_queries, dom, min_seconds=0.3, sync_each=False, 
             lps = rec["roofline"]["launches"] / steps
             rec["roofline"]["launches_per_step"] = lps
             if lps > 1.01:
-                rec["roofline"]["launch_mix"] = (f"{lps:g} launches of the class per step (threshold stage -- sample pass or seed-prefix store kernel -- + main scan): "
+                rec["roofline"]["launch_mix"] = (f"{lps:g} launches of the class per step (seed-prefix store kernel + append scan): "
                                                  "avg_launch_ms / *_per_launch are class totals / launches; kernel_ms_per_step holds the per-step class time")
     return rec
 
@@ -309,9 +311,9 @@ def sub_benchmarks(eng, synth, queries_to_csr, build_index, OKAPI, q16_pool, tok
     """The BASELINE.json configurations the headline is NOT quoted on, and the reference's own call pattern (one query at
     a time), timed on the corpus that is already resident: each with its own step count (>= 0.3 s of timed work),
     kernel-class times from the library's HIP events and a roofline block.  Roughly 10 s of wall time in all."""
-    from easyrag_amd._lib import ERH_K_BM25_MERGE, ERH_K_BM25_SCAN, ERH_K_DENSE_SCAN, ERH_K_DENSE_SELECT, ERH_K_FUSE
+    from easyrag_amd._lib import ERH_K_BM25_MERGE, ERH_K_BM25_SCAN, ERH_K_DENSE_SAMPLE, ERH_K_DENSE_SCAN, ERH_K_DENSE_SELECT, ERH_K_FUSE
     classes = (("dense_scan", ERH_K_DENSE_SCAN), ("dense_select", ERH_K_DENSE_SELECT), ("bm25_scan", ERH_K_BM25_SCAN),
-               ("bm25_merge", ERH_K_BM25_MERGE), ("fuse", ERH_K_FUSE))
+               ("bm25_merge", ERH_K_BM25_MERGE), ("fuse", ERH_K_FUSE), ("dense_sample", ERH_K_DENSE_SAMPLE))
     out = {}
     q256 = [q[:256].contiguous() for q in q16_pool]
     csr256 = [queries_to_csr(t[:256]) for t in tok_pool]
@@ -394,7 +396,7 @@ def main(argv=None, platform=None):
         raise SystemExit(spawn_ranks(args, argv))
     import torch
     from easyrag_amd import dist as erd
-    from easyrag_amd._lib import ERH_K_BM25_MERGE, ERH_K_BM25_SCAN, ERH_K_DENSE_SCAN, ERH_K_DENSE_SELECT, ERH_K_FUSE
+    from easyrag_amd._lib import ERH_K_BM25_MERGE, ERH_K_BM25_SCAN, ERH_K_DENSE_SAMPLE, ERH_K_DENSE_SCAN, ERH_K_DENSE_SELECT, ERH_K_FUSE
     from easyrag_amd.index import BM25S, OKAPI
     plat = platform if platform is not None else GpuPlatform()
     synth, queries_to_csr, build_bm25_index_from_postings = plat.synth, plat.queries_to_csr, plat.build_index
@@ -507,7 +509,7 @@ def main(argv=None, platform=None):
     if rank == 0:
         kt = {name: eng.kernel_time(cls) for name, cls in
               (("dense_scan", ERH_K_DENSE_SCAN), ("dense_select", ERH_K_DENSE_SELECT), ("bm25_scan", ERH_K_BM25_SCAN),
-               ("bm25_merge", ERH_K_BM25_MERGE), ("fuse", ERH_K_FUSE))}
+               ("bm25_merge", ERH_K_BM25_MERGE), ("fuse", ERH_K_FUSE), ("dense_sample", ERH_K_DENSE_SAMPLE))}
         per_step = {k_: (v["ms"] / args.steps) for k_, v in kt.items()}
         dom = "bm25_scan" if args.workload == "bm25" else "dense_scan"
         kd = kt[dom]
@@ -517,11 +519,13 @@ def main(argv=None, platform=None):
             roof["launches_per_step"] = roof["launches"] / args.steps
             if args.workload != "bm25":
                 key, main = ("dense_b1024", "pp5") if args.workload == "hybrid" else ("dense_b256", "pp3")
-                roof["counters"] = pmc_counters(args, key, main, per_step["dense_scan"])
+                roof["counters"] = pmc_counters(args, key, main, per_step["dense_scan"],
+                                                ("pp5",) if args.workload == "hybrid" else ("pp3", "store"))
             if dom == "dense_scan" and roof["launches"] > args.steps:
-                roof["launch_mix"] = ("the dense-scan class has two launches per step -- the threshold stage (sample pass of the scan "
-                                      "kernel from 512 queries on, the seed-prefix store kernel below) and the main scan; per-launch "
-                                      "figures are class totals / launches, rocprofv3 lists the two kernels separately")
+                roof["launch_mix"] = ("the dense-scan class has two launches per step -- the seed-prefix store kernel (real scan work over "
+                                      "the first rows) and the append scan over the rest; per-launch figures are class totals / launches, "
+                                      "rocprofv3 lists the two kernels separately.  (From 512 queries on the threshold comes from a sample "
+                                      "pass with its own class, dense_sample, and the scan class is ONE kernel.)")
         cpu = None
         if world == 1 and args.cpu_queries > 0:
             payload = payload_check = None

@@ -27,7 +27,7 @@ ERH_F16, ERH_F32 = 0, 1
 ERH_BM25_OKAPI, ERH_BM25_BM25S = 0, 1
 ERH_DENSE_EXACT, ERH_DENSE_FAST = 0, 1
 ERH_BM25_SLOTS = 4
-ERH_K_DENSE_SCAN, ERH_K_DENSE_SELECT, ERH_K_BM25_SCAN, ERH_K_BM25_MERGE, ERH_K_FUSE = range(5)
+ERH_K_DENSE_SCAN, ERH_K_DENSE_SELECT, ERH_K_BM25_SCAN, ERH_K_BM25_MERGE, ERH_K_FUSE, ERH_K_DENSE_SAMPLE = range(6)
 
 _vp, _i32, _i64, _dbl = C.c_void_p, C.c_int, C.c_int64, C.c_double
 

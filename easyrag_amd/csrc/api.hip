@@ -363,6 +363,11 @@ int dense_topk_dev(erh_handle *h, const void *q_dev, int q_dtype, int normalize_
         const int64_t cand = N - rounds * step;
         if (cand >= std::max<int64_t>(n0 / 4, 16 * (int64_t)k) && cand < n0) n0 = cand;
     }
+    // batches on the 384 x 256 tile whose threshold comes from the stored prefix (dir filters, deep ranks): the prefix ends on a tile
+    // boundary of that kernel -- 32640 = 85 x 384 instead of 32768 -- so the append stage can start there (c0 % 384 == 0); otherwise
+    // it would fall back to the 256 x 256 scan (filtered 1024-query batch: scan class -1.4 ... -2 %, profiles/r05j_ab_filtered.log)
+    if (h->opt_dense_tile384 && Bpad >= 2 * QT && n0 < N && n0 >= 4 * erh::dense_scan_pp5_rows())
+        n0 = n0 / erh::dense_scan_pp5_rows() * erh::dense_scan_pp5_rows();
     const int ld = round_up((int)n0, 256);
     HIPCHK(h, h->S0.ensure((size_t)Bpad * ld * 4));
     uint32_t *flags = h->flags.as<uint32_t>();   // [0] overflow, [1] maxerr (float bits), [2] uncertified
@@ -465,8 +470,8 @@ int dense_topk_dev(erh_handle *h, const void *q_dev, int q_dtype, int normalize_
             sio.seed_top = h->seed_top.as<float>();
             h->stats.dense_sample_passes += 1;
             const int lean = 1 | 8 | (dense_rot_stages(h, d, Bpad) << 8);
-            // (the pass books no work: the sampled rows are scanned again below, and N rows are what the algorithm needs)
-            { ProfScope ps(h, st, ERH_K_DENSE_SCAN, 0, 0);
+            // (the pass books no work: the sampled rows are scanned again below, and N rows are what the algorithm needs; its own class)
+            { ProfScope ps(h, st, ERH_K_DENSE_SAMPLE, 0, 0);
               HIPCHK(h, erh::launch_dense_scan_pp(X, N, d, 0, rows_seed, Q16, Bpad, B, h->tau.as<float>(), nullptr, nullptr,
                                                   h->cand.as<ErhCand>(), h->cand_cnt.as<uint32_t>(), cap, flags, h->n_cus, 0,
                                                   nullptr, lean, nullptr, &sio, st)); }

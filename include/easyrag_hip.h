@@ -270,7 +270,11 @@ int erh_unpack_topk(erh_handle *h, const void *gathered_rows, int n_queries, int
 #define ERH_K_BM25_SCAN    2   /* posting scatter-add + running top-k */
 #define ERH_K_BM25_MERGE   3
 #define ERH_K_FUSE         4   /* RRF / fusion */
-#define ERH_K_COUNT        5
+#define ERH_K_DENSE_SAMPLE 5   /* sample pass of the dense scan (batches padded to >= 512 queries): one tile per chunk stream scored WITHOUT
+                                  thresholds to draw the threshold sample; the rows are scanned again by the main launch, so it books no
+                                  algorithmic work -- its own class since round 5, so that ERH_K_DENSE_SCAN at those batch sizes is ONE kernel
+                                  whose per-launch figures are what rocprofv3 lists for it */
+#define ERH_K_COUNT        6
 int erh_set_profiling(erh_handle *h, int enable);
 /* Sum of event-measured milliseconds and number of launches since the last reset. */
 int erh_get_kernel_time(erh_handle *h, int kernel_class, double *total_ms, int64_t *launches);

@@ -23,12 +23,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
 from easyrag_amd import synth  # noqa: E402
-from easyrag_amd._lib import ERH_K_BM25_MERGE, ERH_K_BM25_SCAN, ERH_K_DENSE_SCAN, ERH_K_DENSE_SELECT, ERH_K_FUSE  # noqa: E402
+from easyrag_amd._lib import ERH_K_BM25_MERGE, ERH_K_BM25_SCAN, ERH_K_DENSE_SAMPLE, ERH_K_DENSE_SCAN, ERH_K_DENSE_SELECT, ERH_K_FUSE  # noqa: E402
 from easyrag_amd.engine import RetrievalEngine, queries_to_csr  # noqa: E402
 from easyrag_amd.index import BM25S, OKAPI, build_bm25_index_from_postings  # noqa: E402
 
 CLASSES = (("dense_scan", ERH_K_DENSE_SCAN), ("dense_select", ERH_K_DENSE_SELECT), ("bm25_scan", ERH_K_BM25_SCAN),
-           ("bm25_merge", ERH_K_BM25_MERGE), ("fuse", ERH_K_FUSE))
+           ("bm25_merge", ERH_K_BM25_MERGE), ("fuse", ERH_K_FUSE), ("dense_sample", ERH_K_DENSE_SAMPLE))
 
 
 def main():
@@ -46,6 +46,8 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--pool", type=int, default=4)
+    ap.add_argument("--dirs", type=int, default=0, help="> 0: every query carries a `dir` filter (document i belongs to dir i %% D, query b asks for b %% D), "
+                                                        "as every query of the reference's real workload does (src/data/question.jsonl)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     n, d, vocab, B = args.chunks, args.dim, args.vocab, args.batch
@@ -63,15 +65,20 @@ def main():
         idx = build_bm25_index_from_postings(indptr, doc, tf, lens, BM25S if args.variant == "bm25s" else OKAPI, compute_payload=False)
         eng.set_bm25(idx, payload_on_device=True)
         csr_pool = [queries_to_csr(synth.token_queries(flat, lens, vocab, B, seed=2000 + p)) for p in range(args.pool)]
-    eng.set_doc_meta(n, None, None)
+    filt = None
+    if args.dirs > 0:
+        eng.set_doc_meta(n, None, (np.arange(n) % args.dirs).astype(np.int16))
+        filt = (np.arange(B) % args.dirs).astype(np.int16)
+    else:
+        eng.set_doc_meta(n, None, None)
     k = args.k or (288 if args.workload == "dense" else 192)
 
     def call(p):
         if args.workload == "hybrid":
-            return eng.hybrid_topk(q_pool[p], *csr_pool[p], k_dense=288, k_sparse=192, K=60, topk=10, device_out=True)
+            return eng.hybrid_topk(q_pool[p], *csr_pool[p], k_dense=288, k_sparse=192, K=60, topk=10, device_out=True, filter_dir=filt)
         if args.workload == "dense":
-            return eng.dense_topk(q_pool[p], k, device_out=True)
-        return eng.bm25_topk(*csr_pool[p], k, device_out=True)
+            return eng.dense_topk(q_pool[p], k, device_out=True, filter_dir=filt)
+        return eng.bm25_topk(*csr_pool[p], k, device_out=True, filter_dir=filt)
 
     def parse(spec):
         name, vals = spec.split("=")
