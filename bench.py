@@ -188,7 +188,7 @@ def okapi_literal_loop(idx, queries, n_docs=50_000, n_queries=8):
                     "linear extrapolation in the number of documents, stated not measured"}
 
 
-def pmc_traffic(args, kernel_class, algorithmic_bytes):
+def pmc_traffic(args, kernel_class, algorithmic_bytes, launches_per_step=1.0):
     """HBM bytes per launch of the dominant kernel class from the committed PMC pass (scripts/gpu_traffic.sh ->
     profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE in its own run, x2 gfx950 correction).  bench.py cannot
     sample counters itself, so the figure is only attached when this run's shape is the profiled one (default
@@ -206,7 +206,9 @@ def pmc_traffic(args, kernel_class, algorithmic_bytes):
         return {"traffic": None, "traffic_note": "profiles/pmc_traffic.json was collected on different kernel sources (stale)"}
     if not default_shape or rec.get("kernel_class") != kernel_class:
         return {"traffic": None}
-    t = float(rec["hbm_bytes_per_launch"])
+    # bytes per STEP of the kernels of the class / this run's timed launches of the class per step (a timed launch may hold two
+    # kernels: the BM25 scan and its -- normally empty -- redo launch)
+    t = float(rec.get("hbm_bytes_per_step", rec["hbm_bytes_per_launch"] * rec.get("launches_per_step", 1.0))) / max(launches_per_step, 1e-9)
     return {"traffic": t, "traffic_unit": "bytes/launch", "traffic_over_algorithmic": t / algorithmic_bytes,
             "traffic_source": "profiles/pmc_traffic.json (" + rec["command"] + "; " + rec["correction"] + ")"}
 
@@ -529,8 +531,8 @@ def main(argv=None, platform=None):
         kd = kt[dom]
         roof = roofline_of(kd, dom)
         if roof is not None:
-            roof.update(pmc_traffic(args, dom, roof["algorithmic_bytes_per_launch"]))
             roof["launches_per_step"] = roof["launches"] / args.steps
+            roof.update(pmc_traffic(args, dom, roof["algorithmic_bytes_per_launch"], roof["launches_per_step"]))
             if args.workload != "bm25":
                 key, main = ("dense_b1024", "pp5") if args.workload == "hybrid" else ("dense_b256", "pp3")
                 roof["counters"] = pmc_counters(args, key, main, per_step["dense_scan"],
