@@ -184,6 +184,8 @@ struct erh_handle {
     // exhaustive path (select.hip): per-query "not certifiable from the candidate list" flags, work space, and what
     // the last dense call needs for further rounds from the host (more than dense_exhaustive_max() flagged queries)
     DevBuf bad, ex_ws;
+    DevBuf fin_ws;                           // dense_finalize_kernel, several workgroups per query (batches of <= 64): sync words + exact scores
+    int opt_dense_fin_split = 1;
     struct LastDense {
         bool valid = false, hybrid = false;
         int B = 0, k = 0;
@@ -371,6 +373,18 @@ int dense_topk_dev(erh_handle *h, const void *q_dev, int q_dtype, int normalize_
     const int ld = round_up((int)n0, 256);
     HIPCHK(h, h->S0.ensure((size_t)Bpad * ld * 4));
     uint32_t *flags = h->flags.as<uint32_t>();   // [0] overflow, [1] maxerr (float bits), [2] uncertified
+    // small batches: work space of the final kernel's several-workgroups-per-query mode (zeroed once; the kernel leaves it zero)
+    double *fin_s64 = nullptr;
+    uint32_t *fin_sync = nullptr;
+    if (h->opt_dense_fin_split && B <= erh::dense_finalize_split_max()) {
+        if (!h->fin_ws.p) {
+            const size_t sync_bytes = (size_t)erh::dense_finalize_split_max() * 8;
+            HIPCHK(h, h->fin_ws.ensure(sync_bytes + (size_t)erh::dense_finalize_split_max() * erh::kDenseRescoreMax * 8));
+            HIPCHK(h, hipMemsetAsync(h->fin_ws.p, 0, sync_bytes, st));
+        }
+        fin_sync = h->fin_ws.as<uint32_t>();
+        fin_s64 = reinterpret_cast<double *>(h->fin_ws.as<char>() + (size_t)erh::dense_finalize_split_max() * 8);
+    }
 
     h->qt_valid = false;
     h->qt5_valid = false;
@@ -490,7 +504,7 @@ int dense_topk_dev(erh_handle *h, const void *q_dev, int q_dtype, int normalize_
               HIPCHK(h, erh::launch_dense_finalize(B, k, mode, h->qnorm.as<float>(), h->xnorm_max, d, X, Q16,
                                                    h->cand.as<ErhCand>(), h->cand_cnt.as<uint32_t>(), cap, d_ids, d_sc, d_len,
                                                    reinterpret_cast<float *>(flags + 1), flags + 2, bad, N, h->pos_mul, h->pos_inv,
-                                                   h->tau.as<float>(), st));
+                                                   h->tau.as<float>(), h->n_cus, fin_s64, fin_sync, st));
               HIPCHK(h, erh::launch_dense_exhaustive(bad, B, 0, k, X, N, d, Q16, filter_dev,
                                                      h->has_dir ? h->dir_id.as<int16_t>() : nullptr, h->pos_inv, h->ex_ws.p,
                                                      flags, h->n_cus, d_ids, d_sc, d_len, h->dstats.as<unsigned long long>(), st)); }
@@ -583,7 +597,7 @@ int dense_topk_dev(erh_handle *h, const void *q_dev, int q_dtype, int normalize_
       HIPCHK(h, erh::launch_dense_finalize(B, k, mode, h->qnorm.as<float>(), h->xnorm_max, d, X, Q16,
                                            h->cand.as<ErhCand>(), h->cand_cnt.as<uint32_t>(), cap, d_ids, d_sc, d_len,
                                            reinterpret_cast<float *>(flags + 1), flags + 2, bad, N, h->pos_mul, h->pos_inv,
-                                           speculate ? h->tau.as<float>() : nullptr, st));
+                                           speculate ? h->tau.as<float>() : nullptr, h->n_cus, fin_s64, fin_sync, st));
       // queries the candidate budgets could not certify get their exact answer from the exhaustive path (two empty
       // launches when there are none); it also settles the overflow word: set only if more than
       // dense_exhaustive_max() queries were flagged, in which case dense_check_flags runs further rounds
@@ -818,7 +832,7 @@ int erh_destroy(erh_handle *h) {
                       &h->o_ids, &h->o_sc, &h->o_len, &h->qptr, &h->qtok, &h->part_sc, &h->part_ids, &h->part_len,
                       &h->hy_sids, &h->hy_ssc, &h->hy_slen, &h->hy_dids, &h->hy_dsc, &h->hy_dlen,
                       &h->fa_ids, &h->fa_sc, &h->fa_len, &h->fb_ids, &h->fb_sc, &h->fb_len,
-                      &h->scores_tmp, &h->scores_wide, &h->dbg, &h->dstats, &h->dir_pos, &h->seed_need, &h->bad, &h->ex_ws, &h->bm_redo};
+                      &h->scores_tmp, &h->scores_wide, &h->dbg, &h->dstats, &h->dir_pos, &h->seed_need, &h->bad, &h->ex_ws, &h->bm_redo, &h->fin_ws};
     for (DevBuf *b : bufs) b->release();
     for (auto &b : h->bm) b.release();
     if (h->comm || h->comm_pending) (void)erh_comm_destroy(h);
@@ -854,6 +868,7 @@ int erh_set_option(erh_handle *h, const char *name, int64_t value) {
         h->n_cus = value == 0 ? h->n_cus_dev : (int)value;
         return ERH_OK;
     }
+    if (!strcmp(name, "dense_fin_split")) { h->opt_dense_fin_split = value != 0; return ERH_OK; }
     if (!strcmp(name, "dense_tile384")) { h->opt_dense_tile384 = value != 0; return ERH_OK; }
     if (!strcmp(name, "dense_tile384_max_mb")) { h->opt_tile384_max_mb = value; h->xt384_nomem = false; return ERH_OK; }
     if (!strcmp(name, "dense_tiled")) { h->opt_dense_tiled = value != 0; return ERH_OK; }   // building the copy: at the next erh_set_dense

@@ -109,7 +109,10 @@ hipError_t launch_dense_finalize(int B, int k, int mode, const float *qnorm, flo
                                  const ErhCand *cand, const uint32_t *cand_cnt, int cap,
                                  int32_t *out_ids, double *out_scores, int32_t *out_len,
                                  float *diag_maxerr, uint32_t *diag_uncert, uint32_t *bad, int64_t N, int64_t pos_mul,
-                                 int64_t pos_inv, const float *tau_verify, hipStream_t st);
+                                 int64_t pos_inv, const float *tau_verify, int n_cus,
+                                 double *ws_s64 /* null, or dense_finalize_split_max() x kDenseRescoreMax doubles */,
+                                 uint32_t *ws_sync /* null, or 2 x dense_finalize_split_max() words, zero between calls */, hipStream_t st);
+int dense_finalize_split_max();
 // Exhaustive path for the queries flagged in bad[] (select.hip): exact fp64 scores of every chunk + streaming top-k.
 int dense_exhaustive_max();
 size_t dense_exhaustive_bytes(int64_t N);

@@ -418,27 +418,35 @@ __global__ __launch_bounds__(kFinThreads, (QR <= 2) ? 4 : 2) void dense_finalize
     int32_t *__restrict__ out_ids, double *__restrict__ out_scores, int32_t *__restrict__ out_len,
     float *__restrict__ diag_maxerr, uint32_t *__restrict__ diag_uncert, uint32_t *__restrict__ bad,
     int64_t N, int64_t pos_mul, int64_t pos_inv /* candidates carry stored positions: orig = pos * pos_inv mod N */,
-    const float *__restrict__ tau /* nullptr: thresholds were guaranteed bounds, nothing to verify */) {
+    const float *__restrict__ tau /* nullptr: thresholds were guaranteed bounds, nothing to verify */,
+    int G /* workgroups per query (round 5; small batches, EXACT mode): each re-scores every G-th row of the margin set, the last one
+             to finish ranks and emits.  1: one workgroup per query does everything */,
+    double *__restrict__ ws_s64 /* G > 1: [B][kDenseRescoreMax] exact scores handed to the last workgroup */,
+    uint32_t *__restrict__ ws_sync /* G > 1: [B][2] {arrival counter, max error bits}, zero between calls */) {
     __shared__ __attribute__((aligned(16))) uint64_t buf[kFinBuf];
     __shared__ uint32_t tmax[kFinSlots];
     __shared__ double r_s64[erh::kDenseRescoreMax];
     __shared__ int32_t r_idx[erh::kDenseRescoreMax];
     __shared__ float r_s32[erh::kDenseRescoreMax];
     __shared__ int32_t r_pos[erh::kDenseRescoreMax];                    // stored position of the candidate (row of X)
-    __shared__ int s_cnt, s_m, s_lvl;
+    __shared__ int s_cnt, s_m, s_lvl, s_last;
     __shared__ unsigned int s_maxerr;
-    const int q = blockIdx.x, tid = threadIdx.x;
+    // Small batches are latency-bound here: ONE workgroup gathering a query's ~300 rows of 2 KiB takes 51 us at one query per call (a
+    // dozen dependent gather rounds).  With G workgroups per query every one repeats the cheap part (pivot, gather of the candidates
+    // above it, sort: the same result in each, the keys are distinct), re-scores its share of the rows, and the last to arrive ranks.
+    const int q = G > 1 ? (int)blockIdx.x / G : (int)blockIdx.x, part = G > 1 ? (int)blockIdx.x % G : 0, tid = threadIdx.x;
+    const bool lead = part == 0;                                        // side effects that must happen once per query
     int c = (int)cand_cnt[q];
     if (c > cap) {                                                      // appends were dropped: not answerable from the list
-        if (tid == 0) bad[q] = 1u;
+        if (tid == 0 && lead) bad[q] = 1u;
         c = cap;
     }
     const ErhCand *mine = cand + (int64_t)q * cap;
     const int kk = k < c ? k : c;
     int32_t *o_ids = out_ids + (int64_t)q * k;
     double *o_sc = out_scores + (int64_t)q * k;
-    if (tid == 0) { out_len[q] = kk; s_cnt = 0; s_m = 0; s_maxerr = 0; s_lvl = 0; }
-    for (int i = kk + tid; i < k; i += kFinThreads) { o_ids[i] = -1; o_sc[i] = 0.0; }
+    if (tid == 0) { if (lead) out_len[q] = kk; s_cnt = 0; s_m = 0; s_maxerr = 0; s_lvl = 0; s_last = 1; }
+    if (lead) for (int i = kk + tid; i < k; i += kFinThreads) { o_ids[i] = -1; o_sc[i] = 0.0; }
     if (kk == 0) return;                                                // uniform
 
     const float delta = 0.5f * margin_of(qnorm[q], xnorm_max, d);
@@ -469,7 +477,7 @@ __global__ __launch_bounds__(kFinThreads, (QR <= 2) ? 4 : 2) void dense_finalize
         if ((tid & 63) == 0 && n_lvl) atomicAdd(&s_lvl, n_lvl);
     }
     erh_bitonic_desc<uint32_t>(tmax, kFinSlots);                        // begins and ends with a barrier
-    if (tau && tid == 0 && lvl > -INFINITY && s_lvl < k) bad[q] = 1u;   // the speculation failed: exhaustive path
+    if (tau && tid == 0 && lead && lvl > -INFINITY && s_lvl < k) bad[q] = 1u;   // the speculation failed: exhaustive path
     float gather_thr = -INFINITY;
     if (kk <= kFinSlots && tmax[kk - 1] != 0u) gather_thr = erh_ord2f(tmax[kk - 1]) - ((mode == 1) ? 0.f : 2.0f * delta);
     for (int i = tid; i < c; i += kFinThreads) {
@@ -482,7 +490,7 @@ __global__ __launch_bounds__(kFinThreads, (QR <= 2) ? 4 : 2) void dense_finalize
     __syncthreads();
     int g = s_cnt;
     if (g > kFinBuf) {                                                  // uniform; pathological tie clusters only
-        if (tid == 0) { bad[q] = 1u; atomicAdd(diag_uncert, 1u); }
+        if (tid == 0 && lead) { bad[q] = 1u; atomicAdd(diag_uncert, 1u); }
         g = kFinBuf;
     }
     const int ns = erh_next_pow2(g < 2 ? 2 : g);
@@ -549,10 +557,11 @@ __global__ __launch_bounds__(kFinThreads, (QR <= 2) ? 4 : 2) void dense_finalize
             }                                                                                         \
         }                                                                                             \
     } while (0)
-    int e0 = wave * RW;
+    const int e_step = G * kWaves * RW;                                 // (G > 1: workgroup `part` takes every G-th group of rows)
+    int e0 = (part * kWaves + wave) * RW;
     if (e0 < m) ERH_FIN_LOAD(xa, e0);
-    for (; e0 < m; e0 += kWaves * RW) {
-        const int e1 = e0 + kWaves * RW;
+    for (; e0 < m; e0 += e_step) {
+        const int e1 = e0 + e_step;
         if (e1 < m) ERH_FIN_LOAD(xb, e1);                               // next pair in flight during the sums below
         double acc[RW];
 #pragma unroll
@@ -593,6 +602,7 @@ __global__ __launch_bounds__(kFinThreads, (QR <= 2) ? 4 : 2) void dense_finalize
             for (int r = 0; r < RW; ++r) {
                 if (e0 + r < m) {
                     r_s64[e0 + r] = acc[r];
+                    if (G > 1) ws_s64[(int64_t)q * erh::kDenseRescoreMax + e0 + r] = acc[r];
                     err = fmaxf(err, fabsf((float)(acc[r] - (double)r_s32[e0 + r])));
                 }
             }
@@ -604,6 +614,28 @@ __global__ __launch_bounds__(kFinThreads, (QR <= 2) ? 4 : 2) void dense_finalize
             for (int t = 0; t < QR; ++t) xa[r][t] = xb[r][t];
     }
 #undef ERH_FIN_LOAD
+    if (G > 1) {
+        // hand-over: scores and error to memory, fence (every writer its own stores), take a ticket; all but the last workgroup of
+        // the query are done
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) {
+            atomicMax(&ws_sync[2 * q + 1], s_maxerr);
+            __threadfence();
+            const unsigned int t = atomicAdd(&ws_sync[2 * q], 1u);
+            s_last = (t == (unsigned int)G - 1u) ? 1 : 0;
+        }
+        __syncthreads();
+        if (!s_last) return;                                            // uniform
+        __threadfence();
+        for (int i = tid; i < m; i += kFinThreads)
+            r_s64[i] = __builtin_nontemporal_load(ws_s64 + (int64_t)q * erh::kDenseRescoreMax + i);   // (every row was written by exactly one workgroup)
+        if (tid == 0) {
+            s_maxerr = atomicExch(&ws_sync[2 * q + 1], 0u);             // ... and the words are zero again for the next call
+            ws_sync[2 * q] = 0u;
+        }
+        __syncthreads();
+    }
     // order by (fp64 desc, index asc): one small record sort (m <= 1024), then the first kk entries are the answer
     const int mp = erh_next_pow2(m < 2 ? 2 : m);
     for (int t = m + tid; t < mp; t += kFinThreads) { r_s64[t] = -INFINITY; r_idx[t] = 0x7fffffff; }
@@ -882,16 +914,27 @@ hipError_t launch_cand_refine(int B, int k, const float *qnorm, float xnorm_max,
     return hipGetLastError();
 }
 
+// Batches up to this size run 16 workgroups per query in the final kernel: one query per call -2.4 % wall (0.502 -> 0.490 ms), two -1.9 %,
+// four -0.5 %, eight +2.7 %, sixteen +11 % (profiles/r05m_ab_fin_split.log): the redundant pivot / sort stage of 16 x B workgroups costs more
+// than the shared row gathers save as soon as the queries alone spread over the chip.
+int dense_finalize_split_max() { return 2; }
+
 hipError_t launch_dense_finalize(int B, int k, int mode, const float *qnorm, float xnorm_max, int d,
                                  const _Float16 *X, const _Float16 *Q16,
                                  const ErhCand *cand, const uint32_t *cand_cnt, int cap,
                                  int32_t *out_ids, double *out_scores, int32_t *out_len,
                                  float *diag_maxerr, uint32_t *diag_uncert, uint32_t *bad, int64_t N,
-                                 int64_t pos_mul, int64_t pos_inv, const float *tau_verify, hipStream_t st) {
+                                 int64_t pos_mul, int64_t pos_inv, const float *tau_verify, int n_cus, double *ws_s64,
+                                 uint32_t *ws_sync, hipStream_t st) {
+    // workgroups per query: small batches spread a query's row gathers over the chip (EXACT mode only; the work space is optional)
+    int G = 1;
+    if (mode == 0 && ws_s64 && ws_sync && B <= dense_finalize_split_max())
+        G = 16;
+    (void)n_cus;
 #define ERH_FIN_LAUNCH(QR)                                                                                  \
-    hipLaunchKernelGGL(dense_finalize_kernel<QR>, dim3(B), dim3(kFinThreads), 0, st, k, mode, qnorm, xnorm_max, d, X, Q16, \
+    hipLaunchKernelGGL(dense_finalize_kernel<QR>, dim3(B * G), dim3(kFinThreads), 0, st, k, mode, qnorm, xnorm_max, d, X, Q16, \
                        cand, cand_cnt, cap, out_ids, out_scores, out_len, diag_maxerr, diag_uncert, bad, N, pos_mul, \
-                       pos_inv, tau_verify)
+                       pos_inv, tau_verify, G, ws_s64, ws_sync)
     if (d <= 512) ERH_FIN_LAUNCH(1);
     else if (d <= 1024) ERH_FIN_LAUNCH(2);
     else ERH_FIN_LAUNCH(4);
