@@ -270,7 +270,7 @@ def roofline_of(kd, dom):
     return roof
 
 
-def run_sub(eng, classes, fn, n_queries, dom, min_seconds=0.3, sync_each=False, what=""):
+def run_sub(eng, classes, fn, n_queries, dom, min_seconds=0.3, sync_each=False, what="", check_each=False):
     """One sub-benchmark on the resident corpus: enough steps for >= min_seconds of timed work, kernel classes from the
     library's event timers, roofline of `dom`.  sync_each: host-visible latency of single calls (B = 1)."""
     import torch
@@ -289,7 +289,9 @@ def run_sub(eng, classes, fn, n_queries, dom, min_seconds=0.3, sync_each=False, 
     t0 = time.perf_counter()
     for i in range(steps):
         fn(i)
-        if sync_each:
+        if check_each:
+            eng.dense_check()                  # what a caller does before it reads device outputs: synchronise + the call's flag words
+        elif sync_each:
             torch.cuda.synchronize()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -328,12 +330,12 @@ def sub_benchmarks(eng, synth, queries_to_csr, build_index, OKAPI, q16_pool, tok
     q1 = [q[:1].contiguous() for q in q16_pool]
     csr1 = [queries_to_csr(t[:1]) for t in tok_pool]
     out["dense_b1_top288_latency"] = run_sub(
-        eng, classes, lambda i: eng.dense_topk(q1[i % pool], 288, device_out=True), 1, "dense_scan", sync_each=True,
-        what="one query per call (the reference's call pattern), dense top-288, host-visible latency per call")
+        eng, classes, lambda i: eng.dense_topk(q1[i % pool], 288, device_out=True), 1, "dense_scan", sync_each=True, check_each=True,
+        what="one query per call (the reference's call pattern), dense top-288, host-visible latency per call incl. erh_dense_check")
     out["hybrid_b1_latency"] = run_sub(
         eng, classes, lambda i: eng.hybrid_topk(q1[i % pool], *csr1[i % pool], k_dense=288, k_sparse=192, K=60, topk=10,
-                                                device_out=True), 1, "dense_scan", sync_each=True,
-        what="one query per call, dense(288)+BM25(192)+RRF top-10, host-visible latency per call")
+                                                device_out=True), 1, "dense_scan", sync_each=True, check_each=True,
+        what="one query per call, dense(288)+BM25(192)+RRF top-10, host-visible latency per call incl. erh_dense_check")
     # the reference's default BM25 (bm25_type 0 = rank-bm25 Okapi, float64): a second index slot over the same postings
     indptr, doc, tf, lens = postings
     idx_ok = build_index(indptr, doc, tf, lens, OKAPI, compute_payload=False)

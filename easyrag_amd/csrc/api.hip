@@ -507,7 +507,7 @@ int dense_topk_dev(erh_handle *h, const void *q_dev, int q_dtype, int normalize_
                                                    h->tau.as<float>(), h->n_cus, fin_s64, fin_sync, st));
               HIPCHK(h, erh::launch_dense_exhaustive(bad, B, 0, k, X, N, d, Q16, filter_dev,
                                                      h->has_dir ? h->dir_id.as<int16_t>() : nullptr, h->pos_inv, h->ex_ws.p,
-                                                     flags, h->n_cus, d_ids, d_sc, d_len, h->dstats.as<unsigned long long>(), st)); }
+                                                     flags, h->n_cus, d_ids, d_sc, d_len, h->dstats.as<unsigned long long>(), 1 /* count only */, st)); }
             h->last = erh_handle::LastDense();
             h->last.valid = true;
             h->last.B = B; h->last.k = k; h->last.filter_dev = filter_dev;
@@ -598,12 +598,12 @@ int dense_topk_dev(erh_handle *h, const void *q_dev, int q_dtype, int normalize_
                                            h->cand.as<ErhCand>(), h->cand_cnt.as<uint32_t>(), cap, d_ids, d_sc, d_len,
                                            reinterpret_cast<float *>(flags + 1), flags + 2, bad, N, h->pos_mul, h->pos_inv,
                                            speculate ? h->tau.as<float>() : nullptr, h->n_cus, fin_s64, fin_sync, st));
-      // queries the candidate budgets could not certify get their exact answer from the exhaustive path (two empty
-      // launches when there are none); it also settles the overflow word: set only if more than
-      // dense_exhaustive_max() queries were flagged, in which case dense_check_flags runs further rounds
+      // queries the candidate budgets could not certify get their exact answer from the exhaustive path: the call enqueues the
+      // COUNT only (one workgroup; it settles the "unanswered" word and the flagged count), dense_check_flags -- the synchronisation
+      // point every caller passes before it reads results -- runs the exact rounds when, and only when, the count is not zero
       HIPCHK(h, erh::launch_dense_exhaustive(bad, B, 0, k, X, N, d, Q16, filter_dev,
                                              h->has_dir ? h->dir_id.as<int16_t>() : nullptr, h->pos_inv, h->ex_ws.p,
-                                             flags, h->n_cus, d_ids, d_sc, d_len, h->dstats.as<unsigned long long>(), st)); }
+                                             flags, h->n_cus, d_ids, d_sc, d_len, h->dstats.as<unsigned long long>(), 1 /* count only */, st)); }
     h->last = erh_handle::LastDense();
     h->last.valid = true;
     h->last.B = B; h->last.k = k; h->last.filter_dev = filter_dev;
@@ -611,9 +611,9 @@ int dense_topk_dev(erh_handle *h, const void *q_dev, int q_dtype, int normalize_
     return ERH_OK;
 }
 
-// Read the flag words of the last dense call (synchronises the stream).  If more queries were flagged than one
-// device-side round of the exhaustive path handles, the remaining rounds run here (and a fused call's RRF is redone
-// over the corrected dense lists), so the caller always gets an answer.
+// Read the flag words of the last dense call (synchronises the stream).  If queries were flagged for the exhaustive path, its
+// rounds run here, dense_exhaustive_max() queries at a time (and a fused call's RRF is redone over the corrected dense lists),
+// so the caller always gets an answer.
 int dense_check_flags(erh_handle *h, hipStream_t st) {
     uint32_t f[4] = {0, 0, 0, 0};
     HIPCHK(h, hipMemcpyAsync(f, h->flags.p, sizeof f, hipMemcpyDeviceToHost, st));
@@ -621,12 +621,12 @@ int dense_check_flags(erh_handle *h, hipStream_t st) {
     if (f[0] && h->last.valid) {
         const int total = (int)f[3], per = erh::dense_exhaustive_max();
         const erh_handle::LastDense &L = h->last;
-        for (int skip = per; skip < total; skip += per)
+        for (int skip = 0; skip < total; skip += per)          // (the call enqueued the count only: every answering round runs here)
             HIPCHK(h, erh::launch_dense_exhaustive(h->bad.as<uint32_t>(), L.B, skip, L.k, h->X.as<_Float16>(), h->N, h->d,
                                                    h->Q16.as<_Float16>(), L.filter_dev,
                                                    h->has_dir ? h->dir_id.as<int16_t>() : nullptr, h->pos_inv,
                                                    h->ex_ws.p, h->flags.as<uint32_t>(), h->n_cus, L.d_ids, L.d_sc,
-                                                   L.d_len, h->dstats.as<unsigned long long>(), st));
+                                                   L.d_len, h->dstats.as<unsigned long long>(), 0, st));
         if (L.hybrid) {
             const int32_t *cid = h->has_content ? h->content_id.as<int32_t>() : nullptr;
             HIPCHK(h, erh::launch_rrf(h->hy_sids.as<int32_t>(), h->hy_slen.as<int32_t>(), L.k_sparse, L.d_ids, L.d_len,

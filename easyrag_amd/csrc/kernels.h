@@ -121,6 +121,8 @@ hipError_t launch_dense_exhaustive(const uint32_t *bad, int B, int skip, int k, 
                                    int64_t pos_inv, void *ws, uint32_t *flags, int n_cus,
                                    int32_t *out_ids, double *out_scores, int32_t *out_len,
                                    unsigned long long *stats /* null, or the handle's device counters: [0] += flagged queries */,
+                                   int collect_only /* 1: count the flagged queries (flag words, counter) and stop: what a call enqueues;
+                                                       0: one answering round (collect + the two exact kernels) from skip on */,
                                    hipStream_t st);
 
 // ---- bm25.hip --------------------------------------------------------------------------------

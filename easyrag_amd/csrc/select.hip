@@ -659,10 +659,12 @@ __global__ __launch_bounds__(kFinThreads, (QR <= 2) ? 4 : 2) void dense_finalize
 //   2. dense_exact_select_kernel one workgroup per flagged query streams its S64 row through a 2048-entry list kept
 //                               under an exact (score, index) threshold -- ties resolve by original index as always --
 //                               and writes the query's final top-k over whatever the pruned pipeline wrote.
-// Both are always enqueued (they cost two empty launches when nothing is flagged) so device-output pipelines such
-// as erh_hybrid_topk stay free of host round trips.  kExMax flagged queries are handled per call on the device; more
-// than that (a batch that is pathological as a whole) is finished by further rounds from the host at the next
-// synchronisation point (api.hip: dense_check_flags).
+// Round 5: a call itself enqueues only the collect kernel (one workgroup: how many queries are flagged -> the call's flag words and
+// the device counter of erh_get_stat); the two exact kernels are enqueued by the call's synchronisation point (api.hip:
+// dense_check_flags -- inside every host-output call, erh_dense_check for device outputs, which the ABI has always required
+// before results are read) and only when the flag word says that a query needs them, kExMax flagged queries per round.  The
+// common case -- nothing flagged -- used to pay two empty launches per call for keeping up to kExMax answers free of a host
+// round trip that every caller makes anyway.
 constexpr int kExGroup = 4;
 constexpr int kExMax = 16;
 constexpr int kExCap = 2048;
@@ -671,7 +673,8 @@ constexpr int kExCap = 2048;
 __global__ __launch_bounds__(1024) void dense_bad_collect_kernel(const uint32_t *__restrict__ bad, int B, int skip,
                                                                 int32_t *__restrict__ list, int32_t *__restrict__ count,
                                                                 uint32_t *__restrict__ flags,
-                                                                unsigned long long *__restrict__ stats /* erh_get_stat: [0] += flagged queries (first round only) */) {
+                                                                unsigned long long *__restrict__ stats /* erh_get_stat: [0] += flagged queries (the call's own collect only) */,
+                                                                int answer /* 1: the exact kernels of this round follow; 0: count only (what a call enqueues) */) {
     __shared__ int s_base, s_taken;
     const int tid = threadIdx.x;
     if (tid == 0) { s_base = 0; s_taken = 0; }
@@ -699,10 +702,10 @@ __global__ __launch_bounds__(1024) void dense_bad_collect_kernel(const uint32_t 
     if (tid == 0) {
         count[0] = s_taken;
         count[1] = s_base;
-        flags[0] = (s_base > skip + kExMax) ? 1u : 0u;                   // still unanswered after this round
+        flags[0] = (answer ? s_base > skip + kExMax : s_base > 0) ? 1u : 0u;   // flagged queries still unanswered after this launch
         flags[3] = (uint32_t)s_base;
-        if (s_base <= skip + kExMax) flags[2] = 0u;                      // every flagged query gets its exact answer
-        if (stats && skip == 0 && s_base) atomicAdd(&stats[0], (unsigned long long)s_base);
+        if (answer && s_base <= skip + kExMax) flags[2] = 0u;            // every flagged query gets its exact answer
+        if (stats && !answer && s_base) atomicAdd(&stats[0], (unsigned long long)s_base);
     }
 }
 
@@ -950,11 +953,13 @@ hipError_t launch_dense_exhaustive(const uint32_t *bad, int B, int skip, int k, 
                                    const _Float16 *Q16, const int16_t *filter_dir, const int16_t *dir_id,
                                    int64_t pos_inv, void *ws, uint32_t *flags, int n_cus,
                                    int32_t *out_ids, double *out_scores, int32_t *out_len, unsigned long long *stats,
-                                   hipStream_t st) {
+                                   int collect_only, hipStream_t st) {
     double *S64 = reinterpret_cast<double *>(ws);
     int32_t *list = reinterpret_cast<int32_t *>(S64 + (size_t)kExMax * (size_t)N);
     int32_t *count = list + kExMax;
-    hipLaunchKernelGGL(dense_bad_collect_kernel, dim3(1), dim3(1024), 0, st, bad, B, skip, list, count, flags, stats);
+    hipLaunchKernelGGL(dense_bad_collect_kernel, dim3(1), dim3(1024), 0, st, bad, B, skip, list, count, flags, stats,
+                       collect_only ? 0 : 1);
+    if (collect_only) return hipGetLastError();
     const size_t lds = (size_t)kExGroup * d * 2;
     hipError_t e = hipFuncSetAttribute((const void *)dense_exact_all_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);

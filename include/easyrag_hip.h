@@ -345,9 +345,11 @@ int erh_reset_kernel_time(erh_handle *h);
 int erh_set_option(erh_handle *h, const char *name, int64_t value);
 
 /* REQUIRED after a dense / hybrid call with DEVICE outputs, before the rows are read or sent anywhere (erh_sync is not
- * a substitute): synchronise `stream` and read the call's flag words (host-output calls do this themselves).  Queries whose candidate budgets overflowed are answered by the exhaustive path on the
- * device, up to 16 per call without any host involvement; if a call flagged more, the remaining rounds (and, for a
- * fused call, the RRF over the corrected lists) are run here, so that the results are complete when this returns. */
+ * a substitute): synchronise `stream` and read the call's flag words (host-output calls do this themselves).  Queries whose candidate
+ * budgets overflowed are answered by the exhaustive path: the call itself only COUNTS them on the device (one small launch); the exact
+ * rounds -- 16 queries at a time -- and, for a fused call, the RRF over the corrected lists run here, when and only when the count is
+ * not zero, so that the results are complete when this returns.  (Until round 5 a call enqueued the first round itself and paid two
+ * empty launches for it in the normal case.) */
 int erh_dense_check(erh_handle *h, void *stream);
 
 /* Measurement only: with option "debug_counters" = 1 the scan kernels add per-section shader-clock sums
