@@ -123,6 +123,9 @@ struct erh_handle {
     int64_t Nmeta = 0;
     DevBuf content_id, dir_id;
     bool has_content = false, has_dir = false;
+    DevBuf dir_rng;                          // {first document, last + 1} of every dir class (erh_set_doc_meta): a filtered BM25 query walks those tiles only
+    int dir_rng_n = 0;
+    int opt_bm25_dir_range = 1;
     // work space
     DevBuf qin, Q16, qnorm, tau, S0, cand, cand_cnt, flags, filt, filt2, seed_need;
     DevBuf o_ids, o_sc, o_len;              // staging for host outputs
@@ -692,7 +695,9 @@ int bm25_topk_dev(erh_handle *h, const int32_t *qptr_dev, const int32_t *qtok_de
                                                   (uint32_t)S.nnz, S.qmax,
                                                   tab, n_tab, tshift, S.Nb, qptr_dev, qtok_dev, q_order,
                                                   B, k, segs, cut_mul, filter_dev, dir, p_sc, p_ids, p_len, h->bm_redo.as<uint32_t>(),
-                                                  h->dstats.as<unsigned long long>(), h->opt_bm25_ablate, dbg, st);
+                                                  h->dstats.as<unsigned long long>(),
+                                                  (filter_dev && h->opt_bm25_dir_range && h->dir_rng_n > 0) ? h->dir_rng.as<int32_t>() : nullptr,
+                                                  h->dir_rng_n, h->opt_bm25_ablate, dbg, st);
             if (e != hipSuccess) return e;
             // near-tie floods (rare): those workgroups are scanned again by the exact block scan (same document ranges per
             // segment: the cuts are expressed in the block scan's own tiles), the others exit at once
@@ -832,7 +837,7 @@ int erh_destroy(erh_handle *h) {
                       &h->o_ids, &h->o_sc, &h->o_len, &h->qptr, &h->qtok, &h->part_sc, &h->part_ids, &h->part_len,
                       &h->hy_sids, &h->hy_ssc, &h->hy_slen, &h->hy_dids, &h->hy_dsc, &h->hy_dlen,
                       &h->fa_ids, &h->fa_sc, &h->fa_len, &h->fb_ids, &h->fb_sc, &h->fb_len,
-                      &h->scores_tmp, &h->scores_wide, &h->dbg, &h->dstats, &h->dir_pos, &h->seed_need, &h->bad, &h->ex_ws, &h->bm_redo, &h->fin_ws};
+                      &h->scores_tmp, &h->scores_wide, &h->dbg, &h->dstats, &h->dir_pos, &h->seed_need, &h->bad, &h->ex_ws, &h->bm_redo, &h->fin_ws, &h->dir_rng};
     for (DevBuf *b : bufs) b->release();
     for (auto &b : h->bm) b.release();
     if (h->comm || h->comm_pending) (void)erh_comm_destroy(h);
@@ -868,6 +873,7 @@ int erh_set_option(erh_handle *h, const char *name, int64_t value) {
         h->n_cus = value == 0 ? h->n_cus_dev : (int)value;
         return ERH_OK;
     }
+    if (!strcmp(name, "bm25_dir_range")) { h->opt_bm25_dir_range = value != 0; return ERH_OK; }
     if (!strcmp(name, "dense_fin_split")) { h->opt_dense_fin_split = value != 0; return ERH_OK; }
     if (!strcmp(name, "dense_tile384")) { h->opt_dense_tile384 = value != 0; return ERH_OK; }
     if (!strcmp(name, "dense_tile384_max_mb")) { h->opt_tile384_max_mb = value; h->xt384_nomem = false; return ERH_OK; }
@@ -1479,9 +1485,28 @@ int erh_set_doc_meta(erh_handle *h, int64_t N, const int32_t *content_id, const 
         HIPCHK(h, h->content_id.ensure((size_t)N * 4));
         HIPCHK(h, hipMemcpy(h->content_id.p, content_id, (size_t)N * 4, hipMemcpyHostToDevice));
     }
+    h->dir_rng_n = 0;
     if (dir_id) {
         HIPCHK(h, h->dir_id.ensure((size_t)N * 2));
         HIPCHK(h, hipMemcpy(h->dir_id.p, dir_id, (size_t)N * 2, hipMemcpyHostToDevice));
+        // document range of every class: where its documents are one block (the reference's dirs are: its loader walks the
+        // directories one after the other) a filtered BM25 query skips every tile outside it
+        int maxc = -1;
+        for (int64_t i = 0; i < N; ++i) maxc = dir_id[i] > maxc ? dir_id[i] : maxc;
+        if (maxc >= 0 && N <= 2147483647LL) {
+            std::vector<int32_t> rng((size_t)(maxc + 1) * 2);
+            for (int c = 0; c <= maxc; ++c) { rng[2 * c] = 2147483647; rng[2 * c + 1] = 0; }
+            for (int64_t i = 0; i < N; ++i) {
+                const int c = dir_id[i];
+                if (c < 0) continue;
+                if ((int32_t)i < rng[2 * c]) rng[2 * c] = (int32_t)i;
+                rng[2 * c + 1] = (int32_t)i + 1;
+            }
+            for (int c = 0; c <= maxc; ++c) if (rng[2 * c + 1] == 0) rng[2 * c] = 0;
+            HIPCHK(h, h->dir_rng.ensure(rng.size() * 4));
+            HIPCHK(h, hipMemcpy(h->dir_rng.p, rng.data(), rng.size() * 4, hipMemcpyHostToDevice));
+            h->dir_rng_n = maxc + 1;
+        }
     }
     h->has_content = content_id != nullptr;
     h->has_dir = dir_id != nullptr;

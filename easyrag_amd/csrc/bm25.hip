@@ -1388,6 +1388,8 @@ __global__ __launch_bounds__(C::NT, 4 /* waves per SIMD: two 512-thread workgrou
     const int16_t *__restrict__ filter_dir, const int16_t *__restrict__ dir_id,
     double *__restrict__ part_scores, int32_t *__restrict__ part_ids, int32_t *__restrict__ part_len,
     uint32_t *__restrict__ redo, unsigned long long *__restrict__ stats /* null, or erh_get_stat's device counters */,
+    const int32_t *__restrict__ dir_rng /* null, or {first document, last + 1} per dir class: a filtered query walks only the tiles of its class */,
+    int dir_rng_n,
     int abl /* measurement builds: 1 no adds, 2 no posting loads, 4 no clear, 8 one descriptor set */,
     unsigned long long *__restrict__ dbg) {
     constexpr int NT = C::NT, TILE = C::TILE, NW = C::NW, CAP = C::CAP, WORDS = C::WORDS, U = C::U;
@@ -1420,9 +1422,25 @@ __global__ __launch_bounds__(C::NT, 4 /* waves per SIMD: two 512-thread workgrou
     const int nq = q_indptr[q + 1] - qs;
     const int fd = filter_dir ? (int)filter_dir[q] : -1;
     const int n_cut = (n_tiles + cut_mul - 1) / cut_mul;
-    const int t_begin = (int)((int64_t)n_cut * seg / segs) * cut_mul;
+    int t_begin = (int)((int64_t)n_cut * seg / segs) * cut_mul;
     int t_end = (int)((int64_t)n_cut * (seg + 1) / segs) * cut_mul;
     t_end = t_end < n_tiles ? t_end : n_tiles;
+    // Filter push-down as a tile range (round 5): the reference's `dir` is the first path component of a file and its loader walks the
+    // directories one after the other (ref:src/easyrag/custom/transformation.py:70, ingestion.py:79-87), so the documents of a dir
+    // are one contiguous block; a query filtered on it walks the tiles of that block only.  The segment cuts stay where they are
+    // (the exact scan of a redone segment covers the same documents); interleaved classes simply span every tile.
+    if (fd >= 0 && dir_rng) {
+        int lo = 0, hi = 0;
+        if (fd < dir_rng_n) { lo = dir_rng[2 * fd]; hi = dir_rng[2 * fd + 1]; }
+        if (hi <= lo) {
+            t_end = t_begin;                                              // no document carries this class
+        } else {
+            const int b0 = lo / TILE, b1 = (hi + TILE - 1) / TILE;
+            t_begin = t_begin > b0 ? t_begin : b0;
+            t_end = t_end < b1 ? t_end : b1;
+            t_end = t_end > t_begin ? t_end : t_begin;
+        }
+    }
     const int64_t out_base = ((int64_t)q * segs + seg) * k;
     const double keep_frac = 1.0 - 3.0 * 1.01 * (double)(nq + 2) * 5.9604644775390625e-08;   // 1 - 3 eps
     // units a sum can exceed the real one by (as_drop_threshold): one per truncation + 1 the payload has gone through
@@ -1841,7 +1859,8 @@ hipError_t launch_bm25_ascan(int variant, int small, const int64_t *indptr, cons
                              int n_tab, int tshift, int64_t N, const int32_t *q_indptr, const int32_t *q_tok,
                              const int32_t *q_order, int B, int k, int segs, int cut_mul, const int16_t *filter_dir,
                              const int16_t *dir_id, double *part_scores, int32_t *part_ids, int32_t *part_len, uint32_t *redo,
-                             unsigned long long *stats, int ablate, unsigned long long *dbg, hipStream_t st) {
+                             unsigned long long *stats, const int32_t *dir_rng, int dir_rng_n, int ablate, unsigned long long *dbg,
+                             hipStream_t st) {
     if (B <= 0) return hipSuccess;
     if (cut_mul < 1) cut_mul = 1;
     const int tile = bm25_ascan_tile_docs(small);
@@ -1850,7 +1869,7 @@ hipError_t launch_bm25_ascan(int variant, int small, const int64_t *indptr, cons
 #define ERH_AS_LAUNCH(ST, CFG, POST)                                                                                 \
     hipLaunchKernelGGL((bm25_ascan_kernel<ST, CFG>), grid, dim3(CFG::NT), CFG::BYTES, st, indptr, doc_ids,           \
                        (const ST *)payload, POST, nnz, qmax, g16, tile_off, n_tab, tshift, n_tiles, N, q_indptr,      \
-                       q_tok, q_order, k, segs, cut_mul, filter_dir, dir_id, part_scores, part_ids, part_len, redo, stats, ablate, dbg)
+                       q_tok, q_order, k, segs, cut_mul, filter_dir, dir_id, part_scores, part_ids, part_len, redo, stats, dir_rng, dir_rng_n, ablate, dbg)
 #define ERH_AS_SHAPES(ST)                                                                                            \
     do {                                                                                                             \
         if (small == 2 && post16) ERH_AS_LAUNCH(ST, AsPack16, post16);                                               \

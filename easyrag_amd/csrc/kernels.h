@@ -162,6 +162,7 @@ hipError_t launch_bm25_ascan(int variant, int small /* 0: 1024 threads; 1: 512 t
                              const int16_t *filter_dir, const int16_t *dir_id,
                              double *part_scores, int32_t *part_ids, int32_t *part_len, uint32_t *redo,
                              unsigned long long *stats /* null, or the handle's device counters: [1] += (query, segment) pairs handed to the exact scan */,
+                             const int32_t *dir_rng /* null, or int32[2 * dir_rng_n]: {first document, last + 1} of every dir class */, int dir_rng_n,
                              int ablate /* measurement builds only */, unsigned long long *dbg, hipStream_t st);
 // 4-byte postings of the packed scan {document & 32767, (q >> g) + 1 in 16 bits}: nnz + 8 words (zeros behind the postings)
 int bm25_post16_shift(double qmax);

@@ -326,6 +326,9 @@ int erh_reset_kernel_time(erh_handle *h);
  *                         tiles, two documents per accumulator word (16-bit sums, payloads shifted per query); 1 = 512 threads,
  *                         16384-document tiles, 32-bit sums (both: 80 KiB of LDS, two workgroups = two queries per CU);
  *                         0 = always 1024 threads, 32768-document tiles.  Same results, bit for bit
+ *   bm25_dir_range (1)    fixed-point scan with a dir filter: the query walks only the posting tiles that hold documents of its class
+ *                         (erh_set_doc_meta records every class's first and last document; the reference's dirs are contiguous blocks
+ *                         of its document order, so a filter on one of four dirs skips three quarters of the tile passes); 0 = all tiles
  *   bm25_post16 (1)       packed shape: read 4-byte postings {15-bit document offset in the tile, 16-bit payload} (built when an
  *                         index is set while bm25_small = 2; + 4 bytes per posting); 0 = the 8-byte fixed-point postings
  *   bm25_crossing (1)     wave-owned scan: survivors from threshold crossings noted in the token loop instead of a sweep

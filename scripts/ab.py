@@ -48,6 +48,8 @@ def main():
     ap.add_argument("--pool", type=int, default=4)
     ap.add_argument("--dirs", type=int, default=0, help="> 0: every query carries a `dir` filter (document i belongs to dir i %% D, query b asks for b %% D), "
                                                         "as every query of the reference's real workload does (src/data/question.jsonl)")
+    ap.add_argument("--dir-layout", default="mod", choices=["mod", "block"], help="mod: document i in dir i %% D (interleaved); block: D contiguous blocks, "
+                                                                                 "as the reference's loader produces them (it walks the directories one after the other)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     n, d, vocab, B = args.chunks, args.dim, args.vocab, args.batch
@@ -67,7 +69,7 @@ def main():
         csr_pool = [queries_to_csr(synth.token_queries(flat, lens, vocab, B, seed=2000 + p)) for p in range(args.pool)]
     filt = None
     if args.dirs > 0:
-        eng.set_doc_meta(n, None, (np.arange(n) % args.dirs).astype(np.int16))
+        eng.set_doc_meta(n, None, ((np.arange(n) % args.dirs) if args.dir_layout == "mod" else (np.arange(n) * args.dirs // n)).astype(np.int16))
         filt = (np.arange(B) % args.dirs).astype(np.int16)
     else:
         eng.set_doc_meta(n, None, None)

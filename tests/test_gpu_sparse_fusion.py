@@ -396,3 +396,49 @@ def test_bm25_full_size_properties(engine):
             np.add.at(acc, idx.doc_ids[s:e], idx.payload[s:e])
         want = bm25_filter(acc, k)
         assert list(ids[b, :ln[b]]) == [w[0] for w in want] and list(sc[b, :ln[b]]) == [w[1] for w in want]
+
+
+@pytest.mark.parametrize("variant", [OKAPI, BM25S])
+def test_bm25_dir_filter_as_tile_range(engine, bm25_kernel, variant):
+    """Round 5: a dir filter becomes a tile range.  The reference's `dir` is the first path component and its loader walks the
+    directories one after the other (ref transformation.py:70, ingestion.py:79-87), so a dir is one block of consecutive documents:
+    the fixed-point scan walks only the tiles of the filtered class.  Blocks of unequal size that cut through tiles, a class with a
+    single document, one that is split in two (its range then spans the block between), a class nobody carries and one beyond the
+    table, queries without a filter in the same batch; few queries (document-range segments + merge) and many.  Same lists as the
+    oracle's masked walk, and as the scan over all tiles (bm25_dir_range = 0)."""
+    n_docs, vocab = 90000, 3000
+    flat, lens = synth.token_corpus(n_docs, vocab, seed=17, mean_len=14)
+    docs = [list(map(int, d)) for d in synth.split_docs(flat, lens)]
+    ora = _oracle_for(variant, docs)
+    idx = build_bm25_index(docs, variant)
+    engine.set_bm25(idx)
+    dir_id = np.zeros(n_docs, np.int16)
+    dir_id[20000:52000] = 1                       # ends inside a tile
+    dir_id[52000:52001] = 2                       # one document
+    dir_id[52001:70000] = 3
+    dir_id[70000:] = 5                            # (class 4: nobody)
+    dir_id[100:200] = 3                           # class 3 is split: its range spans classes 0 .. 2
+    engine.set_doc_meta(n_docs, None, dir_id)
+    try:
+        for B in (5, 40):
+            queries = [list(map(int, q)) for q in synth.token_queries(flat, lens, vocab, B, seed=31 + B)]
+            filt = np.array([(-1, 0, 1, 2, 3, 5, 4, 9)[b % 8] for b in range(B)], np.int16)
+            qi, qt = queries_to_csr([idx.tokens_to_ids(q) for q in queries])
+            got = {}
+            for rng_on in (1, 0):
+                engine.set_option("bm25_dir_range", rng_on)
+                got[rng_on] = engine.bm25_topk(qi, qt, 50, filter_dir=filt)
+            engine.set_option("bm25_dir_range", 1)
+            for a, b in zip(got[1], got[0]):
+                assert np.array_equal(a, b)
+            ids, sc, ln = got[1]
+            for b, q in enumerate(queries):
+                mask = None if filt[b] < 0 else dir_id == filt[b]
+                want = bm25_filter(_oracle_scores(ora, variant, q), 50, mask)
+                assert ln[b] == len(want), (B, b)
+                assert list(ids[b, :ln[b]]) == [w[0] for w in want] and list(sc[b, :ln[b]]) == [w[1] for w in want], (B, b)
+                if filt[b] in (4, 9):
+                    assert ln[b] == 0
+    finally:
+        engine.set_option("bm25_dir_range", 1)
+        engine.set_doc_meta(n_docs, None, None)
