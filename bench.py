@@ -354,17 +354,18 @@ def sub_benchmarks(eng, synth, queries_to_csr, build_index, OKAPI, q16_pool, tok
         eng.free_bm25_slot(1)
         eng._select(0)
     # the reference's REAL call pattern carries a `dir` filter on every query (all 103 questions of src/data/question.jsonl name their
-    # document; pipeline.py:301-312 -> filter_dict / qdrant filters, retrievers.py:278,283): four dirs, document i in dir i % 4, query b
-    # asks for dir b % 4, the same column pushed down into both routes
+    # document; pipeline.py:301-312 -> filter_dict / qdrant filters, retrievers.py:278,283): four dirs as four contiguous blocks of
+    # documents -- `dir` is the first path component and the reference's loader walks the directories one after the other
+    # (transformation.py:70, ingestion.py:79-87) --, query b asks for dir b % 4, the same column pushed down into both routes
     n_docs = int(eng.n_dense)
-    eng.set_doc_meta(n_docs, None, (np.arange(n_docs) % 4).astype(np.int16))
+    eng.set_doc_meta(n_docs, None, (np.arange(n_docs) * 4 // n_docs).astype(np.int16))
     filt = (np.arange(int(q16_pool[0].shape[0])) % 4).astype(np.int16)
     try:
         out["hybrid_b1024_dir_filter"] = run_sub(
             eng, classes, lambda i: eng.hybrid_topk(q16_pool[i % pool], *csr_pool[i % pool], k_dense=288, k_sparse=192, K=60, topk=10,
                                                     device_out=True, filter_dir=filt), int(q16_pool[0].shape[0]), "dense_scan",
-            what="configs[3] with a per-query dir filter on both routes (4 dirs of 250k chunks each): the staged dense path (store kernel + "
-                 "seed select + filtered append scan on the 384 x 256 tile) and the filtered BM25 scan")
+            what="configs[3] with a per-query dir filter on both routes (4 dirs = 4 contiguous blocks of 250k chunks): the staged dense path "
+                 "(store kernel + seed select + filtered append scan on the 384 x 256 tile) and the BM25 scan over the tiles of the query's dir only")
     finally:
         eng.set_doc_meta(n_docs, None, None)
     # the reference's own vector size (ref src/configs/easyrag.yaml:15-16: gte-Qwen2-7B, vector_size 3584): the same 2.05 GB of chunk
