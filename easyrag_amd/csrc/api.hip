@@ -17,6 +17,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <map>
 #include <vector>
 
 #include "kernels.h"
@@ -97,6 +98,10 @@ struct erh_handle {
     // the corpus is sorted by topic.  (1, 1) = stored as given (option dense_shuffle = 0).
     int64_t pos_mul = 1, pos_inv = 1;
     int opt_dense_shuffle = 1;
+    // What a dense call scans: the whole matrix (global: X with its placement; the tiled copies belong to it) or, for queries
+    // filtered on a dir whose documents are one block, that block's own copy with its own placement (round 5, DenseBlocks below).
+    struct DenseView { const _Float16 *X = nullptr; int64_t N = 0, mul = 1, inv = 1; bool global = true; } view;
+    void view_global() { view.X = X.as<_Float16>(); view.N = N; view.mul = pos_mul; view.inv = pos_inv; view.global = true; }
     DevBuf dir_pos;                         // dir id by stored position (built on demand)
     bool dir_pos_valid = false;
     // bm25 state: up to ERH_BM25_SLOTS independent indices (e.g. the content route and the know_path route of the
@@ -123,6 +128,29 @@ struct erh_handle {
     int64_t Nmeta = 0;
     DevBuf content_id, dir_id;
     bool has_content = false, has_dir = false;
+    // Dense route by dir block (round 5): where a dir's documents are one block of consecutive documents (the reference's layout) the
+    // block gets its OWN copy with its own golden-ratio placement (Xb: block c at rows [lo_c, lo_c + n_c), built on the first filtered
+    // call), and the queries filtered on that dir scan n_c rows instead of N -- through the same kernels, as a view.
+    struct DenseBlocks {
+        bool valid = false;
+        std::vector<int64_t> lo, n, mul, inv;                      // per class; n = 0: not a block (scattered, empty or too small)
+    } blocks;
+    DevBuf Xb, blk_tmp;
+    std::vector<int32_t> dir_lo_h, dir_hi_h, dir_cnt_h;           // per class, from erh_set_doc_meta
+    int opt_dense_dir_blocks = 1;
+    int64_t opt_dir_block_min_rows = 4096;
+    bool routed_done = false;                                      // the last dense call ran as routed groups
+    bool routed_pending = false;                                   // ... whose flag words (r_flags) have not been read yet
+    struct RoutedGroup { int c, at, n; };                          // dir class (-1: the ordinary call), first row in r_idx / r_q, queries
+    struct Routed {
+        std::vector<RoutedGroup> groups;
+        int q_dtype = 0, normalize_q = 0, B = 0, k = 0, mode = 0;
+        int32_t *d_ids = nullptr; double *d_sc = nullptr; int32_t *d_len = nullptr;
+    } routed;
+    DevBuf r_idx, r_q, r_ids, r_sc, r_len, r_filt, r_flags;       // the batch in group order (rows, filter values), a group's results, every group's flag words
+    uint32_t *r_flags_host = nullptr;                              // pinned
+    std::vector<int32_t> r_idx_host;
+    std::vector<int16_t> r_filt_host;
     DevBuf dir_rng;                          // {first document, last + 1} of every dir class (erh_set_doc_meta): a filtered BM25 query walks those tiles only
     int dir_rng_n = 0;
     int opt_bm25_dir_range = 1;
@@ -142,7 +170,7 @@ struct erh_handle {
     DevBuf dstats;
     struct Stats {
         int64_t dense_calls = 0, dense_scan_pp5 = 0, dense_scan_pp3 = 0, dense_scan_gemv = 0, dense_scan_tile = 0,
-                dense_sample_passes = 0, dense_tile384_nomem = 0, bm25_calls = 0, hybrid_calls = 0;
+                dense_sample_passes = 0, dense_tile384_nomem = 0, bm25_calls = 0, hybrid_calls = 0, dense_block_groups = 0;
     } stats;
     // multi-GPU exchange (erh_comm_* / erh_allgather_topk): RCCL communicator + packed send / receive rows
     void *comm = nullptr;
@@ -192,6 +220,7 @@ struct erh_handle {
     struct LastDense {
         bool valid = false, hybrid = false;
         int B = 0, k = 0;
+        const _Float16 *X = nullptr; int64_t N = 0, pos_inv = 1;      // what the call scanned (a view)
         const int16_t *filter_dev = nullptr;
         int32_t *d_ids = nullptr; double *d_sc = nullptr; int32_t *d_len = nullptr;
         // hybrid: the fusion to redo after the dense lists changed
@@ -287,7 +316,9 @@ hipError_t scan_append(erh_handle *h, const _Float16 *X, int64_t N, int d, int64
     }
     const int abl = h->opt_dense_ablate;
     const bool pp_code = abl == 0 || abl == 7 || abl == 8 || (abl >= 11 && abl <= 18) || (abl >= 20 && abl <= 24);
-    if (h->qt5_valid && h->xt384_valid && abl == 0 && X == h->X.as<_Float16>()) {
+    const bool own_x = X == h->view.X;                        // the view's matrix itself (padded; not a gathered block of debug rows)
+    const bool global_x = own_x && h->view.global;            // ... and the handle's whole matrix: its tiled copies apply
+    if (h->qt5_valid && h->xt384_valid && abl == 0 && global_x) {
         // 384 x 256 tile over the tiled copies (the caller checked the options and built the copies)
         hipError_t e = erh::launch_dense_scan_pp5(h->Xt384.as<_Float16>(), N, d, c0, c1, h->Qt.as<_Float16>(), Bpad, B, tau, filt,
                                                   dir, cand, cnt, cap, flags, h->n_cus,
@@ -295,7 +326,7 @@ hipError_t scan_append(erh_handle *h, const _Float16 *X, int64_t N, int d, int64
         if (e != hipErrorInvalidValue) { h->stats.dense_scan_pp5 += (c1 > c0); return e; }
         (void)hipGetLastError();
     }
-    if (h->opt_dense_pp >= 4 && pp_code && X == h->X.as<_Float16>() && h->xt_valid && h->qt_valid) {
+    if (h->opt_dense_pp >= 4 && pp_code && global_x && h->xt_valid && h->qt_valid) {
         // both operands from their tiled copies (dense_scan_pp4_kernel)
         hipError_t e = erh::launch_dense_scan_pp4(h->Xt.as<_Float16>(), N, d, c0, c1, h->Qt.as<_Float16>(), Bpad, B, tau, filt,
                                                   dir, cand, cnt, cap, flags, h->n_cus, h->opt_dense_ablate,
@@ -306,10 +337,10 @@ hipError_t scan_append(erh_handle *h, const _Float16 *X, int64_t N, int d, int64
         (void)hipGetLastError();
     }
     if (h->opt_dense_pp && pp_code) {
-        const bool own = X == h->X.as<_Float16>();
+        const bool own = own_x;
         const int QT = erh::dense_scan_q_tile();
         // the strict ping-pong kernel streams the tiled copy when there is one and the stage starts on a tile boundary
-        const bool tiled = own && h->opt_dense_pp >= 3 && h->opt_dense_tiled && h->xt_valid && h->opt_dense_var == 0 &&
+        const bool tiled = global_x && h->opt_dense_pp >= 3 && h->opt_dense_tiled && h->xt_valid && h->opt_dense_var == 0 &&
                            c0 % QT == 0;
         const int var = tiled ? 2 : h->opt_dense_var;
         uint32_t *sync = nullptr;
@@ -343,8 +374,11 @@ int dense_topk_dev(erh_handle *h, const void *q_dev, int q_dtype, int normalize_
                    const int16_t *filter_dev, int mode, int32_t *d_ids, double *d_sc, int32_t *d_len, hipStream_t st) {
     const int QT = erh::dense_scan_q_tile();
     const int Bpad = round_up(B, QT);
+    h->routed_done = false;
     const int d = h->d;
-    const int64_t N = h->N;
+    const int64_t N = h->view.N;
+    const int64_t pos_mul = h->view.mul, pos_inv = h->view.inv;
+    const bool global_view = h->view.global;
     const int cap = erh::kDenseCapMax;
     HIPCHK(h, h->Q16.ensure((size_t)Bpad * d * 2));
     HIPCHK(h, h->qnorm.ensure((size_t)Bpad * 4));
@@ -371,7 +405,7 @@ int dense_topk_dev(erh_handle *h, const void *q_dev, int q_dtype, int normalize_
     // batches on the 384 x 256 tile whose threshold comes from the stored prefix (dir filters, deep ranks): the prefix ends on a tile
     // boundary of that kernel -- 32640 = 85 x 384 instead of 32768 -- so the append stage can start there (c0 % 384 == 0); otherwise
     // it would fall back to the 256 x 256 scan (filtered 1024-query batch: scan class -1.4 ... -2 %, profiles/r05j_ab_filtered.log)
-    if (h->opt_dense_tile384 && Bpad >= 2 * QT && n0 < N && n0 >= 4 * erh::dense_scan_pp5_rows())
+    if (h->opt_dense_tile384 && global_view && Bpad >= 2 * QT && n0 < N && n0 >= 4 * erh::dense_scan_pp5_rows())
         n0 = n0 / erh::dense_scan_pp5_rows() * erh::dense_scan_pp5_rows();
     const int ld = round_up((int)n0, 256);
     HIPCHK(h, h->S0.ensure((size_t)Bpad * ld * 4));
@@ -395,14 +429,14 @@ int dense_topk_dev(erh_handle *h, const void *q_dev, int q_dtype, int normalize_
       HIPCHK(h, erh::launch_prep_queries(q_dev, q_dtype, normalize_q, B, Bpad, d, h->Q16.as<_Float16>(),
                                          h->qnorm.as<float>(), bad, flags, st));
       // the tiled-operand scan reads the query block as stage images too (512 KiB per 256 queries, once per call)
-      if (h->opt_dense_pp >= 4 && h->xt_valid && d % 64 == 0 && B > erh::dense_gemv_max_queries()) {
+      if (h->opt_dense_pp >= 4 && global_view && h->xt_valid && d % 64 == 0 && B > erh::dense_gemv_max_queries()) {
           HIPCHK(h, h->Qt.ensure((size_t)Bpad * d * 2));
           HIPCHK(h, erh::launch_dense_tile_rows(h->Q16.as<_Float16>(), Bpad, d, h->Qt.p, st));
           h->qt_valid = true;
       }
       // the 384 x 256 scan of batches padded to >= 512 queries: the chunk matrix' 384-row tiled copy (once per erh_set_dense, here
       // on first use) and the query block as stage images (512 KiB per 256 queries, per call)
-      if (h->opt_dense_tile384 && Bpad >= 2 * QT && h->opt_dense_pp == 3 && h->opt_dense_var == 0 && h->opt_dense_ablate == 0 &&
+      if (h->opt_dense_tile384 && global_view && Bpad >= 2 * QT && h->opt_dense_pp == 3 && h->opt_dense_var == 0 && h->opt_dense_ablate == 0 &&
           !h->opt_dense_sync && d % 64 == 0 && d / 32 >= 8 && N >= 2 * erh::dense_scan_pp5_rows()) {
           if (!h->xt384_valid && !h->xt384_nomem) {
               const int rows = erh::dense_scan_pp5_rows();
@@ -432,16 +466,17 @@ int dense_topk_dev(erh_handle *h, const void *q_dev, int q_dtype, int normalize_
           }
       } }
 
-    const _Float16 *X = h->X.as<_Float16>();
+    const _Float16 *X = h->view.X;
     const _Float16 *Q16 = h->Q16.as<_Float16>();
+    if (filter_dev && !global_view) return h->fail(ERH_ERR_INVALID, "dense block view with a filter");
     const int16_t *dir = nullptr;                 // dir id by stored position, only needed when a filter is present
     if (filter_dev && h->has_dir) {
-        if (h->pos_mul == 1) {
+        if (pos_mul == 1) {
             dir = h->dir_id.as<int16_t>();
         } else {
             if (!h->dir_pos_valid) {
                 HIPCHK(h, h->dir_pos.ensure((size_t)N * 2));
-                HIPCHK(h, erh::launch_permute_dir(h->dir_id.as<int16_t>(), N, h->pos_inv, h->dir_pos.as<int16_t>(), st));
+                HIPCHK(h, erh::launch_permute_dir(h->dir_id.as<int16_t>(), N, pos_inv, h->dir_pos.as<int16_t>(), st));
                 h->dir_pos_valid = true;
             }
             dir = h->dir_pos.as<int16_t>();
@@ -468,7 +503,7 @@ int dense_topk_dev(erh_handle *h, const void *q_dev, int q_dtype, int normalize_
         // queries: 128 streams -> 32768; the pass takes a tile time whatever the number of streams)
         const int seed_tiles = n_streams > 0 ? (int)std::max<int64_t>(1, std::min<int64_t>(h->opt_n0, 16384) / ((int64_t)n_streams * QT)) : 0;
         const int64_t rows_seed = (int64_t)seed_tiles * n_streams * QT;
-        const bool tiled_run = h->opt_dense_tiled && h->xt_valid;
+        const bool tiled_run = h->opt_dense_tiled && h->xt_valid && global_view;
         const int n_cells = seed_tiles * n_streams * 4;
         const int rank = (rows_seed > 0 && rows_seed <= N) ? erh_dense_seed_rank(k, rows_seed, N) : k;
         // From 512 queries on: below, the sampled rows scanned twice (one tile per stream = 65536 rows at 256 queries) cost more
@@ -506,14 +541,14 @@ int dense_topk_dev(erh_handle *h, const void *q_dev, int q_dtype, int normalize_
             { ProfScope ps(h, st, ERH_K_DENSE_SELECT, 0, 0);
               HIPCHK(h, erh::launch_dense_finalize(B, k, mode, h->qnorm.as<float>(), h->xnorm_max, d, X, Q16,
                                                    h->cand.as<ErhCand>(), h->cand_cnt.as<uint32_t>(), cap, d_ids, d_sc, d_len,
-                                                   reinterpret_cast<float *>(flags + 1), flags + 2, bad, N, h->pos_mul, h->pos_inv,
+                                                   reinterpret_cast<float *>(flags + 1), flags + 2, bad, N, pos_mul, pos_inv,
                                                    h->tau.as<float>(), h->n_cus, fin_s64, fin_sync, st));
               HIPCHK(h, erh::launch_dense_exhaustive(bad, B, 0, k, X, N, d, Q16, filter_dev,
-                                                     h->has_dir ? h->dir_id.as<int16_t>() : nullptr, h->pos_inv, h->ex_ws.p,
+                                                     (filter_dev && h->has_dir) ? h->dir_id.as<int16_t>() : nullptr, pos_inv, h->ex_ws.p,
                                                      flags, h->n_cus, d_ids, d_sc, d_len, h->dstats.as<unsigned long long>(), 1 /* count only */, st)); }
             h->last = erh_handle::LastDense();
             h->last.valid = true;
-            h->last.B = B; h->last.k = k; h->last.filter_dev = filter_dev;
+            h->last.B = B; h->last.k = k; h->last.filter_dev = filter_dev; h->last.X = X; h->last.N = N; h->last.pos_inv = pos_inv;
             h->last.d_ids = d_ids; h->last.d_sc = d_sc; h->last.d_len = d_len;
             return ERH_OK;
         }
@@ -599,17 +634,17 @@ int dense_topk_dev(erh_handle *h, const void *q_dev, int q_dtype, int normalize_
     { ProfScope ps(h, st, ERH_K_DENSE_SELECT, 0, 0);
       HIPCHK(h, erh::launch_dense_finalize(B, k, mode, h->qnorm.as<float>(), h->xnorm_max, d, X, Q16,
                                            h->cand.as<ErhCand>(), h->cand_cnt.as<uint32_t>(), cap, d_ids, d_sc, d_len,
-                                           reinterpret_cast<float *>(flags + 1), flags + 2, bad, N, h->pos_mul, h->pos_inv,
+                                           reinterpret_cast<float *>(flags + 1), flags + 2, bad, N, pos_mul, pos_inv,
                                            speculate ? h->tau.as<float>() : nullptr, h->n_cus, fin_s64, fin_sync, st));
       // queries the candidate budgets could not certify get their exact answer from the exhaustive path: the call enqueues the
       // COUNT only (one workgroup; it settles the "unanswered" word and the flagged count), dense_check_flags -- the synchronisation
       // point every caller passes before it reads results -- runs the exact rounds when, and only when, the count is not zero
       HIPCHK(h, erh::launch_dense_exhaustive(bad, B, 0, k, X, N, d, Q16, filter_dev,
-                                             h->has_dir ? h->dir_id.as<int16_t>() : nullptr, h->pos_inv, h->ex_ws.p,
+                                             (filter_dev && h->has_dir) ? h->dir_id.as<int16_t>() : nullptr, pos_inv, h->ex_ws.p,
                                              flags, h->n_cus, d_ids, d_sc, d_len, h->dstats.as<unsigned long long>(), 1 /* count only */, st)); }
     h->last = erh_handle::LastDense();
     h->last.valid = true;
-    h->last.B = B; h->last.k = k; h->last.filter_dev = filter_dev;
+    h->last.B = B; h->last.k = k; h->last.filter_dev = filter_dev; h->last.X = X; h->last.N = N; h->last.pos_inv = pos_inv;
     h->last.d_ids = d_ids; h->last.d_sc = d_sc; h->last.d_len = d_len;
     return ERH_OK;
 }
@@ -617,7 +652,50 @@ int dense_topk_dev(erh_handle *h, const void *q_dev, int q_dtype, int normalize_
 // Read the flag words of the last dense call (synchronises the stream).  If queries were flagged for the exhaustive path, its
 // rounds run here, dense_exhaustive_max() queries at a time (and a fused call's RRF is redone over the corrected dense lists),
 // so the caller always gets an answer.
+int routed_group_run(erh_handle *h, const erh_handle::RoutedGroup &g, hipStream_t st);
+int routed_group_scatter(erh_handle *h, const erh_handle::RoutedGroup &g, hipStream_t st);
+
 int dense_check_flags(erh_handle *h, hipStream_t st) {
+    if (h->routed_done) {
+        if (!h->routed_pending) { HIPCHK(h, hipStreamSynchronize(st)); return ERH_OK; }
+        // A routed call: every group left its flag words in r_flags.  A group with flagged queries is run again on its own, to the
+        // end (its exhaustive rounds included), and scattered over its first answer; a fused call's RRF is redone then.
+        const erh_handle::LastDense saved = h->last;
+        const size_t ng = h->routed.groups.size();
+        HIPCHK(h, hipMemcpyAsync(h->r_flags_host, h->r_flags.p, ng * 16, hipMemcpyDeviceToHost, st));
+        HIPCHK(h, hipStreamSynchronize(st));
+        h->routed_pending = false;
+        double maxerr = 0;
+        int uncert = 0, exhaustive = 0;
+        bool redone = false;
+        for (size_t gi = 0; gi < ng; ++gi) {
+            uint32_t f[4];
+            memcpy(f, h->r_flags_host + 4 * gi, 16);
+            if (f[0]) {
+                int rc = routed_group_run(h, h->routed.groups[gi], st);           // (clears routed_done: the check below is the ordinary one)
+                if (rc == ERH_OK) rc = dense_check_flags(h, st);
+                if (rc == ERH_OK) rc = routed_group_scatter(h, h->routed.groups[gi], st);
+                if (rc != ERH_OK) return rc;
+                maxerr = std::max(maxerr, h->diag_maxerr); uncert += h->diag_uncert; exhaustive += h->diag_exhaustive;
+                redone = true;
+            } else {
+                float me;
+                memcpy(&me, &f[1], 4);
+                maxerr = std::max(maxerr, (double)me); uncert += (int32_t)f[2];
+            }
+        }
+        if (redone && saved.hybrid) {
+            const int32_t *cid = h->has_content ? h->content_id.as<int32_t>() : nullptr;
+            HIPCHK(h, erh::launch_rrf(h->hy_sids.as<int32_t>(), h->hy_slen.as<int32_t>(), saved.k_sparse, saved.d_ids, saved.d_len,
+                                      saved.k, cid, saved.B, saved.K, saved.topk, saved.f_ids, saved.f_sc, saved.f_len, st));
+        }
+        if (redone) HIPCHK(h, hipStreamSynchronize(st));
+        h->last = erh_handle::LastDense();
+        h->routed_done = true;
+        h->diag_maxerr = maxerr; h->diag_uncert = uncert; h->diag_exhaustive = exhaustive;
+        h->diag_margin = 2.0 * (double)h->d * 1.1920929e-7 * (double)h->xnorm_max;
+        return ERH_OK;
+    }
     uint32_t f[4] = {0, 0, 0, 0};
     HIPCHK(h, hipMemcpyAsync(f, h->flags.p, sizeof f, hipMemcpyDeviceToHost, st));
     HIPCHK(h, hipStreamSynchronize(st));
@@ -625,9 +703,9 @@ int dense_check_flags(erh_handle *h, hipStream_t st) {
         const int total = (int)f[3], per = erh::dense_exhaustive_max();
         const erh_handle::LastDense &L = h->last;
         for (int skip = 0; skip < total; skip += per)          // (the call enqueued the count only: every answering round runs here)
-            HIPCHK(h, erh::launch_dense_exhaustive(h->bad.as<uint32_t>(), L.B, skip, L.k, h->X.as<_Float16>(), h->N, h->d,
+            HIPCHK(h, erh::launch_dense_exhaustive(h->bad.as<uint32_t>(), L.B, skip, L.k, L.X, L.N, h->d,
                                                    h->Q16.as<_Float16>(), L.filter_dev,
-                                                   h->has_dir ? h->dir_id.as<int16_t>() : nullptr, h->pos_inv,
+                                                   (L.filter_dev && h->has_dir) ? h->dir_id.as<int16_t>() : nullptr, L.pos_inv,
                                                    h->ex_ws.p, h->flags.as<uint32_t>(), h->n_cus, L.d_ids, L.d_sc,
                                                    L.d_len, h->dstats.as<unsigned long long>(), 0, st));
         if (L.hybrid) {
@@ -645,6 +723,130 @@ int dense_check_flags(erh_handle *h, hipStream_t st) {
     h->diag_exhaustive = (int32_t)f[3];
     h->diag_margin = 2.0 * (double)h->d * 1.1920929e-7 * (double)h->xnorm_max;   // for a unit-norm query
     if (f[0]) return h->fail(ERH_ERR_OVERFLOW, "dense candidate list overflowed and the exhaustive path could not finish");
+    return ERH_OK;
+}
+
+constexpr int kRoutedGroupsMax = 8;
+
+// One group of a routed dense call (dense_topk_routed): its queries (rows [at, at + n) of r_q) against its dir's block as a view, or
+// the ordinary call with the group's filter values; results in r_ids / r_sc / r_len, then scattered to the caller's rows.
+int routed_group_run(erh_handle *h, const erh_handle::RoutedGroup &g, hipStream_t st) {
+    const erh_handle::Routed &R = h->routed;
+    const size_t row_bytes = (size_t)h->d * (R.q_dtype == ERH_F16 ? 2 : 4);
+    const int16_t *sub_filter = nullptr;
+    if (g.c >= 0) {
+        h->view.X = h->Xb.as<_Float16>() + (size_t)h->blocks.lo[g.c] * h->d;
+        h->view.N = h->blocks.n[g.c]; h->view.mul = h->blocks.mul[g.c]; h->view.inv = h->blocks.inv[g.c]; h->view.global = false;
+    } else if (g.c == -1) {
+        sub_filter = h->r_filt.as<int16_t>() + g.at;
+    }
+    const int rc = dense_topk_dev(h, h->r_q.as<char>() + (size_t)g.at * row_bytes, R.q_dtype, R.normalize_q, g.n, R.k, sub_filter, R.mode,
+                                  h->r_ids.as<int32_t>(), h->r_sc.as<double>(), h->r_len.as<int32_t>(), st);
+    h->view_global();
+    return rc;
+}
+
+int routed_group_scatter(erh_handle *h, const erh_handle::RoutedGroup &g, hipStream_t st) {
+    const erh_handle::Routed &R = h->routed;
+    HIPCHK(h, erh::launch_scatter_topk_rows(h->r_ids.as<int32_t>(), h->r_sc.as<double>(), h->r_len.as<int32_t>(), h->r_idx.as<int32_t>() + g.at,
+                                            g.n, R.k, g.c >= 0 ? (int32_t)h->blocks.lo[g.c] : 0, R.d_ids, R.d_sc, R.d_len, st));
+    return ERH_OK;
+}
+
+// The per-dir copies of the chunk matrix (see erh_handle::DenseBlocks): built on the first filtered call after erh_set_dense /
+// erh_set_doc_meta; the blocks' rows come back in the caller's order through the gather kernel and are placed by their own multiplier.
+int ensure_dense_blocks(erh_handle *h, hipStream_t st) {
+    if (h->blocks.valid) return ERH_OK;
+    const int nc = (int)h->dir_cnt_h.size();
+    const int d = h->d;
+    h->blocks.lo.assign(nc, 0); h->blocks.n.assign(nc, 0); h->blocks.mul.assign(nc, 1); h->blocks.inv.assign(nc, 1);
+    bool any = false;
+    for (int c = 0; c < nc; ++c) {
+        const int64_t cnt = h->dir_cnt_h[c], lo = h->dir_lo_h[c], hi = h->dir_hi_h[c];
+        if (cnt >= h->opt_dir_block_min_rows && hi - lo == cnt && hi <= h->N) { h->blocks.lo[c] = lo; h->blocks.n[c] = cnt; any = true; }
+    }
+    if (any) {
+        HIPCHK(h, h->Xb.ensure((size_t)(h->N + erh::kDensePadRows) * d * 2));
+        HIPCHK(h, hipMemsetAsync(h->Xb.as<char>() + (size_t)h->N * d * 2, 0, (size_t)erh::kDensePadRows * d * 2, st));
+        for (int c = 0; c < nc; ++c) {
+            const int64_t cnt = h->blocks.n[c];
+            if (!cnt) continue;
+            int64_t mul = 1, inv = 1;
+            if (h->opt_dense_shuffle && cnt > 2) choose_placement(cnt, &mul, &inv);
+            h->blocks.mul[c] = mul; h->blocks.inv[c] = inv;
+            HIPCHK(h, h->blk_tmp.ensure((size_t)cnt * d * 2));
+            HIPCHK(h, erh::launch_gather_rows(h->X.as<_Float16>(), h->blocks.lo[c], cnt, d, h->pos_mul, h->N, h->blk_tmp.as<_Float16>(), st));
+            HIPCHK(h, erh::launch_permute_rows(h->blk_tmp.as<_Float16>(), cnt, d, h->Xb.as<_Float16>() + (size_t)h->blocks.lo[c] * d, 0, mul, cnt, st));
+        }
+        HIPCHK(h, hipStreamSynchronize(st));
+        h->blk_tmp.release();
+    }
+    h->blocks.valid = true;
+    return ERH_OK;
+}
+
+// Dense top-k with the dir filter pushed down as a ROW RANGE where it can be: the batch's queries are grouped by filter class; a
+// class whose documents are one block scans that block's copy (n_c rows, no filter, ids shifted by the block's first document),
+// everything else -- unfiltered queries, scattered or small classes -- runs the ordinary call with its filter column.  Each group is
+// completed (erh_dense_check's work) before its rows are scattered to the caller's order.  filter_host: the caller's host column.
+int dense_topk_routed(erh_handle *h, const void *q_dev, int q_dtype, int normalize_q, int B, int k, const int16_t *filter_host,
+                      const int16_t *filter_dev, int mode, int32_t *d_ids, double *d_sc, int32_t *d_len, hipStream_t st) {
+    const int nc = (int)h->dir_cnt_h.size();
+    h->routed_pending = false;
+    bool route = h->opt_dense_dir_blocks && filter_host && filter_dev && h->has_dir && nc > 0 && h->Nmeta == h->N && h->opt_dense_ablate == 0;
+    std::map<int, std::vector<int32_t>> groups;
+    if (route) {
+        if (!h->blocks.valid) { int rc = ensure_dense_blocks(h, st); if (rc != ERH_OK) return rc; }
+        bool any_block = false;
+        for (int b = 0; b < B; ++b) {
+            const int f = filter_host[b];
+            const bool blk = f >= 0 && f < nc && h->blocks.n[f] > 0;
+            any_block = any_block || blk;
+            groups[blk ? f : -1].push_back(b);
+        }
+        // every group is a pipeline of its own (a dozen launches and a synchronisation): worth it for a handful of dirs per batch
+        route = any_block && groups.size() <= (size_t)kRoutedGroupsMax;
+    }
+    if (!route) return dense_topk_dev(h, q_dev, q_dtype, normalize_q, B, k, filter_dev, mode, d_ids, d_sc, d_len, st);
+    const size_t row_bytes = (size_t)h->d * (q_dtype == ERH_F16 ? 2 : 4);
+    HIPCHK(h, h->r_idx.ensure((size_t)B * 4));
+    HIPCHK(h, h->r_q.ensure((size_t)B * row_bytes));
+    HIPCHK(h, h->r_ids.ensure((size_t)B * k * 4));
+    HIPCHK(h, h->r_sc.ensure((size_t)B * k * 8));
+    HIPCHK(h, h->r_len.ensure((size_t)B * 4));
+    HIPCHK(h, h->r_filt.ensure((size_t)B * 2));
+    HIPCHK(h, h->r_flags.ensure((size_t)kRoutedGroupsMax * 16));
+    if (!h->r_flags_host) HIPCHK(h, hipHostMalloc(reinterpret_cast<void **>(&h->r_flags_host), (size_t)kRoutedGroupsMax * 16, hipHostMallocDefault));
+    erh_handle::Routed &R = h->routed;
+    R.groups.clear();
+    R.q_dtype = q_dtype; R.normalize_q = normalize_q; R.B = B; R.k = k; R.mode = mode;
+    R.d_ids = d_ids; R.d_sc = d_sc; R.d_len = d_len;
+    h->r_idx_host.clear();
+    h->r_filt_host.clear();
+    for (auto &g : groups) {
+        bool any_filter = false;
+        for (int32_t b : g.second) any_filter = any_filter || filter_host[b] >= 0;
+        // (c = -2: the ordinary group without any filter value -- no filter column at all)
+        R.groups.push_back({g.first >= 0 ? g.first : (any_filter ? -1 : -2), (int)h->r_idx_host.size(), (int)g.second.size()});
+        for (int32_t b : g.second) { h->r_idx_host.push_back(b); h->r_filt_host.push_back(filter_host[b]); }
+    }
+    HIPCHK(h, hipMemcpyAsync(h->r_idx.p, h->r_idx_host.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(h, hipMemcpyAsync(h->r_filt.p, h->r_filt_host.data(), (size_t)B * 2, hipMemcpyHostToDevice, st));
+    // the batch in group order: a copy of the library's own, so a group can be run again at erh_dense_check time
+    HIPCHK(h, erh::launch_gather_query_rows(q_dev, h->r_idx.as<int32_t>(), B, (int)row_bytes, h->r_q.p, st));
+    for (size_t gi = 0; gi < R.groups.size(); ++gi) {
+        int rc = routed_group_run(h, R.groups[gi], st);
+        if (rc != ERH_OK) return rc;
+        // the group's flag words, kept aside (the next group's query preparation clears them): read all at once in dense_check_flags
+        HIPCHK(h, hipMemcpyAsync(h->r_flags.as<char>() + gi * 16, h->flags.p, 16, hipMemcpyDeviceToDevice, st));
+        rc = routed_group_scatter(h, R.groups[gi], st);
+        if (rc != ERH_OK) return rc;
+        h->stats.dense_block_groups += (R.groups[gi].c >= 0);
+    }
+    h->last = erh_handle::LastDense();
+    h->last.B = B; h->last.k = k; h->last.d_ids = d_ids; h->last.d_sc = d_sc; h->last.d_len = d_len;   // (a fused call's RRF redo reads these)
+    h->routed_done = true;
+    h->routed_pending = true;
     return ERH_OK;
 }
 
@@ -837,8 +1039,9 @@ int erh_destroy(erh_handle *h) {
                       &h->o_ids, &h->o_sc, &h->o_len, &h->qptr, &h->qtok, &h->part_sc, &h->part_ids, &h->part_len,
                       &h->hy_sids, &h->hy_ssc, &h->hy_slen, &h->hy_dids, &h->hy_dsc, &h->hy_dlen,
                       &h->fa_ids, &h->fa_sc, &h->fa_len, &h->fb_ids, &h->fb_sc, &h->fb_len,
-                      &h->scores_tmp, &h->scores_wide, &h->dbg, &h->dstats, &h->dir_pos, &h->seed_need, &h->bad, &h->ex_ws, &h->bm_redo, &h->fin_ws, &h->dir_rng};
+                      &h->scores_tmp, &h->scores_wide, &h->dbg, &h->dstats, &h->dir_pos, &h->seed_need, &h->bad, &h->ex_ws, &h->bm_redo, &h->fin_ws, &h->dir_rng, &h->Xb, &h->blk_tmp, &h->r_idx, &h->r_q, &h->r_ids, &h->r_sc, &h->r_len, &h->r_filt, &h->r_flags};
     for (DevBuf *b : bufs) b->release();
+    if (h->r_flags_host) (void)hipHostFree(h->r_flags_host);
     for (auto &b : h->bm) b.release();
     if (h->comm || h->comm_pending) (void)erh_comm_destroy(h);
     h->gather_send.release();
@@ -873,6 +1076,8 @@ int erh_set_option(erh_handle *h, const char *name, int64_t value) {
         h->n_cus = value == 0 ? h->n_cus_dev : (int)value;
         return ERH_OK;
     }
+    if (!strcmp(name, "dense_dir_blocks")) { h->opt_dense_dir_blocks = value != 0; return ERH_OK; }
+    if (!strcmp(name, "dense_dir_block_min_rows")) { if (value < 1) return h->fail(ERH_ERR_INVALID, "dense_dir_block_min_rows"); h->opt_dir_block_min_rows = value; h->blocks.valid = false; return ERH_OK; }
     if (!strcmp(name, "bm25_dir_range")) { h->opt_bm25_dir_range = value != 0; return ERH_OK; }
     if (!strcmp(name, "dense_fin_split")) { h->opt_dense_fin_split = value != 0; return ERH_OK; }
     if (!strcmp(name, "dense_tile384")) { h->opt_dense_tile384 = value != 0; return ERH_OK; }
@@ -948,7 +1153,7 @@ int erh_reset_kernel_time(erh_handle *h) {
 
 int erh_dense_check(erh_handle *h, void *stream) {
     if (!h) return ERH_ERR_INVALID;
-    if (!h->flags.p || !h->last.valid) return ERH_OK;           // no dense route has run on this handle
+    if (!h->flags.p || (!h->last.valid && !h->routed_done)) return ERH_OK;           // no dense route has run on this handle
     HIPCHK(h, hipSetDevice(h->device));
     return dense_check_flags(h, (hipStream_t)stream);
 }
@@ -986,7 +1191,7 @@ int erh_get_stat(erh_handle *h, const char *name, int64_t *value) {
         {"dense_calls", T.dense_calls}, {"dense_scan_pp5_launches", T.dense_scan_pp5}, {"dense_scan_pp3_launches", T.dense_scan_pp3},
         {"dense_scan_gemv_launches", T.dense_scan_gemv}, {"dense_scan_tile_launches", T.dense_scan_tile},
         {"dense_sample_passes", T.dense_sample_passes}, {"dense_tile384_nomem", T.dense_tile384_nomem},
-        {"bm25_calls", T.bm25_calls}, {"hybrid_calls", T.hybrid_calls}};
+        {"bm25_calls", T.bm25_calls}, {"hybrid_calls", T.hybrid_calls}, {"dense_block_groups", T.dense_block_groups}};
     for (const auto &e : host)
         if (!strcmp(name, e.n)) { *value = e.v; return ERH_OK; }
     const int di = !strcmp(name, "dense_exhaustive_queries") ? 0 : !strcmp(name, "bm25_redo_segments") ? 1 : -1;
@@ -1031,6 +1236,8 @@ int erh_set_dense(erh_handle *h, const void *x, int64_t n, int d, int dtype, int
     h->xt384_valid = false;
     h->xt384_nomem = false;
     h->Xt384.release();
+    h->blocks.valid = false;
+    h->Xb.release();
     HIPCHK(h, h->X.ensure((size_t)(n + erh::kDensePadRows) * d * 2));   // zero rows behind the matrix: tiles may run past N
     HIPCHK(h, hipMemsetAsync(h->X.as<char>() + (size_t)n * d * 2, 0, (size_t)erh::kDensePadRows * d * 2, st_pad));
     const hipMemcpyKind kind = is_device_ptr ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
@@ -1074,6 +1281,7 @@ int erh_set_dense(erh_handle *h, const void *x, int64_t n, int d, int dtype, int
     h->xnorm_max = xn;
     h->N = n;
     h->d = d;
+    h->view_global();
     // tiled copy for the ping-pong scan (dense_scan.hip: dense_tile_rows_kernel); d / 32 >= 8 stages as the kernel wants
     h->xt384_valid = false;                // (the 384-row copy is rebuilt on first use)
     h->xt_valid = false;
@@ -1486,6 +1694,8 @@ int erh_set_doc_meta(erh_handle *h, int64_t N, const int32_t *content_id, const 
         HIPCHK(h, hipMemcpy(h->content_id.p, content_id, (size_t)N * 4, hipMemcpyHostToDevice));
     }
     h->dir_rng_n = 0;
+    h->blocks.valid = false;
+    h->dir_lo_h.clear(); h->dir_hi_h.clear(); h->dir_cnt_h.clear();
     if (dir_id) {
         HIPCHK(h, h->dir_id.ensure((size_t)N * 2));
         HIPCHK(h, hipMemcpy(h->dir_id.p, dir_id, (size_t)N * 2, hipMemcpyHostToDevice));
@@ -1503,6 +1713,9 @@ int erh_set_doc_meta(erh_handle *h, int64_t N, const int32_t *content_id, const 
                 rng[2 * c + 1] = (int32_t)i + 1;
             }
             for (int c = 0; c <= maxc; ++c) if (rng[2 * c + 1] == 0) rng[2 * c] = 0;
+            h->dir_lo_h.assign((size_t)maxc + 1, 0); h->dir_hi_h.assign((size_t)maxc + 1, 0); h->dir_cnt_h.assign((size_t)maxc + 1, 0);
+            for (int c = 0; c <= maxc; ++c) { h->dir_lo_h[c] = rng[2 * c]; h->dir_hi_h[c] = rng[2 * c + 1]; }
+            for (int64_t i = 0; i < N; ++i) if (dir_id[i] >= 0) h->dir_cnt_h[dir_id[i]] += 1;
             HIPCHK(h, h->dir_rng.ensure(rng.size() * 4));
             HIPCHK(h, hipMemcpy(h->dir_rng.p, rng.data(), rng.size() * 4, hipMemcpyHostToDevice));
             h->dir_rng_n = maxc + 1;
@@ -1575,7 +1788,7 @@ int erh_dense_topk(erh_handle *h, const void *q, int q_dtype, int q_is_device, i
         d_ids = h->o_ids.as<int32_t>(); d_sc = h->o_sc.as<double>(); d_len = h->o_len.as<int32_t>();
     }
     h->stats.dense_calls += 1;
-    rc = dense_topk_dev(h, qd, q_dtype, normalize_q, B, k, filt, mode, d_ids, d_sc, d_len, st);
+    rc = dense_topk_routed(h, qd, q_dtype, normalize_q, B, k, filter_dir, filt, mode, d_ids, d_sc, d_len, st);
     if (rc != ERH_OK) return rc;
     if (!out_is_device) {
         rc = dense_check_flags(h, st);                  // (may run further exhaustive rounds before the copy)
@@ -1772,8 +1985,8 @@ int erh_hybrid_topk(erh_handle *h, const void *q, int q_dtype, int q_is_device, 
         if (rc != ERH_OK) { if (st_sparse != st) (void)hipStreamSynchronize(st_sparse); return rc; }
     }
     h->fork_after_scan = (ov == 2);
-    rc = dense_topk_dev(h, qd, q_dtype, normalize_q, B, k_dense, filt_d, ERH_DENSE_EXACT, h->hy_dids.as<int32_t>(),
-                        h->hy_dsc.as<double>(), h->hy_dlen.as<int32_t>(), st);
+    rc = dense_topk_routed(h, qd, q_dtype, normalize_q, B, k_dense, filter_dense, filt_d, ERH_DENSE_EXACT, h->hy_dids.as<int32_t>(),
+                           h->hy_dsc.as<double>(), h->hy_dlen.as<int32_t>(), st);
     h->fork_after_scan = false;
     if (ov == 2) {                                   // fork behind the dense scan: the sparse route runs beside the selection kernels
         if (rc != ERH_OK) return rc;

@@ -113,6 +113,10 @@ hipError_t launch_dense_finalize(int B, int k, int mode, const float *qnorm, flo
                                  double *ws_s64 /* null, or dense_finalize_split_max() x kDenseRescoreMax doubles */,
                                  uint32_t *ws_sync /* null, or 2 x dense_finalize_split_max() words, zero between calls */, hipStream_t st);
 int dense_finalize_split_max();
+// dense calls routed by dir block: gather the rows idx[0..n) of a query block (row_bytes % 16 == 0), scatter a group's results back
+hipError_t launch_gather_query_rows(const void *q, const int32_t *idx, int n, int row_bytes, void *out, hipStream_t st);
+hipError_t launch_scatter_topk_rows(const int32_t *ids, const double *sc, const int32_t *len, const int32_t *idx, int n, int k,
+                                    int32_t id_offset, int32_t *out_ids, double *out_sc, int32_t *out_len, hipStream_t st);
 // Exhaustive path for the queries flagged in bad[] (select.hip): exact fp64 scores of every chunk + streaming top-k.
 int dense_exhaustive_max();
 size_t dense_exhaustive_bytes(int64_t N);

@@ -7,6 +7,8 @@
 // (a valid lower bound of the k-th best fp32 score) - margin, margin = 2*delta(q),
 // delta(q) = d * 2^-23 * ||q|| * max_i ||x_i|| >= |fp32 score - exact score| for any summation order.
 // Everything that survives is ranked by (fp64 score desc, index asc) in EXACT mode.
+#include <algorithm>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -393,6 +395,32 @@ __global__ __launch_bounds__(kSelThreads) void cand_refine_kernel(
         mine[i] = e;
     }
     if (tid == 0) { cand_cnt[q] = (uint32_t)m; tau[q] = t_new; }
+}
+
+// ---- dense calls routed by dir block (api.hip: dense_topk_routed): the queries of one group gathered into a contiguous block, and
+// the group's results scattered back to the caller's rows with the block's first document added to the ids --------------------
+__global__ __launch_bounds__(256) void gather_query_rows_kernel(const int4 *__restrict__ q, const int32_t *__restrict__ idx, int n,
+                                                               int row_vec /* 16-byte pieces per row */, int4 *__restrict__ out) {
+    const int64_t total = (int64_t)n * row_vec;
+    for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (int64_t)gridDim.x * 256) {
+        const int r = (int)(o / row_vec), c = (int)(o - (int64_t)r * row_vec);
+        out[o] = q[(int64_t)idx[r] * row_vec + c];
+    }
+}
+
+__global__ __launch_bounds__(256) void scatter_topk_rows_kernel(const int32_t *__restrict__ ids, const double *__restrict__ sc,
+                                                               const int32_t *__restrict__ len, const int32_t *__restrict__ idx, int n,
+                                                               int k, int32_t id_offset, int32_t *__restrict__ out_ids,
+                                                               double *__restrict__ out_sc, int32_t *__restrict__ out_len) {
+    const int64_t total = (int64_t)n * k;
+    for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (int64_t)gridDim.x * 256) {
+        const int r = (int)(o / k), c = (int)(o - (int64_t)r * k);
+        const int64_t dst = (int64_t)idx[r] * k + c;
+        const int32_t id = ids[o];
+        out_ids[dst] = id >= 0 ? id + id_offset : id;
+        out_sc[dst] = sc[o];
+        if (c == 0) out_len[idx[r]] = len[r];
+    }
 }
 
 // ---- final: select, pinned fp64 re-score of the margin set, rank, emit ------------------------------------------
@@ -942,6 +970,24 @@ hipError_t launch_dense_finalize(int B, int k, int mode, const float *qnorm, flo
     else if (d <= 1024) ERH_FIN_LAUNCH(2);
     else ERH_FIN_LAUNCH(4);
 #undef ERH_FIN_LAUNCH
+    return hipGetLastError();
+}
+
+hipError_t launch_gather_query_rows(const void *q, const int32_t *idx, int n, int row_bytes, void *out, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    if (row_bytes % 16 != 0) return hipErrorInvalidValue;
+    const int64_t total = (int64_t)n * (row_bytes / 16);
+    hipLaunchKernelGGL(gather_query_rows_kernel, dim3((unsigned)std::min<int64_t>(4096, (total + 255) / 256)), dim3(256), 0, st,
+                       (const int4 *)q, idx, n, row_bytes / 16, (int4 *)out);
+    return hipGetLastError();
+}
+
+hipError_t launch_scatter_topk_rows(const int32_t *ids, const double *sc, const int32_t *len, const int32_t *idx, int n, int k,
+                                    int32_t id_offset, int32_t *out_ids, double *out_sc, int32_t *out_len, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    const int64_t total = (int64_t)n * k;
+    hipLaunchKernelGGL(scatter_topk_rows_kernel, dim3((unsigned)std::min<int64_t>(4096, (total + 255) / 256)), dim3(256), 0, st, ids,
+                       sc, len, idx, n, k, id_offset, out_ids, out_sc, out_len);
     return hipGetLastError();
 }
 

@@ -329,6 +329,11 @@ int erh_reset_kernel_time(erh_handle *h);
  *   bm25_dir_range (1)    fixed-point scan with a dir filter: the query walks only the posting tiles that hold documents of its class
  *                         (erh_set_doc_meta records every class's first and last document; the reference's dirs are contiguous blocks
  *                         of its document order, so a filter on one of four dirs skips three quarters of the tile passes); 0 = all tiles
+ *   dense_dir_blocks (1)  dense route with a dir filter: queries whose dir is one block of consecutive documents scan a copy of that
+ *                         block (own row placement, built on the first filtered call, + 2 d bytes per chunk) instead of the whole
+ *                         matrix with a filter column -- the batch is grouped by dir on the host, up to 8 groups per call, each
+ *                         completed before its rows go back to the caller's order; 0 = always the filter column.  Same results
+ *   dense_dir_block_min_rows (4096)  smallest dir that gets a block of its own
  *   bm25_post16 (1)       packed shape: read 4-byte postings {15-bit document offset in the tile, 16-bit payload} (built when an
  *                         index is set while bm25_small = 2; + 4 bytes per posting); 0 = the 8-byte fixed-point postings
  *   bm25_crossing (1)     wave-owned scan: survivors from threshold crossings noted in the token loop instead of a sweep
@@ -378,6 +383,7 @@ int erh_dense_exhaustive_count(erh_handle *h, int32_t *count);
  *   dense_sample_passes                                threshold samples drawn by the scan kernel itself (dense_selfseed)
  *   dense_tile384_nomem                                times the 384-row copy of the chunk matrix did not fit and the 256 x 256 scan took over
  *   dense_exhaustive_queries                           queries answered by the exhaustive path (device counter; summed over calls)
+ *   dense_block_groups                                 query groups answered from their dir's block (dense_dir_blocks)
  *   bm25_redo_segments                                 (query, segment) pairs the fixed-point scan handed to the exact block scan (device counter)
  * Reading a device counter synchronises the device.  Unknown name: ERH_ERR_INVALID. */
 int erh_get_stat(erh_handle *h, const char *name, int64_t *value);

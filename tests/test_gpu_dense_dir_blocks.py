@@ -1,0 +1,229 @@
+"""GPU parity, dense route with the `dir` filter pushed down as a ROW RANGE (round 5).
+
+The reference filters every real query on its document directory (retrievers.py:148-166 builds the qdrant `must` filter from
+`filter_dict`; pipeline/rag.py sets it per query from the question's "document" field), and its loader walks the directories
+one after the other, so each dir is one block of consecutive chunks.  libeasyrag_hip keeps a copy of every such block with
+the block's own row placement and lets a filtered query scan its block only; the results must be what the filter column on
+the whole matrix gives (dense_dir_blocks = 0, itself checked against the oracle's masked ranking throughout the suite) and what
+the oracle gives: ids in the caller's numbering, fp64 scores bit for bit, canonical ties.
+"""
+import numpy as np
+import pytest
+
+from oracle import dense_exact_topk, to_f16_unit
+
+pytestmark = pytest.mark.gpu
+
+
+def _blocks(sizes):
+    return np.repeat(np.arange(len(sizes)), sizes).astype(np.int16)
+
+
+def _same(a, b):
+    (ia, sa, la), (ib, sb, lb) = a, b
+    assert np.array_equal(la, lb)
+    for i in range(len(la)):
+        assert np.array_equal(ia[i, :la[i]], ib[i, :lb[i]]), i
+        assert np.array_equal(sa[i, :la[i]].view(np.uint64), sb[i, :lb[i]].view(np.uint64)), i
+
+
+def _check_oracle(x, q16, k, dir_id, filt, got, rows):
+    ids, sc, ln = got
+    for i in rows:
+        mask = None if filt[i] < 0 else dir_id == filt[i]
+        oid, osc = dense_exact_topk(x, q16[i], k, mask)
+        assert ln[i] == len(oid), i
+        assert np.array_equal(ids[i, :ln[i]], oid), i
+        assert np.array_equal(sc[i, :ln[i]].view(np.uint64), osc.view(np.uint64)), i
+
+
+@pytest.fixture
+def blocks_opts(engine):
+    yield engine
+    engine.set_option("dense_dir_blocks", 1)
+    engine.set_option("dense_dir_block_min_rows", 4096)
+    engine.set_option("dense_shuffle", 1)
+
+
+def test_blocks_mixed_batch_against_oracle(blocks_opts):
+    """Four dirs of uneven size (one below the block minimum), a batch mixing all of them with unfiltered queries: three block
+    groups + one ordinary group with a filter column, scattered back to the caller's order."""
+    engine = blocks_opts
+    rng = np.random.default_rng(501)
+    sizes = [5000, 12000, 3000, 20000]
+    n, d, b, k = sum(sizes), 128, 48, 50
+    x = to_f16_unit(rng.standard_normal((n, d)) + 0.4 * rng.standard_normal(d))
+    q16 = to_f16_unit(x[rng.integers(0, n, b)].astype(np.float32) + 0.3 * rng.standard_normal((b, d)))
+    dir_id = _blocks(sizes)
+    filt = rng.integers(-1, 4, b).astype(np.int16)
+    filt[:5] = [-1, 0, 1, 2, 3]
+    engine.set_dense(x)
+    engine.set_doc_meta(n, None, dir_id)
+    engine.set_option("dense_dir_blocks", 0)
+    plain = engine.dense_topk(q16, k, filter_dir=filt)
+    engine.set_option("dense_dir_blocks", 1)
+    engine.reset_stats()
+    routed = engine.dense_topk(q16, k, filter_dir=filt)
+    assert engine.stat("dense_block_groups") == 3                 # dirs 0, 1, 3; dir 2 (3000 rows) rides with the unfiltered queries
+    assert engine.dense_diag()["uncertified"] == 0
+    _same(plain, routed)
+    _check_oracle(x, q16, k, dir_id, filt, routed, range(b))
+    # device outputs: complete after dense_check, identical
+    import torch
+    out = engine.dense_topk(torch.from_numpy(q16).cuda(), k, device_out=True, filter_dir=filt)
+    engine.dense_check()
+    dev = tuple(t.cpu().numpy() for t in out)
+    _same(routed, dev)
+    # a second matrix on the same handle: the blocks follow it
+    x2 = to_f16_unit(rng.standard_normal((n, d)))
+    engine.set_dense(x2)
+    engine.set_doc_meta(n, None, dir_id)
+    again = engine.dense_topk(q16, k, filter_dir=filt)
+    _check_oracle(x2, q16, k, dir_id, filt, again, (0, 1, 2, 3, 4, b - 1))
+
+
+def test_blocks_ties_across_blocks_and_tiny_blocks(blocks_opts):
+    """The same 300 chunks repeated in every block (exact ties between blocks and inside them; ids must stay inside the asked
+    block, lowest first), blocks smaller than k (the list is the block) and of one row, with the block minimum lowered to 1."""
+    engine = blocks_opts
+    rng = np.random.default_rng(502)
+    d, k = 64, 40
+    base = to_f16_unit(rng.standard_normal((300, d)))
+    sizes = [1, 30, 300, 900, 2400]
+    x = np.concatenate([np.tile(base, (max(1, s // 300), 1))[:s] if s >= 300 else base[:s] for s in sizes])
+    n = x.shape[0]
+    assert n == sum(sizes)
+    dir_id = _blocks(sizes)
+    b = 20
+    q16 = to_f16_unit(base[rng.integers(0, 300, b)].astype(np.float32) + 0.05 * rng.standard_normal((b, d)))
+    filt = (np.arange(b) % 5).astype(np.int16)
+    engine.set_option("dense_dir_block_min_rows", 1)
+    engine.set_dense(x)
+    engine.set_doc_meta(n, None, dir_id)
+    engine.reset_stats()
+    routed = engine.dense_topk(q16, k, filter_dir=filt)
+    assert engine.stat("dense_block_groups") == 5
+    ids, sc, ln = routed
+    assert list(ln[:5]) == [1, 30, 40, 40, 40]
+    _check_oracle(x, q16, k, dir_id, filt, routed, range(b))
+    engine.set_option("dense_dir_blocks", 0)
+    _same(engine.dense_topk(q16, k, filter_dir=filt), routed)
+
+
+def test_blocks_exhaustive_path_inside_a_block(blocks_opts):
+    """A block that is one chunk 6000 times: every candidate budget overflows on ties, the group's queries take the exhaustive
+    path INSIDE the block (its rows, its ids shifted by the block's first document)."""
+    engine = blocks_opts
+    rng = np.random.default_rng(503)
+    d, k = 128, 64
+    a = to_f16_unit(rng.standard_normal((5000, d)))
+    one = to_f16_unit(rng.standard_normal((1, d)))
+    c = to_f16_unit(rng.standard_normal((7000, d)))
+    x = np.concatenate([a, np.repeat(one, 6000, axis=0), c])
+    n = x.shape[0]
+    dir_id = _blocks([5000, 6000, 7000])
+    b = 9
+    q16 = to_f16_unit(one.astype(np.float32) + 0.2 * rng.standard_normal((b, d)))
+    filt = np.array([1, 1, 1, 0, 2, 1, -1, 0, 2], np.int16)
+    engine.set_dense(x)
+    engine.set_doc_meta(n, None, dir_id)
+    routed = engine.dense_topk(q16, k, filter_dir=filt)
+    diag = engine.dense_diag()
+    assert diag["uncertified"] == 0 and diag["exhaustive"] >= 4    # the four queries of dir 1 at least (the unfiltered one sees the ties too)
+    ids, sc, ln = routed
+    for i in np.flatnonzero(filt == 1):
+        assert np.array_equal(ids[i], np.arange(5000, 5000 + k))   # all ties: lowest ids of the block
+    _check_oracle(x, q16, k, dir_id, filt, routed, range(b))
+    # device outputs: the flagged group is run again inside erh_dense_check
+    import torch
+    from easyrag_amd import synth
+    from easyrag_amd.engine import queries_to_csr
+    from easyrag_amd.index import BM25S, build_bm25_index_from_postings
+    out = engine.dense_topk(torch.from_numpy(q16).cuda(), k, device_out=True, filter_dir=filt)
+    engine.dense_check()
+    assert engine.dense_diag()["exhaustive"] == diag["exhaustive"]
+    _same(routed, tuple(t.cpu().numpy() for t in out))
+    # the fused call on top: its RRF is redone over the corrected dense lists (host and device outputs, against the filter column)
+    dev = torch.device("cuda", 0)
+    indptr, doc, tf, lens, flat = synth.token_csr_torch(n, 4096, seed=9, device=dev)
+    engine.set_bm25(build_bm25_index_from_postings(indptr, doc, tf, lens, BM25S, compute_payload=False), payload_on_device=True)
+    csr = queries_to_csr(synth.token_queries(flat, lens, 4096, b, seed=90))
+    engine.set_option("dense_dir_blocks", 0)
+    want = engine.hybrid_topk(q16, *csr, k_dense=k, k_sparse=50, K=60, topk=10, filter_dir=filt)
+    engine.set_option("dense_dir_blocks", 1)
+    got = engine.hybrid_topk(q16, *csr, k_dense=k, k_sparse=50, K=60, topk=10, filter_dir=filt)
+    out = engine.hybrid_topk(torch.from_numpy(q16).cuda(), *csr, k_dense=k, k_sparse=50, K=60, topk=10, filter_dir=filt, device_out=True)
+    engine.dense_check()
+    for a_, b_, c_ in zip(want, got, out):
+        a_, b_, c_ = np.asarray(a_), np.asarray(b_), c_.cpu().numpy()
+        assert np.array_equal(a_.view(np.uint64) if a_.dtype == np.float64 else a_, b_.view(np.uint64) if b_.dtype == np.float64 else b_)
+        assert np.array_equal(a_.view(np.uint64) if a_.dtype == np.float64 else a_, c_.view(np.uint64) if c_.dtype == np.float64 else c_)
+
+
+def test_blocks_not_used_for_scattered_dirs_or_many_groups(blocks_opts):
+    """Interleaved dirs (i % 4) are no blocks; twelve dirs in one batch are more groups than the route takes: both answer through
+    the filter column, with the same results."""
+    engine = blocks_opts
+    rng = np.random.default_rng(504)
+    n, d, b, k = 30000, 64, 36, 25
+    x = to_f16_unit(rng.standard_normal((n, d)))
+    q16 = to_f16_unit(rng.standard_normal((b, d)))
+    engine.set_option("dense_dir_block_min_rows", 1)
+    engine.set_dense(x)
+    dir_id = (np.arange(n) % 4).astype(np.int16)
+    engine.set_doc_meta(n, None, dir_id)
+    filt = (np.arange(b) % 4).astype(np.int16)
+    engine.reset_stats()
+    got = engine.dense_topk(q16, k, filter_dir=filt)
+    assert engine.stat("dense_block_groups") == 0
+    _check_oracle(x, q16, k, dir_id, filt, got, (0, 1, 2, 3, b - 1))
+    dir_id = _blocks([2500] * 12)
+    engine.set_doc_meta(n, None, dir_id)
+    filt = (np.arange(b) % 12).astype(np.int16)
+    got = engine.dense_topk(q16, k, filter_dir=filt)
+    assert engine.stat("dense_block_groups") == 0
+    _check_oracle(x, q16, k, dir_id, filt, got, (0, 5, 11, b - 1))
+    filt = (np.arange(b) % 3 + 4).astype(np.int16)                 # three of the twelve: routed
+    got = engine.dense_topk(q16, k, filter_dir=filt)
+    assert engine.stat("dense_block_groups") == 3
+    _check_oracle(x, q16, k, dir_id, filt, got, (0, 1, 2, b - 1))
+
+
+def test_blocks_large_batch_and_hybrid(blocks_opts):
+    """640 queries over four blocks of 50000 chunks (groups of 160 queries on the 256 x 256 scan over 50000 rows each) against the
+    filter column on the 384 x 256 scan over all 200000 rows; the hybrid call on top of both gives the same fused lists."""
+    import torch
+    from easyrag_amd import synth
+    from easyrag_amd.engine import queries_to_csr
+    from easyrag_amd.index import BM25S, build_bm25_index_from_postings
+    engine = blocks_opts
+    n, d, b, k = 200_000, 256, 640, 288
+    dev = torch.device("cuda", 0)
+    xt = synth.dense_corpus_torch(n, d, seed=7, device=dev)
+    qt = synth.dense_queries_torch(xt, b, seed=70)
+    x = xt.cpu().numpy()
+    q16 = qt.cpu().numpy()
+    dir_id = _blocks([50000] * 4)
+    filt = ((np.arange(b) * 7) % 4).astype(np.int16)
+    engine.set_dense(xt)
+    engine.set_doc_meta(n, None, dir_id)
+    engine.set_option("dense_dir_blocks", 0)
+    plain = engine.dense_topk(q16, k, filter_dir=filt)
+    engine.set_option("dense_dir_blocks", 1)
+    engine.reset_stats()
+    routed = engine.dense_topk(q16, k, filter_dir=filt)
+    assert engine.stat("dense_block_groups") == 4
+    assert engine.dense_diag()["uncertified"] == 0
+    _same(plain, routed)
+    _check_oracle(x, q16, k, dir_id, filt, routed, (0, 1, 2, 3, 317, b - 1))
+    indptr, doc, tf, lens, flat = synth.token_csr_torch(n, 32768, seed=8, device=dev)
+    engine.set_bm25(build_bm25_index_from_postings(indptr, doc, tf, lens, BM25S, compute_payload=False), payload_on_device=True)
+    csr = queries_to_csr(synth.token_queries(flat, lens, 32768, b, seed=80))
+    outs = []
+    for on in (0, 1):
+        engine.set_option("dense_dir_blocks", on)
+        outs.append(engine.hybrid_topk(q16, *csr, k_dense=288, k_sparse=192, K=60, topk=10, filter_dir=filt))
+    engine.set_option("dense_dir_blocks", 1)
+    for a, c in zip(outs[0], outs[1]):
+        a, c = np.asarray(a), np.asarray(c)
+        assert np.array_equal(a.view(np.uint64) if a.dtype == np.float64 else a, c.view(np.uint64) if c.dtype == np.float64 else c)
