@@ -361,11 +361,20 @@ def sub_benchmarks(eng, synth, queries_to_csr, build_index, OKAPI, q16_pool, tok
     eng.set_doc_meta(n_docs, None, (np.arange(n_docs) * 4 // n_docs).astype(np.int16))
     filt = (np.arange(int(q16_pool[0].shape[0])) % 4).astype(np.int16)
     try:
+        eng.reset_stats()
         out["hybrid_b1024_dir_filter"] = run_sub(
             eng, classes, lambda i: eng.hybrid_topk(q16_pool[i % pool], *csr_pool[i % pool], k_dense=288, k_sparse=192, K=60, topk=10,
                                                     device_out=True, filter_dir=filt), int(q16_pool[0].shape[0]), "dense_scan",
-            what="configs[3] with a per-query dir filter on both routes (4 dirs = 4 contiguous blocks of 250k chunks): the staged dense path "
-                 "(store kernel + seed select + filtered append scan on the 384 x 256 tile) and the BM25 scan over the tiles of the query's dir only")
+            what="configs[3] with a per-query dir filter on both routes (4 dirs = 4 contiguous blocks of 250k chunks): the dense route as 4 groups "
+                 "of 256 queries, each over its dir's block copy (dense_dir_blocks; store kernel + seed select + append scan on the 256 x 256 tile "
+                 "per group), the BM25 scan over the tiles of the query's dir only")
+        out["hybrid_b1024_dir_filter"]["dense_block_groups_per_step"] = eng.stat("dense_block_groups") / max(1, eng.stat("hybrid_calls"))
+        f1 = [filt[p % 4:p % 4 + 1].copy() for p in range(pool)]
+        out["hybrid_b1_dir_filter_latency"] = run_sub(
+            eng, classes, lambda i: eng.hybrid_topk(q1[i % pool], *csr1[i % pool], k_dense=288, k_sparse=192, K=60, topk=10,
+                                                    device_out=True, filter_dir=f1[i % pool]), 1, "dense_scan", sync_each=True, check_each=True,
+            what="one query per call WITH its dir filter (the reference's real call), dense(288)+BM25(192)+RRF top-10 over the dir's block and "
+                 "posting tiles, host-visible latency per call incl. erh_dense_check")
     finally:
         eng.set_doc_meta(n_docs, None, None)
     # the reference's own vector size (ref src/configs/easyrag.yaml:15-16: gte-Qwen2-7B, vector_size 3584): the same 2.05 GB of chunk

@@ -766,7 +766,17 @@ int ensure_dense_blocks(erh_handle *h, hipStream_t st) {
         if (cnt >= h->opt_dir_block_min_rows && hi - lo == cnt && hi <= h->N) { h->blocks.lo[c] = lo; h->blocks.n[c] = cnt; any = true; }
     }
     if (any) {
-        HIPCHK(h, h->Xb.ensure((size_t)(h->N + erh::kDensePadRows) * d * 2));
+        // The block copies are a second chunk matrix.  Like the 384-row copy: a corpus that leaves no room for it keeps the filter
+        // column (no blocks until the next erh_set_dense / erh_set_doc_meta); dense_tile384_max_mb bounds both copies (test hook).
+        const size_t want = (size_t)(h->N + erh::kDensePadRows) * d * 2;
+        const hipError_t ea = (h->opt_tile384_max_mb >= 0 && want > ((size_t)h->opt_tile384_max_mb << 20)) ? hipErrorOutOfMemory : h->Xb.ensure(want);
+        if (ea == hipErrorOutOfMemory) {
+            (void)hipGetLastError();
+            h->blocks.n.assign(nc, 0);
+            h->blocks.valid = true;
+            return ERH_OK;
+        }
+        HIPCHK(h, ea);
         HIPCHK(h, hipMemsetAsync(h->Xb.as<char>() + (size_t)h->N * d * 2, 0, (size_t)erh::kDensePadRows * d * 2, st));
         for (int c = 0; c < nc; ++c) {
             const int64_t cnt = h->blocks.n[c];
@@ -804,8 +814,25 @@ int dense_topk_routed(erh_handle *h, const void *q_dev, int q_dtype, int normali
             any_block = any_block || blk;
             groups[blk ? f : -1].push_back(b);
         }
-        // every group is a pipeline of its own (a dozen launches and a synchronisation): worth it for a handful of dirs per batch
         route = any_block && groups.size() <= (size_t)kRoutedGroupsMax;
+        // Every group is a pipeline of its own (a dozen launches), and a scan of few queries is bound by the matrix bytes, which the
+        // groups of one batch read one block each -- together the whole matrix again.  So the route pays where one group's block is a
+        // fraction of the matrix (one query, one dir per batch) or where the scan is MFMA-bound (groups of hundreds of queries), and
+        // loses in between (4 dirs x 4 ... 64 queries: +64 ... +70 % per call).  dense_dir_blocks = 1 decides by an estimate from the
+        // measured scan times of both shapes (profiles/r05y_ab_dir_blocks.log), = 2 always routes.
+        if (route && h->opt_dense_dir_blocks == 1) {
+            const double unit = (double)h->d / 1024.0 / 250000.0;         // the tables: ms per 250 000 rows x 1024 dims
+            const double per_group = 0.1;                                   // threshold + selection kernels and launches of one pipeline
+            auto block_ms = [](int n) { return n <= 8 ? 0.12 : n <= 16 ? 0.155 : n <= 64 ? 0.26 : 0.21 * ((n + 255) / 256); };
+            auto whole_ms = [](int n) { return n <= 16 ? 0.11 : n <= 64 ? 0.14 : n <= 256 ? 0.19 : 0.04 + 0.435 * ((n + 255) / 256) / 4.0; };
+            double routed_ms = 0;
+            for (auto &g : groups) {
+                const int n = (int)g.second.size();
+                routed_ms += per_group + (g.first >= 0 ? block_ms(n) * (double)h->blocks.n[g.first] : whole_ms(n) * (double)h->N) * unit;
+            }
+            const double plain_ms = per_group + whole_ms(B) * (double)h->N * unit;
+            route = routed_ms < 0.85 * plain_ms;
+        }
     }
     if (!route) return dense_topk_dev(h, q_dev, q_dtype, normalize_q, B, k, filter_dev, mode, d_ids, d_sc, d_len, st);
     const size_t row_bytes = (size_t)h->d * (q_dtype == ERH_F16 ? 2 : 4);
@@ -1076,7 +1103,7 @@ int erh_set_option(erh_handle *h, const char *name, int64_t value) {
         h->n_cus = value == 0 ? h->n_cus_dev : (int)value;
         return ERH_OK;
     }
-    if (!strcmp(name, "dense_dir_blocks")) { h->opt_dense_dir_blocks = value != 0; return ERH_OK; }
+    if (!strcmp(name, "dense_dir_blocks")) { if (value < 0 || value > 2) return h->fail(ERH_ERR_INVALID, "dense_dir_blocks"); h->opt_dense_dir_blocks = (int)value; return ERH_OK; }
     if (!strcmp(name, "dense_dir_block_min_rows")) { if (value < 1) return h->fail(ERH_ERR_INVALID, "dense_dir_block_min_rows"); h->opt_dir_block_min_rows = value; h->blocks.valid = false; return ERH_OK; }
     if (!strcmp(name, "bm25_dir_range")) { h->opt_bm25_dir_range = value != 0; return ERH_OK; }
     if (!strcmp(name, "dense_fin_split")) { h->opt_dense_fin_split = value != 0; return ERH_OK; }

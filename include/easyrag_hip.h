@@ -295,7 +295,8 @@ int erh_reset_kernel_time(erh_handle *h);
  *                         (dense_scan_pp5_kernel; the 384-row copy of the chunk matrix, + N * d * 2 bytes, is built on first use);
  *                         0 = the 256 x 256 tile for every batch size
  *   dense_tile384_max_mb (-1)  test hook: a 384-row copy larger than this many MiB is refused as if its allocation had failed
- *                         (the 256 x 256 scan then serves every batch; -1 = no limit)
+ *                         (the 256 x 256 scan then serves every batch; -1 = no limit); the per-dir block copies (dense_dir_blocks)
+ *                         obey the same bound and fall back the same way (to the filter column)
  *   dense_selfseed (1)    batches padded to >= 512 queries: the scan kernel draws the threshold sample itself (a pass without
  *                         thresholds over one tile per chunk stream, the two best scores of every 64-row cell) and then scans
  *                         all rows; 0 = store kernel + S0 + seed select for every batch size
@@ -331,8 +332,13 @@ int erh_reset_kernel_time(erh_handle *h);
  *                         of its document order, so a filter on one of four dirs skips three quarters of the tile passes); 0 = all tiles
  *   dense_dir_blocks (1)  dense route with a dir filter: queries whose dir is one block of consecutive documents scan a copy of that
  *                         block (own row placement, built on the first filtered call, + 2 d bytes per chunk) instead of the whole
- *                         matrix with a filter column -- the batch is grouped by dir on the host, up to 8 groups per call, each
- *                         completed before its rows go back to the caller's order; 0 = always the filter column.  Same results
+ *                         matrix with a filter column -- the batch is grouped by dir on the host, up to 8 groups per call, every
+ *                         group through the same kernels as a view, results back in the caller's order; the groups' flag words are
+ *                         read together by erh_dense_check / the host-output copy (a flagged group is run again to the end).
+ *                         1 = where an estimate from measured scan times says it pays (one query, one dir per batch, groups of
+ *                         hundreds of queries: 1024 queries over 4 dirs 2.72 -> 1.76 ms, one query 0.62 -> 0.30 ms; not 4 dirs x
+ *                         4 ... 64 queries, where every group re-reads a block and pays its own pipeline: +64 ... +70 %);
+ *                         2 = whenever the batch has a block dir; 0 = always the filter column.  Same results
  *   dense_dir_block_min_rows (4096)  smallest dir that gets a block of its own
  *   bm25_post16 (1)       packed shape: read 4-byte postings {15-bit document offset in the tile, 16-bit payload} (built when an
  *                         index is set while bm25_small = 2; + 4 bytes per posting); 0 = the 8-byte fixed-point postings

@@ -39,6 +39,7 @@ def _check_oracle(x, q16, k, dir_id, filt, got, rows):
 
 @pytest.fixture
 def blocks_opts(engine):
+    engine.set_option("dense_dir_blocks", 2)                        # every batch with a block dir takes the route (1 = by estimate)
     yield engine
     engine.set_option("dense_dir_blocks", 1)
     engine.set_option("dense_dir_block_min_rows", 4096)
@@ -61,7 +62,7 @@ def test_blocks_mixed_batch_against_oracle(blocks_opts):
     engine.set_doc_meta(n, None, dir_id)
     engine.set_option("dense_dir_blocks", 0)
     plain = engine.dense_topk(q16, k, filter_dir=filt)
-    engine.set_option("dense_dir_blocks", 1)
+    engine.set_option("dense_dir_blocks", 2)
     engine.reset_stats()
     routed = engine.dense_topk(q16, k, filter_dir=filt)
     assert engine.stat("dense_block_groups") == 3                 # dirs 0, 1, 3; dir 2 (3000 rows) rides with the unfiltered queries
@@ -150,7 +151,7 @@ def test_blocks_exhaustive_path_inside_a_block(blocks_opts):
     csr = queries_to_csr(synth.token_queries(flat, lens, 4096, b, seed=90))
     engine.set_option("dense_dir_blocks", 0)
     want = engine.hybrid_topk(q16, *csr, k_dense=k, k_sparse=50, K=60, topk=10, filter_dir=filt)
-    engine.set_option("dense_dir_blocks", 1)
+    engine.set_option("dense_dir_blocks", 2)
     got = engine.hybrid_topk(q16, *csr, k_dense=k, k_sparse=50, K=60, topk=10, filter_dir=filt)
     out = engine.hybrid_topk(torch.from_numpy(q16).cuda(), *csr, k_dense=k, k_sparse=50, K=60, topk=10, filter_dir=filt, device_out=True)
     engine.dense_check()
@@ -187,6 +188,17 @@ def test_blocks_not_used_for_scattered_dirs_or_many_groups(blocks_opts):
     got = engine.dense_topk(q16, k, filter_dir=filt)
     assert engine.stat("dense_block_groups") == 3
     _check_oracle(x, q16, k, dir_id, filt, got, (0, 1, 2, b - 1))
+    # no room for the block copies (the test hook that also bounds the 384-row copy): the filter column answers
+    engine.set_option("dense_tile384_max_mb", 0)
+    try:
+        engine.set_doc_meta(n, None, dir_id)
+        engine.reset_stats()
+        got = engine.dense_topk(q16, k, filter_dir=filt)
+        assert engine.stat("dense_block_groups") == 0
+        _check_oracle(x, q16, k, dir_id, filt, got, (0, 1, 2, b - 1))
+    finally:
+        engine.set_option("dense_tile384_max_mb", -1)
+        engine.set_doc_meta(n, None, dir_id)
 
 
 def test_blocks_large_batch_and_hybrid(blocks_opts):
@@ -209,7 +221,7 @@ def test_blocks_large_batch_and_hybrid(blocks_opts):
     engine.set_doc_meta(n, None, dir_id)
     engine.set_option("dense_dir_blocks", 0)
     plain = engine.dense_topk(q16, k, filter_dir=filt)
-    engine.set_option("dense_dir_blocks", 1)
+    engine.set_option("dense_dir_blocks", 2)
     engine.reset_stats()
     routed = engine.dense_topk(q16, k, filter_dir=filt)
     assert engine.stat("dense_block_groups") == 4
@@ -221,7 +233,7 @@ def test_blocks_large_batch_and_hybrid(blocks_opts):
     csr = queries_to_csr(synth.token_queries(flat, lens, 32768, b, seed=80))
     outs = []
     for on in (0, 1):
-        engine.set_option("dense_dir_blocks", on)
+        engine.set_option("dense_dir_blocks", 2 * on)
         outs.append(engine.hybrid_topk(q16, *csr, k_dense=288, k_sparse=192, K=60, topk=10, filter_dir=filt))
     engine.set_option("dense_dir_blocks", 1)
     for a, c in zip(outs[0], outs[1]):

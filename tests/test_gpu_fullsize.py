@@ -273,6 +273,56 @@ def test_hybrid_configs3_filters_and_duplicate_contents(engine, dense_data, spar
         engine.set_doc_meta(N, None, None)
 
 
+def test_hybrid_configs3_dir_blocks(engine, dense_data, sparse_data):
+    """The reference's real call pattern at full size: every query filtered on its document directory, the directories four
+    contiguous blocks of uneven size (400k / 350k / 150k / 100k chunks).  With the library's defaults the dense route answers
+    each dir's queries from that dir's block copy (dense_dir_blocks: 4 groups of 256 queries) and the BM25 scan walks the dir's
+    posting tiles only; the fused lists must be the oracle's for the sampled queries and, for all 1024, bit for bit what the
+    filter column over the whole matrix gives (dense_dir_blocks = 0).  One query per call takes the same route."""
+    import torch
+    x, q = dense_data
+    queries = sparse_data[4]
+    idx = host_index(sparse_data, BM25S)
+    dir_id = np.repeat(np.arange(4), [400_000, 350_000, 150_000, 100_000]).astype(np.int16)
+    assert dir_id.shape[0] == N
+    filt = (np.arange(1024) % 4).astype(np.int16)
+    sample = list(range(0, 1024, 41))[:24]
+    engine.set_dense(x)
+    engine.set_bm25(idx, payload_on_device=True)
+    engine.set_doc_meta(N, None, dir_id)
+    qi, qt = queries_to_csr(queries)
+    try:
+        engine.reset_stats()
+        ids, sc, ln = engine.hybrid_topk(q, qi, qt, k_dense=288, k_sparse=192, K=60, topk=10, filter_dir=filt)
+        assert engine.stat("dense_block_groups") == 4 and engine.stat("dense_scan_pp5_launches") == 0
+        assert engine.dense_diag()["uncertified"] == 0
+        allowed = [torch.from_numpy(dir_id == filt[b]).to(x.device) for b in sample]
+        dense_want = dense_oracle_topk(x, q[sample], 288, allowed)
+        for (did, dsc), b in zip(dense_want, sample):
+            sp = sparse_oracle_topk(idx, queries[b], 192, dir_id == filt[b])
+            want = reciprocal_rank_fusion([[Item(i, i, s) for i, s in sp],
+                                           [Item(int(i), int(i), float(s)) for i, s in zip(did, dsc)]], K=60, topk=10)
+            assert list(ids[b, :ln[b]]) == [w.idx for w in want], f"query {b}: fused ids differ"
+            assert list(sc[b, :ln[b]]) == [w.score for w in want], f"query {b}: fused scores differ"
+        d_ids, d_sc, d_ln = engine.dense_topk(q, 288, filter_dir=filt)
+        for (did, dsc), b in zip(dense_want, sample):
+            assert np.array_equal(d_ids[b, :d_ln[b]], did) and np.array_equal(d_sc[b, :d_ln[b]], dsc)
+        # one query per call: its dir's block only
+        engine.reset_stats()
+        for (did, dsc), b in list(zip(dense_want, sample))[:4]:
+            i1, s1, l1 = engine.dense_topk(q[b:b + 1], 288, filter_dir=filt[b:b + 1])
+            assert np.array_equal(i1[0, :l1[0]], did) and np.array_equal(s1[0, :l1[0]], dsc)
+        assert engine.stat("dense_block_groups") == 4
+        engine.set_option("dense_dir_blocks", 0)
+        ids0, sc0, ln0 = engine.hybrid_topk(q, qi, qt, k_dense=288, k_sparse=192, K=60, topk=10, filter_dir=filt)
+        p_ids, p_sc, p_ln = engine.dense_topk(q, 288, filter_dir=filt)
+        assert np.array_equal(ln0, ln) and np.array_equal(ids0, ids) and np.array_equal(sc0.view(np.uint64), sc.view(np.uint64))
+        assert np.array_equal(p_ln, d_ln) and np.array_equal(p_ids, d_ids) and np.array_equal(p_sc.view(np.uint64), d_sc.view(np.uint64))
+    finally:
+        engine.set_option("dense_dir_blocks", 1)
+        engine.set_doc_meta(N, None, None)
+
+
 # ---- the reference's own vector size: d = 3584 (ref:src/configs/easyrag.yaml:15-16, gte-Qwen2-7B-instruct) ------------------------
 N3584, D3584 = 285_696, 3584          # 744 x 384 rows x 3584 halves = 2.05 GB: the byte volume of the 1M x 1024 configurations
 
