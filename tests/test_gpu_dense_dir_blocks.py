@@ -83,6 +83,44 @@ def test_blocks_mixed_batch_against_oracle(blocks_opts):
     _check_oracle(x2, q16, k, dir_id, filt, again, (0, 1, 2, 3, 4, b - 1))
 
 
+def test_blocks_fp32_queries_fast_mode_and_device_inputs(blocks_opts):
+    """The other faces of erh_dense_topk through the route: fp32 queries normalised on the device (the gathered batch keeps the caller's
+    dtype), device-resident queries, and ERH_DENSE_FAST (ranked by the fp32 MFMA score: within 1e-3 of the exact list, ids inside
+    the asked dir)."""
+    import torch
+    from easyrag_amd import _lib
+    engine = blocks_opts
+    rng = np.random.default_rng(505)
+    sizes = [6000, 9000, 5000]
+    n, d, b, k = sum(sizes), 192, 21, 30
+    x32 = (rng.standard_normal((n, d)) * 2).astype(np.float32)
+    q32 = (x32[rng.integers(0, n, b)] + 0.8 * rng.standard_normal((b, d))).astype(np.float32) * 0.3
+    dir_id = _blocks(sizes)
+    filt = (np.arange(b) % 4 - 1).astype(np.int16)                  # -1 (no filter), 0, 1, 2
+    engine.set_dense(x32, normalize=True)
+    engine.set_doc_meta(n, None, dir_id)
+    engine.set_option("dense_dir_blocks", 0)
+    plain = engine.dense_topk(q32, k, filter_dir=filt, normalize_q=True)
+    engine.set_option("dense_dir_blocks", 2)
+    engine.reset_stats()
+    routed = engine.dense_topk(q32, k, filter_dir=filt, normalize_q=True)
+    assert engine.stat("dense_block_groups") == 3
+    _same(plain, routed)
+    dev_q = engine.dense_topk(torch.from_numpy(q32).cuda(), k, filter_dir=filt, normalize_q=True)
+    _same(plain, dev_q)
+    x16 = to_f16_unit(x32)
+    q16 = to_f16_unit(q32)
+    engine.set_dense(x16)                                           # (the host's rounding of the unit rows, as the oracle has them)
+    engine.set_doc_meta(n, None, dir_id)
+    _check_oracle(x16, q16, k, dir_id, filt, engine.dense_topk(q16, k, filter_dir=filt), range(b))
+    fids, fsc, fln = engine.dense_topk(q16, k, filter_dir=filt, mode=_lib.ERH_DENSE_FAST)
+    eids, esc, eln = engine.dense_topk(q16, k, filter_dir=filt)
+    assert np.array_equal(fln, eln)
+    for i in range(b):
+        assert np.max(np.abs(fsc[i] - esc[i])) < 1e-3 and len(set(fids[i]) & set(eids[i])) >= k - 2
+        assert filt[i] < 0 or np.all(dir_id[fids[i]] == filt[i])
+
+
 def test_blocks_ties_across_blocks_and_tiny_blocks(blocks_opts):
     """The same 300 chunks repeated in every block (exact ties between blocks and inside them; ids must stay inside the asked
     block, lowest first), blocks smaller than k (the list is the block) and of one row, with the block minimum lowered to 1."""
