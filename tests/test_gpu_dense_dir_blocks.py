@@ -277,3 +277,33 @@ def test_blocks_large_batch_and_hybrid(blocks_opts):
     for a, c in zip(outs[0], outs[1]):
         a, c = np.asarray(a), np.asarray(c)
         assert np.array_equal(a.view(np.uint64) if a.dtype == np.float64 else a, c.view(np.uint64) if c.dtype == np.float64 else c)
+
+
+@pytest.mark.parametrize("seed", [601, 602, 603, 604, 605, 606])
+def test_blocks_random_shapes_against_filter_column(blocks_opts, seed):
+    """Seeded random shapes -- 2 ... 7 dirs of 1 ... 9000 chunks (some below the block minimum, some empty classes in between), 1 ... 300
+    queries with k up to 300 and filter values that include none (-1), classes without documents and classes beyond the table: the route and
+    the filter column must agree on every list, bit for bit; a sample of the queries is checked against the oracle."""
+    engine = blocks_opts
+    rng = np.random.default_rng(seed)
+    n_dirs = int(rng.integers(2, 8))
+    sizes = [int(rng.choice([1, 40, 700, 3000, 9000])) for _ in range(n_dirs)]
+    labels = rng.permutation(n_dirs + 2)[:n_dirs]                    # class ids in any order, two ids of the range unused
+    dir_id = np.concatenate([np.full(s, l, np.int16) for s, l in zip(sizes, labels)])
+    n = int(dir_id.shape[0])
+    d = int(rng.choice([64, 128, 320]))
+    b = int(rng.choice([1, 7, 65, 300]))
+    k = int(rng.choice([1, 10, 100, 300]))
+    x = to_f16_unit(rng.standard_normal((n, d)) + 0.3 * rng.standard_normal(d))
+    q16 = to_f16_unit(x[rng.integers(0, n, b)].astype(np.float32) + 0.4 * rng.standard_normal((b, d)))
+    filt = rng.integers(-1, n_dirs + 4, b).astype(np.int16)
+    engine.set_option("dense_dir_block_min_rows", int(rng.choice([1, 500, 4096])))
+    engine.set_dense(x)
+    engine.set_doc_meta(n, None, dir_id)
+    engine.set_option("dense_dir_blocks", 0)
+    plain = engine.dense_topk(q16, k, filter_dir=filt)
+    engine.set_option("dense_dir_blocks", 2)
+    routed = engine.dense_topk(q16, k, filter_dir=filt)
+    assert engine.dense_diag()["uncertified"] == 0
+    _same(plain, routed)
+    _check_oracle(x, q16, k, dir_id, filt, routed, sorted(set([0, b // 2, b - 1])))
