@@ -269,14 +269,20 @@ def test_blocks_large_batch_and_hybrid(blocks_opts):
     indptr, doc, tf, lens, flat = synth.token_csr_torch(n, 32768, seed=8, device=dev)
     engine.set_bm25(build_bm25_index_from_postings(indptr, doc, tf, lens, BM25S, compute_payload=False), payload_on_device=True)
     csr = queries_to_csr(synth.token_queries(flat, lens, 32768, b, seed=80))
-    outs = []
-    for on in (0, 1):
-        engine.set_option("dense_dir_blocks", 2 * on)
-        outs.append(engine.hybrid_topk(q16, *csr, k_dense=288, k_sparse=192, K=60, topk=10, filter_dir=filt))
+    # the same filter on both routes, then a different dir per route and no filter on the sparse one (the reference keeps the two apart:
+    # filter_dict -> BM25, filters -> Qdrant; retrievers.py:278,283)
+    other = ((filt + 1) % 4).astype(np.int16)
+    for f_sparse, f_dense in ((filt, "same"), (filt, other), (None, other)):
+        outs = []
+        for on in (0, 1):
+            engine.set_option("dense_dir_blocks", 2 * on)
+            engine.reset_stats()
+            outs.append(engine.hybrid_topk(q16, *csr, k_dense=288, k_sparse=192, K=60, topk=10, filter_dir=f_sparse, filter_dense=f_dense))
+            assert engine.stat("dense_block_groups") == 4 * on
+        for a, c in zip(outs[0], outs[1]):
+            a, c = np.asarray(a), np.asarray(c)
+            assert np.array_equal(a.view(np.uint64) if a.dtype == np.float64 else a, c.view(np.uint64) if c.dtype == np.float64 else c)
     engine.set_option("dense_dir_blocks", 1)
-    for a, c in zip(outs[0], outs[1]):
-        a, c = np.asarray(a), np.asarray(c)
-        assert np.array_equal(a.view(np.uint64) if a.dtype == np.float64 else a, c.view(np.uint64) if c.dtype == np.float64 else c)
 
 
 @pytest.mark.parametrize("seed", [601, 602, 603, 604, 605, 606])
