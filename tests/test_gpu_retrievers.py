@@ -312,3 +312,60 @@ def test_vector_store_restart_round_trip(corpus, tmp_path):
     finally:
         for s in (first, second, third):
             s.engine.close()
+
+
+def test_hybrid_retriever_on_a_corpus_loaded_dir_by_dir(tokenizer):
+    """The reference's loader walks the document directories one after the other (ingestion.py:79-87), so the nodes of a dir are consecutive;
+    its pipeline then sets `filters` / `filter_dict` to the question's dir on every query (pipeline.py:301-312).  On such a corpus the dense
+    route answers from the dir's block copy (dense_dir_blocks; block minimum lowered to this corpus' size): same nodes and scores as the
+    oracle composition, for the single-query call the pipeline makes and for a batch."""
+    texts = make_text_corpus(1500, 150, seed=17)
+    sizes = {"umac": 600, "rcp": 500, "director": 250, "emsplus": 150}
+    dirs = np.repeat(list(sizes), list(sizes.values()))
+    nodes = [TextNode(text=t, metadata={"dir": str(dirs[i])}, id_=f"n{i}") for i, t in enumerate(texts)]
+    emb = FakeEmbedder()
+    vecs = np.asarray([emb.get_query_embedding("doc:" + t + str(i)) for i, t in enumerate(texts)], np.float32)
+    sparse = BM25Retriever.from_defaults(nodes=nodes, tokenizer=tokenizer, similarity_top_k=192, stopwords=STOP, bm25_type=0)
+    store = HipVectorStore(nodes, vecs, engine=sparse.engine)
+    dense = QdrantRetriever(store, emb, similarity_top_k=288)
+    eng = sparse.engine
+    eng.set_option("dense_dir_block_min_rows", 1)
+    eng.set_option("dense_dir_blocks", 2)
+    try:
+        x16 = to_f16_unit(vecs)
+        toks = [tokenize_and_remove_stopwords(tokenizer, n.get_content(), STOP) for n in nodes]
+        ora = BM25Okapi(toks, 1.5, 0.75, 0.25)
+        key = {}
+        cid = [key.setdefault(n.get_content(), i) for i, n in enumerate(nodes)]
+        hy = HybridRetriever(dense, sparse, retrieval_type=3, topk=50)
+        queries = ["w5 w9 w3", "w14 w2 w2 w60 w8", "w7 w30"]
+        for dname in ("rcp", "emsplus"):
+            hy.filter_dict, hy.filters = {"dir": dname}, {"dir": dname}
+            mask = dirs == dname
+            want_all = []
+            for query in queries:
+                q16 = to_f16_unit(np.asarray(emb.get_query_embedding(query), np.float32))
+                sp = bm25_filter(ora.get_scores(tokenize_and_remove_stopwords(tokenizer, query, STOP)), 192, mask)
+                did, dsc = dense_exact_topk(x16, q16, 288, mask)
+                want_all.append(reciprocal_rank_fusion([[Item(i, cid[i], s) for i, s in sp],
+                                                        [Item(int(i), cid[int(i)], float(s)) for i, s in zip(did, dsc)]], topk=50))
+            eng.reset_stats()
+            out = asyncio.run(hy.aretrieve(queries[0]))
+            assert eng.stat("dense_block_groups") == 1
+            assert [g.node.node_id for g in out] == [nodes[w.idx].node_id for w in want_all[0]]
+            assert [g.score for g in out] == [w.score for w in want_all[0]]
+            assert all(g.node.metadata["dir"] == dname for g in out)
+            for got, want in zip(hy.retrieve_batch(queries), want_all):
+                assert [g.node.node_id for g in got] == [nodes[w.idx].node_id for w in want]
+                assert [g.score for g in got] == [w.score for w in want]
+            # the dense retriever on its own, as QdrantRetriever._aretrieve with `filters` set (retrievers.py:37-52)
+            dense.filters = {"dir": dname}
+            q16 = to_f16_unit(np.asarray(emb.get_query_embedding(queries[1]), np.float32))
+            did, dsc = dense_exact_topk(x16, q16, 288, mask)
+            got = dense.retrieve(queries[1])
+            assert [g.node.node_id for g in got] == [nodes[i].node_id for i in did]
+    finally:
+        eng.set_option("dense_dir_block_min_rows", 4096)
+        eng.set_option("dense_dir_blocks", 1)
+        sparse.filter_dict = None
+        dense.filters = None
