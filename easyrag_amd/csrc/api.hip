@@ -128,15 +128,18 @@ struct erh_handle {
     int64_t Nmeta = 0;
     DevBuf content_id, dir_id;
     bool has_content = false, has_dir = false;
-    // Dense route by dir block (round 5): where a dir's documents are one block of consecutive documents (the reference's layout) the
-    // block gets its OWN copy with its own golden-ratio placement (Xb: block c at rows [lo_c, lo_c + n_c), built on the first filtered
-    // call), and the queries filtered on that dir scan n_c rows instead of N -- through the same kernels, as a view.
+    // Dense route by dir block (round 5): every dir class of at least dense_dir_block_min_rows documents gets its OWN copy with its own
+    // golden-ratio placement (Xb: block c at rows [lo_c, lo_c + n_c), its documents in ascending order -- one run of the caller's numbering
+    // in the reference's layout, gathered from anywhere otherwise; built on the first filtered call), and the queries filtered on that dir
+    // scan n_c rows instead of N -- through the same kernels, as a view.
     struct DenseBlocks {
         bool valid = false;
         std::vector<int64_t> lo, n, mul, inv;                      // per class; n = 0: not a block (scattered, empty or too small)
     } blocks;
-    DevBuf Xb, blk_tmp;
+    DevBuf Xb, blk_tmp, blk_ids;
     std::vector<int32_t> dir_lo_h, dir_hi_h, dir_cnt_h;           // per class, from erh_set_doc_meta
+    std::vector<int32_t> dir_order_h;                              // the documents that carry a class, ordered by (class, document)
+    std::vector<int64_t> dir_off_h;                                // class c: dir_order_h[dir_off_h[c] .. dir_off_h[c + 1])
     int opt_dense_dir_blocks = 1;
     int64_t opt_dir_block_min_rows = 4096;
     bool routed_done = false;                                      // the last dense call ran as routed groups
@@ -749,7 +752,8 @@ int routed_group_run(erh_handle *h, const erh_handle::RoutedGroup &g, hipStream_
 int routed_group_scatter(erh_handle *h, const erh_handle::RoutedGroup &g, hipStream_t st) {
     const erh_handle::Routed &R = h->routed;
     HIPCHK(h, erh::launch_scatter_topk_rows(h->r_ids.as<int32_t>(), h->r_sc.as<double>(), h->r_len.as<int32_t>(), h->r_idx.as<int32_t>() + g.at,
-                                            g.n, R.k, g.c >= 0 ? (int32_t)h->blocks.lo[g.c] : 0, R.d_ids, R.d_sc, R.d_len, st));
+                                            g.n, R.k, g.c >= 0 ? (int32_t)h->blocks.lo[g.c] : 0, g.c >= 0 ? h->blk_ids.as<int32_t>() : nullptr,
+                                            R.d_ids, R.d_sc, R.d_len, st));
     return ERH_OK;
 }
 
@@ -761,9 +765,10 @@ int ensure_dense_blocks(erh_handle *h, hipStream_t st) {
     const int d = h->d;
     h->blocks.lo.assign(nc, 0); h->blocks.n.assign(nc, 0); h->blocks.mul.assign(nc, 1); h->blocks.inv.assign(nc, 1);
     bool any = false;
-    for (int c = 0; c < nc; ++c) {
-        const int64_t cnt = h->dir_cnt_h[c], lo = h->dir_lo_h[c], hi = h->dir_hi_h[c];
-        if (cnt >= h->opt_dir_block_min_rows && hi - lo == cnt && hi <= h->N) { h->blocks.lo[c] = lo; h->blocks.n[c] = cnt; any = true; }
+    const int64_t total = (int64_t)h->dir_order_h.size();              // documents that carry a class, in (class, document) order
+    for (int c = 0; c < nc && total <= h->N; ++c) {
+        const int64_t cnt = h->dir_cnt_h[c];
+        if (cnt >= h->opt_dir_block_min_rows) { h->blocks.lo[c] = h->dir_off_h[c]; h->blocks.n[c] = cnt; any = true; }
     }
     if (any) {
         // The block copies are a second chunk matrix.  Like the 384-row copy: a corpus that leaves no room for it keeps the filter
@@ -777,7 +782,11 @@ int ensure_dense_blocks(erh_handle *h, hipStream_t st) {
             return ERH_OK;
         }
         HIPCHK(h, ea);
-        HIPCHK(h, hipMemsetAsync(h->Xb.as<char>() + (size_t)h->N * d * 2, 0, (size_t)erh::kDensePadRows * d * 2, st));
+        HIPCHK(h, hipMemsetAsync(h->Xb.as<char>() + (size_t)total * d * 2, 0, (size_t)erh::kDensePadRows * d * 2, st));
+        // row r of block c is the caller's document blk_ids[lo_c + r]: the class' documents in ascending order (ties keep their order),
+        // wherever they lie in the caller's numbering -- one run when the corpus was loaded dir by dir, scattered otherwise
+        HIPCHK(h, h->blk_ids.ensure((size_t)total * 4));
+        HIPCHK(h, hipMemcpyAsync(h->blk_ids.p, h->dir_order_h.data(), (size_t)total * 4, hipMemcpyHostToDevice, st));
         for (int c = 0; c < nc; ++c) {
             const int64_t cnt = h->blocks.n[c];
             if (!cnt) continue;
@@ -785,7 +794,8 @@ int ensure_dense_blocks(erh_handle *h, hipStream_t st) {
             if (h->opt_dense_shuffle && cnt > 2) choose_placement(cnt, &mul, &inv);
             h->blocks.mul[c] = mul; h->blocks.inv[c] = inv;
             HIPCHK(h, h->blk_tmp.ensure((size_t)cnt * d * 2));
-            HIPCHK(h, erh::launch_gather_rows(h->X.as<_Float16>(), h->blocks.lo[c], cnt, d, h->pos_mul, h->N, h->blk_tmp.as<_Float16>(), st));
+            HIPCHK(h, erh::launch_gather_rows(h->X.as<_Float16>(), h->blk_ids.as<int32_t>(), h->blocks.lo[c], cnt, d, h->pos_mul, h->N,
+                                              h->blk_tmp.as<_Float16>(), st));
             HIPCHK(h, erh::launch_permute_rows(h->blk_tmp.as<_Float16>(), cnt, d, h->Xb.as<_Float16>() + (size_t)h->blocks.lo[c] * d, 0, mul, cnt, st));
         }
         HIPCHK(h, hipStreamSynchronize(st));
@@ -795,9 +805,9 @@ int ensure_dense_blocks(erh_handle *h, hipStream_t st) {
     return ERH_OK;
 }
 
-// Dense top-k with the dir filter pushed down as a ROW RANGE where it can be: the batch's queries are grouped by filter class; a
-// class whose documents are one block scans that block's copy (n_c rows, no filter, ids shifted by the block's first document),
-// everything else -- unfiltered queries, scattered or small classes -- runs the ordinary call with its filter column.  Each group is
+// Dense top-k with the dir filter pushed down as a ROW RANGE: the batch's queries are grouped by filter class; a class with a block
+// copy scans that copy (n_c rows, no filter, block rows mapped back to the caller's document ids), everything else -- unfiltered
+// queries, small or unknown classes -- runs the ordinary call with its filter column.  Each group is
 // completed (erh_dense_check's work) before its rows are scattered to the caller's order.  filter_host: the caller's host column.
 int dense_topk_routed(erh_handle *h, const void *q_dev, int q_dtype, int normalize_q, int B, int k, const int16_t *filter_host,
                       const int16_t *filter_dev, int mode, int32_t *d_ids, double *d_sc, int32_t *d_len, hipStream_t st) {
@@ -1066,7 +1076,7 @@ int erh_destroy(erh_handle *h) {
                       &h->o_ids, &h->o_sc, &h->o_len, &h->qptr, &h->qtok, &h->part_sc, &h->part_ids, &h->part_len,
                       &h->hy_sids, &h->hy_ssc, &h->hy_slen, &h->hy_dids, &h->hy_dsc, &h->hy_dlen,
                       &h->fa_ids, &h->fa_sc, &h->fa_len, &h->fb_ids, &h->fb_sc, &h->fb_len,
-                      &h->scores_tmp, &h->scores_wide, &h->dbg, &h->dstats, &h->dir_pos, &h->seed_need, &h->bad, &h->ex_ws, &h->bm_redo, &h->fin_ws, &h->dir_rng, &h->Xb, &h->blk_tmp, &h->r_idx, &h->r_q, &h->r_ids, &h->r_sc, &h->r_len, &h->r_filt, &h->r_flags};
+                      &h->scores_tmp, &h->scores_wide, &h->dbg, &h->dstats, &h->dir_pos, &h->seed_need, &h->bad, &h->ex_ws, &h->bm_redo, &h->fin_ws, &h->dir_rng, &h->Xb, &h->blk_tmp, &h->blk_ids, &h->r_idx, &h->r_q, &h->r_ids, &h->r_sc, &h->r_len, &h->r_filt, &h->r_flags};
     for (DevBuf *b : bufs) b->release();
     if (h->r_flags_host) (void)hipHostFree(h->r_flags_host);
     for (auto &b : h->bm) b.release();
@@ -1265,6 +1275,7 @@ int erh_set_dense(erh_handle *h, const void *x, int64_t n, int d, int dtype, int
     h->Xt384.release();
     h->blocks.valid = false;
     h->Xb.release();
+    h->blk_ids.release();
     HIPCHK(h, h->X.ensure((size_t)(n + erh::kDensePadRows) * d * 2));   // zero rows behind the matrix: tiles may run past N
     HIPCHK(h, hipMemsetAsync(h->X.as<char>() + (size_t)n * d * 2, 0, (size_t)erh::kDensePadRows * d * 2, st_pad));
     const hipMemcpyKind kind = is_device_ptr ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
@@ -1337,7 +1348,7 @@ int erh_get_dense_rows(erh_handle *h, int64_t row0, int64_t rows, void *out_f16,
         HIPCHK(h, h->scores_tmp.ensure((size_t)rows * d * 2));
         dst = h->scores_tmp.as<_Float16>();
     }
-    HIPCHK(h, erh::launch_gather_rows(h->X.as<_Float16>(), row0, rows, d, h->pos_mul, h->N, dst, st));
+    HIPCHK(h, erh::launch_gather_rows(h->X.as<_Float16>(), nullptr, row0, rows, d, h->pos_mul, h->N, dst, st));
     if (!out_is_device) HIPCHK(h, hipMemcpyAsync(out_f16, dst, (size_t)rows * d * 2, hipMemcpyDeviceToHost, st));
     HIPCHK(h, hipStreamSynchronize(st));
     return ERH_OK;
@@ -1722,7 +1733,7 @@ int erh_set_doc_meta(erh_handle *h, int64_t N, const int32_t *content_id, const 
     }
     h->dir_rng_n = 0;
     h->blocks.valid = false;
-    h->dir_lo_h.clear(); h->dir_hi_h.clear(); h->dir_cnt_h.clear();
+    h->dir_lo_h.clear(); h->dir_hi_h.clear(); h->dir_cnt_h.clear(); h->dir_order_h.clear(); h->dir_off_h.clear();
     if (dir_id) {
         HIPCHK(h, h->dir_id.ensure((size_t)N * 2));
         HIPCHK(h, hipMemcpy(h->dir_id.p, dir_id, (size_t)N * 2, hipMemcpyHostToDevice));
@@ -1743,6 +1754,11 @@ int erh_set_doc_meta(erh_handle *h, int64_t N, const int32_t *content_id, const 
             h->dir_lo_h.assign((size_t)maxc + 1, 0); h->dir_hi_h.assign((size_t)maxc + 1, 0); h->dir_cnt_h.assign((size_t)maxc + 1, 0);
             for (int c = 0; c <= maxc; ++c) { h->dir_lo_h[c] = rng[2 * c]; h->dir_hi_h[c] = rng[2 * c + 1]; }
             for (int64_t i = 0; i < N; ++i) if (dir_id[i] >= 0) h->dir_cnt_h[dir_id[i]] += 1;
+            h->dir_off_h.assign((size_t)maxc + 2, 0);
+            for (int c = 0; c <= maxc; ++c) h->dir_off_h[c + 1] = h->dir_off_h[c] + h->dir_cnt_h[c];
+            h->dir_order_h.resize((size_t)h->dir_off_h[maxc + 1]);
+            { std::vector<int64_t> at(h->dir_off_h.begin(), h->dir_off_h.end() - 1);
+              for (int64_t i = 0; i < N; ++i) if (dir_id[i] >= 0) h->dir_order_h[(size_t)at[dir_id[i]]++] = (int32_t)i; }
             HIPCHK(h, h->dir_rng.ensure(rng.size() * 4));
             HIPCHK(h, hipMemcpy(h->dir_rng.p, rng.data(), rng.size() * 4, hipMemcpyHostToDevice));
             h->dir_rng_n = maxc + 1;
@@ -2065,7 +2081,7 @@ int erh_debug_dense_scores(erh_handle *h, const void *q_f16_host, int B, int64_t
     HIPCHK(h, erh::launch_prep_queries(h->qin.p, ERH_F16, 0, B, Bpad, d, h->Q16.as<_Float16>(), h->qnorm.as<float>(), nullptr, nullptr, st));
     // the requested ORIGINAL rows, gathered into a contiguous block
     HIPCHK(h, h->scores_tmp.ensure((size_t)rows * d * 2));
-    HIPCHK(h, erh::launch_gather_rows(h->X.as<_Float16>(), row0, rows, d, h->pos_mul, h->N, h->scores_tmp.as<_Float16>(), st));
+    HIPCHK(h, erh::launch_gather_rows(h->X.as<_Float16>(), nullptr, row0, rows, d, h->pos_mul, h->N, h->scores_tmp.as<_Float16>(), st));
     const _Float16 *Xg = h->scores_tmp.as<_Float16>();
     if (use_mfma) {
         const int ld = round_up(rows, 256);

@@ -83,8 +83,8 @@ hipError_t launch_convert_rows(const float *x, int64_t n, int d, int normalize, 
                                int64_t mul, int64_t N, hipStream_t st);
 hipError_t launch_permute_rows(const _Float16 *x, int64_t n, int d, _Float16 *out_base, int64_t r0, int64_t mul,
                                int64_t N, hipStream_t st);
-hipError_t launch_gather_rows(const _Float16 *X, int64_t row0, int64_t n, int d, int64_t mul, int64_t N, _Float16 *out,
-                              hipStream_t st);
+hipError_t launch_gather_rows(const _Float16 *X, const int32_t *rows /* null: original rows row0 ..; else rows[row0 ..] */, int64_t row0,
+                              int64_t n, int d, int64_t mul, int64_t N, _Float16 *out, hipStream_t st);
 hipError_t launch_permute_dir(const int16_t *dir_id, int64_t N, int64_t inv, int16_t *out, hipStream_t st);
 // max L2 norm over fp16 rows -> *out (float, device)
 hipError_t launch_row_norm_max(const _Float16 *x, int64_t n, int d, float *out, hipStream_t st);
@@ -116,7 +116,8 @@ int dense_finalize_split_max();
 // dense calls routed by dir block: gather the rows idx[0..n) of a query block (row_bytes % 16 == 0), scatter a group's results back
 hipError_t launch_gather_query_rows(const void *q, const int32_t *idx, int n, int row_bytes, void *out, hipStream_t st);
 hipError_t launch_scatter_topk_rows(const int32_t *ids, const double *sc, const int32_t *len, const int32_t *idx, int n, int k,
-                                    int32_t id_offset, int32_t *out_ids, double *out_sc, int32_t *out_len, hipStream_t st);
+                                    int32_t id_offset, const int32_t *id_map /* null: id + id_offset; else id_map[id_offset + id] */,
+                                    int32_t *out_ids, double *out_sc, int32_t *out_len, hipStream_t st);
 // Exhaustive path for the queries flagged in bad[] (select.hip): exact fp64 scores of every chunk + streaming top-k.
 int dense_exhaustive_max();
 size_t dense_exhaustive_bytes(int64_t N);

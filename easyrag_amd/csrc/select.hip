@@ -99,12 +99,14 @@ __global__ __launch_bounds__(256) void permute_rows_kernel(const _Float16 *__res
     }
 }
 
-// Original rows [row0, row0 + n) gathered back into a contiguous block (debug scores path).
-__global__ __launch_bounds__(256) void gather_rows_kernel(const _Float16 *__restrict__ X, int64_t row0, int64_t n, int d,
-                                                         int64_t mul, int64_t N, _Float16 *__restrict__ out) {
+// Original rows [row0, row0 + n) -- or, with a list, the original rows rows[row0 .. row0 + n) -- gathered back into a contiguous block
+// (debug scores path; the per-dir block copies).
+__global__ __launch_bounds__(256) void gather_rows_kernel(const _Float16 *__restrict__ X, const int32_t *__restrict__ rows, int64_t row0,
+                                                         int64_t n, int d, int64_t mul, int64_t N, _Float16 *__restrict__ out) {
     const int vec = d / 8;
     for (int64_t row = blockIdx.x; row < n; row += gridDim.x) {
-        const half8 *in = reinterpret_cast<const half8 *>(X + erh_mulmod(row0 + row, mul, N) * d);
+        const int64_t orig = rows ? (int64_t)rows[row0 + row] : row0 + row;
+        const half8 *in = reinterpret_cast<const half8 *>(X + erh_mulmod(orig, mul, N) * d);
         half8 *o = reinterpret_cast<half8 *>(out + row * d);
         for (int i = threadIdx.x; i < vec; i += 256) o[i] = in[i];
     }
@@ -410,14 +412,15 @@ __global__ __launch_bounds__(256) void gather_query_rows_kernel(const int4 *__re
 
 __global__ __launch_bounds__(256) void scatter_topk_rows_kernel(const int32_t *__restrict__ ids, const double *__restrict__ sc,
                                                                const int32_t *__restrict__ len, const int32_t *__restrict__ idx, int n,
-                                                               int k, int32_t id_offset, int32_t *__restrict__ out_ids,
-                                                               double *__restrict__ out_sc, int32_t *__restrict__ out_len) {
+                                                               int k, int32_t id_offset, const int32_t *__restrict__ id_map,
+                                                               int32_t *__restrict__ out_ids, double *__restrict__ out_sc,
+                                                               int32_t *__restrict__ out_len) {
     const int64_t total = (int64_t)n * k;
     for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (int64_t)gridDim.x * 256) {
         const int r = (int)(o / k), c = (int)(o - (int64_t)r * k);
         const int64_t dst = (int64_t)idx[r] * k + c;
         const int32_t id = ids[o];
-        out_ids[dst] = id >= 0 ? id + id_offset : id;
+        out_ids[dst] = id < 0 ? id : (id_map ? id_map[id_offset + id] : id + id_offset);   // (a block's rows -> the caller's document ids)
         out_sc[dst] = sc[o];
         if (c == 0) out_len[idx[r]] = len[r];
     }
@@ -883,11 +886,11 @@ hipError_t launch_permute_rows(const _Float16 *x, int64_t n, int d, _Float16 *ou
     return hipGetLastError();
 }
 
-hipError_t launch_gather_rows(const _Float16 *X, int64_t row0, int64_t n, int d, int64_t mul, int64_t N, _Float16 *out,
+hipError_t launch_gather_rows(const _Float16 *X, const int32_t *rows, int64_t row0, int64_t n, int d, int64_t mul, int64_t N, _Float16 *out,
                               hipStream_t st) {
     if (n <= 0) return hipSuccess;
     const unsigned grid = (unsigned)(n < 65536 ? n : 65536);
-    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid), dim3(256), 0, st, X, row0, n, d, mul, N, out);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid), dim3(256), 0, st, X, rows, row0, n, d, mul, N, out);
     return hipGetLastError();
 }
 
@@ -983,11 +986,12 @@ hipError_t launch_gather_query_rows(const void *q, const int32_t *idx, int n, in
 }
 
 hipError_t launch_scatter_topk_rows(const int32_t *ids, const double *sc, const int32_t *len, const int32_t *idx, int n, int k,
-                                    int32_t id_offset, int32_t *out_ids, double *out_sc, int32_t *out_len, hipStream_t st) {
+                                    int32_t id_offset, const int32_t *id_map, int32_t *out_ids, double *out_sc, int32_t *out_len,
+                                    hipStream_t st) {
     if (n <= 0) return hipSuccess;
     const int64_t total = (int64_t)n * k;
     hipLaunchKernelGGL(scatter_topk_rows_kernel, dim3((unsigned)std::min<int64_t>(4096, (total + 255) / 256)), dim3(256), 0, st, ids,
-                       sc, len, idx, n, k, id_offset, out_ids, out_sc, out_len);
+                       sc, len, idx, n, k, id_offset, id_map, out_ids, out_sc, out_len);
     return hipGetLastError();
 }
 

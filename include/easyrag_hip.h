@@ -330,15 +330,16 @@ int erh_reset_kernel_time(erh_handle *h);
  *   bm25_dir_range (1)    fixed-point scan with a dir filter: the query walks only the posting tiles that hold documents of its class
  *                         (erh_set_doc_meta records every class's first and last document; the reference's dirs are contiguous blocks
  *                         of its document order, so a filter on one of four dirs skips three quarters of the tile passes); 0 = all tiles
- *   dense_dir_blocks (1)  dense route with a dir filter: queries whose dir is one block of consecutive documents scan a copy of that
- *                         block (own row placement, built on the first filtered call, + 2 d bytes per chunk) instead of the whole
- *                         matrix with a filter column -- the batch is grouped by dir on the host, up to 8 groups per call, every
- *                         group through the same kernels as a view, results back in the caller's order; the groups' flag words are
- *                         read together by erh_dense_check / the host-output copy (a flagged group is run again to the end).
+ *   dense_dir_blocks (1)  dense route with a dir filter: queries scan a copy of their dir's chunks (the dir's documents in ascending order
+ *                         -- one run in the reference's dir-by-dir layout, gathered from anywhere otherwise --, own row placement, built on
+ *                         the first filtered call, + 2 d bytes per chunk) instead of the whole matrix with a filter column -- the batch is
+ *                         grouped by dir on the host, up to 8 groups per call, every group through the same kernels as a view, results
+ *                         back in the caller's order and numbering; the groups' flag words are read together by erh_dense_check / the
+ *                         host-output copy (a flagged group is run again to the end).
  *                         1 = where an estimate from measured scan times says it pays (one query, one dir per batch, groups of
  *                         hundreds of queries: 1024 queries over 4 dirs 2.72 -> 1.76 ms, one query 0.62 -> 0.30 ms; not 4 dirs x
  *                         4 ... 64 queries, where every group re-reads a block and pays its own pipeline: +64 ... +70 %);
- *                         2 = whenever the batch has a block dir; 0 = always the filter column.  Same results
+ *                         2 = whenever the batch has a dir with a block; 0 = always the filter column.  Same results
  *   dense_dir_block_min_rows (4096)  smallest dir that gets a block of its own
  *   bm25_post16 (1)       packed shape: read 4-byte postings {15-bit document offset in the tile, 16-bit payload} (built when an
  *                         index is set while bm25_small = 2; + 4 bytes per posting); 0 = the 8-byte fixed-point postings

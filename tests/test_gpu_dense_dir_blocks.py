@@ -1,10 +1,11 @@
 """GPU parity, dense route with the `dir` filter pushed down as a ROW RANGE (round 5).
 
-The reference filters every real query on its document directory (retrievers.py:148-166 builds the qdrant `must` filter from
-`filter_dict`; pipeline/rag.py sets it per query from the question's "document" field), and its loader walks the directories
-one after the other, so each dir is one block of consecutive chunks.  libeasyrag_hip keeps a copy of every such block with
-the block's own row placement and lets a filtered query scan its block only; the results must be what the filter column on
-the whole matrix gives (dense_dir_blocks = 0, itself checked against the oracle's masked ranking throughout the suite) and what
+The reference filters every real query on its document directory (pipeline.py:301-312 builds `filters` -- a qdrant `must` on `dir`,
+ingestion.py:207-216 -- and `filter_dict` from the question's "document" field and pushes them into the retrievers, pipeline.py:331-341;
+applied at retrievers.py:44-47 and 198-202), and its loader walks the directories one after the other, so each dir is one run of consecutive
+chunks.  libeasyrag_hip keeps a copy of every dir's chunks (wherever they lie in the caller's numbering) with the block's own row placement
+and lets a filtered query scan its block only; the results must be what the filter column on the whole matrix gives (dense_dir_blocks = 0,
+itself checked against the oracle's masked ranking throughout the suite) and what
 the oracle gives: ids in the caller's numbering, fp64 scores bit for bit, canonical ties.
 """
 import numpy as np
@@ -199,9 +200,10 @@ def test_blocks_exhaustive_path_inside_a_block(blocks_opts):
         assert np.array_equal(a_.view(np.uint64) if a_.dtype == np.float64 else a_, c_.view(np.uint64) if c_.dtype == np.float64 else c_)
 
 
-def test_blocks_not_used_for_scattered_dirs_or_many_groups(blocks_opts):
-    """Interleaved dirs (i % 4) are no blocks; twelve dirs in one batch are more groups than the route takes: both answer through
-    the filter column, with the same results."""
+def test_blocks_of_scattered_dirs_and_too_many_groups(blocks_opts):
+    """Interleaved dirs (document i in dir i % 4: a corpus that was NOT loaded dir by dir) get block copies too -- the class' documents
+    gathered in ascending order, block rows mapped back through the id table; twelve dirs in one batch are more groups than the route
+    takes and answer through the filter column."""
     engine = blocks_opts
     rng = np.random.default_rng(504)
     n, d, b, k = 30000, 64, 36, 25
@@ -214,8 +216,12 @@ def test_blocks_not_used_for_scattered_dirs_or_many_groups(blocks_opts):
     filt = (np.arange(b) % 4).astype(np.int16)
     engine.reset_stats()
     got = engine.dense_topk(q16, k, filter_dir=filt)
-    assert engine.stat("dense_block_groups") == 0
-    _check_oracle(x, q16, k, dir_id, filt, got, (0, 1, 2, 3, b - 1))
+    assert engine.stat("dense_block_groups") == 4
+    _check_oracle(x, q16, k, dir_id, filt, got, range(b))
+    engine.set_option("dense_dir_blocks", 0)
+    _same(engine.dense_topk(q16, k, filter_dir=filt), got)
+    engine.set_option("dense_dir_blocks", 2)
+    engine.reset_stats()
     dir_id = _blocks([2500] * 12)
     engine.set_doc_meta(n, None, dir_id)
     filt = (np.arange(b) % 12).astype(np.int16)
@@ -287,7 +293,8 @@ def test_blocks_large_batch_and_hybrid(blocks_opts):
 
 @pytest.mark.parametrize("seed", [601, 602, 603, 604, 605, 606])
 def test_blocks_random_shapes_against_filter_column(blocks_opts, seed):
-    """Seeded random shapes -- 2 ... 7 dirs of 1 ... 9000 chunks (some below the block minimum, some empty classes in between), 1 ... 300
+    """Seeded random shapes -- 2 ... 7 dirs of 1 ... 9000 chunks, as runs of consecutive documents or scattered over the corpus (some below the
+    block minimum, some empty classes in between, some documents without a dir), 1 ... 300
     queries with k up to 300 and filter values that include none (-1), classes without documents and classes beyond the table: the route and
     the filter column must agree on every list, bit for bit; a sample of the queries is checked against the oracle."""
     engine = blocks_opts
@@ -297,6 +304,9 @@ def test_blocks_random_shapes_against_filter_column(blocks_opts, seed):
     labels = rng.permutation(n_dirs + 2)[:n_dirs]                    # class ids in any order, two ids of the range unused
     dir_id = np.concatenate([np.full(s, l, np.int16) for s, l in zip(sizes, labels)])
     n = int(dir_id.shape[0])
+    if seed % 2 == 0:                                                # every other case: the dirs scattered over the corpus, some documents
+        dir_id = rng.permutation(dir_id)                             # without any dir (-1)
+        dir_id[rng.integers(0, n, max(1, n // 50))] = -1
     d = int(rng.choice([64, 128, 320]))
     b = int(rng.choice([1, 7, 65, 300]))
     k = int(rng.choice([1, 10, 100, 300]))
