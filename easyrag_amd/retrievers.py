@@ -212,6 +212,54 @@ class _FilteredCorpus:
             self._push_meta()
         return self._classes.class_of(filter_dict)
 
+    def filter_column(self, filter_dicts: Sequence[Optional[Dict[str, Any]]]) -> Optional[np.ndarray]:
+        """int16[B] class column for a batch whose queries carry their OWN filters (None / {} = unfiltered: -1), or None
+        when no query is filtered.  All filters of one column use one metadata key set (the device holds one class
+        column at a time); `_by_key_set` splits batches that mix key sets."""
+        keys = {tuple(sorted(fd)) for fd in filter_dicts if fd}
+        if not keys:
+            return None
+        if len(keys) > 1:
+            raise ValueError("the filters of one device batch must share their metadata keys")
+        col = np.full(len(filter_dicts), -1, np.int16)
+        for b, fd in enumerate(filter_dicts):
+            if fd:
+                col[b] = self.filter_class(fd)
+        return col
+
+
+_UNSET = object()      # "argument not given": the retriever's scalar attribute (filters / filter_dict) applies to every query
+
+
+def _per_query(value, B: int, to_dict) -> List[Optional[Dict[str, Any]]]:
+    """One filter per query.  `value` is the reference's scalar knob (None, a {key: value} dict, a qdrant Filter: applies
+    to every query, as `retriever.filters = ...` / `.filter_dict = ...` do, ref pipeline.py:333-341) or a list / tuple
+    parallel to the queries (the reference's evaluation loop sets a new filter before every question, main.py:48-52 ->
+    pipeline.py:301-312: a batch of its questions carries one filter EACH)."""
+    if isinstance(value, (list, tuple)):
+        if len(value) != B:
+            raise ValueError(f"per-query filters: {len(value)} filters for {B} queries")
+        return [to_dict(v) for v in value]
+    one = to_dict(value)
+    return [one] * B
+
+
+def _by_key_set(dicts: Sequence[Optional[Dict[str, Any]]]) -> List[List[int]]:
+    """Query positions grouped so that each group's filters share one metadata key set (unfiltered queries join the
+    first group).  The usual batch -- every filter on `dir` -- is ONE group."""
+    groups: Dict[tuple, List[int]] = {}
+    free: List[int] = []
+    for b, fd in enumerate(dicts):
+        if fd:
+            groups.setdefault(tuple(sorted(fd)), []).append(b)
+        else:
+            free.append(b)
+    out = list(groups.values())
+    if not out:
+        return [free] if free else []
+    out[0] = sorted(out[0] + free)
+    return out
+
 
 def _corpus_for(nodes, engine: Optional[RetrievalEngine]) -> _FilteredCorpus:
     """Retrievers built over the same engine share one _FilteredCorpus (and so one metadata upload).  The
@@ -415,11 +463,18 @@ class HipVectorStore:
         return cls(nodes, x, engine=engine, normalize=False)
 
     def query_batch(self, query_embeddings, similarity_top_k: int, filters=None, mode: int = _lib.ERH_DENSE_EXACT):
-        fd = _filter_to_dict(filters)
+        """`filters`: one filter for the whole batch (None, dict, qdrant Filter) or a list with one filter per query."""
         q = _unit_f16(query_embeddings)
-        cls = self.corpus.filter_class(fd)
-        filt = None if cls < 0 else np.full(q.shape[0], cls, np.int16)
-        return self.engine.dense_topk(q, similarity_top_k, filter_dir=filt, mode=mode)
+        B, k = q.shape[0], int(similarity_top_k)
+        dicts = _per_query(filters, B, _filter_to_dict)
+        groups = _by_key_set(dicts)
+        if len(groups) <= 1:
+            return self.engine.dense_topk(q, k, filter_dir=self.corpus.filter_column(dicts), mode=mode)
+        ids, sc, ln = np.full((B, k), -1, np.int32), np.zeros((B, k), np.float64), np.zeros(B, np.int32)
+        for g in groups:                              # filters over different metadata keys: one device column at a time
+            gi, gs, gl = self.engine.dense_topk(q[g], k, filter_dir=self.corpus.filter_column([dicts[b] for b in g]), mode=mode)
+            ids[g], sc[g], ln[g] = gi, gs, gl
+        return ids, sc, ln
 
     def query(self, query_embedding, similarity_top_k: int, filters=None):
         ids, sc, ln = self.query_batch(query_embedding, similarity_top_k, filters)
@@ -475,9 +530,14 @@ class QdrantRetriever(_RetrieverBase):
         nodes, sims = self._vector_store.query(emb, self._similarity_top_k, self.filters)
         return [NodeWithScore(node=n, score=s) for n, s in zip(nodes, sims)]
 
-    def retrieve_batch(self, queries: Sequence[str]) -> List[List[NodeWithScore]]:
+    def retrieve_batch(self, queries: Sequence[str], filters=_UNSET) -> List[List[NodeWithScore]]:
+        """`_retrieve` for a batch.  `filters` (default: the `filters` attribute, for every query) may be a list parallel to
+        `queries`: one qdrant Filter / dict / None per question, as the reference's evaluation loop sets them one at a time."""
+        if len(queries) == 0:
+            return []
         embs = np.asarray([self._embed_model.get_query_embedding(q) for q in queries], dtype=np.float32)
-        ids, sc, ln = self._vector_store.query_batch(embs, self._similarity_top_k, self.filters)
+        ids, sc, ln = self._vector_store.query_batch(embs, self._similarity_top_k,
+                                                     self.filters if filters is _UNSET else filters)
         nodes = self._vector_store.nodes
         return [[NodeWithScore(node=nodes[i], score=float(s)) for i, s in zip(ids[b, :ln[b]], sc[b, :ln[b]])]
                 for b in range(len(queries))]
@@ -601,14 +661,22 @@ class BM25Retriever(_RetrieverBase):
             logger.warning("BM25Retriever does not support embeddings, skipping...")
         return self.retrieve_batch([query_bundle.query_str])[0]
 
-    def retrieve_batch(self, queries: Sequence[str]) -> List[List[NodeWithScore]]:
-        """get_scores + filter for a whole batch, fused on the GPU (no score vector leaves the chip)."""
-        qi, qt = queries_to_csr([self._query_ids(q) for q in queries])
-        cls = self._corpus_state.filter_class(self.filter_dict)
-        filt = None if cls < 0 else np.full(len(queries), cls, np.int16)
-        ids, sc, ln = self.engine.bm25_topk(qi, qt, self._similarity_top_k, filter_dir=filt, slot=self._slot)
-        return [[NodeWithScore(node=self._nodes[i], score=float(s)) for i, s in zip(ids[b, :ln[b]], sc[b, :ln[b]])]
-                for b in range(len(queries))]
+    def retrieve_batch(self, queries: Sequence[str], filter_dicts=_UNSET) -> List[List[NodeWithScore]]:
+        """get_scores + filter for a whole batch, fused on the GPU (no score vector leaves the chip).  `filter_dicts`
+        (default: the `filter_dict` attribute, for every query) may be a list parallel to `queries`: one dict / None each."""
+        B = len(queries)
+        if B == 0:
+            return []
+        dicts = _per_query(self.filter_dict if filter_dicts is _UNSET else filter_dicts, B, lambda v: dict(v) if v else None)
+        tok = [self._query_ids(q) for q in queries]
+        out: List[List[NodeWithScore]] = [[] for _ in range(B)]
+        for g in _by_key_set(dicts):
+            qi, qt = queries_to_csr([tok[b] for b in g])
+            ids, sc, ln = self.engine.bm25_topk(qi, qt, self._similarity_top_k, slot=self._slot,
+                                                filter_dir=self._corpus_state.filter_column([dicts[b] for b in g]))
+            for j, b in enumerate(g):
+                out[b] = [NodeWithScore(node=self._nodes[i], score=float(s)) for i, s in zip(ids[j, :ln[j]], sc[j, :ln[j]])]
+        return out
 
 
 _SCRATCH_LOCK = threading.Lock()
@@ -749,31 +817,39 @@ class HybridRetriever(_RetrieverBase):
         """Route selection + filter push-down + RRF (retrievers.py:276-291)."""
         return self.retrieve_batch([query_bundle.query_str])[0]
 
-    def retrieve_batch(self, queries: Sequence[str]) -> List[List[NodeWithScore]]:
-        """`_aretrieve` for a batch of query strings."""
+    def retrieve_batch(self, queries: Sequence[str], filter_dicts=_UNSET, filters=_UNSET) -> List[List[NodeWithScore]]:
+        """`_aretrieve` for a batch of query strings.  Without the keyword arguments the `filter_dict` / `filters`
+        attributes apply to every query and are pushed into the child retrievers as the reference does
+        (retrievers.py:278,283).  `filter_dicts` (sparse route) / `filters` (dense route) may instead be lists parallel to
+        `queries` -- the reference's evaluation loop changes both before every question (pipeline.py:301-312,331-341), so a
+        batch of its questions needs one filter per query; the child retrievers' attributes are left alone then."""
         sp, de = self.sparse_retriever, self.dense_retriever
+        B = len(queries)
+        if B == 0:
+            return []
+        fs = self.filter_dict if filter_dicts is _UNSET else filter_dicts
+        fdn = self.filters if filters is _UNSET else filters
         if self.retrieval_type != 1:
-            sp.filter_dict = self.filter_dict
+            if filter_dicts is _UNSET:
+                sp.filter_dict = self.filter_dict
             if self.retrieval_type == 2:
-                return sp.retrieve_batch(queries)
+                return sp.retrieve_batch(queries, filter_dicts=fs)
         if self.retrieval_type != 2:
-            de.filters = self.filters
+            if filters is _UNSET:
+                de.filters = self.filters
             if self.retrieval_type == 1:
-                return de.retrieve_batch(queries)
+                return de.retrieve_batch(queries, filters=fdn)
         # filter_dict restricts the sparse route only, filters the dense route only (retrievers.py:278,283)
-        fd_sparse = self.filter_dict or None
-        fd_dense = _filter_to_dict(self.filters)
-        same_column = (not fd_sparse or not fd_dense or tuple(sorted(fd_sparse)) == tuple(sorted(fd_dense)))
-        if not self._fused_possible() or not same_column:
-            sparse, dense = sp.retrieve_batch(queries), de.retrieve_batch(queries)
+        d_sparse = _per_query(fs, B, lambda v: dict(v) if v else None)
+        d_dense = _per_query(fdn, B, _filter_to_dict)
+        key_sets = {tuple(sorted(fd)) for fd in d_sparse + d_dense if fd}
+        if not self._fused_possible() or len(key_sets) > 1:
+            sparse, dense = sp.retrieve_batch(queries, filter_dicts=fs), de.retrieve_batch(queries, filters=fdn)
             return [self.reciprocal_rank_fusion([s, d], topk=self.topk) for s, d in zip(sparse, dense)]
-        # both routes share one engine: BM25 -> dense -> RRF([sparse, dense]) in a single device pipeline
+        # both routes share one engine: BM25 -> dense -> RRF([sparse, dense]) in a single device pipeline, one class column
+        # per route over the shared key set (a query's two filters may still differ, or one of them be absent)
         cstate = sp._corpus_state
-        cls_s, cls_d = cstate.filter_class(fd_sparse), cstate.filter_class(fd_dense)
-        if fd_sparse and fd_dense:                  # same key set: one class table serves both lookups
-            cls_s = cstate.filter_class(fd_sparse)
-        filt_s = None if cls_s < 0 else np.full(len(queries), cls_s, np.int16)
-        filt_d = None if cls_d < 0 else np.full(len(queries), cls_d, np.int16)
+        filt_s, filt_d = cstate.filter_column(d_sparse), cstate.filter_column(d_dense)
         qi, qt = queries_to_csr([sp._query_ids(q) for q in queries])
         embs = _unit_f16(np.asarray([de._embed_model.get_query_embedding(q) for q in queries], dtype=np.float32))
         ids, sc, ln = sp.engine.hybrid_topk(embs, qi, qt, k_dense=de._similarity_top_k,
@@ -781,4 +857,4 @@ class HybridRetriever(_RetrieverBase):
                                             filter_dir=filt_s, filter_dense=filt_d, slot=sp._slot)
         nodes = sp._nodes
         return [[NodeWithScore(node=nodes[i], score=float(s)) for i, s in zip(ids[b, :ln[b]], sc[b, :ln[b]])]
-                for b in range(len(queries))]
+                for b in range(B)]

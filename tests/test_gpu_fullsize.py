@@ -130,6 +130,42 @@ def test_hybrid_configs3_exact(engine, dense_data, sparse_data, variant):
         assert np.array_equal(d_ids[r], did) and np.array_equal(d_sc[r], dsc)
 
 
+@pytest.mark.parametrize("speculate", [1, 0], ids=["speculative-threshold", "guaranteed-bounds"])
+def test_dense_configs1_exact(engine, dense_data, speculate):
+    """BASELINE.json configs[1] ITSELF (the configuration the >= 0.70 HBM target and `sub_benchmarks.dense_b256_top100` are
+    defined on): 1M x 1024 fp16, dense only, 256 queries, k = 100, library defaults -- the seed prefix scored by the store
+    kernel, `seed_select`, ONE 256-query tile of `dense_scan_pp3_kernel` appending from row `dense_n0` to row 1M (the
+    stage-boundary arithmetic at this N), finalize.  40 sampled queries (both ends of the batch, both ends of the query
+    tile's wave columns) against the oracle: ids and pinned-order fp64 scores bit for bit; the whole batch against the
+    structural properties; and with `dense_speculate = 0` (guaranteed bounds + refinement stages) the same lists."""
+    x, q = dense_data
+    b, k = 256, 100
+    engine.set_dense(x)
+    engine.set_doc_meta(N, None, None)
+    engine.set_option("dense_speculate", speculate)
+    try:
+        engine.reset_stats()
+        ids, sc, ln = engine.dense_topk(q[:b].contiguous(), k)
+        st, diag = engine.stats(), engine.dense_diag()
+    finally:
+        engine.set_option("dense_speculate", 1)
+    assert np.all(ln == k)
+    assert diag["uncertified"] == 0 and diag["max_abs_err"] <= diag["margin"] and diag["exhaustive"] == 0, diag
+    # the store kernel + pp3 append pipeline answered: no sample pass, no 384-row tile, no skinny-GEMM stream, no lock-step tiles
+    assert st["dense_scan_pp3_launches"] >= 1 and st["dense_sample_passes"] == 0 and st["dense_scan_pp5_launches"] == 0, st
+    assert st["dense_scan_gemv_launches"] == 0 and st["dense_exhaustive_queries"] == 0, st
+    if speculate:
+        assert st["dense_scan_pp3_launches"] == 1, st                 # one scan stage covers [n0, N)
+    sample = sorted(set(list(range(0, b, 8)) + [1, 63, 64, 127, 128, 191, 254, 255]))
+    assert len(sample) >= 32
+    want = dense_oracle_topk(x, q[sample], k)
+    for (oid, osc), i in zip(want, sample):
+        assert np.array_equal(ids[i], oid), f"query {i}: ids differ"
+        assert np.array_equal(sc[i].view(np.uint64), osc.view(np.uint64)), f"query {i}: fp64 scores differ"
+    for i in range(b):
+        assert len(set(ids[i])) == k and ids[i].min() >= 0 and ids[i].max() < N and np.all(np.diff(sc[i]) <= 0)
+
+
 @pytest.mark.parametrize("variant,k,n_sample", [(BM25S, 100, 32), (BM25S, 192, 32), (OKAPI, 100, 12), (OKAPI, 192, 12)],
                          ids=["bm25s-k100", "bm25s-k192", "okapi-k100", "okapi-k192"])
 @pytest.mark.parametrize("ascan,wscan,crossing", [(1, 0, 1), (0, 1, 2), (0, 1, 0), (0, 0, 0)],

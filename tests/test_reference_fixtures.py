@@ -175,3 +175,107 @@ def test_qdrant_cosine_definition_on_non_unit_vectors():
     assert float(sc[1]) == float(np.float32(0.6))
     ids, sc = qdrant_cosine_search(vecs, [6.0, 8.0], 2, mask=np.array([True, False, True]))
     assert list(ids) == [0, 2] and abs(float(sc[0]) - 0.6) < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bm25_type", [0, 1])
+def test_reference_questions_as_one_filtered_batch(bm25_type):
+    """The reference's evaluation loop (main.py:48-52 -> pipeline.py:301-312, 331-341) sets `filters` / `filter_dict` to the
+    question's own `document` before every question.  All 103 questions WITH THEIR OWN FILTERS as ONE batch through
+    HybridRetriever.retrieve_batch(queries, filter_dicts=[...], filters=[...]) on a corpus loaded dir by dir (ingestion.py:79-87):
+    every list equals the single `aretrieve` call with the attributes poked, and the oracle composition; the same through
+    BM25Retriever.retrieve_batch and QdrantRetriever.retrieve_batch on their own."""
+    import asyncio
+    from easyrag_amd.retrievers import BM25Retriever, HipVectorStore, HybridRetriever, QdrantRetriever
+    from easyrag_amd.schema import TextNode
+    from oracle import dense_exact_topk, reciprocal_rank_fusion, to_f16_unit
+    from oracle.retrievers import Item
+
+    class Embedder:
+        def get_query_embedding(self, text, d=256):
+            import zlib
+            v = np.random.default_rng(zlib.crc32(text.encode())).standard_normal(d).astype(np.float32)
+            return (v / np.linalg.norm(v)).tolist()
+
+    fx = _fixture()
+    texts, dirs = synthetic_text_corpus(fx, n_docs=5000)
+    order = np.argsort(np.array([DIRS.index(d) for d in dirs]), kind="stable")     # the loader walks one directory after the other
+    texts, dirs = [texts[i] for i in order], [dirs[i] for i in order]
+    texts[40] = texts[11]                                                          # equal contents share an RRF key
+    nodes = [TextNode(text=t, metadata={"dir": d}, id_=f"n{i}") for i, (t, d) in enumerate(zip(texts, dirs))]
+    emb, tok, stop = Embedder(), WhitespaceTokenizer(), {""}
+    vecs = np.asarray([emb.get_query_embedding(f"doc{i}:" + t) for i, t in enumerate(texts)], np.float32)
+    sparse = BM25Retriever.from_defaults(nodes=nodes, tokenizer=tok, similarity_top_k=192, stopwords=stop, bm25_type=bm25_type)
+    eng = sparse.engine
+    try:
+        store = HipVectorStore(nodes, vecs, engine=eng)
+        dense = QdrantRetriever(store, emb, similarity_top_k=288)
+        hy = HybridRetriever(dense, sparse, retrieval_type=3, topk=10)
+        eng.set_option("dense_dir_block_min_rows", 1)            # dir blocks at this corpus size (default minimum: 4096 rows)
+        queries = [" ".join(q["tokens"]) for q in fx["queries"]]
+        fds = [{"dir": q["dir"]} for q in fx["queries"]]
+        fds[5] = None                                             # one unfiltered question and one dir nobody carries
+        fds[17] = {"dir": "no-such-dir"}
+        docs = [tokenize_and_remove_stopwords(tok, t, stop) for t in texts]
+        ora = BM25Okapi(docs, 1.5, 0.75, 0.25) if bm25_type == 0 else BM25SLucene(1.5, 0.75).index(docs)
+        x16, dir_arr = to_f16_unit(vecs), np.array(dirs)
+        key = {}
+        cid = [key.setdefault(t, i) for i, t in enumerate(texts)]
+
+        def masks(fd):
+            return None if fd is None else dir_arr == fd["dir"]
+
+        want_sp, want_de, want_hy = [], [], []
+        for q, query, fd in zip(fx["queries"], queries, fds):
+            sp = bm25_filter(ora.get_scores(q["tokens"]), 192, masks(fd))
+            q16 = to_f16_unit(np.asarray(emb.get_query_embedding(query), np.float32))
+            did, dsc = dense_exact_topk(x16, q16, 288, masks(fd))
+            want_sp.append([(nodes[i].node_id, s) for i, s in sp])
+            want_de.append([(nodes[int(i)].node_id, float(s)) for i, s in zip(did, dsc)])
+            fused = reciprocal_rank_fusion([[Item(i, cid[i], s) for i, s in sp],
+                                            [Item(int(i), cid[int(i)], float(s)) for i, s in zip(did, dsc)]], K=60, topk=10)
+            want_hy.append([(nodes[w.idx].node_id, w.score) for w in fused])
+
+        def pairs(lst):
+            return [(g.node.node_id, g.score) for g in lst]
+
+        for blocks in (2, 0):                                     # dir blocks forced / the filter column
+            eng.set_option("dense_dir_blocks", blocks)
+            eng.reset_stats()
+            batch = hy.retrieve_batch(queries, filter_dicts=fds, filters=fds)
+            assert (eng.stat("dense_block_groups") > 0) == (blocks == 2)
+            assert hy.filter_dict is None and sparse.filter_dict is None and dense.filters is None    # no attribute was poked
+            for b in range(len(queries)):
+                assert pairs(batch[b]) == want_hy[b], (blocks, fx["queries"][b]["id"])
+                if fds[b] is not None:
+                    assert all(g.node.metadata["dir"] == fds[b]["dir"] for g in batch[b])
+        eng.set_option("dense_dir_blocks", 1)
+        # 103 single calls, the reference's way: poke the attributes, then aretrieve (pipeline.py:333-341, 400-404)
+        for b, query in enumerate(queries):
+            hy.filter_dict, hy.filters = fds[b], fds[b]
+            assert pairs(asyncio.run(hy.aretrieve(query))) == pairs(batch[b]), fx["queries"][b]["id"]
+        hy.filter_dict = hy.filters = None
+        # each route on its own with per-query filters; a qdrant-style Filter object in the list as well
+        from types import SimpleNamespace as NS
+        qf = [None if fd is None else NS(must=[NS(key="dir", match=NS(value=fd["dir"]))]) for fd in fds]
+        sparse.filter_dict, dense.filters = None, None
+        for got, want in zip(sparse.retrieve_batch(queries, filter_dicts=fds), want_sp):
+            assert pairs(got) == want
+        for got, want in zip(dense.retrieve_batch(queries, filters=qf), want_de):
+            assert pairs(got) == want
+        # route selection 1 / 2 hand the lists down
+        hy.retrieval_type = 2
+        assert [pairs(x) for x in hy.retrieve_batch(queries, filter_dicts=fds)] == want_sp
+        hy.retrieval_type = 1
+        assert [pairs(x) for x in hy.retrieve_batch(queries, filters=fds)] == want_de
+        hy.retrieval_type = 3
+        # the scalar attributes keep working for a whole batch
+        hy.filter_dict, hy.filters = {"dir": "rcp"}, {"dir": "rcp"}
+        one = hy.retrieve_batch(queries[:8])
+        assert [pairs(x) for x in one] == [pairs(x) for x in hy.retrieve_batch(queries[:8], filter_dicts=[{"dir": "rcp"}] * 8,
+                                                                             filters=[{"dir": "rcp"}] * 8)]
+        with pytest.raises(ValueError):
+            hy.retrieve_batch(queries[:8], filter_dicts=fds[:7])
+    finally:
+        sparse.close()
+        eng.close()
