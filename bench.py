@@ -366,9 +366,11 @@ def sub_benchmarks(eng, synth, queries_to_csr, build_index, OKAPI, q16_pool, tok
             eng, classes, lambda i: eng.hybrid_topk(q16_pool[i % pool], *csr_pool[i % pool], k_dense=288, k_sparse=192, K=60, topk=10,
                                                     device_out=True, filter_dir=filt), int(q16_pool[0].shape[0]), "dense_scan",
             what="configs[3] with a per-query dir filter on both routes (4 dirs = 4 contiguous blocks of 250k chunks): the dense route as 4 groups "
-                 "of 256 queries, each over its dir's block copy (dense_dir_blocks; store kernel + seed select + append scan on the 256 x 256 tile "
-                 "per group), the BM25 scan over the tiles of the query's dir only")
+                 "of 256 queries, each over its dir's block copy, all four in ONE launch per stage (dense_dir_blocks + dense_group_launch: a view "
+                 "table per 256-query tile read by the store kernel, seed select, persistent scan on the 256 x 256 tile and the final kernel), "
+                 "the BM25 scan over the tiles of the query's dir only")
         out["hybrid_b1024_dir_filter"]["dense_block_groups_per_step"] = eng.stat("dense_block_groups") / max(1, eng.stat("hybrid_calls"))
+        out["hybrid_b1024_dir_filter"]["dense_grouped_launches_per_step"] = eng.stat("dense_grouped_launches") / max(1, eng.stat("hybrid_calls"))
         f1 = [filt[p % 4:p % 4 + 1].copy() for p in range(pool)]
         out["hybrid_b1_dir_filter_latency"] = run_sub(
             eng, classes, lambda i: eng.hybrid_topk(q1[i % pool], *csr1[i % pool], k_dense=288, k_sparse=192, K=60, topk=10,

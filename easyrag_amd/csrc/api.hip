@@ -117,6 +117,7 @@ struct erh_handle {
     hipStream_t side = nullptr;           // ... created at first use
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool fork_after_scan = false;         // dense_topk_dev records ev_fork behind its last scan launch (hybrid_overlap 2)
+    bool rerun = false;                   // dense_topk_dev is re-running a group of a routed call at its check: its flagged queries were counted already
     int opt_bm25_small = 2;               // fixed-point scan, when k allows: 2 the 512-thread shape with packed 16-bit sums over 32768-document
                                           // tiles (two workgroups per CU), 1 the 512-thread shape over 16384-document tiles, 0 always 1024 threads
     int opt_bm25_post16 = 1;              // packed shape: read the 4-byte postings (built when an index is set; 0: the 8-byte ones)
@@ -142,18 +143,35 @@ struct erh_handle {
     std::vector<int64_t> dir_off_h;                                // class c: dir_order_h[dir_off_h[c] .. dir_off_h[c + 1])
     int opt_dense_dir_blocks = 1;
     int64_t opt_dir_block_min_rows = 4096;
-    bool routed_done = false;                                      // the last dense call ran as routed groups
-    bool routed_pending = false;                                   // ... whose flag words (r_flags) have not been read yet
-    struct RoutedGroup { int c, at, n; };                          // dir class (-1: the ordinary call), first row in r_idx / r_q, queries
+    int64_t opt_route_ridge = 160;                                 // query columns below which a scan of R rows costs like R x ridge (HBM-bound): the route decision's only constant
+    int opt_dense_group_launch = 1;                                // two or more block groups of a batch run as ONE launch per stage (dense_topk_grouped); 0: one pipeline per group
+    // One routed dense call (dense_topk_routed), kept until its synchronisation point (dense_check_flags) has read its flag words:
+    // the batch's groups, where each group's queries lie, and where results go.  Nothing else of a routed call lives on the handle.
+    struct RoutedGroup {
+        int c;          // dir class whose block the group scans; -1: the ordinary call with the group's filter values, -2: ... without a filter column
+        int at, n;      // the group's queries = r_idx[at .. at + n) (caller rows, ascending)
+        int pad_at;     // grouped launch: first row of the group in the padded query block (a multiple of 256); -1: run as its own pipeline
+        int flag_slot;  // which 16-byte record of r_flags holds the flag words of the pipeline that answered it
+    };
     struct Routed {
+        bool done = false;                                         // the last dense call ran routed
+        bool pending = false;                                      // ... and its flag words (r_flags) have not been read yet
         std::vector<RoutedGroup> groups;
+        int n_flag_slots = 0;
+        int grouped_slot = -1;                                     // flag slot of the grouped launch, -1: none in this call
+        int grouped_bpad = 0;                                      // its padded query rows
         int q_dtype = 0, normalize_q = 0, B = 0, k = 0, mode = 0;
         int32_t *d_ids = nullptr; double *d_sc = nullptr; int32_t *d_len = nullptr;
     } routed;
-    DevBuf r_idx, r_q, r_ids, r_sc, r_len, r_filt, r_flags;       // the batch in group order (rows, filter values), a group's results, every group's flag words
+    DevBuf r_idx, r_q, r_ids, r_sc, r_len, r_filt, r_flags;       // the batch in group order (rows, filter values), a group's results, every pipeline's flag words
+    DevBuf r_tab;                                                  // grouped launch: view table + workgroup map + padded-row map, one upload per call
+    DevBuf r_q16;                                                  // ... its fp16 query block, copied aside only when a group has to run again
     uint32_t *r_flags_host = nullptr;                              // pinned
+    size_t r_flags_host_cap = 0;
     std::vector<int32_t> r_idx_host;
     std::vector<int16_t> r_filt_host;
+    std::vector<uint32_t> r_bad_host;
+    std::vector<char> r_tab_host;
     DevBuf dir_rng;                          // {first document, last + 1} of every dir class (erh_set_doc_meta): a filtered BM25 query walks those tiles only
     int dir_rng_n = 0;
     int opt_bm25_dir_range = 1;
@@ -173,7 +191,8 @@ struct erh_handle {
     DevBuf dstats;
     struct Stats {
         int64_t dense_calls = 0, dense_scan_pp5 = 0, dense_scan_pp3 = 0, dense_scan_gemv = 0, dense_scan_tile = 0,
-                dense_sample_passes = 0, dense_tile384_nomem = 0, bm25_calls = 0, hybrid_calls = 0, dense_block_groups = 0;
+                dense_sample_passes = 0, dense_tile384_nomem = 0, bm25_calls = 0, hybrid_calls = 0, dense_block_groups = 0,
+                dense_grouped_launches = 0;
     } stats;
     // multi-GPU exchange (erh_comm_* / erh_allgather_topk): RCCL communicator + packed send / receive rows
     void *comm = nullptr;
@@ -377,7 +396,7 @@ int dense_topk_dev(erh_handle *h, const void *q_dev, int q_dtype, int normalize_
                    const int16_t *filter_dev, int mode, int32_t *d_ids, double *d_sc, int32_t *d_len, hipStream_t st) {
     const int QT = erh::dense_scan_q_tile();
     const int Bpad = round_up(B, QT);
-    h->routed_done = false;
+    h->routed.done = false;
     const int d = h->d;
     const int64_t N = h->view.N;
     const int64_t pos_mul = h->view.mul, pos_inv = h->view.inv;
@@ -548,7 +567,7 @@ int dense_topk_dev(erh_handle *h, const void *q_dev, int q_dtype, int normalize_
                                                    h->tau.as<float>(), h->n_cus, fin_s64, fin_sync, st));
               HIPCHK(h, erh::launch_dense_exhaustive(bad, B, 0, k, X, N, d, Q16, filter_dev,
                                                      (filter_dev && h->has_dir) ? h->dir_id.as<int16_t>() : nullptr, pos_inv, h->ex_ws.p,
-                                                     flags, h->n_cus, d_ids, d_sc, d_len, h->dstats.as<unsigned long long>(), 1 /* count only */, st)); }
+                                                     flags, h->n_cus, d_ids, d_sc, d_len, h->rerun ? nullptr : h->dstats.as<unsigned long long>(), 1 /* count only */, st)); }
             h->last = erh_handle::LastDense();
             h->last.valid = true;
             h->last.B = B; h->last.k = k; h->last.filter_dev = filter_dev; h->last.X = X; h->last.N = N; h->last.pos_inv = pos_inv;
@@ -644,7 +663,7 @@ int dense_topk_dev(erh_handle *h, const void *q_dev, int q_dtype, int normalize_
       // point every caller passes before it reads results -- runs the exact rounds when, and only when, the count is not zero
       HIPCHK(h, erh::launch_dense_exhaustive(bad, B, 0, k, X, N, d, Q16, filter_dev,
                                              (filter_dev && h->has_dir) ? h->dir_id.as<int16_t>() : nullptr, pos_inv, h->ex_ws.p,
-                                             flags, h->n_cus, d_ids, d_sc, d_len, h->dstats.as<unsigned long long>(), 1 /* count only */, st)); }
+                                             flags, h->n_cus, d_ids, d_sc, d_len, h->rerun ? nullptr : h->dstats.as<unsigned long long>(), 1 /* count only */, st)); }
     h->last = erh_handle::LastDense();
     h->last.valid = true;
     h->last.B = B; h->last.k = k; h->last.filter_dev = filter_dev; h->last.X = X; h->last.N = N; h->last.pos_inv = pos_inv;
@@ -655,37 +674,72 @@ int dense_topk_dev(erh_handle *h, const void *q_dev, int q_dtype, int normalize_
 // Read the flag words of the last dense call (synchronises the stream).  If queries were flagged for the exhaustive path, its
 // rounds run here, dense_exhaustive_max() queries at a time (and a fused call's RRF is redone over the corrected dense lists),
 // so the caller always gets an answer.
-int routed_group_run(erh_handle *h, const erh_handle::RoutedGroup &g, hipStream_t st);
+int routed_group_run(erh_handle *h, const erh_handle::RoutedGroup &g, const void *q_rows, int q_dtype, int normalize_q, hipStream_t st);
 int routed_group_scatter(erh_handle *h, const erh_handle::RoutedGroup &g, hipStream_t st);
 
 int dense_check_flags(erh_handle *h, hipStream_t st) {
-    if (h->routed_done) {
-        if (!h->routed_pending) { HIPCHK(h, hipStreamSynchronize(st)); return ERH_OK; }
-        // A routed call: every group left its flag words in r_flags.  A group with flagged queries is run again on its own, to the
-        // end (its exhaustive rounds included), and scattered over its first answer; a fused call's RRF is redone then.
+    if (h->routed.done) {
+        erh_handle::Routed &R = h->routed;
+        if (!R.pending) { HIPCHK(h, hipStreamSynchronize(st)); return ERH_OK; }
+        // A routed call: every pipeline (a group run on its own, or the grouped launch over all block groups) left its flag words in
+        // r_flags.  A group with flagged queries is run again on its own, to the end (its exhaustive rounds included), and scattered
+        // over its first answer; a fused call's RRF is redone then.
         const erh_handle::LastDense saved = h->last;
-        const size_t ng = h->routed.groups.size();
-        HIPCHK(h, hipMemcpyAsync(h->r_flags_host, h->r_flags.p, ng * 16, hipMemcpyDeviceToHost, st));
+        HIPCHK(h, hipMemcpyAsync(h->r_flags_host, h->r_flags.p, (size_t)R.n_flag_slots * 16, hipMemcpyDeviceToHost, st));
         HIPCHK(h, hipStreamSynchronize(st));
-        h->routed_pending = false;
+        R.pending = false;
         double maxerr = 0;
         int uncert = 0, exhaustive = 0;
         bool redone = false;
-        for (size_t gi = 0; gi < ng; ++gi) {
+        auto slot_words = [&](int slot, uint32_t *f) { memcpy(f, h->r_flags_host + 4 * slot, 16); };
+        for (int sl = 0; sl < R.n_flag_slots; ++sl) {                  // what the pipelines without a flagged query certify
             uint32_t f[4];
-            memcpy(f, h->r_flags_host + 4 * gi, 16);
+            slot_words(sl, f);
+            if (f[0]) continue;
+            float me;
+            memcpy(&me, &f[1], 4);
+            maxerr = std::max(maxerr, (double)me); uncert += (int32_t)f[2];
+        }
+        // The grouped launch flags QUERIES (bad[] over its padded rows), not groups: read them, and keep its fp16 query block -- the
+        // re-runs below reuse the work space it lives in.  (The grouped launch is the last pipeline of its call, so both are intact.)
+        const _Float16 *q16_copy = nullptr;
+        if (R.grouped_slot >= 0) {
+            uint32_t f[4];
+            slot_words(R.grouped_slot, f);
             if (f[0]) {
-                int rc = routed_group_run(h, h->routed.groups[gi], st);           // (clears routed_done: the check below is the ordinary one)
-                if (rc == ERH_OK) rc = dense_check_flags(h, st);
-                if (rc == ERH_OK) rc = routed_group_scatter(h, h->routed.groups[gi], st);
-                if (rc != ERH_OK) return rc;
-                maxerr = std::max(maxerr, h->diag_maxerr); uncert += h->diag_uncert; exhaustive += h->diag_exhaustive;
-                redone = true;
-            } else {
-                float me;
-                memcpy(&me, &f[1], 4);
-                maxerr = std::max(maxerr, (double)me); uncert += (int32_t)f[2];
+                h->r_bad_host.resize((size_t)R.grouped_bpad);
+                HIPCHK(h, hipMemcpyAsync(h->r_bad_host.data(), h->bad.p, (size_t)R.grouped_bpad * 4, hipMemcpyDeviceToHost, st));
+                HIPCHK(h, h->r_q16.ensure((size_t)R.grouped_bpad * h->d * 2));
+                HIPCHK(h, hipMemcpyAsync(h->r_q16.p, h->Q16.p, (size_t)R.grouped_bpad * h->d * 2, hipMemcpyDeviceToDevice, st));
+                HIPCHK(h, hipStreamSynchronize(st));
+                q16_copy = h->r_q16.as<_Float16>();
             }
+        }
+        const size_t row_bytes = (size_t)h->d * (R.q_dtype == ERH_F16 ? 2 : 4);
+        for (size_t gi = 0; gi < R.groups.size(); ++gi) {
+            const erh_handle::RoutedGroup g = R.groups[gi];
+            uint32_t f[4];
+            slot_words(g.flag_slot, f);
+            if (!f[0]) continue;
+            const void *q_rows;
+            int dt = R.q_dtype, nq = R.normalize_q;
+            if (g.pad_at >= 0) {                                       // a group of the grouped launch: flagged iff one of its queries is
+                bool any = false;
+                for (int i = 0; i < g.n; ++i) any = any || h->r_bad_host[(size_t)g.pad_at + i] != 0u;
+                if (!any) continue;
+                q_rows = q16_copy + (size_t)g.pad_at * h->d;           // already unit fp16: the same values the first run scored
+                dt = ERH_F16; nq = 0;
+            } else {
+                q_rows = h->r_q.as<char>() + (size_t)g.at * row_bytes;
+            }
+            h->rerun = true;
+            int rc = routed_group_run(h, g, q_rows, dt, nq, st);       // (clears routed.done: the check below is the ordinary one)
+            if (rc == ERH_OK) rc = dense_check_flags(h, st);
+            if (rc == ERH_OK) rc = routed_group_scatter(h, g, st);
+            h->rerun = false;
+            if (rc != ERH_OK) return rc;
+            maxerr = std::max(maxerr, h->diag_maxerr); uncert += h->diag_uncert; exhaustive += h->diag_exhaustive;
+            redone = true;
         }
         if (redone && saved.hybrid) {
             const int32_t *cid = h->has_content ? h->content_id.as<int32_t>() : nullptr;
@@ -694,7 +748,7 @@ int dense_check_flags(erh_handle *h, hipStream_t st) {
         }
         if (redone) HIPCHK(h, hipStreamSynchronize(st));
         h->last = erh_handle::LastDense();
-        h->routed_done = true;
+        R.done = true;
         h->diag_maxerr = maxerr; h->diag_uncert = uncert; h->diag_exhaustive = exhaustive;
         h->diag_margin = 2.0 * (double)h->d * 1.1920929e-7 * (double)h->xnorm_max;
         return ERH_OK;
@@ -729,13 +783,10 @@ int dense_check_flags(erh_handle *h, hipStream_t st) {
     return ERH_OK;
 }
 
-constexpr int kRoutedGroupsMax = 8;
-
-// One group of a routed dense call (dense_topk_routed): its queries (rows [at, at + n) of r_q) against its dir's block as a view, or
-// the ordinary call with the group's filter values; results in r_ids / r_sc / r_len, then scattered to the caller's rows.
-int routed_group_run(erh_handle *h, const erh_handle::RoutedGroup &g, hipStream_t st) {
+// One group of a routed dense call as a pipeline of its own: its queries (`q_rows`, n of them) against its dir's block as a view, or
+// the ordinary call with the group's filter values; results in r_ids / r_sc / r_len (routed_group_scatter puts them into the caller's rows).
+int routed_group_run(erh_handle *h, const erh_handle::RoutedGroup &g, const void *q_rows, int q_dtype, int normalize_q, hipStream_t st) {
     const erh_handle::Routed &R = h->routed;
-    const size_t row_bytes = (size_t)h->d * (R.q_dtype == ERH_F16 ? 2 : 4);
     const int16_t *sub_filter = nullptr;
     if (g.c >= 0) {
         h->view.X = h->Xb.as<_Float16>() + (size_t)h->blocks.lo[g.c] * h->d;
@@ -743,7 +794,7 @@ int routed_group_run(erh_handle *h, const erh_handle::RoutedGroup &g, hipStream_
     } else if (g.c == -1) {
         sub_filter = h->r_filt.as<int16_t>() + g.at;
     }
-    const int rc = dense_topk_dev(h, h->r_q.as<char>() + (size_t)g.at * row_bytes, R.q_dtype, R.normalize_q, g.n, R.k, sub_filter, R.mode,
+    const int rc = dense_topk_dev(h, q_rows, q_dtype, normalize_q, g.n, R.k, sub_filter, R.mode,
                                   h->r_ids.as<int32_t>(), h->r_sc.as<double>(), h->r_len.as<int32_t>(), st);
     h->view_global();
     return rc;
@@ -759,21 +810,23 @@ int routed_group_scatter(erh_handle *h, const erh_handle::RoutedGroup &g, hipStr
 
 // The per-dir copies of the chunk matrix (see erh_handle::DenseBlocks): built on the first filtered call after erh_set_dense /
 // erh_set_doc_meta; the blocks' rows come back in the caller's order through the gather kernel and are placed by their own multiplier.
+// Xb holds the BLOCK classes only, one after the other (a corpus with one large dir and a long tail of small ones pays
+// for the large one, not for a second copy of everything), + kDensePadRows zero rows.
 int ensure_dense_blocks(erh_handle *h, hipStream_t st) {
     if (h->blocks.valid) return ERH_OK;
     const int nc = (int)h->dir_cnt_h.size();
     const int d = h->d;
     h->blocks.lo.assign(nc, 0); h->blocks.n.assign(nc, 0); h->blocks.mul.assign(nc, 1); h->blocks.inv.assign(nc, 1);
-    bool any = false;
+    int64_t rows = 0;
     const int64_t total = (int64_t)h->dir_order_h.size();              // documents that carry a class, in (class, document) order
     for (int c = 0; c < nc && total <= h->N; ++c) {
         const int64_t cnt = h->dir_cnt_h[c];
-        if (cnt >= h->opt_dir_block_min_rows) { h->blocks.lo[c] = h->dir_off_h[c]; h->blocks.n[c] = cnt; any = true; }
+        if (cnt >= h->opt_dir_block_min_rows) { h->blocks.lo[c] = rows; h->blocks.n[c] = cnt; rows += cnt; }
     }
-    if (any) {
-        // The block copies are a second chunk matrix.  Like the 384-row copy: a corpus that leaves no room for it keeps the filter
+    if (rows > 0) {
+        // The block copies are (at most) a second chunk matrix.  Like the 384-row copy: a corpus that leaves no room for it keeps the filter
         // column (no blocks until the next erh_set_dense / erh_set_doc_meta); dense_tile384_max_mb bounds both copies (test hook).
-        const size_t want = (size_t)(h->N + erh::kDensePadRows) * d * 2;
+        const size_t want = (size_t)(rows + erh::kDensePadRows) * d * 2;
         const hipError_t ea = (h->opt_tile384_max_mb >= 0 && want > ((size_t)h->opt_tile384_max_mb << 20)) ? hipErrorOutOfMemory : h->Xb.ensure(want);
         if (ea == hipErrorOutOfMemory) {
             (void)hipGetLastError();
@@ -782,11 +835,15 @@ int ensure_dense_blocks(erh_handle *h, hipStream_t st) {
             return ERH_OK;
         }
         HIPCHK(h, ea);
-        HIPCHK(h, hipMemsetAsync(h->Xb.as<char>() + (size_t)total * d * 2, 0, (size_t)erh::kDensePadRows * d * 2, st));
+        HIPCHK(h, hipMemsetAsync(h->Xb.as<char>() + (size_t)rows * d * 2, 0, (size_t)erh::kDensePadRows * d * 2, st));
         // row r of block c is the caller's document blk_ids[lo_c + r]: the class' documents in ascending order (ties keep their order),
         // wherever they lie in the caller's numbering -- one run when the corpus was loaded dir by dir, scattered otherwise
-        HIPCHK(h, h->blk_ids.ensure((size_t)total * 4));
-        HIPCHK(h, hipMemcpyAsync(h->blk_ids.p, h->dir_order_h.data(), (size_t)total * 4, hipMemcpyHostToDevice, st));
+        std::vector<int32_t> ids((size_t)rows);
+        for (int c = 0; c < nc; ++c)
+            if (h->blocks.n[c])
+                memcpy(ids.data() + h->blocks.lo[c], h->dir_order_h.data() + h->dir_off_h[c], (size_t)h->blocks.n[c] * 4);
+        HIPCHK(h, h->blk_ids.ensure((size_t)rows * 4));
+        HIPCHK(h, hipMemcpyAsync(h->blk_ids.p, ids.data(), (size_t)rows * 4, hipMemcpyHostToDevice, st));
         for (int c = 0; c < nc; ++c) {
             const int64_t cnt = h->blocks.n[c];
             if (!cnt) continue;
@@ -798,92 +855,264 @@ int ensure_dense_blocks(erh_handle *h, hipStream_t st) {
                                               h->blk_tmp.as<_Float16>(), st));
             HIPCHK(h, erh::launch_permute_rows(h->blk_tmp.as<_Float16>(), cnt, d, h->Xb.as<_Float16>() + (size_t)h->blocks.lo[c] * d, 0, mul, cnt, st));
         }
-        HIPCHK(h, hipStreamSynchronize(st));
+        HIPCHK(h, hipStreamSynchronize(st));                           // (`ids` is pageable host memory of this scope)
         h->blk_tmp.release();
     }
     h->blocks.valid = true;
     return ERH_OK;
 }
 
+// ---- the grouped launch (round 6): every block group of a batch in ONE launch per stage ----------------------------------------
+// The batch's block groups are laid out one after the other in a padded query block, each group in whole 256-row query tiles; a table
+// with one entry per query tile (kernels.h: ErhDenseView -- the dir's block copy, its placement, its seed prefix and rank, the chunk
+// streams of the persistent scan that belong to it) is read by every stage instead of one (X, N) pair per launch:
+//   query preparation (rows gathered through q_src, padding rows zeroed) -> seed prefix of every tile's own block scored densely
+//   (dense_scan_store_kernel<.., GROUPED>) -> rank-th best per query = threshold (seed_select_kernel with the table) -> ONE persistent
+//   scan over the rest of all blocks (dense_scan_pp3_kernel<0, 32 | 40>: n_cus workgroups dealt to the tiles in proportion to their
+//   chunk tiles, so the launch takes max over tiles of ceil(chunk tiles / streams) rounds -- four blocks of 250 k rows: 14 rounds
+//   instead of 4 x 4) -> final kernel (pinned fp64 re-score out of the tile's block, results written to the caller's rows with block
+//   rows mapped to document ids: no scatter launch) -> the count of flagged queries.  Seven launches and one 16-byte flag record
+//   whatever the number of groups.  Queries the budgets cannot certify are flagged as always; their GROUPS are then run again as
+//   pipelines of their own at the synchronisation point (dense_check_flags) -- rare, and the code that ran every group before round 6.
+struct GroupedPlan {
+    std::vector<erh::ErhDenseView> views;
+    std::vector<int32_t> wg_view, q_src;
+    int grid = 0, n0_max = 0, bpad = 0;
+    int64_t n_max = 0;
+    bool halfq = true;
+};
+
+// chunk streams per query tile: the smallest number of rounds R with sum ceil(tiles_v / R) <= n_cus, then ceil(tiles_v / R) streams each
+static bool plan_streams(std::vector<erh::ErhDenseView> &views, const std::vector<int64_t> &tiles, int n_cus, int *grid) {
+    int64_t with_work = 0, t_max = 0;
+    for (int64_t t : tiles) { with_work += t > 0; t_max = std::max(t_max, t); }
+    if (with_work > n_cus) return false;
+    int64_t lo = 1, hi = std::max<int64_t>(t_max, 1);
+    auto need = [&](int64_t r) { int64_t s = 0; for (int64_t t : tiles) s += (t + r - 1) / r; return s; };
+    while (lo < hi) { const int64_t mid = (lo + hi) / 2; if (need(mid) <= n_cus) hi = mid; else lo = mid + 1; }
+    int at = 0;
+    for (size_t v = 0; v < views.size(); ++v) {
+        const int nwg = (int)((tiles[v] + lo - 1) / lo);
+        views[v].wg0 = at; views[v].nwg = nwg;
+        at += nwg;
+    }
+    *grid = at;
+    return true;
+}
+
+int dense_topk_grouped(erh_handle *h, const void *q_dev, int q_dtype, int normalize_q, int k, int mode, const GroupedPlan &P,
+                       int32_t *d_ids, double *d_sc, int32_t *d_len, hipStream_t st) {
+    const int d = h->d, Bpad = P.bpad, n_qt = (int)P.views.size();
+    const int cap = erh::kDenseCapMax;
+    const int ld = round_up(std::max(P.n0_max, 1), 256);
+    h->routed.done = false;
+    HIPCHK(h, h->Q16.ensure((size_t)Bpad * d * 2));
+    HIPCHK(h, h->qnorm.ensure((size_t)Bpad * 4));
+    HIPCHK(h, h->tau.ensure((size_t)Bpad * 4));
+    HIPCHK(h, h->cand.ensure((size_t)Bpad * cap * sizeof(ErhCand)));
+    HIPCHK(h, h->cand_cnt.ensure((size_t)Bpad * 4));
+    HIPCHK(h, h->flags.ensure(64));
+    HIPCHK(h, h->seed_need.ensure((size_t)Bpad * 4));
+    HIPCHK(h, h->bad.ensure((size_t)Bpad * 4));
+    HIPCHK(h, h->ex_ws.ensure(erh::dense_exhaustive_bytes(P.n_max)));
+    HIPCHK(h, h->S0.ensure((size_t)Bpad * ld * 4));
+    // the tables: one upload (pageable source: copied out before the call returns)
+    const size_t off_wg = (size_t)n_qt * sizeof(erh::ErhDenseView), off_src = off_wg + (size_t)P.grid * 4, bytes = off_src + (size_t)Bpad * 4;
+    h->r_tab_host.resize(bytes);
+    memcpy(h->r_tab_host.data(), P.views.data(), off_wg);
+    memcpy(h->r_tab_host.data() + off_wg, P.wg_view.data(), (size_t)P.grid * 4);
+    memcpy(h->r_tab_host.data() + off_src, P.q_src.data(), (size_t)Bpad * 4);
+    HIPCHK(h, h->r_tab.ensure(bytes));
+    HIPCHK(h, hipMemcpyAsync(h->r_tab.p, h->r_tab_host.data(), bytes, hipMemcpyHostToDevice, st));
+    erh::ErhGroupIo gio{};
+    gio.views = reinterpret_cast<const erh::ErhDenseView *>(h->r_tab.as<char>());
+    gio.wg_view = reinterpret_cast<const int32_t *>(h->r_tab.as<char>() + off_wg);
+    gio.q_src = reinterpret_cast<const int32_t *>(h->r_tab.as<char>() + off_src);
+    gio.id_map = h->blk_ids.as<int32_t>();
+    uint32_t *flags = h->flags.as<uint32_t>(), *bad = h->bad.as<uint32_t>();
+    h->qt_valid = false;
+    h->qt5_valid = false;
+    { ProfScope ps(h, st, ERH_K_DENSE_SELECT, 0, 0);
+      HIPCHK(h, erh::launch_prep_queries(q_dev, q_dtype, normalize_q, Bpad, Bpad, d, h->Q16.as<_Float16>(), h->qnorm.as<float>(), bad, flags, st,
+                                         gio.q_src)); }
+    // booked work: what the algorithm needs -- every block row once per query tile that scans it
+    double seed_rows = 0, scan_rows = 0;
+    for (const erh::ErhDenseView &v : P.views) { seed_rows += v.n0; scan_rows += (double)(v.N - v.n0); }
+    { ProfScope ps(h, st, ERH_K_DENSE_SCAN, seed_rows * d * 2.0 + (double)Bpad * d * 2.0, 2.0 * seed_rows * 256.0 * d);
+      HIPCHK(h, erh::launch_dense_scan_store_grouped(gio, n_qt, P.n0_max, h->n_cus, h->Q16.as<_Float16>(), Bpad, d, h->S0.as<float>(), ld, st)); }
+    { ProfScope ps(h, st, ERH_K_DENSE_SELECT, 0, 0);
+      HIPCHK(h, erh::launch_seed_select(h->S0.as<float>(), ld, P.n0_max, 0, Bpad, k, k, h->qnorm.as<float>(), h->xnorm_max, d, nullptr, nullptr,
+                                        h->tau.as<float>(), h->cand.as<ErhCand>(), h->cand_cnt.as<uint32_t>(), cap, bad,
+                                        h->seed_need.as<uint32_t>(), st, gio.views)); }
+    if (P.grid > 0) {
+        ProfScope ps(h, st, ERH_K_DENSE_SCAN, scan_rows * d * 2.0 + (double)Bpad * d * 2.0, 2.0 * scan_rows * 256.0 * d);
+        HIPCHK(h, erh::launch_dense_scan_pp_grouped(gio, P.grid, d, h->Q16.as<_Float16>(), Bpad, h->tau.as<float>(), h->cand.as<ErhCand>(),
+                                                    h->cand_cnt.as<uint32_t>(), cap, flags, P.halfq ? 1 : 0, st));
+        h->stats.dense_scan_pp3 += 1;
+    }
+    if (h->fork_after_scan) HIPCHK(h, hipEventRecord(h->ev_fork, st));
+    { ProfScope ps(h, st, ERH_K_DENSE_SELECT, 0, 0);
+      HIPCHK(h, erh::launch_dense_finalize(Bpad, k, mode, h->qnorm.as<float>(), h->xnorm_max, d, nullptr, h->Q16.as<_Float16>(),
+                                           h->cand.as<ErhCand>(), h->cand_cnt.as<uint32_t>(), cap, d_ids, d_sc, d_len,
+                                           reinterpret_cast<float *>(flags + 1), flags + 2, bad, 0, 1, 1, h->tau.as<float>(), h->n_cus,
+                                           nullptr, nullptr, st, &gio));
+      HIPCHK(h, erh::launch_dense_exhaustive(bad, Bpad, 0, k, nullptr, P.n_max, d, h->Q16.as<_Float16>(), nullptr, nullptr, 1, h->ex_ws.p,
+                                             flags, h->n_cus, d_ids, d_sc, d_len, h->dstats.as<unsigned long long>(), 1 /* count only */, st)); }
+    h->stats.dense_grouped_launches += 1;
+    return ERH_OK;
+}
+
 // Dense top-k with the dir filter pushed down as a ROW RANGE: the batch's queries are grouped by filter class; a class with a block
 // copy scans that copy (n_c rows, no filter, block rows mapped back to the caller's document ids), everything else -- unfiltered
-// queries, small or unknown classes -- runs the ordinary call with its filter column.  Each group is
-// completed (erh_dense_check's work) before its rows are scattered to the caller's order.  filter_host: the caller's host column.
+// queries, small or unknown classes -- runs the ordinary call with its filter column.  Two or more block groups run as ONE launch per
+// stage (dense_topk_grouped); a single block group (the reference's one filtered query per call) and the ordinary group are pipelines
+// of their own.  filter_host: the caller's host column.
 int dense_topk_routed(erh_handle *h, const void *q_dev, int q_dtype, int normalize_q, int B, int k, const int16_t *filter_host,
                       const int16_t *filter_dev, int mode, int32_t *d_ids, double *d_sc, int32_t *d_len, hipStream_t st) {
     const int nc = (int)h->dir_cnt_h.size();
-    h->routed_pending = false;
+    erh_handle::Routed &R = h->routed;
+    R.pending = false;
     bool route = h->opt_dense_dir_blocks && filter_host && filter_dev && h->has_dir && nc > 0 && h->Nmeta == h->N && h->opt_dense_ablate == 0;
     std::map<int, std::vector<int32_t>> groups;
+    int n_block_groups = 0;
     if (route) {
         if (!h->blocks.valid) { int rc = ensure_dense_blocks(h, st); if (rc != ERH_OK) return rc; }
-        bool any_block = false;
         for (int b = 0; b < B; ++b) {
             const int f = filter_host[b];
             const bool blk = f >= 0 && f < nc && h->blocks.n[f] > 0;
-            any_block = any_block || blk;
             groups[blk ? f : -1].push_back(b);
         }
-        route = any_block && groups.size() <= (size_t)kRoutedGroupsMax;
-        // Every group is a pipeline of its own (a dozen launches), and a scan of few queries is bound by the matrix bytes, which the
-        // groups of one batch read one block each -- together the whole matrix again.  So the route pays where one group's block is a
-        // fraction of the matrix (one query, one dir per batch) or where the scan is MFMA-bound (groups of hundreds of queries), and
-        // loses in between (4 dirs x 4 ... 64 queries: +64 ... +70 % per call).  dense_dir_blocks = 1 decides by an estimate from the
-        // measured scan times of both shapes (profiles/r05y_ab_dir_blocks.log), = 2 always routes.
-        if (route && h->opt_dense_dir_blocks == 1) {
-            const double unit = (double)h->d / 1024.0 / 250000.0;         // the tables: ms per 250 000 rows x 1024 dims
-            const double per_group = 0.1;                                   // threshold + selection kernels and launches of one pipeline
-            auto block_ms = [](int n) { return n <= 8 ? 0.12 : n <= 16 ? 0.155 : n <= 64 ? 0.26 : 0.21 * ((n + 255) / 256); };
-            auto whole_ms = [](int n) { return n <= 16 ? 0.11 : n <= 64 ? 0.14 : n <= 256 ? 0.19 : 0.04 + 0.435 * ((n + 255) / 256) / 4.0; };
-            double routed_ms = 0;
-            for (auto &g : groups) {
-                const int n = (int)g.second.size();
-                routed_ms += per_group + (g.first >= 0 ? block_ms(n) * (double)h->blocks.n[g.first] : whole_ms(n) * (double)h->N) * unit;
-            }
-            const double plain_ms = per_group + whole_ms(B) * (double)h->N * unit;
-            route = routed_ms < 0.85 * plain_ms;
+        n_block_groups = (int)groups.size() - (groups.count(-1) ? 1 : 0);
+        route = n_block_groups > 0;
+    }
+    const int QT = erh::dense_scan_q_tile();
+    const bool grouped = route && n_block_groups >= 2 && h->opt_dense_group_launch && h->opt_dense_speculate && h->opt_dense_pp >= 1 &&
+                         h->d % 64 == 0 && h->d / 32 >= 8;
+    // Route or not: compare the WORK of the two ways, in row x query-column units.  A scan of R rows against n queries costs
+    // R x max(columns(n), ridge): `columns` is the width the kernel that would run it computes (16-column groups of the skinny-GEMM
+    // stream up to 64 queries, half a query tile up to 128, whole 256-row tiles above), `ridge` (option dense_route_ridge, 160) the
+    // width below which the scan is bound by the matrix bytes and the columns are free -- a property of the chip (HBM bytes per
+    // MFMA flop), not a timing of one box.  dense_dir_blocks = 2 always routes (the parity tests).
+    if (route && h->opt_dense_dir_blocks == 1) {
+        const double ridge = (double)std::max<int64_t>(h->opt_route_ridge, 1);
+        auto cols_plain = [&](int n) { return (double)(n <= 64 ? round_up(n, 16) : n <= 128 ? 128 : round_up(n, QT)); };
+        auto cols_group = [&](int n) { return (double)(n <= 128 ? 128 : round_up(n, QT)); };
+        double routed_work = 0;
+        for (auto &g : groups) {
+            const int n = (int)g.second.size();
+            if (g.first < 0) routed_work += (double)h->N * std::max(cols_plain(n), ridge);
+            else routed_work += (double)h->blocks.n[g.first] * std::max(grouped ? cols_group(n) : cols_plain(n), ridge);
         }
+        route = routed_work < (double)h->N * std::max(cols_plain(B), ridge);
     }
     if (!route) return dense_topk_dev(h, q_dev, q_dtype, normalize_q, B, k, filter_dev, mode, d_ids, d_sc, d_len, st);
-    const size_t row_bytes = (size_t)h->d * (q_dtype == ERH_F16 ? 2 : 4);
-    HIPCHK(h, h->r_idx.ensure((size_t)B * 4));
-    HIPCHK(h, h->r_q.ensure((size_t)B * row_bytes));
-    HIPCHK(h, h->r_ids.ensure((size_t)B * k * 4));
-    HIPCHK(h, h->r_sc.ensure((size_t)B * k * 8));
-    HIPCHK(h, h->r_len.ensure((size_t)B * 4));
-    HIPCHK(h, h->r_filt.ensure((size_t)B * 2));
-    HIPCHK(h, h->r_flags.ensure((size_t)kRoutedGroupsMax * 16));
-    if (!h->r_flags_host) HIPCHK(h, hipHostMalloc(reinterpret_cast<void **>(&h->r_flags_host), (size_t)kRoutedGroupsMax * 16, hipHostMallocDefault));
-    erh_handle::Routed &R = h->routed;
+
+    // ---- the plan: group order, flag slots, and for the grouped launch its tables --------------------------------------------------
     R.groups.clear();
     R.q_dtype = q_dtype; R.normalize_q = normalize_q; R.B = B; R.k = k; R.mode = mode;
     R.d_ids = d_ids; R.d_sc = d_sc; R.d_len = d_len;
+    R.grouped_slot = -1; R.grouped_bpad = 0;
     h->r_idx_host.clear();
     h->r_filt_host.clear();
-    for (auto &g : groups) {
+    GroupedPlan P;
+    std::vector<int64_t> tiles;
+    int n_slots = 0;
+    for (auto &g : groups) {                                            // (the ordinary group, key -1, comes first)
         bool any_filter = false;
         for (int32_t b : g.second) any_filter = any_filter || filter_host[b] >= 0;
-        // (c = -2: the ordinary group without any filter value -- no filter column at all)
-        R.groups.push_back({g.first >= 0 ? g.first : (any_filter ? -1 : -2), (int)h->r_idx_host.size(), (int)g.second.size()});
+        erh_handle::RoutedGroup rg{g.first >= 0 ? g.first : (any_filter ? -1 : -2), (int)h->r_idx_host.size(), (int)g.second.size(), -1, 0};
+        if (g.first >= 0 && grouped) {
+            const int c = g.first;
+            const int64_t Nv = h->blocks.n[c];
+            rg.pad_at = P.bpad;
+            int64_t n0 = std::min<int64_t>(std::min<int64_t>(h->opt_n0, erh::kDenseN0Max), Nv);
+            if (n0 < 1) n0 = 1;
+            const int rank = Nv > n0 ? erh_dense_seed_rank(k, n0, Nv) : k;
+            for (int t0 = 0; t0 < rg.n; t0 += QT) {
+                erh::ErhDenseView v{};
+                v.X = h->Xb.as<_Float16>() + (size_t)h->blocks.lo[c] * h->d;
+                v.N = Nv; v.mul = h->blocks.mul[c]; v.inv = h->blocks.inv[c];
+                v.n0 = (int32_t)n0; v.rank = rank; v.id_lo = (int32_t)h->blocks.lo[c];
+                v.nq = std::min(QT, rg.n - t0);
+                P.views.push_back(v);
+                tiles.push_back((Nv - n0 + QT - 1) / QT);
+                for (int i = 0; i < QT; ++i) P.q_src.push_back(i < v.nq ? g.second[(size_t)t0 + i] : -1);
+                P.halfq = P.halfq && v.nq <= QT / 2;
+                P.n0_max = std::max(P.n0_max, (int)n0);
+                P.n_max = std::max(P.n_max, Nv);
+            }
+            P.bpad += round_up(rg.n, QT);
+        } else {
+            rg.flag_slot = n_slots++;
+        }
+        R.groups.push_back(rg);
         for (int32_t b : g.second) { h->r_idx_host.push_back(b); h->r_filt_host.push_back(filter_host[b]); }
     }
+    bool run_grouped = grouped && !P.views.empty();
+    if (run_grouped) {
+        // more query tiles with work than compute units, or a padded block beyond what the work space should grow to: every group on its own
+        if (P.bpad > 16384 || !plan_streams(P.views, tiles, h->n_cus, &P.grid)) {
+            run_grouped = false;
+            for (auto &rg : R.groups) if (rg.pad_at >= 0) { rg.pad_at = -1; rg.flag_slot = n_slots++; }
+        } else {
+            P.wg_view.resize((size_t)P.grid);
+            for (size_t v = 0; v < P.views.size(); ++v)
+                for (int i = 0; i < P.views[v].nwg; ++i) P.wg_view[(size_t)P.views[v].wg0 + i] = (int32_t)v;
+            R.grouped_slot = n_slots++;
+            R.grouped_bpad = P.bpad;
+            for (auto &rg : R.groups) if (rg.pad_at >= 0) rg.flag_slot = R.grouped_slot;
+        }
+    }
+    R.n_flag_slots = n_slots;
+    const size_t row_bytes = (size_t)h->d * (q_dtype == ERH_F16 ? 2 : 4);
+    HIPCHK(h, h->r_idx.ensure((size_t)B * 4));
+    HIPCHK(h, h->r_flags.ensure((size_t)n_slots * 16));
+    if (h->r_flags_host_cap < (size_t)n_slots * 16) {
+        if (h->r_flags_host) (void)hipHostFree(h->r_flags_host);
+        h->r_flags_host = nullptr; h->r_flags_host_cap = 0;
+        const size_t want = std::max<size_t>((size_t)n_slots * 16, 1024);
+        HIPCHK(h, hipHostMalloc(reinterpret_cast<void **>(&h->r_flags_host), want, hipHostMallocDefault));
+        h->r_flags_host_cap = want;
+    }
     HIPCHK(h, hipMemcpyAsync(h->r_idx.p, h->r_idx_host.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(h, hipMemcpyAsync(h->r_filt.p, h->r_filt_host.data(), (size_t)B * 2, hipMemcpyHostToDevice, st));
-    // the batch in group order: a copy of the library's own, so a group can be run again at erh_dense_check time
-    HIPCHK(h, erh::launch_gather_query_rows(q_dev, h->r_idx.as<int32_t>(), B, (int)row_bytes, h->r_q.p, st));
-    for (size_t gi = 0; gi < R.groups.size(); ++gi) {
-        int rc = routed_group_run(h, R.groups[gi], st);
+    bool any_seq = false;
+    for (const erh_handle::RoutedGroup &rg : R.groups) any_seq = any_seq || rg.pad_at < 0;
+    if (any_seq) {
+        HIPCHK(h, h->r_q.ensure((size_t)B * row_bytes));
+        HIPCHK(h, h->r_ids.ensure((size_t)B * k * 4));
+        HIPCHK(h, h->r_sc.ensure((size_t)B * k * 8));
+        HIPCHK(h, h->r_len.ensure((size_t)B * 4));
+        HIPCHK(h, h->r_filt.ensure((size_t)B * 2));
+        HIPCHK(h, hipMemcpyAsync(h->r_filt.p, h->r_filt_host.data(), (size_t)B * 2, hipMemcpyHostToDevice, st));
+        // the batch in group order: a copy of the library's own, so a group can be run again at erh_dense_check time
+        HIPCHK(h, erh::launch_gather_query_rows(q_dev, h->r_idx.as<int32_t>(), B, (int)row_bytes, h->r_q.p, st));
+    } else {
+        // (a re-run of a group of the grouped launch needs its result rows: sized here, while nothing is in flight)
+        HIPCHK(h, h->r_ids.ensure((size_t)B * k * 4));
+        HIPCHK(h, h->r_sc.ensure((size_t)B * k * 8));
+        HIPCHK(h, h->r_len.ensure((size_t)B * 4));
+    }
+    // ---- groups that are pipelines of their own first, the grouped launch last (its work space must survive until the check) ----------
+    for (const erh_handle::RoutedGroup &rg : R.groups) {
+        if (rg.pad_at >= 0) continue;
+        int rc = routed_group_run(h, rg, h->r_q.as<char>() + (size_t)rg.at * row_bytes, q_dtype, normalize_q, st);
         if (rc != ERH_OK) return rc;
-        // the group's flag words, kept aside (the next group's query preparation clears them): read all at once in dense_check_flags
-        HIPCHK(h, hipMemcpyAsync(h->r_flags.as<char>() + gi * 16, h->flags.p, 16, hipMemcpyDeviceToDevice, st));
-        rc = routed_group_scatter(h, R.groups[gi], st);
+        // the group's flag words, kept aside (the next pipeline's query preparation clears them): read all at once in dense_check_flags
+        HIPCHK(h, hipMemcpyAsync(h->r_flags.as<char>() + (size_t)rg.flag_slot * 16, h->flags.p, 16, hipMemcpyDeviceToDevice, st));
+        rc = routed_group_scatter(h, rg, st);
         if (rc != ERH_OK) return rc;
-        h->stats.dense_block_groups += (R.groups[gi].c >= 0);
+        h->stats.dense_block_groups += (rg.c >= 0);
+    }
+    if (run_grouped) {
+        int rc = dense_topk_grouped(h, q_dev, q_dtype, normalize_q, k, mode, P, d_ids, d_sc, d_len, st);
+        if (rc != ERH_OK) return rc;
+        HIPCHK(h, hipMemcpyAsync(h->r_flags.as<char>() + (size_t)R.grouped_slot * 16, h->flags.p, 16, hipMemcpyDeviceToDevice, st));
+        for (const erh_handle::RoutedGroup &rg : R.groups) h->stats.dense_block_groups += (rg.pad_at >= 0);
     }
     h->last = erh_handle::LastDense();
     h->last.B = B; h->last.k = k; h->last.d_ids = d_ids; h->last.d_sc = d_sc; h->last.d_len = d_len;   // (a fused call's RRF redo reads these)
-    h->routed_done = true;
-    h->routed_pending = true;
+    R.done = true;
+    R.pending = true;
     return ERH_OK;
 }
 
@@ -1076,7 +1305,7 @@ int erh_destroy(erh_handle *h) {
                       &h->o_ids, &h->o_sc, &h->o_len, &h->qptr, &h->qtok, &h->part_sc, &h->part_ids, &h->part_len,
                       &h->hy_sids, &h->hy_ssc, &h->hy_slen, &h->hy_dids, &h->hy_dsc, &h->hy_dlen,
                       &h->fa_ids, &h->fa_sc, &h->fa_len, &h->fb_ids, &h->fb_sc, &h->fb_len,
-                      &h->scores_tmp, &h->scores_wide, &h->dbg, &h->dstats, &h->dir_pos, &h->seed_need, &h->bad, &h->ex_ws, &h->bm_redo, &h->fin_ws, &h->dir_rng, &h->Xb, &h->blk_tmp, &h->blk_ids, &h->r_idx, &h->r_q, &h->r_ids, &h->r_sc, &h->r_len, &h->r_filt, &h->r_flags};
+                      &h->scores_tmp, &h->scores_wide, &h->dbg, &h->dstats, &h->dir_pos, &h->seed_need, &h->bad, &h->ex_ws, &h->bm_redo, &h->fin_ws, &h->dir_rng, &h->Xb, &h->blk_tmp, &h->blk_ids, &h->r_idx, &h->r_q, &h->r_ids, &h->r_sc, &h->r_len, &h->r_filt, &h->r_flags, &h->r_tab, &h->r_q16};
     for (DevBuf *b : bufs) b->release();
     if (h->r_flags_host) (void)hipHostFree(h->r_flags_host);
     for (auto &b : h->bm) b.release();
@@ -1113,6 +1342,8 @@ int erh_set_option(erh_handle *h, const char *name, int64_t value) {
         h->n_cus = value == 0 ? h->n_cus_dev : (int)value;
         return ERH_OK;
     }
+    if (!strcmp(name, "dense_route_ridge")) { if (value < 1 || value > 4096) return h->fail(ERH_ERR_INVALID, "dense_route_ridge"); h->opt_route_ridge = value; return ERH_OK; }
+    if (!strcmp(name, "dense_group_launch")) { h->opt_dense_group_launch = value != 0; return ERH_OK; }
     if (!strcmp(name, "dense_dir_blocks")) { if (value < 0 || value > 2) return h->fail(ERH_ERR_INVALID, "dense_dir_blocks"); h->opt_dense_dir_blocks = (int)value; return ERH_OK; }
     if (!strcmp(name, "dense_dir_block_min_rows")) { if (value < 1) return h->fail(ERH_ERR_INVALID, "dense_dir_block_min_rows"); h->opt_dir_block_min_rows = value; h->blocks.valid = false; return ERH_OK; }
     if (!strcmp(name, "bm25_dir_range")) { h->opt_bm25_dir_range = value != 0; return ERH_OK; }
@@ -1190,7 +1421,7 @@ int erh_reset_kernel_time(erh_handle *h) {
 
 int erh_dense_check(erh_handle *h, void *stream) {
     if (!h) return ERH_ERR_INVALID;
-    if (!h->flags.p || (!h->last.valid && !h->routed_done)) return ERH_OK;           // no dense route has run on this handle
+    if (!h->flags.p || (!h->last.valid && !h->routed.done)) return ERH_OK;           // no dense route has run on this handle
     HIPCHK(h, hipSetDevice(h->device));
     return dense_check_flags(h, (hipStream_t)stream);
 }
@@ -1228,7 +1459,8 @@ int erh_get_stat(erh_handle *h, const char *name, int64_t *value) {
         {"dense_calls", T.dense_calls}, {"dense_scan_pp5_launches", T.dense_scan_pp5}, {"dense_scan_pp3_launches", T.dense_scan_pp3},
         {"dense_scan_gemv_launches", T.dense_scan_gemv}, {"dense_scan_tile_launches", T.dense_scan_tile},
         {"dense_sample_passes", T.dense_sample_passes}, {"dense_tile384_nomem", T.dense_tile384_nomem},
-        {"bm25_calls", T.bm25_calls}, {"hybrid_calls", T.hybrid_calls}, {"dense_block_groups", T.dense_block_groups}};
+        {"bm25_calls", T.bm25_calls}, {"hybrid_calls", T.hybrid_calls}, {"dense_block_groups", T.dense_block_groups},
+        {"dense_grouped_launches", T.dense_grouped_launches}};
     for (const auto &e : host)
         if (!strcmp(name, e.n)) { *value = e.v; return ERH_OK; }
     const int di = !strcmp(name, "dense_exhaustive_queries") ? 0 : !strcmp(name, "bm25_redo_segments") ? 1 : -1;

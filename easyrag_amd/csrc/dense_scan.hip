@@ -217,10 +217,12 @@ __device__ __forceinline__ int mfma_row(int r, int lane) { return (r & 3) + 8 * 
 
 // ---------------------------------------------------------------------------------------------
 // STORE epilogue: S0[q][chunk - c0] for chunks [c0, c0 + nc), all Bpad query rows.
-template <class C>
+// GROUPED (round 6; kernels.h: ErhDenseView): the 256 query rows of a tile score the seed prefix of THEIR OWN matrix -- views[q_row0 / 256]
+// replaces (X, N), its prefix length replaces nc (chunk tiles past it return at once), c0 = 0.
+template <class C, bool GROUPED = false>
 __global__ __launch_bounds__(C::NT) void dense_scan_store_kernel(
     const _Float16 *__restrict__ Q, int Bpad, const _Float16 *__restrict__ X, int64_t N, int d,
-    int64_t c0, int nc, float *__restrict__ S0, int ld_s0) {
+    int64_t c0, int nc, float *__restrict__ S0, int ld_s0, const erh::ErhDenseView *__restrict__ views) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -229,6 +231,11 @@ __global__ __launch_bounds__(C::NT) void dense_scan_store_kernel(
     const int ct = blockIdx.x % n_ctiles, qt = blockIdx.x / n_ctiles;
     const int64_t q_row0 = (int64_t)qt * C::BM;
     const int64_t c_row0 = c0 + (int64_t)ct * C::BN;
+    if constexpr (GROUPED) {
+        const erh::ErhDenseView &v = views[q_row0 >> 8];
+        if (c_row0 >= v.n0) return;                      // whole workgroup, before any barrier
+        X = v.X; N = v.N; nc = v.n0;
+    }
 
     f32x16 acc[C::MT][C::NTL];
     gemm_tile<C, 0>(Q, q_row0, Bpad, X, c_row0, N, d, lds, acc, wave, lane, wave_m, wave_n);
@@ -679,15 +686,28 @@ __global__ __launch_bounds__(256) void dense_tile_rows_kernel(const _Float16 *__
 // for its pieces of stage g+1 (after M_h everything but the youngest 4 (h even) / 8 (h odd) instructions has landed),
 // and M_h overwrites the ring slots of stages h-1 and h, whose last reads (C(h-1)) retired before |B| of stage h-1
 // (lgkmcnt(0) ahead of every |B|).
+// GROUPED (VAR bit 5; round 6): ONE launch serves several matrices.  Every 256-row query tile has its own matrix (a dir's block copy,
+// kernels.h: ErhDenseView) and its own set of chunk streams: workgroup b belongs to query tile gio.wg_view[b] and is stream
+// b - wg0 of that tile's nwg streams, scanning rows [n0, N) of the tile's matrix.  Everything behind the prologue -- rings, segments,
+// epilogue, records -- is the ordinary kernel's; the (X, N, c0, c1) arguments and the block -> (query tile, stream) map are what the table
+// replaces.  Padding rows of a tile carry tau = +inf, so B = Bpad.
 template <int PABL, int VAR>
 __global__ __launch_bounds__(pp::NT) void dense_scan_pp3_kernel(
-    const _Float16 *__restrict__ X, int64_t N, int d, int64_t c0, int64_t c1,
+    const _Float16 *__restrict__ Xg, int64_t Ng, int d, int64_t c0g, int64_t c1g,
     const _Float16 *__restrict__ Q, int Bpad, int B,
     const float *__restrict__ tau, const int16_t *__restrict__ filter_dir, const int16_t *__restrict__ dir_id,
     ErhCand *__restrict__ cand, uint32_t *__restrict__ cand_cnt, int cap, uint32_t *__restrict__ overflow,
     unsigned long long *__restrict__ dbg /* kPpClocks only */, int rot_stages,
     uint32_t *__restrict__ stream_sync /* one zeroed word per stream, or null: see ERH_PP3_STREAM_SYNC */,
-    const erh::ErhSeedIo sio /* VAR bit 4: this launch is the sample pass (kernels.h) */) {
+    const erh::ErhSeedIo sio /* VAR bit 4: this launch is the sample pass (kernels.h) */,
+    const erh::ErhGroupIo gio /* VAR bit 5 */) {
+    constexpr bool GROUPED = (VAR & 32) != 0;
+    const int g_qt = GROUPED ? gio.wg_view[blockIdx.x] : 0;
+    const erh::ErhDenseView *const gv = GROUPED ? gio.views + g_qt : nullptr;
+    const _Float16 *const X = GROUPED ? gv->X : Xg;
+    const int64_t N = GROUPED ? gv->N : Ng;
+    const int64_t c0 = GROUPED ? (int64_t)gv->n0 : c0g;
+    const int64_t c1 = GROUPED ? gv->N : c1g;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -702,9 +722,9 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp3_kernel(
     const int64_t n_ct = (c1 - c0 + pp::BM - 1) / pp::BM;
     const int xcd = blockIdx.x & 7;
     const int jx = blockIdx.x >> 3;
-    const int qt = jx % n_qt;
-    const int stream = (jx / n_qt) * 8 + xcd;
-    const int n_streams = (gridDim.x / (8 * n_qt)) * 8;
+    const int qt = GROUPED ? g_qt : jx % n_qt;
+    const int stream = GROUPED ? (int)blockIdx.x - gv->wg0 : (jx / n_qt) * 8 + xcd;
+    const int n_streams = GROUPED ? gv->nwg : (gridDim.x / (8 * n_qt)) * 8;
     if (stream >= n_ct) return;                                        // whole workgroup, before any barrier
     const int n_tiles = (int)((n_ct - stream + n_streams - 1) / n_streams);
     const int total = n_tiles * nk;                                    // flattened (tile, stage) sequence
@@ -1468,8 +1488,11 @@ static_assert(Cfg1::LDS_BYTES == 80 * 1024, "cfg1");
 
 template <class C>
 hipError_t set_attrs() {
-    hipError_t e = hipFuncSetAttribute((const void *)dense_scan_store_kernel<C>,
+    hipError_t e = hipFuncSetAttribute((const void *)dense_scan_store_kernel<C, false>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void *)dense_scan_store_kernel<C, true>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
     if (e != hipSuccess) return e;
 #define ERH_SET_ABL(A)                                                                                     \
     e = hipFuncSetAttribute((const void *)dense_scan_append_kernel<C, A>,                                  \
@@ -1536,7 +1559,20 @@ hipError_t launch_store(const _Float16 *Q, int Bpad, const _Float16 *X, int64_t 
     const int n_ctiles = (nc + C::BN - 1) / C::BN;
     const int n_qtiles = Bpad / C::BM;
     dim3 grid(n_ctiles * n_qtiles), block(C::NT);
-    hipLaunchKernelGGL(dense_scan_store_kernel<C>, grid, block, C::LDS_BYTES, st, Q, Bpad, X, N, d, c0, nc, S0, ld_s0);
+    hipLaunchKernelGGL((dense_scan_store_kernel<C, false>), grid, block, C::LDS_BYTES, st, Q, Bpad, X, N, d, c0, nc, S0, ld_s0,
+                       (const erh::ErhDenseView *)nullptr);
+    return hipGetLastError();
+}
+
+template <class C>
+hipError_t launch_store_grouped(const erh::ErhDenseView *views, int n0_max, const _Float16 *Q, int Bpad, int d, float *S0, int ld_s0,
+                                hipStream_t st) {
+    static_assert(256 % C::BM == 0, "a query tile of the store kernel lies inside one 256-row tile of the view table");
+    const int n_ctiles = (n0_max + C::BN - 1) / C::BN;
+    const int n_qtiles = Bpad / C::BM;
+    dim3 grid(n_ctiles * n_qtiles), block(C::NT);
+    hipLaunchKernelGGL((dense_scan_store_kernel<C, true>), grid, block, C::LDS_BYTES, st, Q, Bpad, (const _Float16 *)nullptr, (int64_t)0, d,
+                       (int64_t)0, n0_max, S0, ld_s0, views);
     return hipGetLastError();
 }
 
@@ -1619,7 +1655,7 @@ hipError_t launch_pp(const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1
                        tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow, dbg, rot)
 #define ERH_LAUNCH_PP3V(A, V)                                                                              \
     hipLaunchKernelGGL((dense_scan_pp3_kernel<A, V>), grid, block, pp::LDS_BYTES, st, X, N, d, c0, c1, Q, Bpad, B, tau, \
-                       filter_dir, dir_id, cand, cand_cnt, cap, overflow, dbg, rot, stream_sync, sio_v)
+                       filter_dir, dir_id, cand, cand_cnt, cap, overflow, dbg, rot, stream_sync, sio_v, erh::ErhGroupIo{})
 #define ERH_LAUNCH_PP3(A)                                                                                  \
     do {                                                                                                   \
         if (seed) {                                        /* the sample pass: row-major operands, full kernel only */ \
@@ -1628,13 +1664,13 @@ hipError_t launch_pp(const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1
             if (var & 2) ERH_LAUNCH_PP3V(pp3_halfq_mask(A), 10); else ERH_LAUNCH_PP3V(pp3_halfq_mask(A), 8); \
         } else if (var & 2)                                                                                \
             hipLaunchKernelGGL((dense_scan_pp3_kernel<A, 2>), grid, block, pp::LDS_BYTES, st, X, N, d, c0, c1, Q, Bpad, \
-                               B, tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow, dbg, rot, stream_sync, sio_v); \
+                               B, tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow, dbg, rot, stream_sync, sio_v, erh::ErhGroupIo{}); \
         else if ((var & 1) && kPp3LockStep)                                                                \
             hipLaunchKernelGGL((dense_scan_pp3_kernel<A, kPp3LockStep>), grid, block, pp::LDS_BYTES, st, X, N, d, c0, c1, Q, \
-                               Bpad, B, tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow, dbg, rot, stream_sync, sio_v); \
+                               Bpad, B, tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow, dbg, rot, stream_sync, sio_v, erh::ErhGroupIo{}); \
         else                                                                                               \
             hipLaunchKernelGGL((dense_scan_pp3_kernel<A, 0>), grid, block, pp::LDS_BYTES, st, X, N, d, c0, c1, Q, Bpad, \
-                               B, tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow, dbg, rot, stream_sync, sio_v); \
+                               B, tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow, dbg, rot, stream_sync, sio_v, erh::ErhGroupIo{}); \
     } while (0)
 #ifdef ERH_MEASURE
 #define ERH_LAUNCH_PP(A)                                                                                   \
@@ -1707,6 +1743,7 @@ hipError_t dense_scan_init() {
 #define ERH_SET_PP(A) ERH_SET_PP3(A, 0) ERH_SET_PP3(A, 2)
     ERH_SET_PP(0)
     ERH_SET_PP3(0, 8) ERH_SET_PP3(0, 10) ERH_SET_PP3(0, 16) ERH_SET_PP3(0, 24)
+    ERH_SET_PP3(0, 32) ERH_SET_PP3(0, 40)              // the grouped launch (several matrices, one per query tile), whole / half query tile
     e = hipFuncSetAttribute((const void *)dense_scan_pp5_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, pp::LDS_BYTES);
     if (e != hipSuccess) return e;
 #ifdef ERH_MEASURE
@@ -1748,6 +1785,29 @@ hipError_t launch_dense_scan_pp(const _Float16 *X, int64_t N, int d, int64_t c0,
     if (d % (2 * pp::BK) != 0 || d / pp::BK < 8) return hipErrorInvalidValue;   // stage pairs never straddle a tile
     return launch_pp(X, N, d, c0, c1, Q, Bpad, B, tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow, n_cus, pabl,
                      dbg, lean, stream_sync, sio, st);
+}
+
+// The grouped launches (kernels.h: ErhDenseView / ErhGroupIo).  Store: every query tile against the seed prefix of its own matrix;
+// the 128 x 256 configuration when the 256 x 256 grid would leave CUs idle.  Scan: `grid` workgroups = the sum of the tiles' streams.
+hipError_t launch_dense_scan_store_grouped(const ErhGroupIo &gio, int n_qt, int n0_max, int n_cus, const _Float16 *Q, int Bpad, int d,
+                                           float *S0, int ld_s0, hipStream_t st) {
+    if (n0_max <= 0 || n_qt <= 0) return hipSuccess;
+    if ((int64_t)((n0_max + 255) / 256) * n_qt < n_cus) return launch_store_grouped<Cfg1>(gio.views, n0_max, Q, Bpad, d, S0, ld_s0, st);
+    return launch_store_grouped<Cfg0>(gio.views, n0_max, Q, Bpad, d, S0, ld_s0, st);
+}
+
+hipError_t launch_dense_scan_pp_grouped(const ErhGroupIo &gio, int grid, int d, const _Float16 *Q, int Bpad, const float *tau,
+                                        ErhCand *cand, uint32_t *cand_cnt, int cap, uint32_t *overflow, int halfq, hipStream_t st) {
+    if (grid <= 0) return hipSuccess;
+    if (d % (2 * pp::BK) != 0 || d / pp::BK < 8) return hipErrorInvalidValue;
+    const erh::ErhSeedIo sio_v{};
+#define ERH_LAUNCH_PP3G(V)                                                                                 \
+    hipLaunchKernelGGL((dense_scan_pp3_kernel<0, V>), dim3((unsigned)grid), dim3(pp::NT), pp::LDS_BYTES, st, (const _Float16 *)nullptr, \
+                       (int64_t)0, d, (int64_t)0, (int64_t)0, Q, Bpad, Bpad, tau, (const int16_t *)nullptr, (const int16_t *)nullptr, cand, \
+                       cand_cnt, cap, overflow, (unsigned long long *)nullptr, 0, (uint32_t *)nullptr, sio_v, gio)
+    if (halfq) ERH_LAUNCH_PP3G(40); else ERH_LAUNCH_PP3G(32);
+#undef ERH_LAUNCH_PP3G
+    return hipGetLastError();
 }
 
 int dense_scan_pp_streams(int n_cus, int Bpad) {

@@ -18,6 +18,34 @@ struct ErhSeedIo {
     int n_cells;           // seed_tiles * streams * 4
     int mode;              // 0 none, 1 sample pass (no thresholds, no candidates)
 };
+// Grouped dense call (round 6; api.hip: dense_topk_grouped): the batch's queries, grouped by their `dir` filter, are laid out group
+// after group, each group padded to whole 256-row QUERY TILES, and every tile scans ITS OWN matrix -- the dir's block copy -- in the
+// same launch as all the others.  One table entry per query tile; every stage of the pipeline (query preparation, seed-prefix store
+// kernel, seed select, persistent scan, final kernel) reads it instead of taking one matrix per launch.
+struct ErhDenseView {
+    const _Float16 *X;     // first row of the tile's matrix (a block of Xb)
+    int64_t N;             // its rows
+    int64_t mul, inv;      // row placement inside it: document r of the block is stored at (r * mul) mod N, inv the inverse
+    int32_t n0;            // rows [0, n0) are scored densely (store kernel -> S0 -> threshold), rows [n0, N) scanned against it
+    int32_t rank;          // rank of the prefix score that seeds the threshold (erh_dense_seed_rank; k: guaranteed bound)
+    int32_t id_lo;         // block row r is the caller's document id_map[id_lo + r]
+    int32_t wg0, nwg;      // persistent scan: workgroups [wg0, wg0 + nwg) walk this tile's chunk tiles (nwg chunk streams)
+    int32_t nq;            // queries of the tile = its first nq rows; the rest is padding (zero rows, threshold +inf)
+    int32_t pad_[2];
+};
+static_assert(sizeof(ErhDenseView) == 64, "ErhDenseView layout");
+struct ErhGroupIo {
+    const ErhDenseView *views;   // [query tiles]; null = an ordinary launch (one matrix, kernel arguments)
+    const int32_t *wg_view;      // [grid of the persistent scan]: workgroup -> query tile
+    const int32_t *q_src;        // [Bpad]: padded row -> the caller's query row, -1 for padding rows
+    const int32_t *id_map;       // block row -> document id (the handle's blk_ids)
+};
+hipError_t launch_dense_scan_store_grouped(const ErhGroupIo &gio, int n_qt, int n0_max, int n_cus, const _Float16 *Q, int Bpad, int d,
+                                           float *S0, int ld_s0, hipStream_t st);
+hipError_t launch_dense_scan_pp_grouped(const ErhGroupIo &gio, int grid, int d, const _Float16 *Q, int Bpad, const float *tau,
+                                        ErhCand *cand, uint32_t *cand_cnt, int cap, uint32_t *overflow,
+                                        int halfq /* every tile holds at most 128 queries: the other half of the tile is not computed */,
+                                        hipStream_t st);
 // chunk streams (co-resident workgroups per query tile) of the ping-pong scan on n_cus CUs, 0 if the shape does not qualify
 int dense_scan_pp_streams(int n_cus, int Bpad);
 hipError_t dense_scan_init();
@@ -77,7 +105,9 @@ hipError_t select_init();
 // fp32/fp16 -> fp16 query block [Bpad x d] (+ fp32 norm of the fp16 row); rows >= B are zeroed.
 hipError_t launch_prep_queries(const void *q, int q_dtype, int normalize, int B, int Bpad, int d,
                                _Float16 *Q16, float *qnorm, uint32_t *zero_bad /* null, or B words cleared by the kernel */,
-                               uint32_t *zero_flags /* null, or 16 words cleared by the kernel */, hipStream_t st);
+                               uint32_t *zero_flags /* null, or 16 words cleared by the kernel */, hipStream_t st,
+                               const int32_t *q_src = nullptr /* grouped call: row r of the block is the caller's row q_src[r] (-1: a zero
+                                                                  padding row); B == Bpad then */);
 // rows fp32 -> fp16 (optionally L2-normalised) for erh_set_dense
 hipError_t launch_convert_rows(const float *x, int64_t n, int d, int normalize, _Float16 *out_base, int64_t r0,
                                int64_t mul, int64_t N, hipStream_t st);
@@ -99,7 +129,7 @@ hipError_t launch_seed_select(const float *S0, int ld_s0, int n0, int64_t c0, in
                               const float *qnorm, float xnorm_max, int d,
                               const int16_t *filter_dir, const int16_t *dir_id,
                               float *tau, ErhCand *cand, uint32_t *cand_cnt, int cap, uint32_t *bad, uint32_t *need_full,
-                              hipStream_t st);
+                              hipStream_t st, const ErhDenseView *views = nullptr /* grouped call: n0 / rank per query tile, B = Bpad */);
 // Refine: k-th best over the current candidates -> tighter tau; candidates below it are dropped.
 hipError_t launch_cand_refine(int B, int k, const float *qnorm, float xnorm_max, int d,
                               float *tau, ErhCand *cand, uint32_t *cand_cnt, int cap, uint32_t *bad, hipStream_t st);
@@ -111,7 +141,9 @@ hipError_t launch_dense_finalize(int B, int k, int mode, const float *qnorm, flo
                                  float *diag_maxerr, uint32_t *diag_uncert, uint32_t *bad, int64_t N, int64_t pos_mul,
                                  int64_t pos_inv, const float *tau_verify, int n_cus,
                                  double *ws_s64 /* null, or dense_finalize_split_max() x kDenseRescoreMax doubles */,
-                                 uint32_t *ws_sync /* null, or 2 x dense_finalize_split_max() words, zero between calls */, hipStream_t st);
+                                 uint32_t *ws_sync /* null, or 2 x dense_finalize_split_max() words, zero between calls */, hipStream_t st,
+                                 const ErhGroupIo *gio = nullptr /* grouped call: matrix and placement per query tile, results written to the
+                                                                    caller's row q_src[q] with block rows mapped to document ids */);
 int dense_finalize_split_max();
 // dense calls routed by dir block: gather the rows idx[0..n) of a query block (row_bytes % 16 == 0), scatter a group's results back
 hipError_t launch_gather_query_rows(const void *q, const int32_t *idx, int n, int row_bytes, void *out, hipStream_t st);

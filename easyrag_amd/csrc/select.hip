@@ -37,19 +37,21 @@ template <typename TIN>
 __global__ __launch_bounds__(256) void prep_queries_kernel(const TIN *__restrict__ q, int normalize, int B, int d,
                                                           _Float16 *__restrict__ Q16, float *__restrict__ qnorm,
                                                           uint32_t *__restrict__ zero_bad /* null, or B words to clear */,
-                                                          uint32_t *__restrict__ zero_flags /* null, or the call's 16 flag words */) {
+                                                          uint32_t *__restrict__ zero_flags /* null, or the call's 16 flag words */,
+                                                          const int32_t *__restrict__ q_src /* null, or row -> caller's row (-1: padding) */) {
     __shared__ float red[4];
     const int row = blockIdx.x;
+    const int src = q_src ? q_src[row] : (row < B ? row : -1);
     // the call's per-query "uncertified" marks and its flag words start at zero: cleared here instead of by two memset launches
     if (zero_bad && row < B && threadIdx.x == 0) zero_bad[row] = 0u;
     if (zero_flags && row == 0 && threadIdx.x < 16) zero_flags[threadIdx.x] = 0u;
     _Float16 *out = Q16 + (int64_t)row * d;
-    if (row >= B) {
+    if (src < 0) {
         for (int i = threadIdx.x; i < d; i += 256) out[i] = (_Float16)0.f;
         if (threadIdx.x == 0) qnorm[row] = 0.f;
         return;
     }
-    const TIN *in = q + (int64_t)row * d;
+    const TIN *in = q + (int64_t)src * d;
     float inv = 1.f;
     if (normalize) {
         float ss = 0.f;
@@ -224,11 +226,20 @@ __global__ __launch_bounds__(kSelThreads) void seed_select_kernel(
     const float *__restrict__ qnorm, float xnorm_max, int d,
     const int16_t *__restrict__ filter_dir, const int16_t *__restrict__ dir_id,
     float *__restrict__ tau, ErhCand *__restrict__ cand, uint32_t *__restrict__ cand_cnt, int cap,
-    uint32_t *__restrict__ bad, uint32_t *__restrict__ need_full) {
+    uint32_t *__restrict__ bad, uint32_t *__restrict__ need_full,
+    const erh::ErhDenseView *__restrict__ views /* null, or the grouped call's table: prefix length and rank per query tile */) {
     __shared__ int s_nvalid, s_cnt, s_cnt2, s_keep;
     __shared__ uint32_t tmax[kSelThreads];
     __shared__ uint64_t buf[kSeedBuf];
     const int q = blockIdx.x, tid = threadIdx.x;
+    if (views) {
+        const erh::ErhDenseView &v = views[q >> 8];
+        if ((q & 255) >= v.nq) {                       // a padding row of the tile: nothing can pass its threshold
+            if (tid == 0) { tau[q] = INFINITY; cand_cnt[q] = 0u; need_full[q] = 0u; }
+            return;
+        }
+        n0 = v.n0; rank = v.rank;
+    }
     const float *row = S0 + (int64_t)q * ld_s0;
     const int fd = filter_dir ? (int)filter_dir[q] : -1;
     if (tid == 0) { s_nvalid = 0; s_cnt = 0; s_cnt2 = 0; s_keep = 0; need_full[q] = 0u; }
@@ -303,10 +314,15 @@ __global__ __launch_bounds__(kSelThreads) void seed_select_full_kernel(
     const float *__restrict__ qnorm, float xnorm_max, int d,
     const int16_t *__restrict__ filter_dir, const int16_t *__restrict__ dir_id,
     float *__restrict__ tau, ErhCand *__restrict__ cand, uint32_t *__restrict__ cand_cnt, int cap,
-    uint32_t *__restrict__ bad, const uint32_t *__restrict__ need_full) {
+    uint32_t *__restrict__ bad, const uint32_t *__restrict__ need_full, const erh::ErhDenseView *__restrict__ views) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int q = blockIdx.x, tid = threadIdx.x;
     if (!need_full[q]) return;                       // uniform
+    if (views) {
+        const erh::ErhDenseView &v = views[q >> 8];
+        n0 = v.n0; rank = v.rank;
+        np2 = erh_next_pow2(n0 < 2 ? 2 : n0);           // (<= the launch's np2, which was sized for the longest prefix)
+    }
     int &s_cnt = *reinterpret_cast<int *>(smem);
     uint32_t *keys = reinterpret_cast<uint32_t *>(smem + 64);
     const float *row = S0 + (int64_t)q * ld_s0;
@@ -453,7 +469,9 @@ __global__ __launch_bounds__(kFinThreads, (QR <= 2) ? 4 : 2) void dense_finalize
     int G /* workgroups per query (round 5; small batches, EXACT mode): each re-scores every G-th row of the margin set, the last one
              to finish ranks and emits.  1: one workgroup per query does everything */,
     double *__restrict__ ws_s64 /* G > 1: [B][kDenseRescoreMax] exact scores handed to the last workgroup */,
-    uint32_t *__restrict__ ws_sync /* G > 1: [B][2] {arrival counter, max error bits}, zero between calls */) {
+    uint32_t *__restrict__ ws_sync /* G > 1: [B][2] {arrival counter, max error bits}, zero between calls */,
+    const erh::ErhGroupIo gio /* views != null: the grouped call (G == 1) -- matrix and placement of the query's tile, results to the
+                                 caller's row, block rows mapped to document ids */) {
     __shared__ __attribute__((aligned(16))) uint64_t buf[kFinBuf];
     __shared__ uint32_t tmax[kFinSlots];
     __shared__ double r_s64[erh::kDenseRescoreMax];
@@ -467,6 +485,14 @@ __global__ __launch_bounds__(kFinThreads, (QR <= 2) ? 4 : 2) void dense_finalize
     // above it, sort: the same result in each, the keys are distinct), re-scores its share of the rows, and the last to arrive ranks.
     const int q = G > 1 ? (int)blockIdx.x / G : (int)blockIdx.x, part = G > 1 ? (int)blockIdx.x % G : 0, tid = threadIdx.x;
     const bool lead = part == 0;                                        // side effects that must happen once per query
+    int out_row = q, id_lo = 0;
+    if (gio.views) {                                                    // uniform
+        const erh::ErhDenseView &v = gio.views[q >> 8];
+        if ((q & 255) >= v.nq) return;                                  // a padding row
+        X = v.X; N = v.N; pos_mul = v.mul; pos_inv = v.inv; id_lo = v.id_lo;
+        out_row = gio.q_src[q];
+    }
+    const int32_t *const id_map = gio.views ? gio.id_map : nullptr;
     int c = (int)cand_cnt[q];
     if (c > cap) {                                                      // appends were dropped: not answerable from the list
         if (tid == 0 && lead) bad[q] = 1u;
@@ -474,9 +500,9 @@ __global__ __launch_bounds__(kFinThreads, (QR <= 2) ? 4 : 2) void dense_finalize
     }
     const ErhCand *mine = cand + (int64_t)q * cap;
     const int kk = k < c ? k : c;
-    int32_t *o_ids = out_ids + (int64_t)q * k;
-    double *o_sc = out_scores + (int64_t)q * k;
-    if (tid == 0) { if (lead) out_len[q] = kk; s_cnt = 0; s_m = 0; s_maxerr = 0; s_lvl = 0; s_last = 1; }
+    int32_t *o_ids = out_ids + (int64_t)out_row * k;
+    double *o_sc = out_scores + (int64_t)out_row * k;
+    if (tid == 0) { if (lead) out_len[out_row] = kk; s_cnt = 0; s_m = 0; s_maxerr = 0; s_lvl = 0; s_last = 1; }
     if (lead) for (int i = kk + tid; i < k; i += kFinThreads) { o_ids[i] = -1; o_sc[i] = 0.0; }
     if (kk == 0) return;                                                // uniform
 
@@ -530,7 +556,8 @@ __global__ __launch_bounds__(kFinThreads, (QR <= 2) ? 4 : 2) void dense_finalize
 
     if (mode == 1 /* ERH_DENSE_FAST */) {
         for (int i = tid; i < kk; i += kFinThreads) {
-            o_ids[i] = erh_key32_idx(buf[i]);
+            const int32_t o = erh_key32_idx(buf[i]);
+            o_ids[i] = id_map ? id_map[id_lo + o] : o;
             o_sc[i] = (double)erh_key32_score(buf[i]);
         }
         return;
@@ -671,7 +698,7 @@ __global__ __launch_bounds__(kFinThreads, (QR <= 2) ? 4 : 2) void dense_finalize
     const int mp = erh_next_pow2(m < 2 ? 2 : m);
     for (int t = m + tid; t < mp; t += kFinThreads) { r_s64[t] = -INFINITY; r_idx[t] = 0x7fffffff; }
     erh_bitonic_rec_desc<double>(r_s64, r_idx, mp);                     // begins and ends with a barrier
-    for (int t = tid; t < kk; t += kFinThreads) { o_ids[t] = r_idx[t]; o_sc[t] = r_s64[t]; }
+    for (int t = tid; t < kk; t += kFinThreads) { o_ids[t] = id_map ? id_map[id_lo + r_idx[t]] : r_idx[t]; o_sc[t] = r_s64[t]; }
     if (tid == 0) {
         const float me = __uint_as_float(s_maxerr);
         atomicMax((unsigned int *)diag_maxerr, __float_as_uint(me));
@@ -860,13 +887,14 @@ hipError_t select_init() {
 }
 
 hipError_t launch_prep_queries(const void *q, int q_dtype, int normalize, int B, int Bpad, int d,
-                               _Float16 *Q16, float *qnorm, uint32_t *zero_bad, uint32_t *zero_flags, hipStream_t st) {
+                               _Float16 *Q16, float *qnorm, uint32_t *zero_bad, uint32_t *zero_flags, hipStream_t st,
+                               const int32_t *q_src) {
     if (q_dtype == 0)
         hipLaunchKernelGGL(prep_queries_kernel<_Float16>, dim3(Bpad), dim3(256), 0, st,
-                           (const _Float16 *)q, normalize, B, d, Q16, qnorm, zero_bad, zero_flags);
+                           (const _Float16 *)q, normalize, B, d, Q16, qnorm, zero_bad, zero_flags, q_src);
     else
         hipLaunchKernelGGL(prep_queries_kernel<float>, dim3(Bpad), dim3(256), 0, st,
-                           (const float *)q, normalize, B, d, Q16, qnorm, zero_bad, zero_flags);
+                           (const float *)q, normalize, B, d, Q16, qnorm, zero_bad, zero_flags, q_src);
     return hipGetLastError();
 }
 
@@ -912,15 +940,15 @@ hipError_t launch_seed_select(const float *S0, int ld_s0, int n0, int64_t c0, in
                               const float *qnorm, float xnorm_max, int d,
                               const int16_t *filter_dir, const int16_t *dir_id,
                               float *tau, ErhCand *cand, uint32_t *cand_cnt, int cap, uint32_t *bad,
-                              uint32_t *need_full, hipStream_t st) {
-    const int np2 = pow2_ge(n0 < 2 ? 2 : n0);
+                              uint32_t *need_full, hipStream_t st, const ErhDenseView *views) {
+    const int np2 = pow2_ge(n0 < 2 ? 2 : n0);         // (grouped call: n0 = the longest prefix of the table; every tile uses its own)
     if (rank < 1 || rank > k) rank = k;
     hipLaunchKernelGGL(seed_select_kernel, dim3(B), dim3(kSelThreads), 0, st,
                        S0, ld_s0, n0, np2, c0, k, rank, qnorm, xnorm_max, d, filter_dir, dir_id, tau, cand, cand_cnt, cap,
-                       bad, need_full);
+                       bad, need_full, views);
     hipLaunchKernelGGL(seed_select_full_kernel, dim3(B), dim3(kSelThreads), (size_t)np2 * 4 + 64, st,
                        S0, ld_s0, n0, np2, c0, k, rank, qnorm, xnorm_max, d, filter_dir, dir_id, tau, cand, cand_cnt, cap,
-                       bad, need_full);
+                       bad, need_full, views);
     return hipGetLastError();
 }
 
@@ -959,16 +987,18 @@ hipError_t launch_dense_finalize(int B, int k, int mode, const float *qnorm, flo
                                  int32_t *out_ids, double *out_scores, int32_t *out_len,
                                  float *diag_maxerr, uint32_t *diag_uncert, uint32_t *bad, int64_t N,
                                  int64_t pos_mul, int64_t pos_inv, const float *tau_verify, int n_cus, double *ws_s64,
-                                 uint32_t *ws_sync, hipStream_t st) {
+                                 uint32_t *ws_sync, hipStream_t st, const ErhGroupIo *gio) {
     // workgroups per query: small batches spread a query's row gathers over the chip (EXACT mode only; the work space is optional)
     int G = 1;
-    if (mode == 0 && ws_s64 && ws_sync && B <= dense_finalize_split_max())
+    if (mode == 0 && ws_s64 && ws_sync && B <= dense_finalize_split_max() && !gio)
         G = 16;
     (void)n_cus;
+    ErhGroupIo gv{};
+    if (gio) gv = *gio;
 #define ERH_FIN_LAUNCH(QR)                                                                                  \
     hipLaunchKernelGGL(dense_finalize_kernel<QR>, dim3(B * G), dim3(kFinThreads), 0, st, k, mode, qnorm, xnorm_max, d, X, Q16, \
                        cand, cand_cnt, cap, out_ids, out_scores, out_len, diag_maxerr, diag_uncert, bad, N, pos_mul, \
-                       pos_inv, tau_verify, G, ws_s64, ws_sync)
+                       pos_inv, tau_verify, G, ws_s64, ws_sync, gv)
     if (d <= 512) ERH_FIN_LAUNCH(1);
     else if (d <= 1024) ERH_FIN_LAUNCH(2);
     else ERH_FIN_LAUNCH(4);

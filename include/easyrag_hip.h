@@ -332,14 +332,18 @@ int erh_reset_kernel_time(erh_handle *h);
  *                         of its document order, so a filter on one of four dirs skips three quarters of the tile passes); 0 = all tiles
  *   dense_dir_blocks (1)  dense route with a dir filter: queries scan a copy of their dir's chunks (the dir's documents in ascending order
  *                         -- one run in the reference's dir-by-dir layout, gathered from anywhere otherwise --, own row placement, built on
- *                         the first filtered call, + 2 d bytes per chunk) instead of the whole matrix with a filter column -- the batch is
- *                         grouped by dir on the host, up to 8 groups per call, every group through the same kernels as a view, results
- *                         back in the caller's order and numbering; the groups' flag words are read together by erh_dense_check / the
- *                         host-output copy (a flagged group is run again to the end).
- *                         1 = where an estimate from measured scan times says it pays (one query, one dir per batch, groups of
- *                         hundreds of queries: 1024 queries over 4 dirs 2.72 -> 1.76 ms, one query 0.62 -> 0.30 ms; not 4 dirs x
- *                         4 ... 64 queries, where every group re-reads a block and pays its own pipeline: +64 ... +70 %);
+ *                         the first filtered call, + 2 d bytes per chunk of a dir that gets a block) instead of the whole matrix with a
+ *                         filter column.  The batch is grouped by dir on the host; two or more groups run as ONE launch per stage
+ *                         (dense_group_launch: a table with one entry per 256-query tile -- block, placement, seed prefix, chunk streams --
+ *                         read by every kernel of the pipeline; any number of dirs), a single group (one filtered query per call, the
+ *                         reference's pattern) and the queries without a block as pipelines of their own; results come back in the
+ *                         caller's order and numbering; the pipelines' flag words are read together by erh_dense_check / the host-output
+ *                         copy (a group with a flagged query is run again to the end).
+ *                         1 = where the routed work is smaller than the whole-matrix work, in rows x query columns with columns below
+ *                         dense_route_ridge counted as the ridge (a scan that narrow is bound by the matrix bytes);
  *                         2 = whenever the batch has a dir with a block; 0 = always the filter column.  Same results
+ *   dense_group_launch (1)  0: every block group of a batch as a pipeline of its own (the round-5 path; a parity arm)
+ *   dense_route_ridge (160) query columns below which a dense scan is HBM-bound on this chip (the route decision's only constant)
  *   dense_dir_block_min_rows (4096)  smallest dir that gets a block of its own
  *   bm25_post16 (1)       packed shape: read 4-byte postings {15-bit document offset in the tile, 16-bit payload} (built when an
  *                         index is set while bm25_small = 2; + 4 bytes per posting); 0 = the 8-byte fixed-point postings
@@ -391,6 +395,7 @@ int erh_dense_exhaustive_count(erh_handle *h, int32_t *count);
  *   dense_tile384_nomem                                times the 384-row copy of the chunk matrix did not fit and the 256 x 256 scan took over
  *   dense_exhaustive_queries                           queries answered by the exhaustive path (device counter; summed over calls)
  *   dense_block_groups                                 query groups answered from their dir's block (dense_dir_blocks)
+ *   dense_grouped_launches                             calls whose block groups ran as one launch per stage (dense_group_launch)
  *   bm25_redo_segments                                 (query, segment) pairs the fixed-point scan handed to the exact block scan (device counter)
  * Reading a device counter synchronises the device.  Unknown name: ERH_ERR_INVALID. */
 int erh_get_stat(erh_handle *h, const char *name, int64_t *value);

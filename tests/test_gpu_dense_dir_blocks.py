@@ -38,10 +38,15 @@ def _check_oracle(x, q16, k, dir_id, filt, got, rows):
         assert np.array_equal(sc[i, :ln[i]].view(np.uint64), osc.view(np.uint64)), i
 
 
-@pytest.fixture
-def blocks_opts(engine):
-    engine.set_option("dense_dir_blocks", 2)                        # every batch with a block dir takes the route (1 = by estimate)
+@pytest.fixture(params=[1, 0], ids=["one-launch-per-stage", "pipeline-per-group"])
+def blocks_opts(engine, request):
+    """Both ways of running a batch's block groups: ONE launch per stage over all of them through the view table (round 6, the default),
+    and every group as a pipeline of its own (round 5; what a group with a flagged query still falls back to)."""
+    engine.set_option("dense_dir_blocks", 2)                        # every batch with a block dir takes the route (1 = by the work estimate)
+    engine.set_option("dense_group_launch", request.param)
+    engine.group_launch = request.param
     yield engine
+    engine.set_option("dense_group_launch", 1)
     engine.set_option("dense_dir_blocks", 1)
     engine.set_option("dense_dir_block_min_rows", 4096)
     engine.set_option("dense_shuffle", 1)
@@ -53,7 +58,7 @@ def test_blocks_mixed_batch_against_oracle(blocks_opts):
     engine = blocks_opts
     rng = np.random.default_rng(501)
     sizes = [5000, 12000, 3000, 20000]
-    n, d, b, k = sum(sizes), 128, 48, 50
+    n, d, b, k = sum(sizes), 256, 48, 50
     x = to_f16_unit(rng.standard_normal((n, d)) + 0.4 * rng.standard_normal(d))
     q16 = to_f16_unit(x[rng.integers(0, n, b)].astype(np.float32) + 0.3 * rng.standard_normal((b, d)))
     dir_id = _blocks(sizes)
@@ -67,6 +72,7 @@ def test_blocks_mixed_batch_against_oracle(blocks_opts):
     engine.reset_stats()
     routed = engine.dense_topk(q16, k, filter_dir=filt)
     assert engine.stat("dense_block_groups") == 3                 # dirs 0, 1, 3; dir 2 (3000 rows) rides with the unfiltered queries
+    assert engine.stat("dense_grouped_launches") == engine.group_launch
     assert engine.dense_diag()["uncertified"] == 0
     _same(plain, routed)
     _check_oracle(x, q16, k, dir_id, filt, routed, range(b))
@@ -93,7 +99,7 @@ def test_blocks_fp32_queries_fast_mode_and_device_inputs(blocks_opts):
     engine = blocks_opts
     rng = np.random.default_rng(505)
     sizes = [6000, 9000, 5000]
-    n, d, b, k = sum(sizes), 192, 21, 30
+    n, d, b, k = sum(sizes), 256, 21, 30
     x32 = (rng.standard_normal((n, d)) * 2).astype(np.float32)
     q32 = (x32[rng.integers(0, n, b)] + 0.8 * rng.standard_normal((b, d))).astype(np.float32) * 0.3
     dir_id = _blocks(sizes)
@@ -127,7 +133,7 @@ def test_blocks_ties_across_blocks_and_tiny_blocks(blocks_opts):
     block, lowest first), blocks smaller than k (the list is the block) and of one row, with the block minimum lowered to 1."""
     engine = blocks_opts
     rng = np.random.default_rng(502)
-    d, k = 64, 40
+    d, k = 256, 40
     base = to_f16_unit(rng.standard_normal((300, d)))
     sizes = [1, 30, 300, 900, 2400]
     x = np.concatenate([np.tile(base, (max(1, s // 300), 1))[:s] if s >= 300 else base[:s] for s in sizes])
@@ -155,7 +161,7 @@ def test_blocks_exhaustive_path_inside_a_block(blocks_opts):
     path INSIDE the block (its rows, its ids shifted by the block's first document)."""
     engine = blocks_opts
     rng = np.random.default_rng(503)
-    d, k = 128, 64
+    d, k = 256, 64
     a = to_f16_unit(rng.standard_normal((5000, d)))
     one = to_f16_unit(rng.standard_normal((1, d)))
     c = to_f16_unit(rng.standard_normal((7000, d)))
@@ -200,13 +206,13 @@ def test_blocks_exhaustive_path_inside_a_block(blocks_opts):
         assert np.array_equal(a_.view(np.uint64) if a_.dtype == np.float64 else a_, c_.view(np.uint64) if c_.dtype == np.float64 else c_)
 
 
-def test_blocks_of_scattered_dirs_and_too_many_groups(blocks_opts):
+def test_blocks_of_scattered_dirs_and_many_groups(blocks_opts):
     """Interleaved dirs (document i in dir i % 4: a corpus that was NOT loaded dir by dir) get block copies too -- the class' documents
-    gathered in ascending order, block rows mapped back through the id table; twelve dirs in one batch are more groups than the route
-    takes and answer through the filter column."""
+    gathered in ascending order, block rows mapped back through the id table; twelve dirs in one batch are twelve groups (round 5
+    stopped at eight and fell back to the filter column)."""
     engine = blocks_opts
     rng = np.random.default_rng(504)
-    n, d, b, k = 30000, 64, 36, 25
+    n, d, b, k = 30000, 256, 36, 25
     x = to_f16_unit(rng.standard_normal((n, d)))
     q16 = to_f16_unit(rng.standard_normal((b, d)))
     engine.set_option("dense_dir_block_min_rows", 1)
@@ -226,9 +232,13 @@ def test_blocks_of_scattered_dirs_and_too_many_groups(blocks_opts):
     engine.set_doc_meta(n, None, dir_id)
     filt = (np.arange(b) % 12).astype(np.int16)
     got = engine.dense_topk(q16, k, filter_dir=filt)
-    assert engine.stat("dense_block_groups") == 0
-    _check_oracle(x, q16, k, dir_id, filt, got, (0, 5, 11, b - 1))
-    filt = (np.arange(b) % 3 + 4).astype(np.int16)                 # three of the twelve: routed
+    assert engine.stat("dense_block_groups") == 12 and engine.stat("dense_grouped_launches") == engine.group_launch
+    _check_oracle(x, q16, k, dir_id, filt, got, range(b))
+    engine.set_option("dense_dir_blocks", 0)
+    _same(engine.dense_topk(q16, k, filter_dir=filt), got)
+    engine.set_option("dense_dir_blocks", 2)
+    engine.reset_stats()
+    filt = (np.arange(b) % 3 + 4).astype(np.int16)                 # three of the twelve
     got = engine.dense_topk(q16, k, filter_dir=filt)
     assert engine.stat("dense_block_groups") == 3
     _check_oracle(x, q16, k, dir_id, filt, got, (0, 1, 2, b - 1))
@@ -269,6 +279,8 @@ def test_blocks_large_batch_and_hybrid(blocks_opts):
     engine.reset_stats()
     routed = engine.dense_topk(q16, k, filter_dir=filt)
     assert engine.stat("dense_block_groups") == 4
+    assert engine.stat("dense_grouped_launches") == engine.group_launch
+    assert engine.stat("dense_scan_pp3_launches") == (1 if engine.group_launch else 4)      # ONE scan launch over the four blocks
     assert engine.dense_diag()["uncertified"] == 0
     _same(plain, routed)
     _check_oracle(x, q16, k, dir_id, filt, routed, (0, 1, 2, 3, 317, b - 1))
@@ -307,7 +319,7 @@ def test_blocks_random_shapes_against_filter_column(blocks_opts, seed):
     if seed % 2 == 0:                                                # every other case: the dirs scattered over the corpus, some documents
         dir_id = rng.permutation(dir_id)                             # without any dir (-1)
         dir_id[rng.integers(0, n, max(1, n // 50))] = -1
-    d = int(rng.choice([64, 128, 320]))
+    d = int(rng.choice([64, 256, 320]))                              # (64: below the persistent scan's 8 K-stages, every group its own pipeline)
     b = int(rng.choice([1, 7, 65, 300]))
     k = int(rng.choice([1, 10, 100, 300]))
     x = to_f16_unit(rng.standard_normal((n, d)) + 0.3 * rng.standard_normal(d))
@@ -323,3 +335,92 @@ def test_blocks_random_shapes_against_filter_column(blocks_opts, seed):
     assert engine.dense_diag()["uncertified"] == 0
     _same(plain, routed)
     _check_oracle(x, q16, k, dir_id, filt, routed, sorted(set([0, b // 2, b - 1])))
+
+
+def test_grouped_launch_tile_shapes(engine):
+    """The view table's corner cases in one batch of 700 queries: a dir with 300 queries (two query tiles on one block: 256 + 44), dirs
+    with 129 / 128 / 1 queries (whole and half query tiles), a block shorter than the seed prefix (the store kernel scores all of it,
+    no scan stage), a block of 40 rows (fewer than k: the list is the block) and of one row, and queries without a filter riding along
+    as the ordinary group.  Then the same blocks with at most 128 queries each: the half-query-tile instantiation of the scan."""
+    rng = np.random.default_rng(707)
+    sizes = [70000, 45000, 36000, 9000, 40, 1, 52000]
+    n, d, k = sum(sizes), 256, 60
+    x = to_f16_unit(rng.standard_normal((n, d)) + 0.3 * rng.standard_normal(d))
+    dir_id = _blocks(sizes)
+    counts = [300, 129, 128, 60, 9, 3, 1]
+    filt = np.concatenate([np.full(c, i, np.int16) for i, c in enumerate(counts)] + [np.full(70, -1, np.int16)])
+    filt = rng.permutation(filt)
+    b = filt.shape[0]
+    q16 = to_f16_unit(x[rng.integers(0, n, b)].astype(np.float32) + 0.4 * rng.standard_normal((b, d)))
+    engine.set_option("dense_dir_block_min_rows", 1)
+    engine.set_option("dense_dir_blocks", 2)
+    try:
+        engine.set_dense(x)
+        engine.set_doc_meta(n, None, dir_id)
+        engine.reset_stats()
+        got = engine.dense_topk(q16, k, filter_dir=filt)
+        st, diag = engine.stats(), engine.dense_diag()
+        assert st["dense_block_groups"] == 7 and st["dense_grouped_launches"] == 1 and diag["uncertified"] == 0, (st, diag)
+        assert diag["exhaustive"] == 0 and diag["max_abs_err"] <= diag["margin"]
+        engine.set_option("dense_group_launch", 0)
+        _same(engine.dense_topk(q16, k, filter_dir=filt), got)
+        engine.set_option("dense_dir_blocks", 0)
+        _same(engine.dense_topk(q16, k, filter_dir=filt), got)
+        sample = [int(np.flatnonzero(filt == c)[j]) for c in range(7) for j in (0, -1)] + [int(np.flatnonzero(filt < 0)[0])]
+        _check_oracle(x, q16, k, dir_id, filt, got, sample)
+        # at most 128 queries per dir: every tile is a half tile
+        engine.set_option("dense_group_launch", 1)
+        engine.set_option("dense_dir_blocks", 2)
+        keep = np.concatenate([np.flatnonzero(filt == c)[:128] for c in range(7)])
+        engine.reset_stats()
+        half = engine.dense_topk(q16[keep], k, filter_dir=filt[keep])
+        assert engine.stat("dense_grouped_launches") == 1
+        for j, i in enumerate(keep):
+            assert half[2][j] == got[2][i] and np.array_equal(half[0][j], got[0][i])
+            assert np.array_equal(half[1][j].view(np.uint64), got[1][i].view(np.uint64))
+    finally:
+        engine.set_option("dense_group_launch", 1)
+        engine.set_option("dense_dir_blocks", 1)
+        engine.set_option("dense_dir_block_min_rows", 4096)
+
+
+def test_route_decision_by_work(engine):
+    """dense_dir_blocks = 1 (the default) routes where the routed work -- rows x max(query columns, dense_route_ridge) summed over the
+    groups -- is smaller than the whole-matrix work; no table of measured milliseconds.  Four blocks of 30000 rows: one filtered query
+    (a quarter of the rows), 4 x 64 and 4 x 160 queries (half tiles / whole tiles against one padded 256 / 768-column scan of everything)
+    route; 4 x 8 queries do not (32 columns over the matrix once against 4 x a block at the ridge: the same rows)."""
+    rng = np.random.default_rng(808)
+    n, d, k = 120_000, 256, 40
+    x = to_f16_unit(rng.standard_normal((n, d)))
+    dir_id = _blocks([30000] * 4)
+    engine.set_dense(x)
+    engine.set_doc_meta(n, None, dir_id)
+    engine.set_option("dense_dir_blocks", 1)
+    for per_dir, want_groups, want_grouped in ((64, 4, 1), (160, 4, 1), (8, 0, 0)):
+        b = 4 * per_dir
+        q16 = to_f16_unit(rng.standard_normal((b, d)))
+        filt = (np.arange(b) % 4).astype(np.int16)
+        engine.reset_stats()
+        got = engine.dense_topk(q16, k, filter_dir=filt)
+        assert engine.stat("dense_block_groups") == want_groups and engine.stat("dense_grouped_launches") == want_grouped, per_dir
+        _check_oracle(x, q16, k, dir_id, filt, got, (0, 1, b // 2, b - 1))
+    q16 = to_f16_unit(rng.standard_normal((1, d)))
+    engine.reset_stats()
+    got = engine.dense_topk(q16, k, filter_dir=np.array([2], np.int16))
+    assert engine.stat("dense_block_groups") == 1 and engine.stat("dense_grouped_launches") == 0
+    _check_oracle(x, q16, k, dir_id, np.array([2], np.int16), got, (0,))
+    # the ridge is an option: at 1 column every comparison is by columns alone, and 4 x 8 queries (4 x 128 columns of a block = 128 of the
+    # matrix, against 32 of the matrix) still do not route; at 4096 nothing but a smaller row count routes
+    engine.set_option("dense_route_ridge", 4096)
+    try:
+        b = 256
+        q16 = to_f16_unit(rng.standard_normal((b, d)))
+        filt = (np.arange(b) % 4).astype(np.int16)
+        engine.reset_stats()
+        engine.dense_topk(q16, k, filter_dir=filt)
+        assert engine.stat("dense_block_groups") == 0               # the same rows either way
+        filt = (np.arange(b) % 2).astype(np.int16)
+        engine.dense_topk(q16, k, filter_dir=filt)
+        assert engine.stat("dense_block_groups") == 2               # half the rows
+    finally:
+        engine.set_option("dense_route_ridge", 160)
