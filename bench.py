@@ -49,6 +49,10 @@ def parse_args(argv=None):
                                                                 "--backend gloo; the numbers it prints are not a scaling measurement)")
     ap.add_argument("--dump-out", default=None, help="every rank saves the last step's (global) result as <path>.rank<r>.npz (tests)")
     ap.add_argument("--variant", default="bm25s", choices=["bm25s", "okapi"])
+    ap.add_argument("--corpus", default="gaussian", choices=["gaussian", "clustered"], help="chunk embeddings: isotropic Gaussian directions (SURVEY 8d) or "
+                    "the anisotropic topic-sorted corpus of synth.clustered_corpus_torch (random-pair cosine ~0.4, intra-topic ~0.7, 2 %% exact duplicates)")
+    ap.add_argument("--qlen", default="fixed", choices=["fixed", "ref"], help="token queries of 10 tokens (SURVEY 8d) or with the length distribution of the "
+                    "reference's 103 questions (4 ... 45 tokens, mean 10.8)")
     ap.add_argument("--cpu-queries", type=int, default=96, help="queries in the bounded CPU-baseline sample, ~15 s of host work (0 = skip)")
     ap.add_argument("--option", action="append", default=[], help="library option name=value (e.g. dense_n1=131072)")
     ap.add_argument("--sub", type=int, default=1, help="1 (default): after the headline run, time the other BASELINE.json configs and the "
@@ -270,7 +274,7 @@ def roofline_of(kd, dom):
     return roof
 
 
-def run_sub(eng, classes, fn, n_queries, dom, min_seconds=0.3, sync_each=False, what="", check_each=False):
+def run_sub(eng, classes, fn, n_queries, dom, min_seconds=0.3, sync_each=False, what="", check_each=False, path=False):
     """One sub-benchmark on the resident corpus: enough steps for >= min_seconds of timed work, kernel classes from the
     library's event timers, roofline of `dom`.  sync_each: host-visible latency of single calls (B = 1)."""
     import torch
@@ -285,6 +289,8 @@ def run_sub(eng, classes, fn, n_queries, dom, min_seconds=0.3, sync_each=False, 
     steps = int(min(4000, max(10, np.ceil(min_seconds / est))))
     eng.set_profiling(True)
     eng.reset_kernel_time()
+    if path:
+        eng.reset_stats()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(steps):
@@ -300,6 +306,11 @@ def run_sub(eng, classes, fn, n_queries, dom, min_seconds=0.3, sync_each=False, 
     rec = {"what": what, "queries_per_step": n_queries, "steps": steps, "ms_per_step": dt / steps * 1e3,
            "value": n_queries * steps / dt, "unit": "queries/s", "timed_seconds": dt,
            "kernel_ms_per_step": {k_: v["ms"] / steps for k_, v in kt.items()}}
+    if path:
+        # which kernels answered the timed steps, how many queries left the pruned pipeline, and how selective the thresholds were
+        rec["path"] = {k_: v for k_, v in eng.stats().items() if v}
+        rec["path"]["dense_exhaustive_queries"] = eng.stat("dense_exhaustive_queries")
+        rec["dense_candidates_per_query_last_step"] = eng.dense_candidates_last_call() / max(1, n_queries)
     if dom is not None:
         rec["roofline"] = roofline_of(kt[dom], dom)
         if rec["roofline"] is not None:
@@ -311,7 +322,7 @@ def run_sub(eng, classes, fn, n_queries, dom, min_seconds=0.3, sync_each=False, 
     return rec
 
 
-def sub_benchmarks(eng, synth, queries_to_csr, build_index, OKAPI, q16_pool, tok_pool, csr_pool, postings, pool):
+def sub_benchmarks(eng, synth, queries_to_csr, build_index, OKAPI, q16_pool, tok_pool, csr_pool, postings, pool, flat_lens=None):
     """The BASELINE.json configurations the headline is NOT quoted on, and the reference's own call pattern (one query at
     a time), timed on the corpus that is already resident: each with its own step count (>= 0.3 s of timed work),
     kernel-class times from the library's HIP events and a roofline block.  Roughly 10 s of wall time in all."""
@@ -379,9 +390,43 @@ def sub_benchmarks(eng, synth, queries_to_csr, build_index, OKAPI, q16_pool, tok
                  "posting tiles, host-visible latency per call incl. erh_dense_check")
     finally:
         eng.set_doc_meta(n_docs, None, None)
+    # Is the timing an artefact of the synthetic distributions?    (b) first, on the resident corpus: token queries with
+    # the length distribution of the reference's 103 real questions (4 ... 45 tokens, mean 10.8) instead of ten tokens each; then (a) a
+    # second chunk matrix -- anisotropic and topic-sorted like real embedding corpora (two random chunks ~0.4 cosine, one topic ~0.7,
+    # 2 % exact duplicates), queries near corpus members -- under the same BM25 index.  Both report the path counters and the
+    # candidates per query next to the Gaussian / fixed-length figures of the headline.
+    import torch
+    Bq = int(q16_pool[0].shape[0])
+    if flat_lens is not None:
+        flat, lens_, vocab = flat_lens
+        tok_ref = [synth.token_queries(flat, lens_, vocab, Bq, seed=4000 + p, lengths=synth.REF_QUESTION_LENGTHS) for p in range(pool)]
+        csr_ref = [queries_to_csr(t) for t in tok_ref]
+        out["hybrid_b1024_ref_query_lengths"] = run_sub(
+            eng, classes, lambda i: eng.hybrid_topk(q16_pool[i % pool], *csr_ref[i % pool], k_dense=288, k_sparse=192, K=60, topk=10,
+                                                    device_out=True), Bq, "dense_scan", path=True,
+            what="configs[3] with token queries whose lengths follow the reference's 103 questions (4 ... 45 tokens, mean 10.8; 80 % of a "
+                 "query's tokens from its target document, repeats allowed)")
+        out["hybrid_b1024_ref_query_lengths"]["mean_query_tokens"] = float(np.mean([len(t) for t in tok_ref[0]]))
+        out["hybrid_b1024_ref_query_lengths"]["bm25_redo_segments"] = eng.stat("bm25_redo_segments")
+    n_docs, d_ = int(eng.n_dense), int(eng.d)
+    xc = synth.clustered_corpus_torch(n_docs, d_, seed=21, device=q16_pool[0].device)
+    qc = [synth.dense_queries_torch(xc, Bq, seed=5000 + p) for p in range(pool)]
+    eng.set_dense(xc)
+    out["hybrid_b1024_clustered"] = run_sub(
+        eng, classes, lambda i: eng.hybrid_topk(qc[i % pool], *csr_pool[i % pool], k_dense=288, k_sparse=192, K=60, topk=10,
+                                                device_out=True), Bq, "dense_scan", path=True,
+        what="configs[3] on ANISOTROPIC chunk embeddings: topic-sorted rows sqrt(.4) m + sqrt(.3) c_topic + sqrt(.3) noise (2000 topics: "
+             "random-pair cosine ~0.4, intra-topic ~0.7), 2 % exact duplicates, queries = noisy copies of corpus rows; same BM25 index")
+    eng.dense_check()
+    out["hybrid_b1024_clustered"]["dense_exhaustive_queries_last_call"] = eng.dense_diag()["exhaustive"]
+    q256c = [q[:256].contiguous() for q in qc]
+    out["dense_b256_top100_clustered"] = run_sub(
+        eng, classes, lambda i: eng.dense_topk(q256c[i % pool], 100, device_out=True), 256, "dense_scan", path=True,
+        what="configs[1] on the anisotropic corpus")
+    del xc, qc, q256c
+    torch.cuda.empty_cache()
     # the reference's own vector size (ref src/configs/easyrag.yaml:15-16: gte-Qwen2-7B, vector_size 3584): the same 2.05 GB of chunk
     # matrix as 285 696 x 3584 fp16, dense top-100, batch 256 -- LAST, because it replaces the resident 1M x 1024 matrix
-    import torch
     n35, d35 = 285_696, 3584
     x35 = synth.dense_corpus_torch(n35, d35, seed=12, device=q16_pool[0].device)
     q35 = [synth.dense_queries_torch(x35, 256, seed=3000 + p) for p in range(pool)]
@@ -459,7 +504,8 @@ def main(argv=None, platform=None):
     x = idx = None
     q16_pool, csr_pool, tok_pool = [], [], []
     if args.workload in ("hybrid", "dense"):
-        x = synth.dense_corpus_torch(n, d, seed=2, device=dev)
+        x = (synth.clustered_corpus_torch(n, d, seed=21, device=dev) if args.corpus == "clustered"
+             else synth.dense_corpus_torch(n, d, seed=2, device=dev))
         q16_pool = [synth.dense_queries_torch(x, n_global, seed=1000 + p)[lo:hi].contiguous() for p in range(pool)]
         eng.set_dense(x)
     if args.workload in ("hybrid", "bm25"):
@@ -467,8 +513,10 @@ def main(argv=None, platform=None):
         idx = build_bm25_index_from_postings(indptr, doc, tf, lens, variant, compute_payload=False)
         eng.set_bm25(idx, payload_on_device=True)            # IDF*TF/(TF + k1*lenNorm) evaluated by the GPU
         for p in range(pool):
-            tok_pool.append(synth.token_queries(flat, lens, vocab, n_global, seed=2000 + p)[lo:hi])
+            tok_pool.append(synth.token_queries(flat, lens, vocab, n_global, seed=2000 + p,
+                                                lengths=synth.REF_QUESTION_LENGTHS if args.qlen == "ref" else None)[lo:hi])
             csr_pool.append(queries_to_csr(tok_pool[-1]))
+        flat_keep = (flat, lens, vocab) if (args.sub and world == 1 and args.workload == "hybrid") else None   # (the sub-benchmarks draw further queries)
         del flat
     eng.set_doc_meta(n, None, None)
     plat.synchronize()
@@ -534,6 +582,8 @@ def main(argv=None, platform=None):
     if args.workload != "bm25":
         eng.dense_check()
     path_stats = eng.stats() if hasattr(eng, "stats") else None    # (reads the device counters: synchronises, outside the timed region)
+    if path_stats is not None and args.workload != "bm25" and hasattr(eng, "dense_candidates_last_call"):
+        path_stats["dense_candidates_per_query_last_step"] = eng.dense_candidates_last_call() / max(1, B)
 
     rec = None
     if rank == 0:
@@ -602,7 +652,7 @@ def main(argv=None, platform=None):
                        "postings": int(idx.nnz) if idx is not None else 0,
                        "queries_per_gpu": B, "global_batch": B * world,
                        "bm25_variant": args.variant if idx is not None else None,
-                       "query_batches_rotated": pool,
+                       "query_batches_rotated": pool, "corpus": args.corpus, "query_lengths": args.qlen,
                        "parallelism": f"query-sharded x{world}, corpus replicated, all-gather of fused top-k"
                                       + (f" ({shards.mode})" if world > 1 else "")},
             "multi_gpu": None if world == 1 else {
@@ -621,10 +671,10 @@ def main(argv=None, platform=None):
             "path": path_stats,
         }
         default_shape = (args.chunks == 1_000_000 and args.dim == 1024 and args.vocab == 262_144 and args.batch == 0
-                         and not args.option and args.variant == "bm25s")
+                         and not args.option and args.variant == "bm25s" and args.corpus == "gaussian" and args.qlen == "fixed")
         if args.sub and world == 1 and args.workload == "hybrid" and default_shape:
             rec["sub_benchmarks"] = sub_benchmarks(eng, synth, queries_to_csr, build_bm25_index_from_postings, OKAPI,
-                                                   q16_pool, tok_pool, csr_pool, (indptr, doc, tf, lens), pool)
+                                                   q16_pool, tok_pool, csr_pool, (indptr, doc, tf, lens), pool, flat_lens=flat_keep)
         print(json.dumps(rec), flush=True)
     if args.dump_out and out is not None:
         plat.synchronize()

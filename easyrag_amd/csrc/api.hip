@@ -117,6 +117,7 @@ struct erh_handle {
     hipStream_t side = nullptr;           // ... created at first use
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool fork_after_scan = false;         // dense_topk_dev records ev_fork behind its last scan launch (hybrid_overlap 2)
+    int cand_rows = 0;                    // query rows of cand_cnt the last dense pipeline used (erh_get_stat: dense_candidates_last_call)
     bool rerun = false;                   // dense_topk_dev is re-running a group of a routed call at its check: its flagged queries were counted already
     int opt_bm25_small = 2;               // fixed-point scan, when k allows: 2 the 512-thread shape with packed 16-bit sums over 32768-document
                                           // tiles (two workgroups per CU), 1 the 512-thread shape over 16384-document tiles, 0 always 1024 threads
@@ -180,6 +181,16 @@ struct erh_handle {
     DevBuf o_ids, o_sc, o_len;              // staging for host outputs
     DevBuf qptr, qtok, part_sc, part_ids, part_len;
     DevBuf bm_redo;                          // approximate-order scan: (query, segment) pairs that go to the exact block scan
+    // Long queries (round 6): the packed shape's 16-bit sums leave a query of nq tokens (65535 / nq) payload levels and an error bound of
+    // 3 nq units -- from ~30 tokens on the list of "documents that can still reach the top k" no longer shrinks below its capacity and the
+    // query falls back to the exact block scan (1024 queries with the reference's question lengths, 4 ... 45 tokens: 5 such segments,
+    // 0.5 -> 1.7 ms per batch).  A batch whose longest query has more than bm25_long_tokens tokens scans with 32-bit sums (the
+    // 16384-document shape): 0.68 ms.  (Only the long queries on that shape, in a launch of their own beside the packed one -- built and
+    // measured, both stream orders, both 32-bit shapes: 0.84 ... 1.02 ms.  The launches do not overlap usefully, and ONE 45-token query in
+    // one workgroup takes 0.5 ms whatever runs beside it: profiles/r06d_bm25_long_queries.log.)
+    int opt_bm25_long_tokens = 28;
+    DevBuf bm_fin_ids, bm_fin_cnt;           // ... its final lists, handed to the batch-wide finish kernel (bm25_split_finish)
+    int opt_bm25_split_finish = 0;
     DevBuf hy_sids, hy_ssc, hy_slen, hy_dids, hy_dsc, hy_dlen;
     DevBuf fa_ids, fa_sc, fa_len, fb_ids, fb_sc, fb_len;
     DevBuf scores_tmp, scores_wide;
@@ -407,6 +418,7 @@ int dense_topk_dev(erh_handle *h, const void *q_dev, int q_dtype, int normalize_
     HIPCHK(h, h->tau.ensure((size_t)Bpad * 4));
     HIPCHK(h, h->cand.ensure((size_t)B * cap * sizeof(ErhCand)));
     HIPCHK(h, h->cand_cnt.ensure((size_t)B * 4));
+    h->cand_rows = B;
     HIPCHK(h, h->flags.ensure(64));
     HIPCHK(h, h->seed_need.ensure((size_t)B * 4));
     HIPCHK(h, h->bad.ensure((size_t)B * 4));
@@ -427,7 +439,15 @@ int dense_topk_dev(erh_handle *h, const void *q_dev, int q_dtype, int normalize_
     // batches on the 384 x 256 tile whose threshold comes from the stored prefix (dir filters, deep ranks): the prefix ends on a tile
     // boundary of that kernel -- 32640 = 85 x 384 instead of 32768 -- so the append stage can start there (c0 % 384 == 0); otherwise
     // it would fall back to the 256 x 256 scan (filtered 1024-query batch: scan class -1.4 ... -2 %, profiles/r05j_ab_filtered.log)
-    if (h->opt_dense_tile384 && global_view && Bpad >= 2 * QT && n0 < N && n0 >= 4 * erh::dense_scan_pp5_rows())
+    // (only when that kernel can run at all -- the same predicate that builds its operands below, the failed copy included: in every
+    // fall-back a prefix of 32640 rows would take the tiled 256 x 256 path away from the append stage instead)
+    const bool tile384_ok = h->opt_dense_tile384 && global_view && Bpad >= 2 * QT && h->opt_dense_pp == 3 && h->opt_dense_var == 0 &&
+                            h->opt_dense_ablate == 0 && !h->opt_dense_sync && d % 64 == 0 && d / 32 >= 8 &&
+                            N >= 2 * erh::dense_scan_pp5_rows() && !h->xt384_nomem &&
+                            (h->xt384_valid || h->opt_tile384_max_mb < 0 ||
+                             (size_t)((N + erh::dense_scan_pp5_rows() - 1) / erh::dense_scan_pp5_rows()) * erh::dense_scan_pp5_rows() * (size_t)d * 2 <=
+                                 ((size_t)h->opt_tile384_max_mb << 20));
+    if (tile384_ok && n0 < N && n0 >= 4 * erh::dense_scan_pp5_rows())
         n0 = n0 / erh::dense_scan_pp5_rows() * erh::dense_scan_pp5_rows();
     const int ld = round_up((int)n0, 256);
     HIPCHK(h, h->S0.ensure((size_t)Bpad * ld * 4));
@@ -439,8 +459,7 @@ int dense_topk_dev(erh_handle *h, const void *q_dev, int q_dtype, int normalize_
         if (!h->fin_ws.p) {
             const size_t sync_bytes = (size_t)erh::dense_finalize_split_max() * 8;
             HIPCHK(h, h->fin_ws.ensure(sync_bytes + (size_t)erh::dense_finalize_split_max() * erh::kDenseRescoreMax * 8));
-            HIPCHK(h, hipMemsetAsync(h->fin_ws.p, 0, sync_bytes, st));
-        }
+        }                                                   // (the sync words are cleared by every call's query preparation, below)
         fin_sync = h->fin_ws.as<uint32_t>();
         fin_s64 = reinterpret_cast<double *>(h->fin_ws.as<char>() + (size_t)erh::dense_finalize_split_max() * 8);
     }
@@ -449,7 +468,7 @@ int dense_topk_dev(erh_handle *h, const void *q_dev, int q_dtype, int normalize_
     h->qt5_valid = false;
     { ProfScope ps(h, st, ERH_K_DENSE_SELECT, 0, 0);
       HIPCHK(h, erh::launch_prep_queries(q_dev, q_dtype, normalize_q, B, Bpad, d, h->Q16.as<_Float16>(),
-                                         h->qnorm.as<float>(), bad, flags, st));
+                                         h->qnorm.as<float>(), bad, flags, st, nullptr, fin_sync, fin_sync ? 2 * erh::dense_finalize_split_max() : 0));
       // the tiled-operand scan reads the query block as stage images too (512 KiB per 256 queries, once per call)
       if (h->opt_dense_pp >= 4 && global_view && h->xt_valid && d % 64 == 0 && B > erh::dense_gemv_max_queries()) {
           HIPCHK(h, h->Qt.ensure((size_t)Bpad * d * 2));
@@ -459,7 +478,7 @@ int dense_topk_dev(erh_handle *h, const void *q_dev, int q_dtype, int normalize_
       // the 384 x 256 scan of batches padded to >= 512 queries: the chunk matrix' 384-row tiled copy (once per erh_set_dense, here
       // on first use) and the query block as stage images (512 KiB per 256 queries, per call)
       if (h->opt_dense_tile384 && global_view && Bpad >= 2 * QT && h->opt_dense_pp == 3 && h->opt_dense_var == 0 && h->opt_dense_ablate == 0 &&
-          !h->opt_dense_sync && d % 64 == 0 && d / 32 >= 8 && N >= 2 * erh::dense_scan_pp5_rows()) {
+          !h->opt_dense_sync && d % 64 == 0 && d / 32 >= 8 && N >= 2 * erh::dense_scan_pp5_rows()) {      // (tile384_ok without its memory terms)
           if (!h->xt384_valid && !h->xt384_nomem) {
               const int rows = erh::dense_scan_pp5_rows();
               const int64_t n_tiles = (N + rows - 1) / rows;
@@ -911,6 +930,7 @@ int dense_topk_grouped(erh_handle *h, const void *q_dev, int q_dtype, int normal
     HIPCHK(h, h->tau.ensure((size_t)Bpad * 4));
     HIPCHK(h, h->cand.ensure((size_t)Bpad * cap * sizeof(ErhCand)));
     HIPCHK(h, h->cand_cnt.ensure((size_t)Bpad * 4));
+    h->cand_rows = Bpad;
     HIPCHK(h, h->flags.ensure(64));
     HIPCHK(h, h->seed_need.ensure((size_t)Bpad * 4));
     HIPCHK(h, h->bad.ensure((size_t)Bpad * 4));
@@ -1132,7 +1152,10 @@ int bm25_topk_dev(erh_handle *h, const int32_t *qptr_dev, const int32_t *qtok_de
     const int small_docs = erh::bm25_ascan_tile_docs(1);
     const bool have16 = S.tile_docs == small_docs || S.n_tiles16 > 0;
     const bool small_k = ascan && k <= erh::bm25_ascan_small_max_k() && B >= 8;   // (a handful of queries: 16 waves per query finish sooner)
-    const int shape = !small_k ? 0 : h->opt_bm25_small == 2 ? 2 : (h->opt_bm25_small == 1 && have16) ? 1 : 0;
+    int shape_ = !small_k ? 0 : h->opt_bm25_small == 2 ? 2 : (h->opt_bm25_small == 1 && have16) ? 1 : 0;
+    // a batch with a query too long for 16-bit sums: the 32-bit shape for all of it (erh_handle::opt_bm25_long_tokens)
+    if (shape_ == 2 && h->opt_bm25_long_tokens > 0 && max_qlen > h->opt_bm25_long_tokens && h->opt_bm25_ablate == 0) shape_ = have16 ? 1 : 0;
+    const int shape = shape_;
     const bool small = shape != 0;                                        // two workgroups per CU
     const int as_docs = erh::bm25_ascan_tile_docs(shape);
     const int tiles = ascan ? (int)((S.Nb + as_docs - 1) / as_docs) : S.n_tiles;
@@ -1146,9 +1169,14 @@ int bm25_topk_dev(erh_handle *h, const int32_t *qptr_dev, const int32_t *qtok_de
     while (segs > 1 && (int64_t)segs * k > 2048) --segs;
     unsigned long long *dbg = h->opt_debug_counters ? h->dbg.as<unsigned long long>() : nullptr;
     const int32_t *q_order = (h->qorder_valid && qptr_dev == h->qptr.as<int32_t>()) ? h->qorder.as<int32_t>() : nullptr;
+    const bool split_fin = ascan && small && h->opt_bm25_split_finish && h->opt_bm25_ablate == 0;
     if (ascan) {
         HIPCHK(h, h->bm_redo.ensure((size_t)B * segs * 4));
         HIPCHK(h, hipMemsetAsync(h->bm_redo.p, 0, (size_t)B * segs * 4, st));
+    }
+    if (split_fin) {
+        HIPCHK(h, h->bm_fin_ids.ensure((size_t)B * segs * erh::bm25_ascan_fin_cap() * 4));
+        HIPCHK(h, h->bm_fin_cnt.ensure((size_t)B * segs * 4));
     }
     auto scan = [&](double *p_sc, int32_t *p_ids, int32_t *p_len) -> hipError_t {
         if (ascan) {
@@ -1165,7 +1193,8 @@ int bm25_topk_dev(erh_handle *h, const int32_t *qptr_dev, const int32_t *qtok_de
                                                   B, k, segs, cut_mul, filter_dev, dir, p_sc, p_ids, p_len, h->bm_redo.as<uint32_t>(),
                                                   h->dstats.as<unsigned long long>(),
                                                   (filter_dev && h->opt_bm25_dir_range && h->dir_rng_n > 0) ? h->dir_rng.as<int32_t>() : nullptr,
-                                                  h->dir_rng_n, h->opt_bm25_ablate, dbg, st);
+                                                  h->dir_rng_n, h->opt_bm25_ablate, dbg, st,
+                                                  split_fin ? h->bm_fin_ids.as<int32_t>() : nullptr, split_fin ? h->bm_fin_cnt.as<int32_t>() : nullptr);
             if (e != hipSuccess) return e;
             // near-tie floods (rare): those workgroups are scanned again by the exact block scan (same document ranges per
             // segment: the cuts are expressed in the block scan's own tiles), the others exit at once
@@ -1264,6 +1293,8 @@ const char *erh_status_str(int s) {
     }
 }
 
+int erh_comm_destroy(erh_handle *h);
+
 int erh_create(int device, erh_handle **out) {
     if (!out) return ERH_ERR_INVALID;
     *out = nullptr;
@@ -1283,15 +1314,12 @@ int erh_create(int device, erh_handle **out) {
         return ERH_ERR_HIP;
     }
     if (h->dstats.ensure(64) != hipSuccess || hipMemset(h->dstats.p, 0, 64) != hipSuccess) {
-        h->dstats.release();
-        delete h;
+        (void)erh_destroy(h);                              // (everything the handle owns so far, whatever that grows to)
         return ERH_ERR_NOMEM;
     }
     *out = h;
     return ERH_OK;
 }
-
-int erh_comm_destroy(erh_handle *h);
 
 int erh_destroy(erh_handle *h) {
     if (!h) return ERH_ERR_INVALID;
@@ -1305,7 +1333,7 @@ int erh_destroy(erh_handle *h) {
                       &h->o_ids, &h->o_sc, &h->o_len, &h->qptr, &h->qtok, &h->part_sc, &h->part_ids, &h->part_len,
                       &h->hy_sids, &h->hy_ssc, &h->hy_slen, &h->hy_dids, &h->hy_dsc, &h->hy_dlen,
                       &h->fa_ids, &h->fa_sc, &h->fa_len, &h->fb_ids, &h->fb_sc, &h->fb_len,
-                      &h->scores_tmp, &h->scores_wide, &h->dbg, &h->dstats, &h->dir_pos, &h->seed_need, &h->bad, &h->ex_ws, &h->bm_redo, &h->fin_ws, &h->dir_rng, &h->Xb, &h->blk_tmp, &h->blk_ids, &h->r_idx, &h->r_q, &h->r_ids, &h->r_sc, &h->r_len, &h->r_filt, &h->r_flags, &h->r_tab, &h->r_q16};
+                      &h->scores_tmp, &h->scores_wide, &h->dbg, &h->dstats, &h->dir_pos, &h->seed_need, &h->bad, &h->ex_ws, &h->bm_redo, &h->fin_ws, &h->dir_rng, &h->Xb, &h->blk_tmp, &h->blk_ids, &h->r_idx, &h->r_q, &h->r_ids, &h->r_sc, &h->r_len, &h->r_filt, &h->r_flags, &h->r_tab, &h->r_q16, &h->bm_fin_ids, &h->bm_fin_cnt};
     for (DevBuf *b : bufs) b->release();
     if (h->r_flags_host) (void)hipHostFree(h->r_flags_host);
     for (auto &b : h->bm) b.release();
@@ -1342,6 +1370,8 @@ int erh_set_option(erh_handle *h, const char *name, int64_t value) {
         h->n_cus = value == 0 ? h->n_cus_dev : (int)value;
         return ERH_OK;
     }
+    if (!strcmp(name, "bm25_long_tokens")) { if (value < 0 || value > 4096) return h->fail(ERH_ERR_INVALID, "bm25_long_tokens"); h->opt_bm25_long_tokens = (int)value; return ERH_OK; }
+    if (!strcmp(name, "bm25_split_finish")) { h->opt_bm25_split_finish = value != 0; return ERH_OK; }
     if (!strcmp(name, "dense_route_ridge")) { if (value < 1 || value > 4096) return h->fail(ERH_ERR_INVALID, "dense_route_ridge"); h->opt_route_ridge = value; return ERH_OK; }
     if (!strcmp(name, "dense_group_launch")) { h->opt_dense_group_launch = value != 0; return ERH_OK; }
     if (!strcmp(name, "dense_dir_blocks")) { if (value < 0 || value > 2) return h->fail(ERH_ERR_INVALID, "dense_dir_blocks"); h->opt_dense_dir_blocks = (int)value; return ERH_OK; }
@@ -1463,6 +1493,19 @@ int erh_get_stat(erh_handle *h, const char *name, int64_t *value) {
         {"dense_grouped_launches", T.dense_grouped_launches}};
     for (const auto &e : host)
         if (!strcmp(name, e.n)) { *value = e.v; return ERH_OK; }
+    if (!strcmp(name, "dense_candidates_last_call")) {
+        // candidates the scan of the LAST dense pipeline handed to its final kernel, summed over its queries (a routed call: its last
+        // pipeline -- the grouped launch when there was one): how selective the pruning threshold was on this data
+        HIPCHK(h, hipSetDevice(h->device));
+        HIPCHK(h, hipDeviceSynchronize());
+        const int rows = h->cand_rows;
+        std::vector<uint32_t> c((size_t)std::max(rows, 0));
+        if (rows > 0) HIPCHK(h, hipMemcpy(c.data(), h->cand_cnt.p, (size_t)rows * 4, hipMemcpyDeviceToHost));
+        int64_t sum = 0;
+        for (uint32_t v : c) sum += std::min<uint32_t>(v, (uint32_t)erh::kDenseCapMax);
+        *value = sum;
+        return ERH_OK;
+    }
     const int di = !strcmp(name, "dense_exhaustive_queries") ? 0 : !strcmp(name, "bm25_redo_segments") ? 1 : -1;
     if (di < 0) return h->fail(ERH_ERR_INVALID, "erh_get_stat: unknown counter");
     unsigned long long v[2] = {0, 0};

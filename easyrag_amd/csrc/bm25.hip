@@ -1391,7 +1391,9 @@ __global__ __launch_bounds__(C::NT, 4 /* waves per SIMD: two 512-thread workgrou
     const int32_t *__restrict__ dir_rng /* null, or {first document, last + 1} per dir class: a filtered query walks only the tiles of its class */,
     int dir_rng_n,
     int abl /* measurement builds: 1 no adds, 2 no posting loads, 4 no clear, 8 one descriptor set */,
-    unsigned long long *__restrict__ dbg) {
+    unsigned long long *__restrict__ dbg,
+    int32_t *__restrict__ fin_ids /* null, or [B * segs][CAP]: the workgroup hands its final list to bm25_finish_kernel instead of re-scoring it */,
+    int32_t *__restrict__ fin_cnt /* ... [B * segs]: entries of that list, -1: nothing to finish (the segment goes to the exact scan) */) {
     constexpr int NT = C::NT, TILE = C::TILE, NW = C::NW, CAP = C::CAP, WORDS = C::WORDS, U = C::U;
 #ifdef ERH_MEASURE
 #define ERH_ABL(B) (abl & (B))
@@ -1650,12 +1652,22 @@ __global__ __launch_bounds__(C::NT, 4 /* waves per SIMD: two 512-thread workgrou
         if (tid == 0) {
             redo[(int64_t)q * segs + seg] = 1u;
             part_len[(int64_t)q * segs + seg] = 0;
+            if (fin_cnt) fin_cnt[(int64_t)q * segs + seg] = -1;
             if (stats) atomicAdd(&stats[1], 1ull);
         }
         return;
     }
-    if (ERH_ABL(0xff)) { if (tid == 0) part_len[(int64_t)q * segs + seg] = 0; return; }   // (ablations: the list is garbage)
+    if (ERH_ABL(0xff)) { if (tid == 0) { part_len[(int64_t)q * segs + seg] = 0; if (fin_cnt) fin_cnt[(int64_t)q * segs + seg] = -1; } return; }   // (ablations: the list is garbage)
     ERH_SEC(8);
+    if (fin_ids) {
+        // split finish (round 6): the exact re-score + rank of all lists of the batch run in ONE kernel behind the scan (2 M independent
+        // binary searches spread over the chip at 16 waves per CU), and this workgroup's CU slot goes to the next query now
+        const int64_t slot = (int64_t)q * segs + seg;
+        const int n_keep = hdr->ncand;
+        for (int i = tid; i < n_keep; i += NT) fin_ids[slot * CAP + i] = ci[i];
+        if (tid == 0) fin_cnt[slot] = n_keep;
+        return;
+    }
     as_finish_query<ST, C>(smem, hdr, ca, ci, indptr, doc_ids, payload, tile_off, n_tab, C::TAB_SHIFT - tshift, q_tok, qs, nq, k,
                            out_base, (int64_t)q * segs + seg, part_scores, part_ids, part_len, dbg);
     ERH_SEC(9);
@@ -1667,6 +1679,41 @@ __global__ __launch_bounds__(C::NT, 4 /* waves per SIMD: two 512-thread workgrou
 #endif
 #undef ERH_SEC
 #undef ERH_ABL
+}
+
+// The exact re-score + rank of the fixed-point scan's final lists as a kernel of its own (option bm25_split_finish): grid = (segs, B),
+// 256 threads, ~37 KiB of LDS = four workgroups per CU.  Same arithmetic, same order, same output as the scan kernel's tail
+// (as_finish_query is shared): one binary search per (listed document, query token) inside the skip table's tile range, payloads
+// summed in token order in the library's type, rank by counting.
+template <int CAP_>
+struct AsFinCfg {
+    static constexpr int NT = 256, TILE = 0, CAP = CAP_;
+    static constexpr int WORDS = 6144;                                  // 24 KiB: exact sums [CAP] + the (entry, token) payload matrix
+    static constexpr size_t OFF_CA = kAsOffAcc + (size_t)WORDS * 4;
+    static constexpr size_t OFF_CI = OFF_CA + (size_t)CAP * 4;
+    static constexpr size_t BYTES = OFF_CI + (size_t)CAP * 4;
+    static_assert((size_t)WORDS * 4 >= (size_t)CAP * 8 + 2048, "room for the payload matrix behind the exact sums");
+};
+template <typename ST, class F>
+__global__ __launch_bounds__(F::NT) void bm25_finish_kernel(
+    const int64_t *__restrict__ indptr, const int32_t *__restrict__ doc_ids, const ST *__restrict__ payload,
+    const int32_t *__restrict__ tile_off, int n_tab, int tab_shift, const int32_t *__restrict__ q_indptr,
+    const int32_t *__restrict__ q_tok, const int32_t *__restrict__ q_order, int k, int segs, const int32_t *__restrict__ fin_ids,
+    const int32_t *__restrict__ fin_cnt, double *__restrict__ part_scores, int32_t *__restrict__ part_ids, int32_t *__restrict__ part_len) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    BmHdr *hdr = reinterpret_cast<BmHdr *>(smem);
+    uint32_t *ca = reinterpret_cast<uint32_t *>(smem + F::OFF_CA);
+    int32_t *ci = reinterpret_cast<int32_t *>(smem + F::OFF_CI);
+    const int seg = blockIdx.x, q = q_order ? q_order[blockIdx.y] : (int)blockIdx.y, tid = threadIdx.x;   // (the scan launch's queries)
+    const int64_t slot = (int64_t)q * segs + seg;
+    const int n_keep = fin_cnt[slot];
+    if (n_keep < 0) return;                                              // (redo: the exact block scan answers this segment)
+    if (tid == 0) hdr->ncand = n_keep;
+    for (int i = tid; i < n_keep; i += F::NT) ci[i] = fin_ids[slot * F::CAP + i];
+    __syncthreads();
+    const int qs = q_indptr[q];
+    as_finish_query<ST, F>(smem, hdr, ca, ci, indptr, doc_ids, payload, tile_off, n_tab, tab_shift, q_tok, qs, q_indptr[q + 1] - qs, k,
+                           slot * k, slot, part_scores, part_ids, part_len);
 }
 
 // interleaved fixed-point postings of the scan above: post[i] = {document, trunc(p32 * scale) + 1}, post[nnz] = post[nnz + 1] = {-1, 0}
@@ -1804,6 +1851,10 @@ hipError_t bm25_init() {
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void *)bm25_ascan_kernel<double, AsPack16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AsPack16::BYTES);
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void *)bm25_finish_kernel<float, AsFinCfg<AsPack16::CAP>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AsFinCfg<AsPack16::CAP>::BYTES);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void *)bm25_finish_kernel<double, AsFinCfg<AsPack16::CAP>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AsFinCfg<AsPack16::CAP>::BYTES);
+    if (e != hipSuccess) return e;
     return hipFuncSetAttribute((const void *)bm25_merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                8192 * 12 + 64);
 }
@@ -1860,16 +1911,18 @@ hipError_t launch_bm25_ascan(int variant, int small, const int64_t *indptr, cons
                              const int32_t *q_order, int B, int k, int segs, int cut_mul, const int16_t *filter_dir,
                              const int16_t *dir_id, double *part_scores, int32_t *part_ids, int32_t *part_len, uint32_t *redo,
                              unsigned long long *stats, const int32_t *dir_rng, int dir_rng_n, int ablate, unsigned long long *dbg,
-                             hipStream_t st) {
+                             hipStream_t st, int32_t *fin_ids, int32_t *fin_cnt) {
     if (B <= 0) return hipSuccess;
     if (cut_mul < 1) cut_mul = 1;
     const int tile = bm25_ascan_tile_docs(small);
     const int n_tiles = (int)((N + tile - 1) / tile);
     dim3 grid(segs, B);
+    if (!small) { fin_ids = nullptr; fin_cnt = nullptr; }              // (the split finish is built for the 512-thread shapes' list capacity)
 #define ERH_AS_LAUNCH(ST, CFG, POST)                                                                                 \
     hipLaunchKernelGGL((bm25_ascan_kernel<ST, CFG>), grid, dim3(CFG::NT), CFG::BYTES, st, indptr, doc_ids,           \
                        (const ST *)payload, POST, nnz, qmax, g16, tile_off, n_tab, tshift, n_tiles, N, q_indptr,      \
-                       q_tok, q_order, k, segs, cut_mul, filter_dir, dir_id, part_scores, part_ids, part_len, redo, stats, dir_rng, dir_rng_n, ablate, dbg)
+                       q_tok, q_order, k, segs, cut_mul, filter_dir, dir_id, part_scores, part_ids, part_len, redo, stats, dir_rng, dir_rng_n, ablate, dbg, \
+                       fin_ids, fin_cnt)
 #define ERH_AS_SHAPES(ST)                                                                                            \
     do {                                                                                                             \
         if (small == 2 && post16) ERH_AS_LAUNCH(ST, AsPack16, post16);                                               \
@@ -1880,8 +1933,21 @@ hipError_t launch_bm25_ascan(int variant, int small, const int64_t *indptr, cons
     if (variant == 0) ERH_AS_SHAPES(double); else ERH_AS_SHAPES(float);
 #undef ERH_AS_SHAPES
 #undef ERH_AS_LAUNCH
+    if (fin_ids && fin_cnt) {
+        using F = AsFinCfg<AsPack16::CAP>;
+        static_assert(AsPack16::CAP == AsPack::CAP && AsPack::CAP == AsSmall::CAP, "one list capacity for the 512-thread shapes");
+        const int tab_shift = (small == 1 ? AsSmall::TAB_SHIFT : AsPack::TAB_SHIFT) - tshift;
+        if (variant == 0)
+            hipLaunchKernelGGL((bm25_finish_kernel<double, F>), grid, dim3(F::NT), F::BYTES, st, indptr, doc_ids, (const double *)payload, tile_off,
+                               n_tab, tab_shift, q_indptr, q_tok, q_order, k, segs, fin_ids, fin_cnt, part_scores, part_ids, part_len);
+        else
+            hipLaunchKernelGGL((bm25_finish_kernel<float, F>), grid, dim3(F::NT), F::BYTES, st, indptr, doc_ids, (const float *)payload, tile_off,
+                               n_tab, tab_shift, q_indptr, q_tok, q_order, k, segs, fin_ids, fin_cnt, part_scores, part_ids, part_len);
+    }
     return hipGetLastError();
 }
+
+int bm25_ascan_fin_cap() { return AsPack16::CAP; }
 
 // 4-byte postings: the smallest shift g with (qmax >> g) + 1 <= 65535
 int bm25_post16_shift(double qmax) {

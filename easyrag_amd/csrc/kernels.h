@@ -107,7 +107,9 @@ hipError_t launch_prep_queries(const void *q, int q_dtype, int normalize, int B,
                                _Float16 *Q16, float *qnorm, uint32_t *zero_bad /* null, or B words cleared by the kernel */,
                                uint32_t *zero_flags /* null, or 16 words cleared by the kernel */, hipStream_t st,
                                const int32_t *q_src = nullptr /* grouped call: row r of the block is the caller's row q_src[r] (-1: a zero
-                                                                  padding row); B == Bpad then */);
+                                                                  padding row); B == Bpad then */,
+                               uint32_t *zero_extra = nullptr, int n_extra = 0 /* further words the call wants cleared (<= 16: the final
+                                                                                  kernel's sync words -- a faulted launch must not leave a ticket behind) */);
 // rows fp32 -> fp16 (optionally L2-normalised) for erh_set_dense
 hipError_t launch_convert_rows(const float *x, int64_t n, int d, int normalize, _Float16 *out_base, int64_t r0,
                                int64_t mul, int64_t N, hipStream_t st);
@@ -200,7 +202,11 @@ hipError_t launch_bm25_ascan(int variant, int small /* 0: 1024 threads; 1: 512 t
                              double *part_scores, int32_t *part_ids, int32_t *part_len, uint32_t *redo,
                              unsigned long long *stats /* null, or the handle's device counters: [1] += (query, segment) pairs handed to the exact scan */,
                              const int32_t *dir_rng /* null, or int32[2 * dir_rng_n]: {first document, last + 1} of every dir class */, int dir_rng_n,
-                             int ablate /* measurement builds only */, unsigned long long *dbg, hipStream_t st);
+                             int ablate /* measurement builds only */, unsigned long long *dbg, hipStream_t st,
+                             int32_t *fin_ids = nullptr /* split finish: [B * segs][bm25_ascan_fin_cap()] work space: the scan hands its final
+                                                           lists over and ONE batch-wide kernel behind it re-scores and ranks them */,
+                             int32_t *fin_cnt = nullptr /* ... [B * segs] */);
+int bm25_ascan_fin_cap();
 // 4-byte postings of the packed scan {document & 32767, (q >> g) + 1 in 16 bits}: nnz + 8 words (zeros behind the postings)
 int bm25_post16_shift(double qmax);
 hipError_t launch_bm25_post16(const void *post, int64_t nnz, int g, void *post16, hipStream_t st);

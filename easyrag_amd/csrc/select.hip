@@ -38,9 +38,11 @@ __global__ __launch_bounds__(256) void prep_queries_kernel(const TIN *__restrict
                                                           _Float16 *__restrict__ Q16, float *__restrict__ qnorm,
                                                           uint32_t *__restrict__ zero_bad /* null, or B words to clear */,
                                                           uint32_t *__restrict__ zero_flags /* null, or the call's 16 flag words */,
-                                                          const int32_t *__restrict__ q_src /* null, or row -> caller's row (-1: padding) */) {
+                                                          const int32_t *__restrict__ q_src /* null, or row -> caller's row (-1: padding) */,
+                                                          uint32_t *__restrict__ zero_extra, int n_extra) {
     __shared__ float red[4];
     const int row = blockIdx.x;
+    if (zero_extra && row == 0 && (int)threadIdx.x >= 16 && (int)threadIdx.x < 16 + n_extra) zero_extra[threadIdx.x - 16] = 0u;
     const int src = q_src ? q_src[row] : (row < B ? row : -1);
     // the call's per-query "uncertified" marks and its flag words start at zero: cleared here instead of by two memset launches
     if (zero_bad && row < B && threadIdx.x == 0) zero_bad[row] = 0u;
@@ -888,13 +890,14 @@ hipError_t select_init() {
 
 hipError_t launch_prep_queries(const void *q, int q_dtype, int normalize, int B, int Bpad, int d,
                                _Float16 *Q16, float *qnorm, uint32_t *zero_bad, uint32_t *zero_flags, hipStream_t st,
-                               const int32_t *q_src) {
+                               const int32_t *q_src, uint32_t *zero_extra, int n_extra) {
+    if (n_extra > 16) return hipErrorInvalidValue;
     if (q_dtype == 0)
         hipLaunchKernelGGL(prep_queries_kernel<_Float16>, dim3(Bpad), dim3(256), 0, st,
-                           (const _Float16 *)q, normalize, B, d, Q16, qnorm, zero_bad, zero_flags, q_src);
+                           (const _Float16 *)q, normalize, B, d, Q16, qnorm, zero_bad, zero_flags, q_src, zero_extra, n_extra);
     else
         hipLaunchKernelGGL(prep_queries_kernel<float>, dim3(Bpad), dim3(256), 0, st,
-                           (const float *)q, normalize, B, d, Q16, qnorm, zero_bad, zero_flags, q_src);
+                           (const float *)q, normalize, B, d, Q16, qnorm, zero_bad, zero_flags, q_src, zero_extra, n_extra);
     return hipGetLastError();
 }
 

@@ -174,9 +174,11 @@ class QueryShards:
         return self._send, self._recv, self._out
 
     def gather(self, ids, sc, ln, check: bool = True):
-        """All-gather this rank's [B_local x k] result.  `check` (default): erh_dense_check first -- a dense / fused call
-        with device outputs leaves queries that need more than one round of the exhaustive path (and the re-run of the
-        fusion over their corrected lists) to that call, so rows must not leave the rank before it has run."""
+        """All-gather this rank's [B_local x k] result.  `check` (default): erh_dense_check first.  Since round 5 a dense / fused call
+        with device outputs enqueues only the COUNT of the queries its candidate budgets could not certify; EVERY answering round of
+        the exhaustive path (and the re-run of the fusion over the corrected lists, and of a routed call's flagged groups) runs inside
+        erh_dense_check, so rows must not leave the rank before it has run.  check=False is for callers that have called
+        `engine.dense_check()` themselves since the last dense / fused call -- skipping it altogether hands out uncertified lists."""
         lo, hi = self.bounds
         if ids.shape[0] != hi - lo:
             raise ValueError(f"rank {self.rank} must contribute its shard of {hi - lo} queries, got {ids.shape[0]}")

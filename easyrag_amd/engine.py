@@ -486,6 +486,10 @@ class RetrievalEngine:
     def stats(self) -> dict:
         return {n: self.stat(n) for n in self.STAT_NAMES}
 
+    def dense_candidates_last_call(self) -> int:
+        """Candidates the last dense pipeline's scan handed to its final kernel, summed over the queries (synchronises)."""
+        return self.stat("dense_candidates_last_call")
+
     def reset_stats(self):
         self._check(self._lib.erh_reset_stats(self._h))
 

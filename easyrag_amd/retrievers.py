@@ -323,53 +323,76 @@ class HipVectorStore:
             meta = {k: v for k, v in payload.items() if not k.startswith("_") and k not in ("text", "document_id", "doc_id", "ref_doc_id")}
         return getattr(point, "id", None), vec, text, meta
 
+    class _Scroll:
+        """What a scroll over the collection leaves behind: per point its id, text and metadata, and the vectors as one float32
+        block per scrolled batch -- a point's vector never stays around as a Python list (3584 floats are ~115 KB of objects:
+        ~10 GB for 100k chunks), and a point without its vector is reported by the batch that carries it."""
+
+        def __init__(self):
+            self.meta: List[tuple] = []
+            self.blocks: List[np.ndarray] = []
+            self.d: Optional[int] = None
+
+        def add(self, batch) -> None:
+            rows = []
+            for p in batch:
+                pid, vec, text, meta = HipVectorStore._point_fields(p)
+                if vec is None:
+                    raise ValueError(f"point {pid!r} came back without its vector (scroll with with_vectors=True)")
+                if self.d is None:
+                    self.d = len(vec)
+                if len(vec) != self.d:
+                    raise ValueError("points of different vector sizes in one collection")
+                rows.append(vec)
+                self.meta.append((pid, text, meta))
+            if rows:
+                self.blocks.append(np.asarray(rows, dtype=np.float32))
+
+        def row(self, j: int, starts) -> np.ndarray:
+            b = int(np.searchsorted(starts, j, side="right")) - 1
+            return self.blocks[b][j - starts[b]]
+
     @classmethod
-    def _assemble(cls, points, nodes, engine, normalize):
+    def _assemble(cls, scroll: "HipVectorStore._Scroll", nodes, engine, normalize):
         """Scrolled points -> (nodes, [N, d] float32 rows aligned with them).  With `nodes` given every node must find its
         vector: by point id == node_id when all ids match, otherwise by text content -- the key the reference itself joins
         the two routes on (RRF / fusion key = get_content(), ref retrievers.py:245,263): its sparse-route nodes come from a
         second run of the splitter (pipeline.py:160-167) and share no ids with the ingested points.  Among nodes with equal
         text a point with equal `file_path` is preferred, then first come first served.  Without `nodes` the node list is
         rebuilt from the payloads in scroll order (what the reference's QdrantRetriever returns)."""
-        fields = [cls._point_fields(p) for p in points]
+        fields = scroll.meta
         if not fields:
             raise ValueError("the collection is empty (points_count == 0): run the ingestion first, as the reference does")
-        for pid, vec, _, _ in fields:
-            if vec is None:
-                raise ValueError(f"point {pid!r} came back without its vector (scroll with with_vectors=True)")
-        d = len(fields[0][1])
+        d = int(scroll.d)
         if nodes is None:
-            nodes = [TextNode(text=t or "", metadata=dict(m or {}), id_=str(pid)) for pid, _, t, m in fields]
-            order = list(range(len(fields)))
+            nodes = [TextNode(text=t or "", metadata=dict(m or {}), id_=str(pid)) for pid, t, m in fields]
+            return cls(nodes, np.concatenate(scroll.blocks) if len(scroll.blocks) > 1 else scroll.blocks[0], engine=engine, normalize=normalize)
+        nodes = list(nodes)
+        by_id = {str(pid): j for j, (pid, _, _) in enumerate(fields)}
+        if len(by_id) == len(fields) and all(str(n.node_id) in by_id for n in nodes):
+            order = [by_id[str(n.node_id)] for n in nodes]
         else:
-            nodes = list(nodes)
-            by_id = {str(pid): j for j, (pid, _, _, _) in enumerate(fields)}
-            if len(by_id) == len(fields) and all(str(n.node_id) in by_id for n in nodes):
-                order = [by_id[str(n.node_id)] for n in nodes]
-            else:
-                by_text: Dict[Any, List[int]] = {}
-                for j, (_, _, t, _) in enumerate(fields):
-                    by_text.setdefault(t, []).append(j)
-                order, missing = [], 0
-                for n in nodes:
-                    bucket = by_text.get(n.get_content())
-                    if not bucket:
-                        missing += 1
-                        order.append(-1)
-                        continue
-                    fp = n.metadata.get("file_path")
-                    pick = next((j for j in bucket if (fields[j][3] or {}).get("file_path") == fp), bucket[0])
-                    bucket.remove(pick)
-                    order.append(pick)
-                if missing:
-                    raise ValueError(f"{missing} of {len(nodes)} nodes have no point with their text in the collection "
-                                     f"({len(fields)} points): the collection was built from a different corpus / splitter")
-        emb = np.empty((len(nodes), d), np.float32)
+            by_text: Dict[Any, List[int]] = {}
+            for j, (_, t, _) in enumerate(fields):
+                by_text.setdefault(t, []).append(j)
+            order, missing = [], 0
+            for n in nodes:
+                bucket = by_text.get(n.get_content())
+                if not bucket:
+                    missing += 1
+                    order.append(-1)
+                    continue
+                fp = n.metadata.get("file_path")
+                pick = next((j for j in bucket if (fields[j][2] or {}).get("file_path") == fp), bucket[0])
+                bucket.remove(pick)
+                order.append(pick)
+            if missing:
+                raise ValueError(f"{missing} of {len(nodes)} nodes have no point with their text in the collection "
+                                 f"({len(fields)} points): the collection was built from a different corpus / splitter")
+        starts = np.cumsum([0] + [blk.shape[0] for blk in scroll.blocks])[:-1]
+        emb = np.empty((len(nodes), d), np.float32)                   # the one full-size array; filled block row by block row
         for i, j in enumerate(order):
-            v = fields[j][1]
-            if len(v) != d:
-                raise ValueError("points of different vector sizes in one collection")
-            emb[i] = v
+            emb[i] = scroll.row(j, starts)
         return cls(nodes, emb, engine=engine, normalize=normalize)
 
     @classmethod
@@ -377,7 +400,7 @@ class HipVectorStore:
                     batch_size: int = 1024, normalize: bool = True) -> "HipVectorStore":
         """The chunk matrix out of an already populated Qdrant collection (a synchronous `QdrantClient`, or anything with its
         `scroll(collection_name=, limit=, offset=, with_payload=, with_vectors=) -> (points, next_offset)`)."""
-        points, offset = [], None
+        scroll, offset = cls._Scroll(), None
         while True:
             res = client.scroll(collection_name=collection_name, limit=batch_size, offset=offset, with_payload=True,
                                 with_vectors=True)
@@ -386,23 +409,23 @@ class HipVectorStore:
                     res.close()
                 raise TypeError("this client's scroll() is a coroutine (AsyncQdrantClient): use `await HipVectorStore.afrom_qdrant(...)`")
             batch, offset = res
-            points.extend(batch)
+            scroll.add(batch)
             if offset is None or not batch:
                 break
-        return cls._assemble(points, nodes, engine, normalize)
+        return cls._assemble(scroll, nodes, engine, normalize)
 
     @classmethod
     async def afrom_qdrant(cls, client, collection_name: str, nodes=None, engine: Optional[RetrievalEngine] = None,
                            batch_size: int = 1024, normalize: bool = True) -> "HipVectorStore":
         """from_qdrant for the `AsyncQdrantClient` the reference's pipeline holds (ref ingestion.py:163-169)."""
-        points, offset = [], None
+        scroll, offset = cls._Scroll(), None
         while True:
             batch, offset = await client.scroll(collection_name=collection_name, limit=batch_size, offset=offset,
                                                 with_payload=True, with_vectors=True)
-            points.extend(batch)
+            scroll.add(batch)
             if offset is None or not batch:
                 break
-        return cls._assemble(points, nodes, engine, normalize)
+        return cls._assemble(scroll, nodes, engine, normalize)
 
     @staticmethod
     def _fingerprint(nodes) -> str:

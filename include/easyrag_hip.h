@@ -345,6 +345,13 @@ int erh_reset_kernel_time(erh_handle *h);
  *   dense_group_launch (1)  0: every block group of a batch as a pipeline of its own (the round-5 path; a parity arm)
  *   dense_route_ridge (160) query columns below which a dense scan is HBM-bound on this chip (the route decision's only constant)
  *   dense_dir_block_min_rows (4096)  smallest dir that gets a block of its own
+ *   bm25_long_tokens (28) packed shape: a batch whose longest query has MORE tokens than this scans with 32-bit sums (the bm25_small = 1
+ *                         shape) -- 16-bit sums leave a query of nq tokens 65535 / nq payload levels and an error bound of 3 nq units, and
+ *                         from ~30 tokens on the list of documents that can still reach the top k stops shrinking (the query then falls
+ *                         back to the exact block scan: 0.5 -> 1.7 ms per 1024 queries with the reference's question lengths, 4 ... 45
+ *                         tokens; 0.68 ms on the 32-bit shape).  0 = always the packed shape.  Same results
+ *   bm25_split_finish (0) 1: the exact re-score + rank of the scan's final lists as ONE batch-wide kernel behind the scan instead of
+ *                         each workgroup's tail (measured +15 %: the tail overlaps the CU's other workgroup; a parity arm)
  *   bm25_post16 (1)       packed shape: read 4-byte postings {15-bit document offset in the tile, 16-bit payload} (built when an
  *                         index is set while bm25_small = 2; + 4 bytes per posting); 0 = the 8-byte fixed-point postings
  *   bm25_crossing (1)     wave-owned scan: survivors from threshold crossings noted in the token loop instead of a sweep
@@ -396,6 +403,8 @@ int erh_dense_exhaustive_count(erh_handle *h, int32_t *count);
  *   dense_exhaustive_queries                           queries answered by the exhaustive path (device counter; summed over calls)
  *   dense_block_groups                                 query groups answered from their dir's block (dense_dir_blocks)
  *   dense_grouped_launches                             calls whose block groups ran as one launch per stage (dense_group_launch)
+ *   dense_candidates_last_call                         candidates the last dense pipeline's scan handed to its final kernel, summed over
+ *                                                      its queries (read back from the device: synchronises; not reset by erh_reset_stats)
  *   bm25_redo_segments                                 (query, segment) pairs the fixed-point scan handed to the exact block scan (device counter)
  * Reading a device counter synchronises the device.  Unknown name: ERH_ERR_INVALID. */
 int erh_get_stat(erh_handle *h, const char *name, int64_t *value);

@@ -399,3 +399,74 @@ def test_dense_d3584_full_size_exact(engine, dense_3584, b, k):
         assert np.array_equal(sc[i].view(np.uint64), osc.view(np.uint64)), f"query {i}: fp64 scores differ"
     for i in range(b):
         assert len(set(ids[i])) == k and np.all(np.diff(sc[i]) <= 0)
+
+
+# ---- anisotropic, topic-sorted embeddings with exact duplicates (the numbers must not be an artefact of Gaussian data) -----
+@pytest.mark.parametrize("b,k", [(1024, 288), (256, 100), (1, 288)])
+def test_dense_clustered_corpus_exact(engine, b, k):
+    """1M x 1024 chunks of synth.clustered_corpus_torch -- rows sorted by topic, random-pair cosine ~0.4, intra-topic ~0.7, 2 % exact copies of
+    another row of the topic -- with queries that are noisy copies of corpus rows: every member of the query's topic scores far above the
+    rest of the corpus, the duplicates tie exactly.  32 sampled queries against the oracle (ids + pinned-order fp64 scores bit for bit),
+    through the batch regimes the bench times (1024: sample pass + 384 x 256 scan; 256: store kernel + 256 x 256 scan; 1: skinny-GEMM
+    stream), and the whole batch must stay on the pruned pipeline (no query handed to the exhaustive path)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    x = synth.clustered_corpus_torch(N, D, seed=21, device=dev)
+    q = synth.dense_queries_torch(x, b, seed=5000)
+    # the shape the generator promises (fp32 on a sample of rows)
+    xs = x[torch.arange(0, N, 977, device=dev)].float()
+    cos = xs @ xs.T
+    off = cos[~torch.eye(cos.shape[0], dtype=torch.bool, device=dev)]
+    assert 0.33 < float(off.mean()) < 0.47
+    same_topic = (x[:400].float() @ x[:400].float().T)[~torch.eye(400, dtype=torch.bool, device=dev)]
+    assert 0.62 < float(same_topic.mean()) < 0.78
+    engine.set_dense(x)
+    engine.set_doc_meta(N, None, None)
+    engine.reset_stats()
+    ids, sc, ln = engine.dense_topk(q, k)
+    diag, st = engine.dense_diag(), engine.stats()
+    assert np.all(ln == k)
+    assert diag["uncertified"] == 0 and diag["max_abs_err"] <= diag["margin"], diag
+    assert diag["exhaustive"] == 0 and st["dense_exhaustive_queries"] == 0, (diag, st)
+    if b == 1024:
+        assert st["dense_scan_pp5_launches"] == 1 and st["dense_sample_passes"] == 1, st
+    sample = sorted(set(range(0, b, max(1, b // 32))))[:32]
+    want = dense_oracle_topk(x, q[sample], k)
+    for (oid, osc), i in zip(want, sample):
+        assert np.array_equal(ids[i], oid), f"query {i}: ids differ"
+        assert np.array_equal(sc[i].view(np.uint64), osc.view(np.uint64)), f"query {i}: fp64 scores differ"
+    cand = engine.dense_candidates_last_call() / b
+    print(f"clustered corpus, {b} queries, k = {k}: {cand:.0f} candidates per query reached the final kernel")
+    assert k <= cand < 16384
+    del x
+    torch.cuda.empty_cache()
+
+
+def test_bm25_reference_question_lengths_full_size(engine, sparse_data):
+    """configs[2]-sized corpus, 1024 queries with the length distribution of the reference's 103 real questions (4 ... 45 tokens).  On the
+    packed 16-bit shape alone a handful of the longest queries cannot shrink their candidate lists and fall back to the exact block scan
+    (bm25_long_tokens = 0: `bm25_redo_segments` > 0, 3 x the time); by default such a batch scans with 32-bit sums: no redo, same lists.  The longest queries and a sample of the others against the oracle, ids and scores bit for bit."""
+    indptr, doc, tf, lens, _, flat = sparse_data
+    idx = host_index(sparse_data, BM25S)
+    engine.set_bm25(idx)
+    engine.set_doc_meta(N, None, None)
+    qs = synth.token_queries(flat, lens, VOCAB, 1024, seed=4000, lengths=synth.REF_QUESTION_LENGTHS)
+    ql = np.array([len(q) for q in qs])
+    assert ql.max() >= 45 and ql.min() <= 4
+    csr = queries_to_csr(qs)
+    try:
+        engine.reset_stats()
+        ids, sc, ln = engine.bm25_topk(*csr, 192)
+        assert engine.stat("bm25_redo_segments") == 0
+        engine.set_option("bm25_long_tokens", 0)
+        engine.reset_stats()
+        ids0, sc0, ln0 = engine.bm25_topk(*csr, 192)
+        print(f"packed shape alone: {engine.stat('bm25_redo_segments')} (query, segment) pairs went to the exact block scan")
+        assert np.array_equal(ln, ln0) and np.array_equal(ids, ids0) and np.array_equal(sc.view(np.uint64), sc0.view(np.uint64))
+    finally:
+        engine.set_option("bm25_long_tokens", 28)
+    sample = sorted(set(list(np.argsort(-ql)[:10]) + list(range(0, 1024, 73))))
+    for b in sample:
+        want = sparse_oracle_topk(idx, qs[b], 192)
+        assert list(ids[b, :ln[b]]) == [w[0] for w in want], f"query {b} ({ql[b]} tokens): ids differ"
+        assert list(sc[b, :ln[b]]) == [w[1] for w in want], f"query {b} ({ql[b]} tokens): scores differ"

@@ -14,9 +14,10 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(params=[(1, 0, 1, 2, 1), (1, 0, 1, 2, 0), (1, 0, 1, 1, 1), (1, 0, 1, 0, 1), (0, 1, 2, 2, 1), (0, 1, 0, 2, 1),
-                        (0, 0, 0, 2, 1)],
+                        (0, 0, 0, 2, 1), (1, 0, 1, 2, 1, 1), (1, 0, 1, 1, 1, 1)],
                 ids=["approx-scan-packed-4byte", "approx-scan-packed-8byte", "approx-scan-small", "approx-scan-big",
-                     "wave-owned-crossings", "wave-owned-sweep", "block-scan"])
+                     "wave-owned-crossings", "wave-owned-sweep", "block-scan", "approx-scan-packed-4byte-split-finish",
+                     "approx-scan-small-split-finish"])
 def bm25_kernel(request, engine):
     """Every BM25 scan kernel / survivor-selection path must satisfy every parity test (bm25_ascan / bm25_wscan take
     effect at the next set_bm25)."""
@@ -25,7 +26,9 @@ def bm25_kernel(request, engine):
     engine.set_option("bm25_crossing", request.param[2])
     engine.set_option("bm25_small", request.param[3])       # shape of the approximate scan for batches of >= 8 queries
     engine.set_option("bm25_post16", request.param[4])      # packed shape: 4-byte or 8-byte postings
-    yield request.param
+    engine.set_option("bm25_split_finish", request.param[5] if len(request.param) > 5 else 0)   # exact re-score + rank in a kernel of its own
+    yield request.param[:5]
+    engine.set_option("bm25_split_finish", 0)
     engine.set_option("bm25_ascan", 1)
     engine.set_option("bm25_wscan", 0)
     engine.set_option("bm25_crossing", 1)
@@ -442,3 +445,43 @@ def test_bm25_dir_filter_as_tile_range(engine, bm25_kernel, variant):
     finally:
         engine.set_option("bm25_dir_range", 1)
         engine.set_doc_meta(n_docs, None, None)
+
+
+@pytest.mark.parametrize("variant", [BM25S, OKAPI], ids=["bm25s", "okapi"])
+def test_bm25_reference_question_lengths(engine, bm25_kernel, variant):
+    """Queries as long as the reference's real questions (synth.REF_QUESTION_LENGTHS: 4 ... 45 tokens, tokens repeated when the target
+    document is short) in ONE batch: a batch whose longest query exceeds bm25_long_tokens leaves the packed 16-bit shape for the 32-bit
+    one (and with the option at 0 -- always packed -- or 8 the lists are the same); every arm, with and without a dir filter, against
+    the oracle -- ids and scores bit for bit."""
+    rng = np.random.default_rng(88)
+    n, vocab, b, k = 30000, 3000, 103, 60
+    flat, lens = synth.token_corpus(n, vocab, seed=31, mean_len=30)
+    docs = [list(map(int, t)) for t in synth.split_docs(flat, lens)]
+    idx = build_bm25_index(docs, variant)
+    engine.set_bm25(idx)
+    dir_id = np.repeat(np.arange(3), [12000, 10000, 8000]).astype(np.int16)
+    engine.set_doc_meta(n, None, dir_id)
+    ora = _oracle_for(variant, docs)
+    qs = synth.token_queries(flat, lens, vocab, b, seed=32, lengths=sorted(synth.REF_QUESTION_LENGTHS))
+    for i, L in enumerate(sorted(synth.REF_QUESTION_LENGTHS)):       # every length of the reference's questions, the 45-token one included
+        tgt = docs[int(rng.integers(0, n))]
+        qs[i] = np.asarray([tgt[int(j)] for j in rng.integers(0, len(tgt), L)], np.int32)
+    filt = (np.arange(b) % 4 - 1).astype(np.int16)                   # none, 0, 1, 2
+    try:
+        for f in (None, filt):
+            got = {}
+            for long_tokens in (28, 0, 8):
+                engine.set_option("bm25_long_tokens", long_tokens)
+                got[long_tokens] = engine.bm25_topk(*queries_to_csr([idx.tokens_to_ids(list(map(int, q))) for q in qs]), k, filter_dir=f)
+            ids, sc, ln = got[28]
+            for other in (0, 8):
+                assert np.array_equal(ln, got[other][2]) and np.array_equal(ids, got[other][0])
+                assert np.array_equal(sc.view(np.uint64), got[other][1].view(np.uint64))
+            for i in range(b):
+                mask = None if f is None or f[i] < 0 else dir_id == f[i]
+                want = bm25_filter(ora.get_scores(list(map(int, qs[i]))), k, mask)
+                assert list(ids[i, :ln[i]]) == [w[0] for w in want], (i, len(qs[i]))
+                assert list(sc[i, :ln[i]]) == [w[1] for w in want], (i, len(qs[i]))
+    finally:
+        engine.set_option("bm25_long_tokens", 28)
+        engine.set_doc_meta(n, None, None)
