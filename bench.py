@@ -441,6 +441,48 @@ def sub_benchmarks(eng, synth, queries_to_csr, build_index, OKAPI, q16_pool, tok
     return out
 
 
+def shared_sparse_corpus(synth, n, vocab, n_global, pool, qlen, dev, rank, world):
+    """The token corpus (CSR postings) and the query pools of a multi-rank run, generated ONCE per node: rank 0 builds them and writes
+    them to /dev/shm (keyed by the shapes, the seeds and the job's rendezvous port), the others wait at a barrier and read the files --
+    eight ranks of one node would otherwise each sort 56 M tokens and walk them on the same host cores at the same time.
+    Returns (indptr, doc, tf, lens, flat or None, tok_pool_global, shared: bool); world == 1 generates in place and keeps `flat`."""
+    import tempfile
+    import torch
+    lengths = synth.REF_QUESTION_LENGTHS if qlen == "ref" else None
+
+    def generate():
+        indptr, doc, tf, lens, flat = synth.token_csr_torch(n, vocab, seed=3, device=dev)
+        pools = [synth.token_queries(flat, lens, vocab, n_global, seed=2000 + p, lengths=lengths) for p in range(pool)]
+        return indptr, doc, tf, lens, flat, pools
+
+    if world == 1:
+        return (*generate(), False)
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+    key = f"erh_bench_n{n}_v{vocab}_q{n_global}_p{pool}_{qlen}_{os.environ.get('MASTER_PORT', '0')}"
+    path = os.path.join(base, key)
+    if rank == 0:
+        indptr, doc, tf, lens, flat, pools = generate()
+        del flat
+        os.makedirs(path, exist_ok=True)
+        np.save(os.path.join(path, "indptr.npy"), indptr)
+        np.save(os.path.join(path, "doc.npy"), doc)
+        np.save(os.path.join(path, "tf.npy"), tf)
+        np.save(os.path.join(path, "lens.npy"), lens)
+        for p, qs in enumerate(pools):                                   # ragged: one flat array + offsets per pool
+            off = np.zeros(len(qs) + 1, np.int64)
+            off[1:] = np.cumsum([len(q) for q in qs])
+            np.save(os.path.join(path, f"q{p}_tok.npy"), np.concatenate(qs).astype(np.int32) if qs else np.zeros(0, np.int32))
+            np.save(os.path.join(path, f"q{p}_off.npy"), off)
+    torch.distributed.barrier()                                          # the files are complete
+    if rank != 0:
+        indptr, doc, tf, lens = (np.load(os.path.join(path, f"{name}.npy"), mmap_mode="r") for name in ("indptr", "doc", "tf", "lens"))
+        pools = []
+        for p in range(pool):
+            tok, off = np.load(os.path.join(path, f"q{p}_tok.npy")), np.load(os.path.join(path, f"q{p}_off.npy"))
+            pools.append([tok[off[i]:off[i + 1]] for i in range(off.shape[0] - 1)])
+    return indptr, doc, tf, lens, None, pools, path
+
+
 def spawn_ranks(args, argv) -> int:
     """`python bench.py --gpus N` without a launcher: start N ranks under torch.distributed.run on this node (what
     the driver's wrapped form does) and relay their output."""
@@ -502,6 +544,8 @@ def main(argv=None, platform=None):
     shards = erd.QueryShards(n_global, rank, world, engine=eng, mode=args.gather)
     lo, hi = shards.bounds
     x = idx = None
+    corpus_shared = False
+    flat_keep = None
     q16_pool, csr_pool, tok_pool = [], [], []
     if args.workload in ("hybrid", "dense"):
         x = (synth.clustered_corpus_torch(n, d, seed=21, device=dev) if args.corpus == "clustered"
@@ -509,15 +553,21 @@ def main(argv=None, platform=None):
         q16_pool = [synth.dense_queries_torch(x, n_global, seed=1000 + p)[lo:hi].contiguous() for p in range(pool)]
         eng.set_dense(x)
     if args.workload in ("hybrid", "bm25"):
-        indptr, doc, tf, lens, flat = synth.token_csr_torch(n, vocab, seed=3, device=dev)
+        indptr, doc, tf, lens, flat, tok_global, shared_path = shared_sparse_corpus(synth, n, vocab, n_global, pool, args.qlen, dev, rank, world)
         idx = build_bm25_index_from_postings(indptr, doc, tf, lens, variant, compute_payload=False)
         eng.set_bm25(idx, payload_on_device=True)            # IDF*TF/(TF + k1*lenNorm) evaluated by the GPU
         for p in range(pool):
-            tok_pool.append(synth.token_queries(flat, lens, vocab, n_global, seed=2000 + p,
-                                                lengths=synth.REF_QUESTION_LENGTHS if args.qlen == "ref" else None)[lo:hi])
+            tok_pool.append(tok_global[p][lo:hi])
             csr_pool.append(queries_to_csr(tok_pool[-1]))
         flat_keep = (flat, lens, vocab) if (args.sub and world == 1 and args.workload == "hybrid") else None   # (the sub-benchmarks draw further queries)
-        del flat
+        del flat, tok_global
+        if shared_path:
+            plat.synchronize()                               # every rank's uploads out of the shared files are done ...
+            torch.distributed.barrier()
+            if rank == 0:                                    # ... before rank 0 removes them
+                import shutil
+                shutil.rmtree(shared_path, ignore_errors=True)
+            corpus_shared = True
     eng.set_doc_meta(n, None, None)
     plat.synchronize()
     q16 = q16_pool[0] if q16_pool else None
@@ -661,7 +711,9 @@ def main(argv=None, platform=None):
                 "transport": getattr(shards, "transport", None), "shared_device": bool(args.share_device),
                 "setup_s_per_rank": [round(float(v), 3) for v in setup_all],
                 "allgather_ms_per_step": (sum(a.elapsed_time(b) for a, b in gather_events) / max(len(gather_events), 1)),
-                "allgather_what": "rank 0: dense_check + pack kernel + all_gather_into_tensor + unpack kernel (CUDA events)"},
+                "allgather_what": "rank 0: dense_check + pack kernel + all_gather_into_tensor + unpack kernel (CUDA events)",
+                # the token corpus and the query pools were generated once (rank 0) and read by the other ranks from /dev/shm
+                "corpus_shared": corpus_shared},
             "roofline": roof,
             "cpu_baseline": cpu,
             "kernel_ms_per_step": per_step,

@@ -108,12 +108,12 @@ class StubPlatform:
         return self.engines[-1]
 
 
-def _rank_main(rank, world, port, out_dir):
+def _rank_main(rank, world, port, out_dir, extra=()):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import bench
     plat = StubPlatform()
     sys.stdout = open(os.path.join(out_dir, f"stdout{rank}.txt"), "w")
-    res = bench.main(ARGV, platform=plat)
+    res = bench.main(ARGV + list(extra), platform=plat)
     sys.stdout.flush()
     ids, sc, ln = res["out"]
     np.savez(os.path.join(out_dir, f"out{rank}.npz"), ids=ids.numpy(), sc=sc.numpy(), ln=ln.numpy())
@@ -134,6 +134,10 @@ def test_bench_main_two_gloo_ranks(tmp_path):
     mg = rec["multi_gpu"]
     assert mg["rccl_ranks"] == 2 and mg["backend"] == "gloo" and mg["gather_mode"] == "torch" and mg["gather_fallback_reason"] is None
     assert mg["allgather_ms_per_step"] >= 0.0
+    # the token corpus was generated once (rank 0) and read by rank 1 from /dev/shm; the files are gone afterwards
+    assert mg["corpus_shared"] is True and len(mg["setup_s_per_rank"]) == 2
+    import glob
+    assert not glob.glob("/dev/shm/erh_bench_n4096_v512_*")
     assert rec["cpu_baseline"] is None                                                          # rank 0 at N = 1 only
     # every rank holds the GLOBAL result of the last step, equal to the unsharded answer
     from easyrag_amd import synth
@@ -151,3 +155,21 @@ def test_bench_main_two_gloo_ranks(tmp_path):
         calls = json.load(open(tmp_path / f"res{r}.json"))["calls"]
         # per step: the gather checks the dense route's flags before rows leave the rank (4 steps) + the two checks around the timed region
         assert calls.count(["dense_check"]) == 4 + 2 and calls[-1] == ["close"]
+
+
+def test_bench_native_gather_falls_back_on_every_rank(tmp_path):
+    """--gather native on ranks whose engine cannot join an RCCL communicator (here: the stand-in has no erh_comm_* at all; on a
+    box: librccl missing, ncclCommInitRank failing or timing out): the decision is an all-reduce, EVERY rank falls back to the
+    torch.distributed gather, the record says so and carries the reason, and the results are the unsharded answer."""
+    mp.spawn(_rank_main, args=(2, _free_port(), str(tmp_path), ("--gather", "native")), nprocs=2, join=True)
+    rec = json.loads(open(tmp_path / "stdout0.txt").read().strip().splitlines()[0])
+    mg = rec["multi_gpu"]
+    assert mg["gather_mode"] == "torch" and mg["gather_fallback_reason"] and "rank" in mg["gather_fallback_reason"]
+    from easyrag_amd import synth
+    n, vocab, n_global, pool = 4096, 512, 18, 2
+    indptr, doc, tf, lens, flat = synth.token_csr_torch(n, vocab, seed=3, device=torch.device("cpu"))
+    queries = synth.token_queries(flat, lens, vocab, n_global, seed=2000 + (1 + 3 - 1) % pool)
+    want = [_answer(q, 10, n) for q in queries]
+    for r in range(2):
+        z = np.load(tmp_path / f"out{r}.npz")
+        assert np.array_equal(z["ids"], np.stack([w[0] for w in want])) and np.array_equal(z["sc"], np.stack([w[1] for w in want]))
