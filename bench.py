@@ -49,6 +49,8 @@ def parse_args(argv=None):
                                                                 "--backend gloo; the numbers it prints are not a scaling measurement)")
     ap.add_argument("--dump-out", default=None, help="every rank saves the last step's (global) result as <path>.rank<r>.npz (tests)")
     ap.add_argument("--variant", default="bm25s", choices=["bm25s", "okapi"])
+    ap.add_argument("--dirs", type=int, default=0, help="> 0: every query carries a dir filter on both routes, as the reference's real questions do: the corpus is "
+                    "D contiguous blocks of documents (its loader walks the directories one after the other), query b asks for dir b %% D")
     ap.add_argument("--corpus", default="gaussian", choices=["gaussian", "clustered"], help="chunk embeddings: isotropic Gaussian directions (SURVEY 8d) or "
                     "the anisotropic topic-sorted corpus of synth.clustered_corpus_torch (random-pair cosine ~0.4, intra-topic ~0.7, 2 %% exact duplicates)")
     ap.add_argument("--qlen", default="fixed", choices=["fixed", "ref"], help="token queries of 10 tokens (SURVEY 8d) or with the length distribution of the "
@@ -192,17 +194,18 @@ def okapi_literal_loop(idx, queries, n_docs=50_000, n_queries=8):
                     "linear extrapolation in the number of documents, stated not measured"}
 
 
-def pmc_traffic(args, kernel_class, algorithmic_bytes, launches_per_step=1.0):
+def pmc_traffic(args, kernel_class, algorithmic_bytes, launches_per_step=1.0, key=None):
     """HBM bytes per launch of the dominant kernel class from the committed PMC pass (scripts/gpu_traffic.sh ->
     profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE in its own run, x2 gfx950 correction).  bench.py cannot
     sample counters itself, so the figure is only attached when this run's shape is the profiled one (default
     sizes, no option overrides); otherwise traffic stays null."""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
     default_shape = (args.chunks == 1_000_000 and args.dim == 1024 and args.vocab == 262_144 and args.batch == 0
-                     and not args.option and args.variant == "bm25s" and args.gpus == 1)
+                     and not args.option and args.variant == "bm25s" and args.gpus == 1 and args.corpus == "gaussian"
+                     and args.qlen == "fixed" and (args.dirs == 0 or key is not None))
     try:
         table = json.load(open(path))
-        rec = table[args.workload]
+        rec = table[key or args.workload]
     except (OSError, KeyError, ValueError):
         return {"traffic": None}
     from easyrag_amd import _build
@@ -224,7 +227,7 @@ def pmc_counters(args, key, main_class, class_ms_per_step, timed_classes=None):
     "rocprof HBM GB/s and MFMA-busy counters reported against gfx950 peak"."""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_counters.json")
     default_shape = (args.chunks == 1_000_000 and args.dim == 1024 and args.vocab == 262_144 and args.batch == 0
-                     and not args.option and args.variant == "bm25s" and args.gpus == 1)
+                     and not args.option and args.variant == "bm25s" and args.gpus == 1 and args.corpus == "gaussian" and args.qlen == "fixed")
     try:
         table = json.load(open(path))
         entry = table[key]
@@ -568,7 +571,12 @@ def main(argv=None, platform=None):
                 import shutil
                 shutil.rmtree(shared_path, ignore_errors=True)
             corpus_shared = True
-    eng.set_doc_meta(n, None, None)
+    filt = None
+    if args.dirs > 0:
+        eng.set_doc_meta(n, None, (np.arange(n, dtype=np.int64) * args.dirs // n).astype(np.int16))
+        filt = ((lo + np.arange(hi - lo)) % args.dirs).astype(np.int16)
+    else:
+        eng.set_doc_meta(n, None, None)
     plat.synchronize()
     q16 = q16_pool[0] if q16_pool else None
     queries = tok_pool[0] if tok_pool else []
@@ -576,11 +584,13 @@ def main(argv=None, platform=None):
     def local_step(p):
         if args.workload == "hybrid":
             qi, qt = csr_pool[p]
+            if filt is not None:
+                return eng.hybrid_topk(q16_pool[p], qi, qt, k_dense=k_dense, k_sparse=k_sparse, K=60, topk=topk, device_out=True, filter_dir=filt)
             return eng.hybrid_topk(q16_pool[p], qi, qt, k_dense=k_dense, k_sparse=k_sparse, K=60, topk=topk, device_out=True)
         if args.workload == "dense":
-            return eng.dense_topk(q16_pool[p], k_dense, device_out=True)
+            return eng.dense_topk(q16_pool[p], k_dense, device_out=True, **({} if filt is None else {"filter_dir": filt}))
         qi, qt = csr_pool[p]
-        return eng.bm25_topk(qi, qt, k_sparse, device_out=True)
+        return eng.bm25_topk(qi, qt, k_sparse, device_out=True, **({} if filt is None else {"filter_dir": filt}))
 
     counter = [0]
 
@@ -702,7 +712,7 @@ def main(argv=None, platform=None):
                        "postings": int(idx.nnz) if idx is not None else 0,
                        "queries_per_gpu": B, "global_batch": B * world,
                        "bm25_variant": args.variant if idx is not None else None,
-                       "query_batches_rotated": pool, "corpus": args.corpus, "query_lengths": args.qlen,
+                       "query_batches_rotated": pool, "corpus": args.corpus, "query_lengths": args.qlen, "dir_filter_dirs": args.dirs,
                        "parallelism": f"query-sharded x{world}, corpus replicated, all-gather of fused top-k"
                                       + (f" ({shards.mode})" if world > 1 else "")},
             "multi_gpu": None if world == 1 else {
@@ -723,10 +733,22 @@ def main(argv=None, platform=None):
             "path": path_stats,
         }
         default_shape = (args.chunks == 1_000_000 and args.dim == 1024 and args.vocab == 262_144 and args.batch == 0
-                         and not args.option and args.variant == "bm25s" and args.corpus == "gaussian" and args.qlen == "fixed")
+                         and not args.option and args.variant == "bm25s" and args.corpus == "gaussian" and args.qlen == "fixed" and args.dirs == 0)
         if args.sub and world == 1 and args.workload == "hybrid" and default_shape:
             rec["sub_benchmarks"] = sub_benchmarks(eng, synth, queries_to_csr, build_bm25_index_from_postings, OKAPI,
                                                    q16_pool, tok_pool, csr_pool, (indptr, doc, tf, lens), pool, flat_lens=flat_keep)
+            # the committed PMC passes of the other BASELINE configurations (same digest guard as the headline's): MFMA-busy / TD / L2 hit /
+            # effective clock and the FETCH_SIZE traffic of each sub-benchmark's dominant kernel class
+            for name, key, main, timed, tkey in (("dense_b256_top100", "dense_b256", "pp3", ("pp3", "store"), "dense"),
+                                                 ("bm25_b256_top100", "bm25_b256", "ascan", ("ascan",), "bm25"),
+                                                 ("hybrid_b1024_dir_filter", "hybrid_dirs4_b1024", "pp3", ("pp3", "store"), "hybrid_dirs4")):
+                sub = rec["sub_benchmarks"].get(name)
+                if not sub or not sub.get("roofline"):
+                    continue
+                cls = "bm25_scan" if name.startswith("bm25") else "dense_scan"
+                sub["roofline"]["counters"] = pmc_counters(args, key, main, sub["kernel_ms_per_step"].get(cls), timed_classes=timed)
+                sub["roofline"].update(pmc_traffic(args, cls, sub["roofline"]["algorithmic_bytes_per_launch"],
+                                                   sub["roofline"].get("launches_per_step", 1.0), key=tkey))
         print(json.dumps(rec), flush=True)
     if args.dump_out and out is not None:
         plat.synchronize()

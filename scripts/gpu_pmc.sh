@@ -10,6 +10,7 @@ TAG=${3:-a}
 OUT=gpurun_out/pmc_$WL
 mkdir -p $OUT
 export TMPDIR=/tmp
+# (WL "hybrid": the dense kernels of the hybrid step are summarised -- e.g. "--dirs 4 --sub 0", the filtered path of the reference's real calls)
 CMD="python $GRAFT_REPO_ROOT/bench.py --workload $WL --steps 2 --warmup 1 --cpu-queries 0 $OPTS"
 if [[ "$WL" == "bm25" ]]; then
   SETS=("SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES GRBM_GUI_ACTIVE"

@@ -18,7 +18,9 @@ from easyrag_amd import _build  # noqa: E402
 
 STEPS = 4                                      # --steps 3 --warmup 1
 CLASSES = (("hybrid", "dense_scan", r"dense_scan_pp5"), ("dense", "dense_scan", r"dense_scan_pp3|dense_scan_store"),
-           ("bm25", "bm25_scan", r"bm25_[wa]?scan"))
+           ("bm25", "bm25_scan", r"bm25_[wa]?scan"),
+           # the filtered hybrid step (bench.py --dirs 4): the grouped launch's store kernel + the one persistent scan over the four blocks
+           ("hybrid_dirs4", "dense_scan", r"dense_scan_pp3|dense_scan_store"))
 out = {"_kernel_digest": _build._kernel_digest()}
 for wl, klass, pat in CLASSES:
     f = glob.glob(f"gpurun_out/traffic/{wl}/**/*counter_collection.csv", recursive=True)
@@ -38,7 +40,7 @@ for wl, klass, pat in CLASSES:
         "hbm_bytes_per_launch": 2.0 * 1024.0 * kib_per_step / (n / STEPS),
         "correction": "FETCH_SIZE [KiB] x 1024 x 2 (gfx950: 128-byte requests tallied at 64 bytes)",
         "per_kernel_kib": {k: sum(v) / len(v) for k, v in per.items()},
-        "command": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python bench.py --workload {wl} --steps 3 --warmup 1 --cpu-queries 0 --sub 0",
+        "command": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python bench.py --workload {wl.split('_')[0]} {'--dirs 4 ' if 'dirs4' in wl else ''}--steps 3 --warmup 1 --cpu-queries 0 --sub 0",
     }
 json.dump(out, sys.stdout, indent=1)
 print()
