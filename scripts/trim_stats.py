@@ -19,6 +19,11 @@ def short(name: str) -> str:
         s = re.sub(r"(kernel).*", r"\1", s)
         if cfg:
             s += "<%s,%s,%s,%s>" % cfg.groups()
+        tv = re.search(r"(?:pp3_kernel|finalize_kernel|store_kernel\w*)ILi(\d+)E(?:Li(\d+)E)?", name)
+        if tv and "pp3" in s:                                   # <ablation mask, VAR>: VAR 32 / 40 = the grouped launch (round 6), 16 / 24 the sample pass
+            s += "<%s,%s>" % (tv.group(1), tv.group(2))
+        if "store_kernel" in s and "Lb1E" in name:
+            s += "<grouped>"
     return s
 
 
