@@ -656,11 +656,14 @@ def main(argv=None, platform=None):
         roof = roofline_of(kd, dom)
         if roof is not None:
             roof["launches_per_step"] = roof["launches"] / args.steps
-            roof.update(pmc_traffic(args, dom, roof["algorithmic_bytes_per_launch"], roof["launches_per_step"]))
-            if args.workload != "bm25":
-                key, main = ("dense_b1024", "pp5") if args.workload == "hybrid" else ("dense_b256", "pp3")
+            filtered4 = args.workload == "hybrid" and args.dirs == 4      # the filtered step has PMC passes of its own (bench.py --dirs 4)
+            if args.dirs == 0 or filtered4:
+                roof.update(pmc_traffic(args, dom, roof["algorithmic_bytes_per_launch"], roof["launches_per_step"],
+                                        key="hybrid_dirs4" if filtered4 else None))
+            if args.workload != "bm25" and (args.dirs == 0 or filtered4):
+                key, main = (("hybrid_dirs4_b1024", "pp3") if filtered4 else ("dense_b1024", "pp5")) if args.workload == "hybrid" else ("dense_b256", "pp3")
                 roof["counters"] = pmc_counters(args, key, main, per_step["dense_scan"],
-                                                ("pp5",) if args.workload == "hybrid" else ("pp3", "store"))
+                                                ("pp5",) if (args.workload == "hybrid" and not filtered4) else ("pp3", "store"))
             if dom == "dense_scan" and roof["launches"] > args.steps:
                 roof["launch_mix"] = ("the dense-scan class has two launches per step -- the seed-prefix store kernel (real scan work over "
                                       "the first rows) and the append scan over the rest; per-launch figures are class totals / launches, "

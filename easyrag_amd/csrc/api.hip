@@ -145,6 +145,7 @@ struct erh_handle {
     int opt_dense_dir_blocks = 1;
     int64_t opt_dir_block_min_rows = 4096;
     int64_t opt_route_ridge = 160;                                 // query columns below which a scan of R rows costs like R x ridge (HBM-bound): the route decision's only constant
+    int opt_dense_group_sample = 1;                                // ... with thresholds from a sample pass of the scan kernel per view where every view qualifies (0: store kernel + seed select)
     int opt_dense_group_launch = 1;                                // two or more block groups of a batch run as ONE launch per stage (dense_topk_grouped); 0: one pipeline per group
     // One routed dense call (dense_topk_routed), kept until its synchronisation point (dense_check_flags) has read its flag words:
     // the batch's groups, where each group's queries lie, and where results go.  Nothing else of a routed call lives on the handle.
@@ -899,6 +900,8 @@ struct GroupedPlan {
     int grid = 0, n0_max = 0, bpad = 0;
     int64_t n_max = 0;
     bool halfq = true;
+    bool sample = false;        // thresholds from a sample pass of the scan kernel over every view (views[].seed_rows / n_cells) instead of store kernel + S0 + seed select
+    int cells_max = 0;
 };
 
 // chunk streams per query tile: the smallest number of rounds R with sum ceil(tiles_v / R) <= n_cus, then ceil(tiles_v / R) streams each
@@ -935,7 +938,8 @@ int dense_topk_grouped(erh_handle *h, const void *q_dev, int q_dtype, int normal
     HIPCHK(h, h->seed_need.ensure((size_t)Bpad * 4));
     HIPCHK(h, h->bad.ensure((size_t)Bpad * 4));
     HIPCHK(h, h->ex_ws.ensure(erh::dense_exhaustive_bytes(P.n_max)));
-    HIPCHK(h, h->S0.ensure((size_t)Bpad * ld * 4));
+    if (P.sample) HIPCHK(h, h->seed_top.ensure((size_t)Bpad * P.cells_max * 2 * 4));
+    else HIPCHK(h, h->S0.ensure((size_t)Bpad * ld * 4));
     // the tables: one upload (pageable source: copied out before the call returns)
     const size_t off_wg = (size_t)n_qt * sizeof(erh::ErhDenseView), off_src = off_wg + (size_t)P.grid * 4, bytes = off_src + (size_t)Bpad * 4;
     h->r_tab_host.resize(bytes);
@@ -958,12 +962,29 @@ int dense_topk_grouped(erh_handle *h, const void *q_dev, int q_dtype, int normal
     // booked work: what the algorithm needs -- every block row once per query tile that scans it
     double seed_rows = 0, scan_rows = 0;
     for (const erh::ErhDenseView &v : P.views) { seed_rows += v.n0; scan_rows += (double)(v.N - v.n0); }
-    { ProfScope ps(h, st, ERH_K_DENSE_SCAN, seed_rows * d * 2.0 + (double)Bpad * d * 2.0, 2.0 * seed_rows * 256.0 * d);
-      HIPCHK(h, erh::launch_dense_scan_store_grouped(gio, n_qt, P.n0_max, h->n_cus, h->Q16.as<_Float16>(), Bpad, d, h->S0.as<float>(), ld, st)); }
-    { ProfScope ps(h, st, ERH_K_DENSE_SELECT, 0, 0);
-      HIPCHK(h, erh::launch_seed_select(h->S0.as<float>(), ld, P.n0_max, 0, Bpad, k, k, h->qnorm.as<float>(), h->xnorm_max, d, nullptr, nullptr,
-                                        h->tau.as<float>(), h->cand.as<ErhCand>(), h->cand_cnt.as<uint32_t>(), cap, bad,
-                                        h->seed_need.as<uint32_t>(), st, gio.views)); }
+    if (P.sample) {
+        // thresholds from the scan kernel's own sample: rows [0, seed_rows) of every view without thresholds, the two best scores of every
+        // 64-row cell -> the rank-th largest of them per query (the unfiltered path's scheme, per view); the main launch scans ALL rows.
+        // (The pass books no work: its rows are scanned again, and N rows per view are what the algorithm needs.)
+        erh::ErhSeedIo sio{};
+        sio.seed_top = h->seed_top.as<float>();
+        sio.n_cells = P.cells_max;
+        sio.mode = 1;
+        h->stats.dense_sample_passes += 1;
+        { ProfScope ps(h, st, ERH_K_DENSE_SAMPLE, 0, 0);
+          HIPCHK(h, erh::launch_dense_scan_pp_grouped(gio, P.grid, d, h->Q16.as<_Float16>(), Bpad, h->tau.as<float>(), h->cand.as<ErhCand>(),
+                                                      h->cand_cnt.as<uint32_t>(), cap, flags, P.halfq ? 1 : 0, st, &sio)); }
+        { ProfScope ps(h, st, ERH_K_DENSE_SELECT, 0, 0);
+          HIPCHK(h, erh::launch_seed_cells_select(sio.seed_top, P.cells_max * 2, Bpad, k, h->qnorm.as<float>(), h->xnorm_max, d, h->tau.as<float>(),
+                                                  h->cand_cnt.as<uint32_t>(), st, gio.views)); }
+    } else {
+        { ProfScope ps(h, st, ERH_K_DENSE_SCAN, seed_rows * d * 2.0 + (double)Bpad * d * 2.0, 2.0 * seed_rows * 256.0 * d);
+          HIPCHK(h, erh::launch_dense_scan_store_grouped(gio, n_qt, P.n0_max, h->n_cus, h->Q16.as<_Float16>(), Bpad, d, h->S0.as<float>(), ld, st)); }
+        { ProfScope ps(h, st, ERH_K_DENSE_SELECT, 0, 0);
+          HIPCHK(h, erh::launch_seed_select(h->S0.as<float>(), ld, P.n0_max, 0, Bpad, k, k, h->qnorm.as<float>(), h->xnorm_max, d, nullptr, nullptr,
+                                            h->tau.as<float>(), h->cand.as<ErhCand>(), h->cand_cnt.as<uint32_t>(), cap, bad,
+                                            h->seed_need.as<uint32_t>(), st, gio.views)); }
+    }
     if (P.grid > 0) {
         ProfScope ps(h, st, ERH_K_DENSE_SCAN, scan_rows * d * 2.0 + (double)Bpad * d * 2.0, 2.0 * scan_rows * 256.0 * d);
         HIPCHK(h, erh::launch_dense_scan_pp_grouped(gio, P.grid, d, h->Q16.as<_Float16>(), Bpad, h->tau.as<float>(), h->cand.as<ErhCand>(),
@@ -1075,6 +1096,28 @@ int dense_topk_routed(erh_handle *h, const void *q_dev, int q_dtype, int normali
             run_grouped = false;
             for (auto &rg : R.groups) if (rg.pad_at >= 0) { rg.pad_at = -1; rg.flag_slot = n_slots++; }
         } else {
+            // Thresholds from a sample pass (the unfiltered path's scheme, per view) when every view can give one: rows of its first
+            // seed_tiles x streams x 256 positions (>= min(16384, N / 4), at most half of the view), a speculative rank below k, and cells
+            // enough that the rank-th largest of the cells' two best is close to the sample's (2 rank <= cells: a cell with three of the
+            // sample's best hides one: a few ranks of looseness, verified like every speculative threshold).  The scan then covers all rows.
+            if (h->opt_dense_selfseed && h->opt_dense_group_sample) {
+                std::vector<erh::ErhDenseView> vs = P.views;
+                std::vector<int64_t> t_all(vs.size());
+                for (size_t v = 0; v < vs.size(); ++v) t_all[v] = (vs[v].N + QT - 1) / QT;
+                int grid2 = 0, cells_max = 0;
+                bool ok = plan_streams(vs, t_all, h->n_cus, &grid2);
+                for (size_t v = 0; ok && v < vs.size(); ++v) {
+                    const int64_t per = (int64_t)vs[v].nwg * QT;
+                    const int64_t want = std::max<int64_t>(per, std::min<int64_t>(std::min<int64_t>(h->opt_n0, 16384), vs[v].N / 4));
+                    const int64_t seed_tiles = (want + per - 1) / per, rows = seed_tiles * per;
+                    const int rank = erh_dense_seed_rank(k, rows, vs[v].N);
+                    const int64_t cells = seed_tiles * vs[v].nwg * 4;
+                    ok = per > 0 && rows * 2 <= vs[v].N && rank < k && 2 * (int64_t)rank <= cells && cells * 2 <= 12288;
+                    vs[v].n0 = 0; vs[v].rank = rank; vs[v].seed_rows = (int32_t)rows; vs[v].n_cells = (int32_t)cells;
+                    cells_max = std::max(cells_max, (int)cells);
+                }
+                if (ok && erh::seed_cells_select_fits(cells_max * 2)) { P.views = vs; P.grid = grid2; P.sample = true; P.cells_max = cells_max; P.n0_max = 0; }
+            }
             P.wg_view.resize((size_t)P.grid);
             for (size_t v = 0; v < P.views.size(); ++v)
                 for (int i = 0; i < P.views[v].nwg; ++i) P.wg_view[(size_t)P.views[v].wg0 + i] = (int32_t)v;
@@ -1373,6 +1416,7 @@ int erh_set_option(erh_handle *h, const char *name, int64_t value) {
     if (!strcmp(name, "bm25_long_tokens")) { if (value < 0 || value > 4096) return h->fail(ERH_ERR_INVALID, "bm25_long_tokens"); h->opt_bm25_long_tokens = (int)value; return ERH_OK; }
     if (!strcmp(name, "bm25_split_finish")) { h->opt_bm25_split_finish = value != 0; return ERH_OK; }
     if (!strcmp(name, "dense_route_ridge")) { if (value < 1 || value > 4096) return h->fail(ERH_ERR_INVALID, "dense_route_ridge"); h->opt_route_ridge = value; return ERH_OK; }
+    if (!strcmp(name, "dense_group_sample")) { h->opt_dense_group_sample = value != 0; return ERH_OK; }
     if (!strcmp(name, "dense_group_launch")) { h->opt_dense_group_launch = value != 0; return ERH_OK; }
     if (!strcmp(name, "dense_dir_blocks")) { if (value < 0 || value > 2) return h->fail(ERH_ERR_INVALID, "dense_dir_blocks"); h->opt_dense_dir_blocks = (int)value; return ERH_OK; }
     if (!strcmp(name, "dense_dir_block_min_rows")) { if (value < 1) return h->fail(ERH_ERR_INVALID, "dense_dir_block_min_rows"); h->opt_dir_block_min_rows = value; h->blocks.valid = false; return ERH_OK; }

@@ -704,10 +704,11 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp3_kernel(
     constexpr bool GROUPED = (VAR & 32) != 0;
     const int g_qt = GROUPED ? gio.wg_view[blockIdx.x] : 0;
     const erh::ErhDenseView *const gv = GROUPED ? gio.views + g_qt : nullptr;
+    constexpr bool GSEED = GROUPED && (VAR & 16) != 0;                 // the grouped sample pass: rows [0, seed_rows) of the tile's view
     const _Float16 *const X = GROUPED ? gv->X : Xg;
     const int64_t N = GROUPED ? gv->N : Ng;
-    const int64_t c0 = GROUPED ? (int64_t)gv->n0 : c0g;
-    const int64_t c1 = GROUPED ? gv->N : c1g;
+    const int64_t c0 = GROUPED ? (GSEED ? (int64_t)0 : (int64_t)gv->n0) : c0g;
+    const int64_t c1 = GROUPED ? (GSEED ? (int64_t)gv->seed_rows : gv->N) : c1g;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1744,6 +1745,7 @@ hipError_t dense_scan_init() {
     ERH_SET_PP(0)
     ERH_SET_PP3(0, 8) ERH_SET_PP3(0, 10) ERH_SET_PP3(0, 16) ERH_SET_PP3(0, 24)
     ERH_SET_PP3(0, 32) ERH_SET_PP3(0, 40)              // the grouped launch (several matrices, one per query tile), whole / half query tile
+    ERH_SET_PP3(0, 48) ERH_SET_PP3(0, 56)              // ... and its sample pass
     e = hipFuncSetAttribute((const void *)dense_scan_pp5_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, pp::LDS_BYTES);
     if (e != hipSuccess) return e;
 #ifdef ERH_MEASURE
@@ -1797,15 +1799,19 @@ hipError_t launch_dense_scan_store_grouped(const ErhGroupIo &gio, int n_qt, int 
 }
 
 hipError_t launch_dense_scan_pp_grouped(const ErhGroupIo &gio, int grid, int d, const _Float16 *Q, int Bpad, const float *tau,
-                                        ErhCand *cand, uint32_t *cand_cnt, int cap, uint32_t *overflow, int halfq, hipStream_t st) {
+                                        ErhCand *cand, uint32_t *cand_cnt, int cap, uint32_t *overflow, int halfq, hipStream_t st,
+                                        const ErhSeedIo *sio) {
     if (grid <= 0) return hipSuccess;
     if (d % (2 * pp::BK) != 0 || d / pp::BK < 8) return hipErrorInvalidValue;
-    const erh::ErhSeedIo sio_v{};
+    erh::ErhSeedIo sio_v{};
+    if (sio) sio_v = *sio;
 #define ERH_LAUNCH_PP3G(V)                                                                                 \
     hipLaunchKernelGGL((dense_scan_pp3_kernel<0, V>), dim3((unsigned)grid), dim3(pp::NT), pp::LDS_BYTES, st, (const _Float16 *)nullptr, \
                        (int64_t)0, d, (int64_t)0, (int64_t)0, Q, Bpad, Bpad, tau, (const int16_t *)nullptr, (const int16_t *)nullptr, cand, \
                        cand_cnt, cap, overflow, (unsigned long long *)nullptr, 0, (uint32_t *)nullptr, sio_v, gio)
-    if (halfq) ERH_LAUNCH_PP3G(40); else ERH_LAUNCH_PP3G(32);
+    if (sio_v.mode == 1) { if (halfq) ERH_LAUNCH_PP3G(56); else ERH_LAUNCH_PP3G(48); }
+    else if (halfq) ERH_LAUNCH_PP3G(40);
+    else ERH_LAUNCH_PP3G(32);
 #undef ERH_LAUNCH_PP3G
     return hipGetLastError();
 }

@@ -31,7 +31,8 @@ struct ErhDenseView {
     int32_t id_lo;         // block row r is the caller's document id_map[id_lo + r]
     int32_t wg0, nwg;      // persistent scan: workgroups [wg0, wg0 + nwg) walk this tile's chunk tiles (nwg chunk streams)
     int32_t nq;            // queries of the tile = its first nq rows; the rest is padding (zero rows, threshold +inf)
-    int32_t pad_[2];
+    int32_t seed_rows;     // sample-pass mode (n0 == 0): rows [0, seed_rows) = seed_tiles x nwg x 256 are what the sample pass scores ...
+    int32_t n_cells;       // ... into this many 64-row cells (two best scores each) of the tile's queries; 0: the store-kernel mode
 };
 static_assert(sizeof(ErhDenseView) == 64, "ErhDenseView layout");
 struct ErhGroupIo {
@@ -45,7 +46,9 @@ hipError_t launch_dense_scan_store_grouped(const ErhGroupIo &gio, int n_qt, int 
 hipError_t launch_dense_scan_pp_grouped(const ErhGroupIo &gio, int grid, int d, const _Float16 *Q, int Bpad, const float *tau,
                                         ErhCand *cand, uint32_t *cand_cnt, int cap, uint32_t *overflow,
                                         int halfq /* every tile holds at most 128 queries: the other half of the tile is not computed */,
-                                        hipStream_t st);
+                                        hipStream_t st,
+                                        const ErhSeedIo *sio = nullptr /* the grouped SAMPLE PASS: rows [0, seed_rows) of every view, the cells' two best
+                                                                          scores to sio->seed_top[q][sio->n_cells][2] (n_cells: the largest of the views) */);
 // chunk streams (co-resident workgroups per query tile) of the ping-pong scan on n_cus CUs, 0 if the shape does not qualify
 int dense_scan_pp_streams(int n_cus, int Bpad);
 hipError_t dense_scan_init();
@@ -126,7 +129,8 @@ hipError_t launch_row_norm_max(const _Float16 *x, int64_t n, int d, float *out, 
 // launch_dense_finalize when it is given tau_verify)
 bool seed_cells_select_fits(int n_vals);   // the select sorts pow2(n_vals) floats in 48 KiB of LDS
 hipError_t launch_seed_cells_select(const float *seed_top, int n_vals, int B, int rank, const float *qnorm, float xnorm_max, int d,
-                                    float *tau, uint32_t *cand_cnt, hipStream_t st);
+                                    float *tau, uint32_t *cand_cnt, hipStream_t st,
+                                    const ErhDenseView *views = nullptr /* grouped call: cells and rank per query tile, n_vals = the row stride */);
 hipError_t launch_seed_select(const float *S0, int ld_s0, int n0, int64_t c0, int B, int k, int rank,
                               const float *qnorm, float xnorm_max, int d,
                               const int16_t *filter_dir, const int16_t *dir_id,

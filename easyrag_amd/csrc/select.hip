@@ -345,11 +345,20 @@ __global__ __launch_bounds__(kSelThreads) void seed_select_full_kernel(
 // grid = B, block = 256, dynamic LDS = np2 * 4 bytes.
 __global__ __launch_bounds__(256) void seed_cells_select_kernel(
     const float *__restrict__ seed_top, int n_vals, int np2, int rank, const float *__restrict__ qnorm, float xnorm_max, int d,
-    float *__restrict__ tau, uint32_t *__restrict__ cand_cnt) {
+    float *__restrict__ tau, uint32_t *__restrict__ cand_cnt, const erh::ErhDenseView *__restrict__ views) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint32_t *keys = reinterpret_cast<uint32_t *>(smem);
     const int q = blockIdx.x, tid = threadIdx.x;
     const float *row = seed_top + (int64_t)q * n_vals;
+    if (views) {                                                     // grouped call: this tile's cells and rank (n_vals: the row stride)
+        const erh::ErhDenseView &v = views[q >> 8];
+        if ((q & 255) >= v.nq) {                                     // a padding row
+            if (tid == 0) { tau[q] = INFINITY; cand_cnt[q] = 0u; }
+            return;
+        }
+        n_vals = v.n_cells * 2; rank = v.rank;
+        np2 = erh_next_pow2(n_vals < 2 ? 2 : n_vals);
+    }
     for (int i = tid; i < np2; i += 256) {
         uint32_t key = 0u;
         if (i < n_vals) {
@@ -958,12 +967,12 @@ hipError_t launch_seed_select(const float *S0, int ld_s0, int n0, int64_t c0, in
 bool seed_cells_select_fits(int n_vals) { return (size_t)pow2_ge(n_vals < 2 ? 2 : n_vals) * 4 <= 48 * 1024; }
 
 hipError_t launch_seed_cells_select(const float *seed_top, int n_vals, int B, int rank, const float *qnorm, float xnorm_max, int d,
-                                    float *tau, uint32_t *cand_cnt, hipStream_t st) {
+                                    float *tau, uint32_t *cand_cnt, hipStream_t st, const ErhDenseView *views) {
     if (B <= 0) return hipSuccess;
     const int np2 = pow2_ge(n_vals < 2 ? 2 : n_vals);
     if (!seed_cells_select_fits(n_vals)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(seed_cells_select_kernel, dim3(B), dim3(256), (size_t)np2 * 4, st, seed_top, n_vals, np2, rank, qnorm,
-                       xnorm_max, d, tau, cand_cnt);
+                       xnorm_max, d, tau, cand_cnt, views);
     return hipGetLastError();
 }
 

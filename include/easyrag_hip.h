@@ -343,6 +343,8 @@ int erh_reset_kernel_time(erh_handle *h);
  *                         dense_route_ridge counted as the ridge (a scan that narrow is bound by the matrix bytes);
  *                         2 = whenever the batch has a dir with a block; 0 = always the filter column.  Same results
  *   dense_group_launch (1)  0: every block group of a batch as a pipeline of its own (the round-5 path; a parity arm)
+ *   dense_group_sample (1)  grouped launch: thresholds from a sample pass of the scan kernel per view (where every view of the batch can give
+ *                         one) instead of store kernel + seed scores + seed select; 0: always the latter.  Same results
  *   dense_route_ridge (160) query columns below which a dense scan is HBM-bound on this chip (the route decision's only constant)
  *   dense_dir_block_min_rows (4096)  smallest dir that gets a block of its own
  *   bm25_long_tokens (28) packed shape: a batch whose longest query has MORE tokens than this scans with 32-bit sums (the bm25_small = 1

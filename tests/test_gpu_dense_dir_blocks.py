@@ -38,14 +38,17 @@ def _check_oracle(x, q16, k, dir_id, filt, got, rows):
         assert np.array_equal(sc[i, :ln[i]].view(np.uint64), osc.view(np.uint64)), i
 
 
-@pytest.fixture(params=[1, 0], ids=["one-launch-per-stage", "pipeline-per-group"])
+@pytest.fixture(params=[(1, 1), (1, 0), (0, 0)], ids=["one-launch-per-stage", "one-launch-per-stage-store-kernel-seed", "pipeline-per-group"])
 def blocks_opts(engine, request):
-    """Both ways of running a batch's block groups: ONE launch per stage over all of them through the view table (round 6, the default),
-    and every group as a pipeline of its own (round 5; what a group with a flagged query still falls back to)."""
+    """The ways of running a batch's block groups: ONE launch per stage over all of them through the view table (round 6, the default) -- with
+    the thresholds from a sample pass per view where every view qualifies, or always from store kernel + seed select -- and every group as a
+    pipeline of its own (round 5; what a group with a flagged query still falls back to)."""
     engine.set_option("dense_dir_blocks", 2)                        # every batch with a block dir takes the route (1 = by the work estimate)
-    engine.set_option("dense_group_launch", request.param)
-    engine.group_launch = request.param
+    engine.set_option("dense_group_launch", request.param[0])
+    engine.set_option("dense_group_sample", request.param[1])
+    engine.group_launch = request.param[0]
     yield engine
+    engine.set_option("dense_group_sample", 1)
     engine.set_option("dense_group_launch", 1)
     engine.set_option("dense_dir_blocks", 1)
     engine.set_option("dense_dir_block_min_rows", 4096)
@@ -424,3 +427,78 @@ def test_route_decision_by_work(engine):
         assert engine.stat("dense_block_groups") == 2               # half the rows
     finally:
         engine.set_option("dense_route_ridge", 160)
+
+
+def test_grouped_launch_at_the_reference_vector_size(engine):
+    """d = 3584 (the reference's `vector_size`, gte-Qwen2-7B: ref src/configs/easyrag.yaml:15-16) with the reference's real call pattern: every
+    query filtered on its dir, the dirs uneven runs of consecutive chunks (41 / 36 / 15 / 11 % like the 103 questions' documents).  112 K-stages
+    per tile through the grouped store kernel, the grouped persistent scan and the final kernel's d > 2048 tail; ids and pinned-order fp64
+    scores against the oracle, and the filter column bit for bit."""
+    rng = np.random.default_rng(909)
+    sizes = [24600, 21600, 9000, 6600]
+    n, d, b, k = sum(sizes), 3584, 300, 100
+    x = to_f16_unit(rng.standard_normal((n, d), dtype=np.float32))
+    dir_id = _blocks(sizes)
+    filt = rng.choice(4, size=b, p=[0.41, 0.36, 0.15, 0.08]).astype(np.int16)
+    filt[:4] = [0, 1, 2, 3]
+    q16 = to_f16_unit(x[rng.integers(0, n, b)].astype(np.float32) + 0.4 * rng.standard_normal((b, d), dtype=np.float32) / np.sqrt(d) * 8)
+    engine.set_option("dense_dir_blocks", 2)
+    try:
+        engine.set_dense(x)
+        engine.set_doc_meta(n, None, dir_id)
+        engine.reset_stats()
+        got = engine.dense_topk(q16, k, filter_dir=filt)
+        st, diag = engine.stats(), engine.dense_diag()
+        assert st["dense_grouped_launches"] == 1 and st["dense_block_groups"] == 4 and diag["uncertified"] == 0, (st, diag)
+        assert diag["max_abs_err"] <= diag["margin"]
+        engine.set_option("dense_dir_blocks", 0)
+        _same(engine.dense_topk(q16, k, filter_dir=filt), got)
+        _check_oracle(x, q16, k, dir_id, filt, got, (0, 1, 2, 3, 150, b - 1))
+    finally:
+        engine.set_option("dense_dir_blocks", 1)
+        engine.set_doc_meta(n, None, None)
+
+
+def test_grouped_launch_sample_pass(engine):
+    """Three blocks of 120 k / 90 k / 70 k chunks, 200 queries each: every view is large enough for a threshold sample of its own, so the
+    grouped launch draws it with the scan kernel (one sample pass over the first tiles of every view's chunk streams, cell select with the
+    view's rank, the main launch over ALL rows) instead of store kernel + seed scores + seed select.  Same lists as the store-kernel seed, the
+    per-group pipelines and the filter column, bit for bit; a sample of them against the oracle."""
+    rng = np.random.default_rng(1212)
+    sizes = [120_000, 90_000, 70_000]
+    n, d, b, k = sum(sizes), 256, 600, 100
+    x = to_f16_unit(rng.standard_normal((n, d), dtype=np.float32) + 0.3 * rng.standard_normal(d).astype(np.float32))
+    dir_id = _blocks(sizes)
+    filt = (np.arange(b) % 3).astype(np.int16)
+    q16 = to_f16_unit(x[rng.integers(0, n, b)].astype(np.float32) + 0.4 * rng.standard_normal((b, d), dtype=np.float32))
+    engine.set_option("dense_dir_blocks", 2)
+    try:
+        engine.set_dense(x)
+        engine.set_doc_meta(n, None, dir_id)
+        engine.reset_stats()
+        got = engine.dense_topk(q16, k, filter_dir=filt)
+        st, diag = engine.stats(), engine.dense_diag()
+        assert st["dense_grouped_launches"] == 1 and st["dense_sample_passes"] == 1 and st["dense_scan_pp3_launches"] == 1, st
+        assert diag["uncertified"] == 0 and diag["exhaustive"] == 0 and diag["max_abs_err"] <= diag["margin"], diag
+        engine.set_option("dense_group_sample", 0)
+        engine.reset_stats()
+        _same(engine.dense_topk(q16, k, filter_dir=filt), got)
+        assert engine.stat("dense_sample_passes") == 0 and engine.stat("dense_grouped_launches") == 1
+        engine.set_option("dense_group_launch", 0)
+        _same(engine.dense_topk(q16, k, filter_dir=filt), got)
+        engine.set_option("dense_dir_blocks", 0)
+        _same(engine.dense_topk(q16, k, filter_dir=filt), got)
+        _check_oracle(x, q16, k, dir_id, filt, got, (0, 1, 2, 299, 598, 599))
+        # k so deep that a view's speculative rank reaches it: the batch takes the store-kernel seed, same contract
+        engine.set_option("dense_dir_blocks", 2)
+        engine.set_option("dense_group_launch", 1)
+        engine.set_option("dense_group_sample", 1)
+        engine.reset_stats()
+        deep = engine.dense_topk(q16[:90], 700, filter_dir=filt[:90])
+        assert engine.stat("dense_grouped_launches") == 1
+        _check_oracle(x, q16, 700, dir_id, filt, deep, (0, 1, 2))
+    finally:
+        engine.set_option("dense_group_sample", 1)
+        engine.set_option("dense_group_launch", 1)
+        engine.set_option("dense_dir_blocks", 1)
+        engine.set_doc_meta(n, None, None)

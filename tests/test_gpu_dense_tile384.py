@@ -136,12 +136,14 @@ def test_tile384_duplicates_and_dir_filter(engine):
     filt[:4] = (0, 2, -1, 1)
     engine.set_option("dense_n0", 1536)
     engine.set_option("dense_gemv", 0)
+    engine.set_option("dense_dir_blocks", 0)                        # the filter COLUMN on the 384-row tile is what is under test (by default these dirs get block copies)
     try:
         engine.set_dense(x)
         engine.set_doc_meta(n, None, dir_id)
         plain = _both_tiles(engine, lambda: engine.dense_topk(q16, k))
         filtered = _both_tiles(engine, lambda: engine.dense_topk(q16, k, filter_dir=filt))
     finally:
+        engine.set_option("dense_dir_blocks", 1)
         engine.set_option("dense_n0", 32768)
         engine.set_option("dense_gemv", 1)
         engine.set_doc_meta(n, None, None)
@@ -164,11 +166,13 @@ def test_tile384_filter_at_full_seed_prefix(engine):
     filt[::5] = -1
     engine.set_option("dense_n0", 32640)
     engine.set_option("dense_gemv", 0)
+    engine.set_option("dense_dir_blocks", 0)                        # (the filter column: see above)
     try:
         engine.set_dense(x)
         engine.set_doc_meta(n, None, dir_id)
         runs = _both_tiles(engine, lambda: engine.dense_topk(q16, k, filter_dir=filt))
     finally:
+        engine.set_option("dense_dir_blocks", 1)
         engine.set_option("dense_n0", 32768)
         engine.set_option("dense_gemv", 1)
         engine.set_doc_meta(n, None, None)

@@ -186,18 +186,17 @@ def test_real_bench_two_processes_share_the_one_gpu(tmp_path):
         assert np.array_equal(got["scores"].view(np.uint64), want["scores"].view(np.uint64))
 
 
-def test_matrix_copies_are_allocated_on_first_use(engine):
+def test_matrix_copies_are_allocated_on_first_use():
     """Eight ranks of one node each hold a replica of the corpus; the two optional copies of the chunk matrix (the 384-row tiled copy of
     batches padded to >= 512 queries, the per-dir block copies of filtered batches) must not exist before the first call that uses
     them: erh_set_dense leaves one matrix on the device, a 256-query call adds only work space, the first 1024-query call adds the
-    tiled copy, the first filtered call the blocks."""
+    tiled copy, the first filtered call the blocks.  (A handle of its own: the session's engine keeps the buffers of earlier tests.)"""
     import torch
     from easyrag_amd import synth
+    from easyrag_amd.engine import RetrievalEngine
     dev = torch.device("cuda", 0)
     n, d = 400_000, 512
     mat = n * d * 2
-    engine.set_dense(synth.dense_corpus_torch(1000, d, seed=1, device=dev))         # (drops whatever an earlier test left on the handle)
-    torch.cuda.synchronize()
     x = synth.dense_corpus_torch(n, d, seed=5, device=dev)
     q = synth.dense_queries_torch(x, 1024, seed=6)
     torch.cuda.synchronize()
@@ -207,23 +206,26 @@ def test_matrix_copies_are_allocated_on_first_use(engine):
         free, total = torch.cuda.mem_get_info()
         return total - free
 
-    u0 = used()
-    engine.set_dense(x)
-    engine.set_doc_meta(n, None, (np.arange(n) * 4 // n).astype(np.int16))
-    u1 = used()
-    assert 0.95 * mat < u1 - u0 < 1.3 * mat, (u1 - u0, mat)                         # one copy (+ padding rows, metadata)
-    engine.dense_topk(q[:256].contiguous(), 100)
-    u2 = used()
-    assert u2 - u1 < 0.6 * mat, (u2 - u1, mat)                                      # work space (seed scores, candidate lists), no matrix copy
-    engine.dense_topk(q, 288)
-    u3 = used()
-    assert u3 - u2 > 0.9 * mat                                                      # the 384-row tiled copy, on first use
-    engine.dense_topk(q, 288)
-    assert used() - u3 < 0.05 * mat                                                 # ... once
-    filt = (np.arange(1024) % 4).astype(np.int16)
-    engine.reset_stats()
-    engine.dense_topk(q, 288, filter_dir=filt)
-    u4 = used()
-    assert engine.stat("dense_block_groups") == 4 and u4 - u3 > 0.9 * mat           # the dir blocks, on the first filtered call
-    engine.set_doc_meta(n, None, None)
+    eng = RetrievalEngine(0)
+    try:
+        u0 = used()
+        eng.set_dense(x)
+        eng.set_doc_meta(n, None, (np.arange(n) * 4 // n).astype(np.int16))
+        u1 = used()
+        assert 0.95 * mat < u1 - u0 < 1.3 * mat, (u1 - u0, mat)                     # one copy (+ padding rows, metadata)
+        eng.dense_topk(q[:256].contiguous(), 100)
+        u2 = used()
+        assert u2 - u1 < 0.6 * mat, (u2 - u1, mat)                                  # work space (seed scores, candidate lists), no matrix copy
+        eng.dense_topk(q, 288)
+        u3 = used()
+        assert u3 - u2 > 0.9 * mat                                                  # the 384-row tiled copy, on first use
+        eng.dense_topk(q, 288)
+        assert used() - u3 < 0.05 * mat                                             # ... once
+        filt = (np.arange(1024) % 4).astype(np.int16)
+        eng.reset_stats()
+        eng.dense_topk(q, 288, filter_dir=filt)
+        u4 = used()
+        assert eng.stat("dense_block_groups") == 4 and u4 - u3 > 0.9 * mat          # the dir blocks, on the first filtered call
+    finally:
+        eng.close()
     del x
