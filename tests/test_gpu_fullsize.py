@@ -331,6 +331,7 @@ def test_hybrid_configs3_dir_blocks(engine, dense_data, sparse_data):
         engine.reset_stats()
         ids, sc, ln = engine.hybrid_topk(q, qi, qt, k_dense=288, k_sparse=192, K=60, topk=10, filter_dir=filt)
         assert engine.stat("dense_block_groups") == 4 and engine.stat("dense_scan_pp5_launches") == 0
+        assert engine.stat("dense_grouped_launches") == 1 and engine.stat("dense_sample_passes") == 1 and engine.stat("dense_scan_pp3_launches") == 1
         assert engine.dense_diag()["uncertified"] == 0
         allowed = [torch.from_numpy(dir_id == filt[b]).to(x.device) for b in sample]
         dense_want = dense_oracle_topk(x, q[sample], 288, allowed)
@@ -349,12 +350,23 @@ def test_hybrid_configs3_dir_blocks(engine, dense_data, sparse_data):
             i1, s1, l1 = engine.dense_topk(q[b:b + 1], 288, filter_dir=filt[b:b + 1])
             assert np.array_equal(i1[0, :l1[0]], did) and np.array_equal(s1[0, :l1[0]], dsc)
         assert engine.stat("dense_block_groups") == 4
+        # the grouped launch with the store-kernel seed instead of the sample pass, and one pipeline per group: the same lists
+        for name in ("dense_group_sample", "dense_group_launch"):
+            engine.set_option(name, 0)
+            engine.reset_stats()
+            g_ids, g_sc, g_ln = engine.dense_topk(q, 288, filter_dir=filt)
+            assert engine.stat("dense_block_groups") == 4 and engine.stat("dense_sample_passes") == 0
+            assert np.array_equal(g_ln, d_ln) and np.array_equal(g_ids, d_ids) and np.array_equal(g_sc.view(np.uint64), d_sc.view(np.uint64))
+        engine.set_option("dense_group_sample", 1)
+        engine.set_option("dense_group_launch", 1)
         engine.set_option("dense_dir_blocks", 0)
         ids0, sc0, ln0 = engine.hybrid_topk(q, qi, qt, k_dense=288, k_sparse=192, K=60, topk=10, filter_dir=filt)
         p_ids, p_sc, p_ln = engine.dense_topk(q, 288, filter_dir=filt)
         assert np.array_equal(ln0, ln) and np.array_equal(ids0, ids) and np.array_equal(sc0.view(np.uint64), sc.view(np.uint64))
         assert np.array_equal(p_ln, d_ln) and np.array_equal(p_ids, d_ids) and np.array_equal(p_sc.view(np.uint64), d_sc.view(np.uint64))
     finally:
+        engine.set_option("dense_group_sample", 1)
+        engine.set_option("dense_group_launch", 1)
         engine.set_option("dense_dir_blocks", 1)
         engine.set_doc_meta(N, None, None)
 
