@@ -41,6 +41,9 @@ pat = re.compile(r"bm25_[wa]?scan" if wl == "bm25" else r"dense_(scan|gemv)")
 def klass(name):
     if wl == "bm25":
         return "ascan" if "ascan" in name else ("wscan" if "wscan" in name else "scan")
+    m = re.search(r"pp3_kernel(?:<\d+, |ILi\d+ELi)(\d+)", name)
+    if m and int(m.group(1)) & 16:
+        return "pp3_sample"                      # the sample pass (VAR bit 4; 48 / 56: of the grouped launch) has a timing class of its own
     for key in ("pp5", "pp3", "pp2", "_pp_", "persist", "append", "store", "gemv"):
         if key in name:
             return key.strip("_")

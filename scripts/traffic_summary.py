@@ -20,7 +20,8 @@ STEPS = 4                                      # --steps 3 --warmup 1
 CLASSES = (("hybrid", "dense_scan", r"dense_scan_pp5"), ("dense", "dense_scan", r"dense_scan_pp3|dense_scan_store"),
            ("bm25", "bm25_scan", r"bm25_[wa]?scan"),
            # the filtered hybrid step (bench.py --dirs 4): the grouped launch's store kernel + the one persistent scan over the four blocks
-           ("hybrid_dirs4", "dense_scan", r"dense_scan_pp3|dense_scan_store"))
+           # (its sample pass -- VAR 48 / 56 -- has a timing class of its own, like the unfiltered step's)
+           ("hybrid_dirs4", "dense_scan", r"dense_scan_pp3_kernel(<0, |ILi0ELi)(32|40)\b|dense_scan_pp3_kernel(<0, |ILi0ELi)(32|40)E|dense_scan_store"))
 out = {"_kernel_digest": _build._kernel_digest()}
 for wl, klass, pat in CLASSES:
     f = glob.glob(f"gpurun_out/traffic/{wl}/**/*counter_collection.csv", recursive=True)
