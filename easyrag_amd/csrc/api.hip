@@ -544,13 +544,16 @@ int dense_topk_dev(erh_handle *h, const void *q_dev, int q_dtype, int normalize_
         // one tile per chunk stream, more only if that samples fewer than 16384 rows (1024 queries: 64 streams -> 16384 rows, 512
         // queries: 128 streams -> 32768; the pass takes a tile time whatever the number of streams)
         const int seed_tiles = n_streams > 0 ? (int)std::max<int64_t>(1, std::min<int64_t>(h->opt_n0, 16384) / ((int64_t)n_streams * QT)) : 0;
-        const int64_t rows_seed = (int64_t)seed_tiles * n_streams * QT;
+        // (round 6) with MORE streams than the sample needs tiles -- one query tile: 256 streams -- only the first ceil(16384 / 256) streams
+        // take a tile: the pass still lasts one tile time, but the main launch re-scans 16384 rows instead of 65536
+        const bool partial = h->opt_dense_selfseed >= 2 && seed_tiles == 1 && (int64_t)n_streams * QT > std::min<int64_t>(h->opt_n0, 16384);
+        const int64_t rows_seed = partial ? (std::min<int64_t>(h->opt_n0, 16384) + QT - 1) / QT * QT : (int64_t)seed_tiles * n_streams * QT;
         const bool tiled_run = h->opt_dense_tiled && h->xt_valid && global_view;
-        const int n_cells = seed_tiles * n_streams * 4;
+        const int n_cells = partial ? (int)(rows_seed / QT) * 4 : seed_tiles * n_streams * 4;
         const int rank = (rows_seed > 0 && rows_seed <= N) ? erh_dense_seed_rank(k, rows_seed, N) : k;
         // From 512 queries on: below, the sampled rows scanned twice (one tile per stream = 65536 rows at 256 queries) cost more
         // than the store kernel and the select they replace (profiles/r04s_kbench_sample_pass.log).
-        const bool ok = h->opt_dense_selfseed && Bpad >= 2 * QT && h->opt_dense_speculate && h->opt_dense_pp == 3 && h->opt_dense_var == 0 &&
+        const bool ok = h->opt_dense_selfseed && (Bpad >= 2 * QT || partial) && h->opt_dense_speculate && h->opt_dense_pp == 3 && h->opt_dense_var == 0 &&
                         h->opt_dense_ablate == 0 && !h->opt_dense_sync && !tiled_run && !small && !filter_dev && n_streams > 0 &&
                         d % 64 == 0 && d / 32 >= 8 && rows_seed > 0 && N >= 2 * rows_seed && rank < k && 4 * rank <= n_cells &&
                         erh::seed_cells_select_fits(n_cells * 2);   // (its LDS sort: out of reach with the device's CU count, checked anyway)
@@ -1407,7 +1410,7 @@ int erh_set_option(erh_handle *h, const char *name, int64_t value) {
     if (!strcmp(name, "dense_pp")) { if (value < 0 || value > 4) return h->fail(ERH_ERR_INVALID, "dense_pp"); h->opt_dense_pp = (int)value; return ERH_OK; }
     if (!strcmp(name, "dense_n0_auto")) { h->opt_n0_auto = value != 0; return ERH_OK; }
     if (!strcmp(name, "dense_sync")) { h->opt_dense_sync = value != 0; return ERH_OK; }
-    if (!strcmp(name, "dense_selfseed")) { h->opt_dense_selfseed = value != 0; return ERH_OK; }
+    if (!strcmp(name, "dense_selfseed")) { if (value < 0 || value > 2) return h->fail(ERH_ERR_INVALID, "dense_selfseed"); h->opt_dense_selfseed = (int)value; return ERH_OK; }
     if (!strcmp(name, "n_cus")) {          // persistent grids: the CUs the caller's stream may use (a CU-masked stream); 0 = all of the device
         if (value < 0 || value > h->n_cus_dev) return h->fail(ERH_ERR_INVALID, "n_cus");
         h->n_cus = value == 0 ? h->n_cus_dev : (int)value;
