@@ -75,8 +75,11 @@ struct erh_handle {
     std::string err;
     // dense state
     DevBuf X;
-    DevBuf qorder;                           // BM25: workgroup -> query, heaviest posting volume first (bm25_lpt)
+    int32_t *qorder = nullptr;               // BM25: workgroup -> query, heaviest posting volume first (bm25_lpt); a slice of qpack
     std::vector<int32_t> qorder_host;
+    DevBuf qpack;                            // the call's query CSR + launch order, one upload: q_indptr | q_tok | order
+    std::vector<char> qpack_host;
+    int32_t *qptr = nullptr, *qtok = nullptr;
     bool qorder_valid = false;
     DevBuf scan_sync;                        // one counter per chunk-tile stream of the ping-pong scan (dense_sync)
     DevBuf Xt;                               // tiled copy of X for the ping-pong scan (option dense_tiled), valid iff xt_valid
@@ -117,6 +120,9 @@ struct erh_handle {
     hipStream_t side = nullptr;           // ... created at first use
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool fork_after_scan = false;         // dense_topk_dev records ev_fork behind its last scan launch (hybrid_overlap 2)
+    // a routed group run as a pipeline of its own writes its lists straight to the caller's rows, block rows mapped to document ids
+    // (dense_finalize_kernel: ErhGroupIo::row_map / id_map / single_lo) -- set around that dense_topk_dev call only
+    struct ViewOut { bool on = false; const int32_t *id_map = nullptr; int32_t id_lo = 0; const int32_t *row_map = nullptr; } view_out;
     int cand_rows = 0;                    // query rows of cand_cnt the last dense pipeline used (erh_get_stat: dense_candidates_last_call)
     bool rerun = false;                   // dense_topk_dev is re-running a group of a routed call at its check: its flagged queries were counted already
     int opt_bm25_small = 2;               // fixed-point scan, when k allows: 2 the 512-thread shape with packed 16-bit sums over 32768-document
@@ -160,13 +166,16 @@ struct erh_handle {
         bool pending = false;                                      // ... and its flag words (r_flags) have not been read yet
         std::vector<RoutedGroup> groups;
         int n_flag_slots = 0;
+        int last_slot = -1;                                        // the call's last pipeline: its flag words are read from h->flags, not from r_flags
         int grouped_slot = -1;                                     // flag slot of the grouped launch, -1: none in this call
         int grouped_bpad = 0;                                      // its padded query rows
         int q_dtype = 0, normalize_q = 0, B = 0, k = 0, mode = 0;
         int32_t *d_ids = nullptr; double *d_sc = nullptr; int32_t *d_len = nullptr;
     } routed;
-    DevBuf r_idx, r_q, r_ids, r_sc, r_len, r_filt, r_flags;       // the batch in group order (rows, filter values), a group's results, every pipeline's flag words
-    DevBuf r_tab;                                                  // grouped launch: view table + workgroup map + padded-row map, one upload per call
+    DevBuf r_q, r_ids, r_sc, r_len, r_flags;                      // the batch in group order, a group's results, every pipeline's flag words
+    DevBuf r_tab;                                                  // ONE upload per routed call: r_idx | r_filt | (grouped launch:) view table | workgroup map | padded-row map
+    int32_t *r_idx = nullptr;                                      // ... slices of r_tab: the batch's caller rows in group order,
+    int16_t *r_filt = nullptr;                                     // ... and their filter values
     DevBuf r_q16;                                                  // ... its fp16 query block, copied aside only when a group has to run again
     uint32_t *r_flags_host = nullptr;                              // pinned
     size_t r_flags_host_cap = 0;
@@ -180,7 +189,7 @@ struct erh_handle {
     // work space
     DevBuf qin, Q16, qnorm, tau, S0, cand, cand_cnt, flags, filt, filt2, seed_need;
     DevBuf o_ids, o_sc, o_len;              // staging for host outputs
-    DevBuf qptr, qtok, part_sc, part_ids, part_len;
+    DevBuf part_sc, part_ids, part_len;
     DevBuf bm_redo;                          // approximate-order scan: (query, segment) pairs that go to the exact block scan
     // Long queries (round 6): the packed shape's 16-bit sums leave a query of nq tokens (65535 / nq) payload levels and an error bound of
     // 3 nq units -- from ~30 tokens on the list of "documents that can still reach the top k" no longer shrinks below its capacity and the
@@ -465,6 +474,9 @@ int dense_topk_dev(erh_handle *h, const void *q_dev, int q_dtype, int normalize_
         fin_s64 = reinterpret_cast<double *>(h->fin_ws.as<char>() + (size_t)erh::dense_finalize_split_max() * 8);
     }
 
+    erh::ErhGroupIo vo_io{};
+    const erh::ErhGroupIo *vo = nullptr;
+    if (h->view_out.on) { vo_io.id_map = h->view_out.id_map; vo_io.single_lo = h->view_out.id_lo; vo_io.row_map = h->view_out.row_map; vo = &vo_io; }
     h->qt_valid = false;
     h->qt5_valid = false;
     { ProfScope ps(h, st, ERH_K_DENSE_SELECT, 0, 0);
@@ -587,7 +599,7 @@ int dense_topk_dev(erh_handle *h, const void *q_dev, int q_dtype, int normalize_
               HIPCHK(h, erh::launch_dense_finalize(B, k, mode, h->qnorm.as<float>(), h->xnorm_max, d, X, Q16,
                                                    h->cand.as<ErhCand>(), h->cand_cnt.as<uint32_t>(), cap, d_ids, d_sc, d_len,
                                                    reinterpret_cast<float *>(flags + 1), flags + 2, bad, N, pos_mul, pos_inv,
-                                                   h->tau.as<float>(), h->n_cus, fin_s64, fin_sync, st));
+                                                   h->tau.as<float>(), h->n_cus, fin_s64, fin_sync, st, vo));
               HIPCHK(h, erh::launch_dense_exhaustive(bad, B, 0, k, X, N, d, Q16, filter_dev,
                                                      (filter_dev && h->has_dir) ? h->dir_id.as<int16_t>() : nullptr, pos_inv, h->ex_ws.p,
                                                      flags, h->n_cus, d_ids, d_sc, d_len, h->rerun ? nullptr : h->dstats.as<unsigned long long>(), 1 /* count only */, st)); }
@@ -680,7 +692,7 @@ int dense_topk_dev(erh_handle *h, const void *q_dev, int q_dtype, int normalize_
       HIPCHK(h, erh::launch_dense_finalize(B, k, mode, h->qnorm.as<float>(), h->xnorm_max, d, X, Q16,
                                            h->cand.as<ErhCand>(), h->cand_cnt.as<uint32_t>(), cap, d_ids, d_sc, d_len,
                                            reinterpret_cast<float *>(flags + 1), flags + 2, bad, N, pos_mul, pos_inv,
-                                           speculate ? h->tau.as<float>() : nullptr, h->n_cus, fin_s64, fin_sync, st));
+                                           speculate ? h->tau.as<float>() : nullptr, h->n_cus, fin_s64, fin_sync, st, vo));
       // queries the candidate budgets could not certify get their exact answer from the exhaustive path: the call enqueues the
       // COUNT only (one workgroup; it settles the "unanswered" word and the flagged count), dense_check_flags -- the synchronisation
       // point every caller passes before it reads results -- runs the exact rounds when, and only when, the count is not zero
@@ -697,7 +709,7 @@ int dense_topk_dev(erh_handle *h, const void *q_dev, int q_dtype, int normalize_
 // Read the flag words of the last dense call (synchronises the stream).  If queries were flagged for the exhaustive path, its
 // rounds run here, dense_exhaustive_max() queries at a time (and a fused call's RRF is redone over the corrected dense lists),
 // so the caller always gets an answer.
-int routed_group_run(erh_handle *h, const erh_handle::RoutedGroup &g, const void *q_rows, int q_dtype, int normalize_q, hipStream_t st);
+int routed_group_run(erh_handle *h, const erh_handle::RoutedGroup &g, const void *q_rows, int q_dtype, int normalize_q, hipStream_t st, bool direct = false);
 int routed_group_scatter(erh_handle *h, const erh_handle::RoutedGroup &g, hipStream_t st);
 
 int dense_check_flags(erh_handle *h, hipStream_t st) {
@@ -708,7 +720,10 @@ int dense_check_flags(erh_handle *h, hipStream_t st) {
         // r_flags.  A group with flagged queries is run again on its own, to the end (its exhaustive rounds included), and scattered
         // over its first answer; a fused call's RRF is redone then.
         const erh_handle::LastDense saved = h->last;
-        HIPCHK(h, hipMemcpyAsync(h->r_flags_host, h->r_flags.p, (size_t)R.n_flag_slots * 16, hipMemcpyDeviceToHost, st));
+        // (slots are handed out in pipeline order, so the last pipeline's slot is the highest: its words are still in h->flags)
+        if (R.n_flag_slots > 1)
+            HIPCHK(h, hipMemcpyAsync(h->r_flags_host, h->r_flags.p, (size_t)(R.n_flag_slots - 1) * 16, hipMemcpyDeviceToHost, st));
+        HIPCHK(h, hipMemcpyAsync(h->r_flags_host + 4 * (R.n_flag_slots - 1), h->flags.p, 16, hipMemcpyDeviceToHost, st));
         HIPCHK(h, hipStreamSynchronize(st));
         R.pending = false;
         double maxerr = 0;
@@ -808,24 +823,35 @@ int dense_check_flags(erh_handle *h, hipStream_t st) {
 
 // One group of a routed dense call as a pipeline of its own: its queries (`q_rows`, n of them) against its dir's block as a view, or
 // the ordinary call with the group's filter values; results in r_ids / r_sc / r_len (routed_group_scatter puts them into the caller's rows).
-int routed_group_run(erh_handle *h, const erh_handle::RoutedGroup &g, const void *q_rows, int q_dtype, int normalize_q, hipStream_t st) {
+int routed_group_run(erh_handle *h, const erh_handle::RoutedGroup &g, const void *q_rows, int q_dtype, int normalize_q, hipStream_t st, bool direct) {
     const erh_handle::Routed &R = h->routed;
     const int16_t *sub_filter = nullptr;
     if (g.c >= 0) {
         h->view.X = h->Xb.as<_Float16>() + (size_t)h->blocks.lo[g.c] * h->d;
         h->view.N = h->blocks.n[g.c]; h->view.mul = h->blocks.mul[g.c]; h->view.inv = h->blocks.inv[g.c]; h->view.global = false;
     } else if (g.c == -1) {
-        sub_filter = h->r_filt.as<int16_t>() + g.at;
+        sub_filter = h->r_filt + g.at;
+    }
+    // direct: the final kernel writes the group's lists to the caller's rows with block rows mapped to document ids (the call's first
+    // pass: nothing but the final kernel writes results then).  A re-run at the check goes through r_ids + the scatter kernel, because
+    // its exhaustive rounds write unmapped ids.
+    if (direct) {
+        h->view_out.on = true;
+        h->view_out.row_map = h->r_idx + g.at;
+        h->view_out.id_map = g.c >= 0 ? h->blk_ids.as<int32_t>() : nullptr;
+        h->view_out.id_lo = g.c >= 0 ? (int32_t)h->blocks.lo[g.c] : 0;
     }
     const int rc = dense_topk_dev(h, q_rows, q_dtype, normalize_q, g.n, R.k, sub_filter, R.mode,
-                                  h->r_ids.as<int32_t>(), h->r_sc.as<double>(), h->r_len.as<int32_t>(), st);
+                                  direct ? R.d_ids : h->r_ids.as<int32_t>(), direct ? R.d_sc : h->r_sc.as<double>(),
+                                  direct ? R.d_len : h->r_len.as<int32_t>(), st);
+    h->view_out = erh_handle::ViewOut();
     h->view_global();
     return rc;
 }
 
 int routed_group_scatter(erh_handle *h, const erh_handle::RoutedGroup &g, hipStream_t st) {
     const erh_handle::Routed &R = h->routed;
-    HIPCHK(h, erh::launch_scatter_topk_rows(h->r_ids.as<int32_t>(), h->r_sc.as<double>(), h->r_len.as<int32_t>(), h->r_idx.as<int32_t>() + g.at,
+    HIPCHK(h, erh::launch_scatter_topk_rows(h->r_ids.as<int32_t>(), h->r_sc.as<double>(), h->r_len.as<int32_t>(), h->r_idx + g.at,
                                             g.n, R.k, g.c >= 0 ? (int32_t)h->blocks.lo[g.c] : 0, g.c >= 0 ? h->blk_ids.as<int32_t>() : nullptr,
                                             R.d_ids, R.d_sc, R.d_len, st));
     return ERH_OK;
@@ -903,6 +929,7 @@ struct GroupedPlan {
     int grid = 0, n0_max = 0, bpad = 0;
     int64_t n_max = 0;
     bool halfq = true;
+    erh::ErhGroupIo gio{};      // device pointers into the routed call's upload (r_tab)
     bool sample = false;        // thresholds from a sample pass of the scan kernel over every view (views[].seed_rows / n_cells) instead of store kernel + S0 + seed select
     int cells_max = 0;
 };
@@ -943,19 +970,7 @@ int dense_topk_grouped(erh_handle *h, const void *q_dev, int q_dtype, int normal
     HIPCHK(h, h->ex_ws.ensure(erh::dense_exhaustive_bytes(P.n_max)));
     if (P.sample) HIPCHK(h, h->seed_top.ensure((size_t)Bpad * P.cells_max * 2 * 4));
     else HIPCHK(h, h->S0.ensure((size_t)Bpad * ld * 4));
-    // the tables: one upload (pageable source: copied out before the call returns)
-    const size_t off_wg = (size_t)n_qt * sizeof(erh::ErhDenseView), off_src = off_wg + (size_t)P.grid * 4, bytes = off_src + (size_t)Bpad * 4;
-    h->r_tab_host.resize(bytes);
-    memcpy(h->r_tab_host.data(), P.views.data(), off_wg);
-    memcpy(h->r_tab_host.data() + off_wg, P.wg_view.data(), (size_t)P.grid * 4);
-    memcpy(h->r_tab_host.data() + off_src, P.q_src.data(), (size_t)Bpad * 4);
-    HIPCHK(h, h->r_tab.ensure(bytes));
-    HIPCHK(h, hipMemcpyAsync(h->r_tab.p, h->r_tab_host.data(), bytes, hipMemcpyHostToDevice, st));
-    erh::ErhGroupIo gio{};
-    gio.views = reinterpret_cast<const erh::ErhDenseView *>(h->r_tab.as<char>());
-    gio.wg_view = reinterpret_cast<const int32_t *>(h->r_tab.as<char>() + off_wg);
-    gio.q_src = reinterpret_cast<const int32_t *>(h->r_tab.as<char>() + off_src);
-    gio.id_map = h->blk_ids.as<int32_t>();
+    const erh::ErhGroupIo &gio = P.gio;                               // (the tables went up with the routed call's one upload)
     uint32_t *flags = h->flags.as<uint32_t>(), *bad = h->bad.as<uint32_t>();
     h->qt_valid = false;
     h->qt5_valid = false;
@@ -1130,8 +1145,6 @@ int dense_topk_routed(erh_handle *h, const void *q_dev, int q_dtype, int normali
         }
     }
     R.n_flag_slots = n_slots;
-    const size_t row_bytes = (size_t)h->d * (q_dtype == ERH_F16 ? 2 : 4);
-    HIPCHK(h, h->r_idx.ensure((size_t)B * 4));
     HIPCHK(h, h->r_flags.ensure((size_t)n_slots * 16));
     if (h->r_flags_host_cap < (size_t)n_slots * 16) {
         if (h->r_flags_host) (void)hipHostFree(h->r_flags_host);
@@ -1140,39 +1153,61 @@ int dense_topk_routed(erh_handle *h, const void *q_dev, int q_dtype, int normali
         HIPCHK(h, hipHostMalloc(reinterpret_cast<void **>(&h->r_flags_host), want, hipHostMallocDefault));
         h->r_flags_host_cap = want;
     }
-    HIPCHK(h, hipMemcpyAsync(h->r_idx.p, h->r_idx_host.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
+    // ONE upload for everything the call's kernels read from the host (a pageable copy costs ~4 us of host time and ~7 us on the
+    // stream whatever its size): caller rows in group order | their filter values | the grouped launch's tables
+    {
+        const size_t n_qt = run_grouped ? P.views.size() : 0;
+        const size_t off_filt = (size_t)B * 4, off_views = (off_filt + (size_t)B * 2 + 63) / 64 * 64;
+        const size_t off_wg = off_views + n_qt * sizeof(erh::ErhDenseView), off_src = off_wg + (run_grouped ? (size_t)P.grid * 4 : 0);
+        const size_t bytes = off_src + (run_grouped ? (size_t)P.bpad * 4 : 0);
+        h->r_tab_host.resize(bytes);
+        memcpy(h->r_tab_host.data(), h->r_idx_host.data(), (size_t)B * 4);
+        memcpy(h->r_tab_host.data() + off_filt, h->r_filt_host.data(), (size_t)B * 2);
+        if (run_grouped) {
+            memcpy(h->r_tab_host.data() + off_views, P.views.data(), n_qt * sizeof(erh::ErhDenseView));
+            memcpy(h->r_tab_host.data() + off_wg, P.wg_view.data(), (size_t)P.grid * 4);
+            memcpy(h->r_tab_host.data() + off_src, P.q_src.data(), (size_t)P.bpad * 4);
+        }
+        HIPCHK(h, h->r_tab.ensure(bytes));
+        HIPCHK(h, hipMemcpyAsync(h->r_tab.p, h->r_tab_host.data(), bytes, hipMemcpyHostToDevice, st));
+        char *base = h->r_tab.as<char>();
+        h->r_idx = reinterpret_cast<int32_t *>(base);
+        h->r_filt = reinterpret_cast<int16_t *>(base + off_filt);
+        if (run_grouped) {
+            P.gio.views = reinterpret_cast<const erh::ErhDenseView *>(base + off_views);
+            P.gio.wg_view = reinterpret_cast<const int32_t *>(base + off_wg);
+            P.gio.q_src = reinterpret_cast<const int32_t *>(base + off_src);
+            P.gio.id_map = h->blk_ids.as<int32_t>();
+        }
+    }
+    const size_t row_bytes = (size_t)h->d * (q_dtype == ERH_F16 ? 2 : 4);
     bool any_seq = false;
     for (const erh_handle::RoutedGroup &rg : R.groups) any_seq = any_seq || rg.pad_at < 0;
+    HIPCHK(h, h->r_ids.ensure((size_t)B * k * 4));                     // (a re-run of a group of the grouped launch needs its result rows too: sized here, while nothing is in flight)
+    HIPCHK(h, h->r_sc.ensure((size_t)B * k * 8));
+    HIPCHK(h, h->r_len.ensure((size_t)B * 4));
     if (any_seq) {
         HIPCHK(h, h->r_q.ensure((size_t)B * row_bytes));
-        HIPCHK(h, h->r_ids.ensure((size_t)B * k * 4));
-        HIPCHK(h, h->r_sc.ensure((size_t)B * k * 8));
-        HIPCHK(h, h->r_len.ensure((size_t)B * 4));
-        HIPCHK(h, h->r_filt.ensure((size_t)B * 2));
-        HIPCHK(h, hipMemcpyAsync(h->r_filt.p, h->r_filt_host.data(), (size_t)B * 2, hipMemcpyHostToDevice, st));
         // the batch in group order: a copy of the library's own, so a group can be run again at erh_dense_check time
-        HIPCHK(h, erh::launch_gather_query_rows(q_dev, h->r_idx.as<int32_t>(), B, (int)row_bytes, h->r_q.p, st));
-    } else {
-        // (a re-run of a group of the grouped launch needs its result rows: sized here, while nothing is in flight)
-        HIPCHK(h, h->r_ids.ensure((size_t)B * k * 4));
-        HIPCHK(h, h->r_sc.ensure((size_t)B * k * 8));
-        HIPCHK(h, h->r_len.ensure((size_t)B * 4));
+        HIPCHK(h, erh::launch_gather_query_rows(q_dev, h->r_idx, B, (int)row_bytes, h->r_q.p, st));
     }
     // ---- groups that are pipelines of their own first, the grouped launch last (its work space must survive until the check) ----------
+    // (the LAST pipeline's flag words stay where they are -- h->flags -- until the check reads them: no copy behind it)
+    int last_slot = run_grouped ? R.grouped_slot : -1;
+    if (!run_grouped) for (const erh_handle::RoutedGroup &rg : R.groups) last_slot = rg.flag_slot;
+    R.last_slot = last_slot;
     for (const erh_handle::RoutedGroup &rg : R.groups) {
         if (rg.pad_at >= 0) continue;
-        int rc = routed_group_run(h, rg, h->r_q.as<char>() + (size_t)rg.at * row_bytes, q_dtype, normalize_q, st);
+        int rc = routed_group_run(h, rg, h->r_q.as<char>() + (size_t)rg.at * row_bytes, q_dtype, normalize_q, st, true);
         if (rc != ERH_OK) return rc;
         // the group's flag words, kept aside (the next pipeline's query preparation clears them): read all at once in dense_check_flags
-        HIPCHK(h, hipMemcpyAsync(h->r_flags.as<char>() + (size_t)rg.flag_slot * 16, h->flags.p, 16, hipMemcpyDeviceToDevice, st));
-        rc = routed_group_scatter(h, rg, st);
-        if (rc != ERH_OK) return rc;
+        if (rg.flag_slot != last_slot)
+            HIPCHK(h, hipMemcpyAsync(h->r_flags.as<char>() + (size_t)rg.flag_slot * 16, h->flags.p, 16, hipMemcpyDeviceToDevice, st));
         h->stats.dense_block_groups += (rg.c >= 0);
     }
     if (run_grouped) {
         int rc = dense_topk_grouped(h, q_dev, q_dtype, normalize_q, k, mode, P, d_ids, d_sc, d_len, st);
         if (rc != ERH_OK) return rc;
-        HIPCHK(h, hipMemcpyAsync(h->r_flags.as<char>() + (size_t)R.grouped_slot * 16, h->flags.p, 16, hipMemcpyDeviceToDevice, st));
         for (const erh_handle::RoutedGroup &rg : R.groups) h->stats.dense_block_groups += (rg.pad_at >= 0);
     }
     h->last = erh_handle::LastDense();
@@ -1214,7 +1249,7 @@ int bm25_topk_dev(erh_handle *h, const int32_t *qptr_dev, const int32_t *qtok_de
     // (profiles/r03c_small_batch.log: one query, k = 192: 31 segments 0.038 + 0.106 ms, 10 segments 0.052 + 0.027 ms)
     while (segs > 1 && (int64_t)segs * k > 2048) --segs;
     unsigned long long *dbg = h->opt_debug_counters ? h->dbg.as<unsigned long long>() : nullptr;
-    const int32_t *q_order = (h->qorder_valid && qptr_dev == h->qptr.as<int32_t>()) ? h->qorder.as<int32_t>() : nullptr;
+    const int32_t *q_order = (h->qorder_valid && qptr_dev == h->qptr) ? h->qorder : nullptr;
     const bool split_fin = ascan && small && h->opt_bm25_split_finish && h->opt_bm25_ablate == 0;
     if (ascan) {
         HIPCHK(h, h->bm_redo.ensure((size_t)B * segs * 4));
@@ -1300,22 +1335,31 @@ int upload_bm25_queries(erh_handle *h, const int32_t *q_indptr, const int32_t *q
     *bytes = total;
     // longest-processing-time-first order: a query's scan time follows its posting volume (60 k ... 300 k postings), the
     // dispatcher hands out workgroups in index order, and with four workgroups per CU the makespan is set by what starts last
+    // ONE host-to-device copy for the call's query CSR and launch order (round 6: a pageable copy costs ~4 us of host time and ~7 us on the
+    // stream whatever its size, and a single-query call was made of five of them): [q_indptr (B + 1) | q_tok (nt) | launch order (B)]
     h->qorder_valid = false;
-    if (h->opt_bm25_lpt && B > 1) {
+    const bool lpt = h->opt_bm25_lpt && B > 1;
+    const size_t off_tok = (size_t)(B + 1) * 4, off_ord = off_tok + (size_t)std::max(nt, 1) * 4, total_bytes = off_ord + (lpt ? (size_t)B * 4 : 0);
+    h->qpack_host.resize(total_bytes);
+    memcpy(h->qpack_host.data(), q_indptr, (size_t)(B + 1) * 4);
+    if (nt) memcpy(h->qpack_host.data() + off_tok, q_tok, (size_t)nt * 4);
+    if (lpt) {
+        // longest-processing-time-first order: a query's scan time follows its posting volume (60 k ... 300 k postings), the
+        // dispatcher hands out workgroups in index order, and with four workgroups per CU the makespan is set by what starts last
         std::vector<int64_t> cost((size_t)B, 0);
         for (int b = 0; b < B; ++b)
             for (int i = q_indptr[b]; i < q_indptr[b + 1]; ++i) cost[b] += host_indptr[q_tok[i] + 1] - host_indptr[q_tok[i]];
         h->qorder_host.resize((size_t)B);
         for (int b = 0; b < B; ++b) h->qorder_host[b] = b;
         std::stable_sort(h->qorder_host.begin(), h->qorder_host.end(), [&](int32_t x, int32_t y) { return cost[x] > cost[y]; });
-        HIPCHK(h, h->qorder.ensure((size_t)B * 4));
-        HIPCHK(h, hipMemcpyAsync(h->qorder.p, h->qorder_host.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
-        h->qorder_valid = true;
+        memcpy(h->qpack_host.data() + off_ord, h->qorder_host.data(), (size_t)B * 4);
     }
-    HIPCHK(h, h->qptr.ensure((size_t)(B + 1) * 4));
-    HIPCHK(h, h->qtok.ensure((size_t)std::max(nt, 1) * 4));
-    HIPCHK(h, hipMemcpyAsync(h->qptr.p, q_indptr, (size_t)(B + 1) * 4, hipMemcpyHostToDevice, st));
-    if (nt) HIPCHK(h, hipMemcpyAsync(h->qtok.p, q_tok, (size_t)nt * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(h, h->qpack.ensure(total_bytes));
+    HIPCHK(h, hipMemcpyAsync(h->qpack.p, h->qpack_host.data(), total_bytes, hipMemcpyHostToDevice, st));
+    h->qptr = h->qpack.as<int32_t>();
+    h->qtok = reinterpret_cast<int32_t *>(h->qpack.as<char>() + off_tok);
+    h->qorder = lpt ? reinterpret_cast<int32_t *>(h->qpack.as<char>() + off_ord) : nullptr;
+    h->qorder_valid = lpt;
     return ERH_OK;
 }
 
@@ -1374,12 +1418,12 @@ int erh_destroy(erh_handle *h) {
     drain_events(h);
     for (auto &ev : h->pool) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
     if (h->side) { (void)hipStreamDestroy(h->side); (void)hipEventDestroy(h->ev_fork); (void)hipEventDestroy(h->ev_join); }
-    DevBuf *bufs[] = {&h->X, &h->Xt, &h->Xt384, &h->Qt, &h->seed_top, &h->scan_sync, &h->qorder, &h->content_id, &h->dir_id,
+    DevBuf *bufs[] = {&h->X, &h->Xt, &h->Xt384, &h->Qt, &h->seed_top, &h->scan_sync, &h->content_id, &h->dir_id,
                       &h->qin, &h->Q16, &h->qnorm, &h->tau, &h->S0, &h->cand, &h->cand_cnt, &h->flags, &h->filt, &h->filt2,
-                      &h->o_ids, &h->o_sc, &h->o_len, &h->qptr, &h->qtok, &h->part_sc, &h->part_ids, &h->part_len,
+                      &h->o_ids, &h->o_sc, &h->o_len, &h->qpack, &h->part_sc, &h->part_ids, &h->part_len,
                       &h->hy_sids, &h->hy_ssc, &h->hy_slen, &h->hy_dids, &h->hy_dsc, &h->hy_dlen,
                       &h->fa_ids, &h->fa_sc, &h->fa_len, &h->fb_ids, &h->fb_sc, &h->fb_len,
-                      &h->scores_tmp, &h->scores_wide, &h->dbg, &h->dstats, &h->dir_pos, &h->seed_need, &h->bad, &h->ex_ws, &h->bm_redo, &h->fin_ws, &h->dir_rng, &h->Xb, &h->blk_tmp, &h->blk_ids, &h->r_idx, &h->r_q, &h->r_ids, &h->r_sc, &h->r_len, &h->r_filt, &h->r_flags, &h->r_tab, &h->r_q16, &h->bm_fin_ids, &h->bm_fin_cnt};
+                      &h->scores_tmp, &h->scores_wide, &h->dbg, &h->dstats, &h->dir_pos, &h->seed_need, &h->bad, &h->ex_ws, &h->bm_redo, &h->fin_ws, &h->dir_rng, &h->Xb, &h->blk_tmp, &h->blk_ids, &h->r_q, &h->r_ids, &h->r_sc, &h->r_len, &h->r_flags, &h->r_tab, &h->r_q16, &h->bm_fin_ids, &h->bm_fin_cnt};
     for (DevBuf *b : bufs) b->release();
     if (h->r_flags_host) (void)hipHostFree(h->r_flags_host);
     for (auto &b : h->bm) b.release();
@@ -2188,7 +2232,7 @@ int erh_bm25_topk(erh_handle *h, const int32_t *q_indptr, const int32_t *q_tok, 
         d_ids = h->o_ids.as<int32_t>(); d_sc = h->o_sc.as<double>(); d_len = h->o_len.as<int32_t>();
     }
     h->stats.bm25_calls += 1;
-    rc = bm25_topk_dev(h, h->qptr.as<int32_t>(), h->qtok.as<int32_t>(), B, k, filt, d_ids, d_sc, d_len, bytes, max_qlen, st);
+    rc = bm25_topk_dev(h, h->qptr, h->qtok, B, k, filt, d_ids, d_sc, d_len, bytes, max_qlen, st);
     if (rc != ERH_OK) return rc;
     if (!out_is_device) return copy_out(h, B, k, d_ids, d_sc, d_len, out_ids, out_scores, out_len, st);
     return ERH_OK;
@@ -2333,7 +2377,7 @@ int erh_hybrid_topk(erh_handle *h, const void *q, int q_dtype, int q_is_device, 
         st_sparse = h->side;
     }
     auto sparse_route = [&]() -> int {
-        int r = bm25_topk_dev(h, h->qptr.as<int32_t>(), h->qtok.as<int32_t>(), B, k_sparse, filt, h->hy_sids.as<int32_t>(),
+        int r = bm25_topk_dev(h, h->qptr, h->qtok, B, k_sparse, filt, h->hy_sids.as<int32_t>(),
                               h->hy_ssc.as<double>(), h->hy_slen.as<int32_t>(), bytes, max_qlen, st_sparse);
         if (r == ERH_OK && st_sparse != st) {
             hipError_t e_ = hipEventRecord(h->ev_join, st_sparse);

@@ -40,6 +40,10 @@ struct ErhGroupIo {
     const int32_t *wg_view;      // [grid of the persistent scan]: workgroup -> query tile
     const int32_t *q_src;        // [Bpad]: padded row -> the caller's query row, -1 for padding rows
     const int32_t *id_map;       // block row -> document id (the handle's blk_ids)
+    // one view for the whole launch (views == null; a routed group run as a pipeline of its own): the final kernel writes query q to the
+    // caller's row row_map[q] (null: q) and maps ids through id_map[single_lo + id] (null: unchanged) -- no scatter launch behind it
+    const int32_t *row_map;
+    int32_t single_lo;
 };
 hipError_t launch_dense_scan_store_grouped(const ErhGroupIo &gio, int n_qt, int n0_max, int n_cus, const _Float16 *Q, int Bpad, int d,
                                            float *S0, int ld_s0, hipStream_t st);

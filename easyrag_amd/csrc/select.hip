@@ -502,8 +502,11 @@ __global__ __launch_bounds__(kFinThreads, (QR <= 2) ? 4 : 2) void dense_finalize
         if ((q & 255) >= v.nq) return;                                  // a padding row
         X = v.X; N = v.N; pos_mul = v.mul; pos_inv = v.inv; id_lo = v.id_lo;
         out_row = gio.q_src[q];
+    } else {                                                            // one view for the launch: rows / ids of a routed group
+        if (gio.row_map) out_row = gio.row_map[q];
+        id_lo = gio.single_lo;
     }
-    const int32_t *const id_map = gio.views ? gio.id_map : nullptr;
+    const int32_t *const id_map = gio.id_map;
     int c = (int)cand_cnt[q];
     if (c > cap) {                                                      // appends were dropped: not answerable from the list
         if (tid == 0 && lead) bad[q] = 1u;
@@ -1002,7 +1005,7 @@ hipError_t launch_dense_finalize(int B, int k, int mode, const float *qnorm, flo
                                  uint32_t *ws_sync, hipStream_t st, const ErhGroupIo *gio) {
     // workgroups per query: small batches spread a query's row gathers over the chip (EXACT mode only; the work space is optional)
     int G = 1;
-    if (mode == 0 && ws_s64 && ws_sync && B <= dense_finalize_split_max() && !gio)
+    if (mode == 0 && ws_s64 && ws_sync && B <= dense_finalize_split_max() && !(gio && gio->views))
         G = 16;
     (void)n_cus;
     ErhGroupIo gv{};

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """One query per call (the reference's call pattern) under rocprofv3 --kernel-trace --stats: which of the ~20 launches of a dense / fused
-call take the time that is not the 2 GB stream.  python scripts/b1_profile.py [dense|hybrid] [calls]"""
+call take the time that is not the 2 GB stream.  python scripts/b1_profile.py [dense|hybrid|filtered] [calls]
+(filtered: the fused call with its dir filter, four contiguous dirs -- the reference's REAL call)"""
 import os
 import sys
 
@@ -22,14 +23,18 @@ def main():
     eng.set_dense(x)
     q = [synth.dense_queries_torch(x, 1, seed=7 + i) for i in range(4)]
     csr = None
-    if what == "hybrid":
+    if what in ("hybrid", "filtered"):
         indptr, doc, tf, lens, flat = synth.token_csr_torch(n, vocab, seed=3, device=dev)
         idx = build_bm25_index_from_postings(indptr, doc, tf, lens, BM25S, compute_payload=False)
         eng.set_bm25(idx, payload_on_device=True)
         csr = [queries_to_csr(synth.token_queries(flat, lens, vocab, 1, seed=9 + i)) for i in range(4)]
-    eng.set_doc_meta(n, None, None)
+    import numpy as np
+    eng.set_doc_meta(n, None, (np.arange(n) * 4 // n).astype(np.int16) if what == "filtered" else None)
+    filt = [np.array([i % 4], np.int16) for i in range(4)]
     for i in range(calls):
-        if what == "hybrid":
+        if what == "filtered":
+            eng.hybrid_topk(q[i % 4], *csr[i % 4], k_dense=288, k_sparse=192, K=60, topk=10, device_out=True, filter_dir=filt[i % 4])
+        elif what == "hybrid":
             eng.hybrid_topk(q[i % 4], *csr[i % 4], k_dense=288, k_sparse=192, K=60, topk=10, device_out=True)
         else:
             eng.dense_topk(q[i % 4], 288, device_out=True)
