@@ -16,8 +16,8 @@ MEASURE = os.environ.get("ERH_MEASURE", "0") not in ("", "0")
 LIB_PATH = PKG_DIR / ("libeasyrag_hip_measure.so" if MEASURE else "libeasyrag_hip.so")
 STAMP = PKG_DIR / (".libeasyrag_hip_measure.stamp" if MEASURE else ".libeasyrag_hip.stamp")
 
-SOURCES = ["api.hip", "dense_scan.hip", "dense_gemv.hip", "select.hip", "bm25.hip", "fuse.hip", "index_build.hip", "text.hip"]
-HEADERS = ["common.h", "kernels.h"]
+SOURCES = ["api.hip", "pipeline_dense.hip", "pipeline_bm25.hip", "comm.hip", "dense_scan.hip", "dense_gemv.hip", "select.hip", "bm25.hip", "fuse.hip", "index_build.hip", "text.hip"]
+HEADERS = ["common.h", "kernels.h", "handle.h"]
 # kernel generations that compile only into the measurement build (scripts/kbench.py): part of ITS digest, not of the product's
 MEASURE_ONLY = ["measure/dense_scan_persist.inc", "measure/dense_scan_pp12.inc", "measure/dense_scan_pp4.inc"]
 

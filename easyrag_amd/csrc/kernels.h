@@ -1,4 +1,4 @@
-// Launcher prototypes shared between the kernel translation units and the C-ABI (api.hip).
+// Launcher prototypes shared between the kernel translation units and the host side (api.hip, pipeline_dense.hip, pipeline_bm25.hip).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -18,7 +18,7 @@ struct ErhSeedIo {
     int n_cells;           // seed_tiles * streams * 4
     int mode;              // 0 none, 1 sample pass (no thresholds, no candidates)
 };
-// Grouped dense call (round 6; api.hip: dense_topk_grouped): the batch's queries, grouped by their `dir` filter, are laid out group
+// Grouped dense call (round 6; pipeline_dense.hip: dense_topk_grouped): the batch's queries, grouped by their `dir` filter, are laid out group
 // after group, each group padded to whole 256-row QUERY TILES, and every tile scans ITS OWN matrix -- the dir's block copy -- in the
 // same launch as all the others.  One table entry per query tile; every stage of the pipeline (query preparation, seed-prefix store
 // kernel, seed select, persistent scan, final kernel) reads it instead of taking one matrix per launch.

@@ -218,7 +218,7 @@ __device__ __forceinline__ void seed_emit(const float *__restrict__ row, int n0,
 
 // `rank` <= k is the position in the prefix whose score seeds the threshold.  rank == k gives a guaranteed bound (the
 // k-th best of a subset never exceeds the k-th best of the whole).  rank < k is a SPECULATIVE bound: an estimate of
-// where the k-th best of the whole corpus lies, extrapolated from the prefix being an even sample of it (api.hip picks
+// where the k-th best of the whole corpus lies, extrapolated from the prefix being an even sample of it (pipeline_dense.hip picks
 // the rank so that fewer than `rank` of the true top k land in the prefix except with probability < 1e-7 per query).
 // dense_finalize_kernel verifies it -- at least k candidates must score >= threshold + margin -- and hands the
 // query to the exhaustive path otherwise, so the result is exact either way; what the speculation buys is a
@@ -426,7 +426,7 @@ __global__ __launch_bounds__(kSelThreads) void cand_refine_kernel(
     if (tid == 0) { cand_cnt[q] = (uint32_t)m; tau[q] = t_new; }
 }
 
-// ---- dense calls routed by dir block (api.hip: dense_topk_routed): the queries of one group gathered into a contiguous block, and
+// ---- dense calls routed by dir block (pipeline_dense.hip: dense_topk_routed): the queries of one group gathered into a contiguous block, and
 // the group's results scattered back to the caller's rows with the block's first document added to the ids --------------------
 __global__ __launch_bounds__(256) void gather_query_rows_kernel(const int4 *__restrict__ q, const int32_t *__restrict__ idx, int n,
                                                                int row_vec /* 16-byte pieces per row */, int4 *__restrict__ out) {
@@ -732,7 +732,7 @@ __global__ __launch_bounds__(kFinThreads, (QR <= 2) ? 4 : 2) void dense_finalize
 //                               under an exact (score, index) threshold -- ties resolve by original index as always --
 //                               and writes the query's final top-k over whatever the pruned pipeline wrote.
 // Round 5: a call itself enqueues only the collect kernel (one workgroup: how many queries are flagged -> the call's flag words and
-// the device counter of erh_get_stat); the two exact kernels are enqueued by the call's synchronisation point (api.hip:
+// the device counter of erh_get_stat); the two exact kernels are enqueued by the call's synchronisation point (pipeline_dense.hip:
 // dense_check_flags -- inside every host-output call, erh_dense_check for device outputs, which the ABI has always required
 // before results are read) and only when the flag word says that a query needs them, kExMax flagged queries per round.  The
 // common case -- nothing flagged -- used to pay two empty launches per call for keeping up to kExMax answers free of a host

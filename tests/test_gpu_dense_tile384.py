@@ -5,7 +5,7 @@ scan, duplicates + dir filter, a topic-sorted corpus with the row placement off,
 run with dense_tile384 = 1 and = 0, asserted bit-equal to each other AND to the oracle, and each asserting through
 erh_get_stat that the kernel under test is the one that ran ("what's weak" 1a).
 
-How a call reaches pp5 (csrc/api.hip: dense_topk_dev / scan_append): Bpad >= 512, d >= 256, N >= 768 and the scan stage starts
+How a call reaches pp5 (csrc/pipeline_dense.hip: dense_topk_dev / scan_append): Bpad >= 512, d >= 256, N >= 768 and the scan stage starts
 on a multiple of 384 rows -- the sample-pass path (c0 = 0: no filter, N >= 2 * sampled rows, speculative rank) or a staged
 path whose seed prefix dense_n0 is a multiple of 384.
 """
