@@ -778,15 +778,19 @@ int erh_set_doc_meta(erh_handle *h, int64_t N, const int32_t *content_id, const 
 
 // ---- queries ---------------------------------------------------------------------------------------
 
+// A call's host filter column -> device.  `defer`: validate only and hand back the host column (or null when no query is filtered): the
+// caller lets it ride along with the query upload (upload_bm25_queries) instead of paying a copy of its own.
 static int stage_filter(erh_handle *h, const int16_t *filter_dir, int B, int64_t n_docs, hipStream_t st, const int16_t **dev,
-                        DevBuf *buf = nullptr) {
+                        DevBuf *buf = nullptr, const int16_t **defer = nullptr) {
     if (!buf) buf = &h->filt;
     *dev = nullptr;
+    if (defer) *defer = nullptr;
     if (!filter_dir) return ERH_OK;
     bool any = false;
     for (int b = 0; b < B; ++b) any = any || filter_dir[b] >= 0;
     if (!any) return ERH_OK;
     if (!h->has_dir || h->Nmeta < n_docs) return h->fail(ERH_ERR_STATE, "filter given but erh_set_doc_meta(dir_id) not set for all documents");
+    if (defer) { *defer = filter_dir; return ERH_OK; }
     HIPCHK(h, buf->ensure((size_t)B * 2));
     HIPCHK(h, hipMemcpyAsync(buf->p, filter_dir, (size_t)B * 2, hipMemcpyHostToDevice, st));
     *dev = buf->as<int16_t>();
@@ -857,11 +861,12 @@ int erh_bm25_topk(erh_handle *h, const int32_t *q_indptr, const int32_t *q_tok, 
     HIPCHK(h, hipSetDevice(h->device));
     hipStream_t st = (hipStream_t)stream;
     const int16_t *filt = nullptr;
-    int rc = stage_filter(h, filter_dir, B, h->bm[h->cur].Nb, st, &filt);
+    const int16_t *filt_host = nullptr;
+    int rc = stage_filter(h, filter_dir, B, h->bm[h->cur].Nb, st, &filt, nullptr, &filt_host);
     if (rc != ERH_OK) return rc;
     double bytes = 0;
     int max_qlen = 0;
-    rc = upload_bm25_queries(h, q_indptr, q_tok, B, st, h->bm[h->cur].host_indptr, &bytes, &max_qlen);
+    rc = upload_bm25_queries(h, q_indptr, q_tok, B, st, h->bm[h->cur].host_indptr, &bytes, &max_qlen, filt_host, &filt);
     if (rc != ERH_OK) return rc;
     int32_t *d_ids = out_ids; double *d_sc = out_scores; int32_t *d_len = out_len;
     if (!out_is_device) {
@@ -979,18 +984,20 @@ int erh_hybrid_topk(erh_handle *h, const void *q, int q_dtype, int q_is_device, 
     // the two routes are filtered independently, as the reference does (filter_dict -> sparse, filters -> dense;
     // retrievers.py:278,283); equal pointers / equal contents share one staged column
     const int16_t *filt = nullptr, *filt_d = nullptr;
-    int rc = stage_filter(h, filter_sparse, B, h->N, st, &filt);
+    const int16_t *fs_host = nullptr, *fd_host = nullptr;
+    int rc = stage_filter(h, filter_sparse, B, h->N, st, &filt, nullptr, &fs_host);
     if (rc != ERH_OK) return rc;
-    if (filter_dense == filter_sparse || (filter_dense && filter_sparse && !memcmp(filter_dense, filter_sparse, (size_t)B * 2))) {
-        filt_d = filt;
-    } else {
-        rc = stage_filter(h, filter_dense, B, h->N, st, &filt_d, &h->filt2);
+    const bool same_col = filter_dense == filter_sparse || (filter_dense && filter_sparse && !memcmp(filter_dense, filter_sparse, (size_t)B * 2));
+    if (!same_col) {
+        rc = stage_filter(h, filter_dense, B, h->N, st, &filt_d, &h->filt2, &fd_host);
         if (rc != ERH_OK) return rc;
     }
     double bytes = 0;
     int max_qlen = 0;
-    rc = upload_bm25_queries(h, q_indptr, q_tok, B, st, h->bm[h->cur].host_indptr, &bytes, &max_qlen);
+    // (the filter columns ride along with the query CSR: one host-to-device copy for all of them)
+    rc = upload_bm25_queries(h, q_indptr, q_tok, B, st, h->bm[h->cur].host_indptr, &bytes, &max_qlen, fs_host, &filt, fd_host, &filt_d);
     if (rc != ERH_OK) return rc;
+    if (same_col) filt_d = filt;
     const void *qd = nullptr;
     rc = stage_query_block(h, q, q_dtype, q_is_device, B, st, &qd);
     if (rc != ERH_OK) return rc;

@@ -351,5 +351,7 @@ int bm25_topk_dev(erh_handle *h, const int32_t *qptr_dev, const int32_t *qtok_de
                   const int16_t *filter_dev, int32_t *d_ids, double *d_sc, int32_t *d_len, double postings_bytes,
                   int max_qlen, hipStream_t st);
 int upload_bm25_queries(erh_handle *h, const int32_t *q_indptr, const int32_t *q_tok, int B, hipStream_t st,
-                        const std::vector<int64_t> &host_indptr, double *bytes, int *max_qlen);
+                        const std::vector<int64_t> &host_indptr, double *bytes, int *max_qlen,
+                        const int16_t *filt_a = nullptr, const int16_t **filt_a_dev = nullptr /* validated host filter column(s) that ride along */,
+                        const int16_t *filt_b = nullptr, const int16_t **filt_b_dev = nullptr);
 

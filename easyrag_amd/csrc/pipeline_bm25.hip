@@ -102,7 +102,8 @@ int bm25_topk_dev(erh_handle *h, const int32_t *qptr_dev, const int32_t *qtok_de
 
 // Upload the query CSR; returns the algorithmic posting bytes of the batch in *bytes (0 if an id is bad -> error).
 int upload_bm25_queries(erh_handle *h, const int32_t *q_indptr, const int32_t *q_tok, int B, hipStream_t st,
-                        const std::vector<int64_t> &host_indptr, double *bytes, int *max_qlen) {
+                        const std::vector<int64_t> &host_indptr, double *bytes, int *max_qlen,
+                        const int16_t *filt_a, const int16_t **filt_a_dev, const int16_t *filt_b, const int16_t **filt_b_dev) {
     if (q_indptr[0] != 0) return h->fail(ERH_ERR_INVALID, "q_indptr[0] must be 0");
     int longest = 0;
     for (int b = 0; b < B; ++b) {
@@ -125,8 +126,12 @@ int upload_bm25_queries(erh_handle *h, const int32_t *q_indptr, const int32_t *q
     // stream whatever its size, and a single-query call was made of five of them): [q_indptr (B + 1) | q_tok (nt) | launch order (B)]
     h->qorder_valid = false;
     const bool lpt = h->opt_bm25_lpt && B > 1;
-    const size_t off_tok = (size_t)(B + 1) * 4, off_ord = off_tok + (size_t)std::max(nt, 1) * 4, total_bytes = off_ord + (lpt ? (size_t)B * 4 : 0);
+    // ... | filter column(s) of the call (validated by the caller; int16 per query), so that a filtered call needs no copy of its own for them
+    const size_t off_tok = (size_t)(B + 1) * 4, off_ord = off_tok + (size_t)std::max(nt, 1) * 4, off_fa = off_ord + (lpt ? (size_t)B * 4 : 0);
+    const size_t off_fb = off_fa + (filt_a ? ((size_t)B * 2 + 3) / 4 * 4 : 0), total_bytes = off_fb + (filt_b ? (size_t)B * 2 : 0);
     h->qpack_host.resize(total_bytes);
+    if (filt_a) memcpy(h->qpack_host.data() + off_fa, filt_a, (size_t)B * 2);
+    if (filt_b) memcpy(h->qpack_host.data() + off_fb, filt_b, (size_t)B * 2);
     memcpy(h->qpack_host.data(), q_indptr, (size_t)(B + 1) * 4);
     if (nt) memcpy(h->qpack_host.data() + off_tok, q_tok, (size_t)nt * 4);
     if (lpt) {
@@ -146,6 +151,8 @@ int upload_bm25_queries(erh_handle *h, const int32_t *q_indptr, const int32_t *q
     h->qtok = reinterpret_cast<int32_t *>(h->qpack.as<char>() + off_tok);
     h->qorder = lpt ? reinterpret_cast<int32_t *>(h->qpack.as<char>() + off_ord) : nullptr;
     h->qorder_valid = lpt;
+    if (filt_a_dev) *filt_a_dev = filt_a ? reinterpret_cast<const int16_t *>(h->qpack.as<char>() + off_fa) : nullptr;
+    if (filt_b_dev) *filt_b_dev = filt_b ? reinterpret_cast<const int16_t *>(h->qpack.as<char>() + off_fb) : nullptr;
     return ERH_OK;
 }
 
