@@ -101,6 +101,8 @@ int erh_set_option(erh_handle *h, const char *name, int64_t value) {
     }
     if (!strcmp(name, "bm25_long_tokens")) { if (value < 0 || value > 4096) return h->fail(ERH_ERR_INVALID, "bm25_long_tokens"); h->opt_bm25_long_tokens = (int)value; return ERH_OK; }
     if (!strcmp(name, "bm25_split_finish")) { h->opt_bm25_split_finish = value != 0; return ERH_OK; }
+    if (!strcmp(name, "bm25_mixed")) { h->opt_bm25_mixed = value != 0; return ERH_OK; }
+    if (!strcmp(name, "bm25_long_segs")) { if (value < 1 || value > 16) return h->fail(ERH_ERR_INVALID, "bm25_long_segs"); h->opt_bm25_long_segs = (int)value; return ERH_OK; }
     if (!strcmp(name, "dense_route_ridge")) { if (value < 1 || value > 4096) return h->fail(ERH_ERR_INVALID, "dense_route_ridge"); h->opt_route_ridge = value; return ERH_OK; }
     if (!strcmp(name, "dense_group_sample")) { h->opt_dense_group_sample = value != 0; return ERH_OK; }
     if (!strcmp(name, "dense_group_launch")) { h->opt_dense_group_launch = value != 0; return ERH_OK; }
@@ -220,7 +222,7 @@ int erh_get_stat(erh_handle *h, const char *name, int64_t *value) {
         {"dense_scan_gemv_launches", T.dense_scan_gemv}, {"dense_scan_tile_launches", T.dense_scan_tile},
         {"dense_sample_passes", T.dense_sample_passes}, {"dense_tile384_nomem", T.dense_tile384_nomem},
         {"bm25_calls", T.bm25_calls}, {"hybrid_calls", T.hybrid_calls}, {"dense_block_groups", T.dense_block_groups},
-        {"dense_grouped_launches", T.dense_grouped_launches}};
+        {"dense_grouped_launches", T.dense_grouped_launches}, {"bm25_mixed_launches", T.bm25_mixed_launches}};
     for (const auto &e : host)
         if (!strcmp(name, e.n)) { *value = e.v; return ERH_OK; }
     if (!strcmp(name, "dense_candidates_last_call")) {

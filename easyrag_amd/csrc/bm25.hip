@@ -837,6 +837,8 @@ using AsSmall = AsCfg<512, 16384>;
 using AsPack = AsCfg<512, 32768, true>;
 using AsPack16 = AsCfg<512, 32768, true, true>;
 static_assert(AsBig::BYTES <= 160 * 1024 && 2 * AsSmall::BYTES <= 160 * 1024 && 2 * AsPack::BYTES <= 160 * 1024, "fixed-point scan LDS layouts");
+constexpr size_t kAsMixedBytes = AsPack16::BYTES > AsSmall::BYTES ? AsPack16::BYTES : AsSmall::BYTES;   // bm25_ascan_mixed_kernel: either body
+static_assert(2 * kAsMixedBytes <= 160 * 1024, "two workgroups of the mixed launch per CU");
 
 struct AsHdr {
     uint32_t thetaq;                // k-th best fixed-point sum seen so far (0: fewer than k candidates yet)
@@ -1377,8 +1379,9 @@ __device__ __forceinline__ void as_finish_query(char *smem, BmHdr *hdr, uint32_t
 
 // grid = (segs, B), block = C::NT.  tile_off has n_tab + 1 entries per term at a granularity of C::TILE >> tshift documents;
 // post = the interleaved fixed-point postings with two sentinels {document -1, q 0} at index nnz.
+// The body is a device function: bm25_ascan_kernel runs it for every workgroup of a launch, bm25_ascan_mixed_kernel picks the shape per query.
 template <typename ST, class C>
-__global__ __launch_bounds__(C::NT, 4 /* waves per SIMD: two 512-thread workgroups per CU */) void bm25_ascan_kernel(
+__device__ __forceinline__ void as_scan_query(
     const int64_t *__restrict__ indptr, const int32_t *__restrict__ doc_ids, const ST *__restrict__ payload,
     const void *__restrict__ post /* as_uint2 {document, q}, or for C::P16 the 4-byte postings */, uint32_t nnz,
     double qmax /* largest fixed-point payload of the index */, int g16 /* C::P16: the 4-byte postings hold (q >> g16) + 1 */,
@@ -1393,7 +1396,8 @@ __global__ __launch_bounds__(C::NT, 4 /* waves per SIMD: two 512-thread workgrou
     int abl /* measurement builds: 1 no adds, 2 no posting loads, 4 no clear, 8 one descriptor set */,
     unsigned long long *__restrict__ dbg,
     int32_t *__restrict__ fin_ids /* null, or [B * segs][CAP]: the workgroup hands its final list to bm25_finish_kernel instead of re-scoring it */,
-    int32_t *__restrict__ fin_cnt /* ... [B * segs]: entries of that list, -1: nothing to finish (the segment goes to the exact scan) */) {
+    int32_t *__restrict__ fin_cnt /* ... [B * segs]: entries of that list, -1: nothing to finish (the segment goes to the exact scan) */,
+    const int q, const int seg /* the workgroup's query and document-range segment (of `segs`): its lists go to slot q * segs + seg */) {
     constexpr int NT = C::NT, TILE = C::TILE, NW = C::NW, CAP = C::CAP, WORDS = C::WORDS, U = C::U;
 #ifdef ERH_MEASURE
 #define ERH_ABL(B) (abl & (B))
@@ -1417,7 +1421,7 @@ __global__ __launch_bounds__(C::NT, 4 /* waves per SIMD: two 512-thread workgrou
     uint32_t *hist = reinterpret_cast<uint32_t *>(smem + C::OFF_HIST);
     uint32_t *dummy = reinterpret_cast<uint32_t *>(smem + C::OFF_DUMMY);
 
-    const int seg = blockIdx.x, q = q_order ? q_order[blockIdx.y] : (int)blockIdx.y, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int qs = q_indptr[q];
@@ -1443,7 +1447,7 @@ __global__ __launch_bounds__(C::NT, 4 /* waves per SIMD: two 512-thread workgrou
             t_end = t_end > t_begin ? t_end : t_begin;
         }
     }
-    const int64_t out_base = ((int64_t)q * segs + seg) * k;
+    const int64_t out_slot = (int64_t)q * segs + seg, out_base = out_slot * k;
     const double keep_frac = 1.0 - 3.0 * 1.01 * (double)(nq + 2) * 5.9604644775390625e-08;   // 1 - 3 eps
     // units a sum can exceed the real one by (as_drop_threshold): one per truncation + 1 the payload has gone through
     const int n_err = C::P16 ? 3 * nq : C::PACK ? 2 * nq : nq;
@@ -1650,26 +1654,26 @@ __global__ __launch_bounds__(C::NT, 4 /* waves per SIMD: two 512-thread workgrou
     if (!stop) as_shrink<CAP>(hdr, h2, ca, ci, hist, k, keep_frac, n_err, 0);     // final list: k entries + the near ties of the k-th
     if (h2->redo) {                                                       // workgroup-uniform
         if (tid == 0) {
-            redo[(int64_t)q * segs + seg] = 1u;
-            part_len[(int64_t)q * segs + seg] = 0;
-            if (fin_cnt) fin_cnt[(int64_t)q * segs + seg] = -1;
+            redo[out_slot] = 1u;
+            part_len[out_slot] = 0;
+            if (fin_cnt) fin_cnt[out_slot] = -1;
             if (stats) atomicAdd(&stats[1], 1ull);
         }
         return;
     }
-    if (ERH_ABL(0xff)) { if (tid == 0) { part_len[(int64_t)q * segs + seg] = 0; if (fin_cnt) fin_cnt[(int64_t)q * segs + seg] = -1; } return; }   // (ablations: the list is garbage)
+    if (ERH_ABL(0xff)) { if (tid == 0) { part_len[out_slot] = 0; if (fin_cnt) fin_cnt[out_slot] = -1; } return; }   // (ablations: the list is garbage)
     ERH_SEC(8);
     if (fin_ids) {
         // split finish (round 6): the exact re-score + rank of all lists of the batch run in ONE kernel behind the scan (2 M independent
         // binary searches spread over the chip at 16 waves per CU), and this workgroup's CU slot goes to the next query now
-        const int64_t slot = (int64_t)q * segs + seg;
+        const int64_t slot = out_slot;
         const int n_keep = hdr->ncand;
         for (int i = tid; i < n_keep; i += NT) fin_ids[slot * CAP + i] = ci[i];
         if (tid == 0) fin_cnt[slot] = n_keep;
         return;
     }
     as_finish_query<ST, C>(smem, hdr, ca, ci, indptr, doc_ids, payload, tile_off, n_tab, C::TAB_SHIFT - tshift, q_tok, qs, nq, k,
-                           out_base, (int64_t)q * segs + seg, part_scores, part_ids, part_len, dbg);
+                           out_base, out_slot, part_scores, part_ids, part_len, dbg);
     ERH_SEC(9);
 #ifdef ERH_MEASURE
     if (dbg && tid == 0) {
@@ -1679,6 +1683,67 @@ __global__ __launch_bounds__(C::NT, 4 /* waves per SIMD: two 512-thread workgrou
 #endif
 #undef ERH_SEC
 #undef ERH_ABL
+}
+
+template <typename ST, class C>
+__global__ __launch_bounds__(C::NT, 4 /* waves per SIMD: two 512-thread workgroups per CU */) void bm25_ascan_kernel(
+    const int64_t *__restrict__ indptr, const int32_t *__restrict__ doc_ids, const ST *__restrict__ payload,
+    const void *__restrict__ post, uint32_t nnz, double qmax, int g16,
+    const int32_t *__restrict__ tile_off, int n_tab, int tshift, int n_tiles, int64_t N,
+    const int32_t *__restrict__ q_indptr, const int32_t *__restrict__ q_tok, const int32_t *__restrict__ q_order, int k,
+    int segs, int cut_mul, const int16_t *__restrict__ filter_dir, const int16_t *__restrict__ dir_id,
+    double *__restrict__ part_scores, int32_t *__restrict__ part_ids, int32_t *__restrict__ part_len,
+    uint32_t *__restrict__ redo, unsigned long long *__restrict__ stats, const int32_t *__restrict__ dir_rng, int dir_rng_n,
+    int abl, unsigned long long *__restrict__ dbg, int32_t *__restrict__ fin_ids, int32_t *__restrict__ fin_cnt) {
+    as_scan_query<ST, C>(indptr, doc_ids, payload, post, nnz, qmax, g16, tile_off, n_tab, tshift, n_tiles, N, q_indptr, q_tok, q_order, k, segs, cut_mul,
+                         filter_dir, dir_id, part_scores, part_ids, part_len, redo, stats, dir_rng, dir_rng_n, abl, dbg, fin_ids, fin_cnt,
+                         q_order ? q_order[blockIdx.y] : (int)blockIdx.y, (int)blockIdx.x);
+}
+
+// One launch, two shapes (round 6): a query of more than `long_tokens` tokens is too coarse on 16-bit sums (as_pack_shift leaves it 65535 / nq
+// payload levels and an error of 3 nq of them: its lists never shrink), but sending the WHOLE batch to the 32-bit shape for the sake of a few long
+// questions costs every short one 20 % (1024 queries with the reference's question lengths, 32 of them longer than 28 tokens: 0.66 ms on the
+// 32-bit shape, 0.54 when the long ones are left out and the rest scans packed; profiles/r06m_bm25_segs_probe.log).  Here the workgroup of a long
+// query runs the 32-bit body over 16384-document tiles (AsSmall), every other one the packed body over the 4-byte postings (AsPack16) --
+// both 512 threads, 80 KiB of LDS, 128 VGPRs, the same segment cuts (cut_mul), the same outputs.  *_s: the 32-bit shape's posting copy and skip table.
+template <typename ST>
+__global__ __launch_bounds__(AsPack16::NT, 4) void bm25_ascan_mixed_kernel(
+    const int64_t *__restrict__ indptr, const int32_t *__restrict__ doc_ids, const ST *__restrict__ payload,
+    const void *__restrict__ post, uint32_t nnz, double qmax, int g16,
+    const int32_t *__restrict__ tile_off, int n_tab, int tshift, int n_tiles, int64_t N,
+    const int32_t *__restrict__ q_indptr, const int32_t *__restrict__ q_tok, const int32_t *__restrict__ q_order, int k,
+    int segs, int cut_mul, const int16_t *__restrict__ filter_dir, const int16_t *__restrict__ dir_id,
+    double *__restrict__ part_scores, int32_t *__restrict__ part_ids, int32_t *__restrict__ part_len,
+    uint32_t *__restrict__ redo, unsigned long long *__restrict__ stats, const int32_t *__restrict__ dir_rng, int dir_rng_n,
+    unsigned long long *__restrict__ dbg,
+    int long_tokens, const void *__restrict__ post_s, const int32_t *__restrict__ tile_off_s, int n_tab_s, int tshift_s, int n_tiles_s, int cut_mul_s,
+    const int32_t *__restrict__ q_items /* null: grid = (segs, B) as every other scan; else grid = (1, items), item = query | segment << 24 -- a long
+                                           query comes as segs_l items (its documents cut into segs_l ranges: one 45-token question in ONE workgroup
+                                           is the launch's tail otherwise), every other query as one */,
+    int segs_l, double *__restrict__ l_scores, int32_t *__restrict__ l_ids, int32_t *__restrict__ l_len /* [B][segs_l] partial lists of the long queries */,
+    uint32_t *__restrict__ l_redo) {
+    static_assert(AsPack16::NT == AsSmall::NT, "one block size for both bodies");
+    int q, seg;
+    if (q_items) {
+        const int item = q_items[blockIdx.y];
+        q = item & 0xffffff;
+        seg = (int)((uint32_t)item >> 24);
+    } else {
+        q = q_order ? q_order[blockIdx.y] : (int)blockIdx.y;
+        seg = (int)blockIdx.x;
+    }
+    const int nq = q_indptr[q + 1] - q_indptr[q];
+    if (nq > long_tokens) {                                                // workgroup-uniform
+        if (q_items)
+            as_scan_query<ST, AsSmall>(indptr, doc_ids, payload, post_s, nnz, qmax, g16, tile_off_s, n_tab_s, tshift_s, n_tiles_s, N, q_indptr, q_tok, q_order, k,
+                                       segs_l, cut_mul_s, filter_dir, dir_id, l_scores, l_ids, l_len, l_redo, stats, dir_rng, dir_rng_n, 0, dbg, nullptr, nullptr, q, seg);
+        else
+            as_scan_query<ST, AsSmall>(indptr, doc_ids, payload, post_s, nnz, qmax, g16, tile_off_s, n_tab_s, tshift_s, n_tiles_s, N, q_indptr, q_tok, q_order, k,
+                                       segs, cut_mul_s, filter_dir, dir_id, part_scores, part_ids, part_len, redo, stats, dir_rng, dir_rng_n, 0, dbg, nullptr, nullptr, q, seg);
+    } else {
+        as_scan_query<ST, AsPack16>(indptr, doc_ids, payload, post, nnz, qmax, g16, tile_off, n_tab, tshift, n_tiles, N, q_indptr, q_tok, q_order, k,
+                                    segs, cut_mul, filter_dir, dir_id, part_scores, part_ids, part_len, redo, stats, dir_rng, dir_rng_n, 0, dbg, nullptr, nullptr, q, seg);
+    }
 }
 
 // The exact re-score + rank of the fixed-point scan's final lists as a kernel of its own (option bm25_split_finish): grid = (segs, B),
@@ -1755,12 +1820,12 @@ __global__ void narrow_f64_kernel(const double *__restrict__ in, int64_t n, floa
 __global__ __launch_bounds__(kBmThreads) void bm25_merge_kernel(
     int k, int segs, int P, const double *__restrict__ part_scores, const int32_t *__restrict__ part_ids,
     const int32_t *__restrict__ part_len, int32_t *__restrict__ out_ids, double *__restrict__ out_scores,
-    int32_t *__restrict__ out_len) {
+    int32_t *__restrict__ out_len, const int32_t *__restrict__ q_list /* null, or workgroup -> query (the long queries of a mixed launch) */) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int &s_n = *reinterpret_cast<int *>(smem);
     double *cs = reinterpret_cast<double *>(smem + 64);
     int32_t *ci = reinterpret_cast<int32_t *>(smem + 64 + (size_t)P * 8);
-    const int q = blockIdx.x, tid = threadIdx.x;
+    const int q = q_list ? q_list[blockIdx.x] : (int)blockIdx.x, tid = threadIdx.x;
     if (tid == 0) s_n = 0;
     for (int i = tid; i < P; i += kBmThreads) { cs[i] = -1.0; ci[i] = 0x7fffffff; }
     __syncthreads();
@@ -1850,6 +1915,10 @@ hipError_t bm25_init() {
     e = hipFuncSetAttribute((const void *)bm25_ascan_kernel<float, AsPack16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AsPack16::BYTES);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void *)bm25_ascan_kernel<double, AsPack16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AsPack16::BYTES);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void *)bm25_ascan_mixed_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAsMixedBytes);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void *)bm25_ascan_mixed_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAsMixedBytes);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void *)bm25_finish_kernel<float, AsFinCfg<AsPack16::CAP>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AsFinCfg<AsPack16::CAP>::BYTES);
     if (e != hipSuccess) return e;
@@ -1947,6 +2016,34 @@ hipError_t launch_bm25_ascan(int variant, int small, const int64_t *indptr, cons
     return hipGetLastError();
 }
 
+// The packed shape for every query of at most `long_tokens` tokens, the 32-bit 16384-document shape for the longer ones, in ONE launch.
+// post16 / tile_off / n_tab / tshift: what the packed body walks (32768-document tiles); *_s: the same for the 32-bit body.  cut_mul / cut_mul_s:
+// both bodies cut their segments at the same documents.
+hipError_t launch_bm25_ascan_mixed(int variant, const int64_t *indptr, const int32_t *doc_ids, const void *payload,
+                                   const void *post16, int g16, uint32_t nnz, double qmax, const int32_t *tile_off, int n_tab, int tshift, int cut_mul,
+                                   const void *post_s, const int32_t *tile_off_s, int n_tab_s, int tshift_s, int cut_mul_s, int long_tokens,
+                                   int64_t N, const int32_t *q_indptr, const int32_t *q_tok, const int32_t *q_order, int B, int k, int segs,
+                                   const int16_t *filter_dir, const int16_t *dir_id, double *part_scores, int32_t *part_ids, int32_t *part_len,
+                                   uint32_t *redo, unsigned long long *stats, const int32_t *dir_rng, int dir_rng_n, unsigned long long *dbg,
+                                   hipStream_t st, const int32_t *q_items, int n_items, int segs_l, double *l_scores, int32_t *l_ids, int32_t *l_len,
+                                   uint32_t *l_redo) {
+    if (B <= 0) return hipSuccess;
+    const int n_tiles = (int)((N + AsPack16::TILE - 1) / AsPack16::TILE), n_tiles_s = (int)((N + AsSmall::TILE - 1) / AsSmall::TILE);
+    if (q_items && (segs != 1 || n_items < B || !l_scores || !l_ids || !l_len || !l_redo)) return hipErrorInvalidValue;
+    const dim3 grid = q_items ? dim3(1, n_items) : dim3(segs, B);
+    if (variant == 0)
+        hipLaunchKernelGGL((bm25_ascan_mixed_kernel<double>), grid, dim3(AsPack16::NT), kAsMixedBytes, st, indptr, doc_ids, (const double *)payload, post16,
+                           nnz, qmax, g16, tile_off, n_tab, tshift, n_tiles, N, q_indptr, q_tok, q_order, k, segs, cut_mul, filter_dir, dir_id,
+                           part_scores, part_ids, part_len, redo, stats, dir_rng, dir_rng_n, dbg,
+                           long_tokens, post_s, tile_off_s, n_tab_s, tshift_s, n_tiles_s, cut_mul_s, q_items, segs_l, l_scores, l_ids, l_len, l_redo);
+    else
+        hipLaunchKernelGGL((bm25_ascan_mixed_kernel<float>), grid, dim3(AsPack16::NT), kAsMixedBytes, st, indptr, doc_ids, (const float *)payload, post16,
+                           nnz, qmax, g16, tile_off, n_tab, tshift, n_tiles, N, q_indptr, q_tok, q_order, k, segs, cut_mul, filter_dir, dir_id,
+                           part_scores, part_ids, part_len, redo, stats, dir_rng, dir_rng_n, dbg,
+                           long_tokens, post_s, tile_off_s, n_tab_s, tshift_s, n_tiles_s, cut_mul_s, q_items, segs_l, l_scores, l_ids, l_len, l_redo);
+    return hipGetLastError();
+}
+
 int bm25_ascan_fin_cap() { return AsPack16::CAP; }
 
 // 4-byte postings: the smallest shift g with (qmax >> g) + 1 <= 65535
@@ -2027,11 +2124,11 @@ hipError_t launch_bm25_payload_sign(int variant, const void *payload, int64_t nn
 
 hipError_t launch_bm25_merge(int B, int k, int segs, const double *part_scores, const int32_t *part_ids,
                              const int32_t *part_len, int32_t *out_ids, double *out_scores, int32_t *out_len,
-                             hipStream_t st) {
+                             hipStream_t st, const int32_t *q_list) {
     if (B <= 0) return hipSuccess;
     const int P = pow2_ge(segs * k < 2 ? 2 : segs * k);
     hipLaunchKernelGGL(bm25_merge_kernel, dim3(B), dim3(kBmThreads), (size_t)P * 12 + 64, st,
-                       k, segs, P, part_scores, part_ids, part_len, out_ids, out_scores, out_len);
+                       k, segs, P, part_scores, part_ids, part_len, out_ids, out_scores, out_len, q_list);
     return hipGetLastError();
 }
 

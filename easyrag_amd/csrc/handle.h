@@ -79,6 +79,10 @@ struct erh_handle {
     std::vector<char> qpack_host;
     int32_t *qptr = nullptr, *qtok = nullptr;
     bool qorder_valid = false;
+    // a batch with queries longer than bm25_long_tokens (upload_bm25_queries): the launch items of the mixed scan -- query | segment << 24, a long
+    // query as bm25_long_segs items, heaviest first -- and the list of the long queries; slices of qpack, valid for the call's query CSR only
+    int32_t *qitems = nullptr, *qlong = nullptr;
+    int n_qitems = 0, n_qlong = 0, qitems_segs = 0;
     DevBuf scan_sync;                        // one counter per chunk-tile stream of the ping-pong scan (dense_sync)
     DevBuf Xt;                               // tiled copy of X for the ping-pong scan (option dense_tiled), valid iff xt_valid
     DevBuf Qt;                               // tiled copy of the query block of the current call (dense_pp = 4)
@@ -196,7 +200,12 @@ struct erh_handle {
     // 16384-document shape): 0.68 ms.  (Only the long queries on that shape, in a launch of their own beside the packed one -- built and
     // measured, both stream orders, both 32-bit shapes: 0.84 ... 1.02 ms.  The launches do not overlap usefully, and ONE 45-token query in
     // one workgroup takes 0.5 ms whatever runs beside it: profiles/r06d_bm25_long_queries.log.)
+    //   bm25_mixed (later in round 6): ONE launch whose workgroups pick their body by the length of their query -- the 32-bit body for the
+    // queries longer than bm25_long_tokens, the packed one for all others (bm25_ascan_mixed_kernel); 0 = the whole batch on the 32-bit shape.
     int opt_bm25_long_tokens = 28;
+    int opt_bm25_mixed = 1;
+    int opt_bm25_long_segs = 4;              // mixed launch at one segment per query (>= 512 queries): document ranges a LONG query is cut into (1: none)
+    DevBuf lpart_sc, lpart_ids, lpart_len, l_redo;   // ... their partial lists [B][bm25_long_segs][k] and redo words
     DevBuf bm_fin_ids, bm_fin_cnt;           // ... its final lists, handed to the batch-wide finish kernel (bm25_split_finish)
     int opt_bm25_split_finish = 0;
     DevBuf hy_sids, hy_ssc, hy_slen, hy_dids, hy_dsc, hy_dlen;
@@ -211,7 +220,7 @@ struct erh_handle {
     struct Stats {
         int64_t dense_calls = 0, dense_scan_pp5 = 0, dense_scan_pp3 = 0, dense_scan_gemv = 0, dense_scan_tile = 0,
                 dense_sample_passes = 0, dense_tile384_nomem = 0, bm25_calls = 0, hybrid_calls = 0, dense_block_groups = 0,
-                dense_grouped_launches = 0;
+                dense_grouped_launches = 0, bm25_mixed_launches = 0;
     } stats;
     // multi-GPU exchange (erh_comm_* / erh_allgather_topk): RCCL communicator + packed send / receive rows
     void *comm = nullptr;

@@ -200,6 +200,19 @@ int bm25_ascan_tile_docs(int small);   // 32768, or 16384 for the two-workgroups
 int bm25_ascan_small_max_k();
 float bm25_post_scale(float pmax);
 hipError_t launch_bm25_post(const int32_t *doc_ids, const float *pay32, int64_t nnz, float scale, void *post, hipStream_t st);
+// packed shape for the queries of at most long_tokens tokens, 32-bit 16384-document shape (*_s) for the longer ones, one launch (bm25.hip)
+hipError_t launch_bm25_ascan_mixed(int variant, const int64_t *indptr, const int32_t *doc_ids, const void *payload,
+                                   const void *post16, int g16, uint32_t nnz, double qmax, const int32_t *tile_off, int n_tab, int tshift, int cut_mul,
+                                   const void *post_s, const int32_t *tile_off_s, int n_tab_s, int tshift_s, int cut_mul_s, int long_tokens,
+                                   int64_t N, const int32_t *q_indptr, const int32_t *q_tok, const int32_t *q_order, int B, int k, int segs,
+                                   const int16_t *filter_dir, const int16_t *dir_id, double *part_scores, int32_t *part_ids, int32_t *part_len,
+                                   uint32_t *redo, unsigned long long *stats, const int32_t *dir_rng, int dir_rng_n, unsigned long long *dbg,
+                                   hipStream_t st,
+                                   const int32_t *q_items = nullptr /* segs == 1 only: grid = n_items workgroups, item = query | segment << 24: a long query as
+                                                                       segs_l items whose partial lists go to l_* [B][segs_l] (merged by the caller:
+                                                                       launch_bm25_merge with the list of long queries), every other query as one item */,
+                                   int n_items = 0, int segs_l = 1, double *l_scores = nullptr, int32_t *l_ids = nullptr, int32_t *l_len = nullptr,
+                                   uint32_t *l_redo = nullptr);
 hipError_t launch_bm25_ascan(int variant, int small /* 0: 1024 threads; 1: 512 threads, 16384-document tiles; 2: packed 16-bit sums */,
                              const int64_t *indptr, const int32_t *doc_ids, const void *payload,
                              const void *post, const void *post16 /* shape 2: the 4-byte postings (launch_bm25_post16), or null */, int g16,
@@ -234,7 +247,7 @@ hipError_t launch_bm25_wscan(int variant, const int64_t *indptr, const int32_t *
 hipError_t launch_bm25_payload_sign(int variant, const void *payload, int64_t nnz, uint32_t *flag, hipStream_t st);
 hipError_t launch_bm25_merge(int B, int k, int segs, const double *part_scores, const int32_t *part_ids,
                              const int32_t *part_len, int32_t *out_ids, double *out_scores, int32_t *out_len,
-                             hipStream_t st);
+                             hipStream_t st, const int32_t *q_list = nullptr /* workgroup -> query: B = its length */);
 // scores[doc] += payload for one term (launched once per query token, in order) -> get_scores parity
 hipError_t launch_bm25_add_term(int variant, const int64_t *indptr, const int32_t *doc_ids, const void *payload,
                                 int32_t term, void *scores, hipStream_t st);

@@ -475,7 +475,7 @@ class RetrievalEngine:
 
     STAT_NAMES = ("dense_calls", "bm25_calls", "hybrid_calls", "dense_scan_pp5_launches", "dense_scan_pp3_launches",
                   "dense_scan_gemv_launches", "dense_scan_tile_launches", "dense_sample_passes", "dense_tile384_nomem",
-                  "dense_exhaustive_queries", "bm25_redo_segments", "dense_block_groups", "dense_grouped_launches")
+                  "dense_exhaustive_queries", "bm25_redo_segments", "dense_block_groups", "dense_grouped_launches", "bm25_mixed_launches")
 
     def stat(self, name: str) -> int:
         """One counter of erh_get_stat (which kernels answered the calls since the last reset_stats)."""

@@ -352,6 +352,11 @@ int erh_reset_kernel_time(erh_handle *h);
  *                         from ~30 tokens on the list of documents that can still reach the top k stops shrinking (the query then falls
  *                         back to the exact block scan: 0.5 -> 1.7 ms per 1024 queries with the reference's question lengths, 4 ... 45
  *                         tokens; 0.68 ms on the 32-bit shape).  0 = always the packed shape.  Same results
+ *   bm25_mixed (1)        such a batch runs as ONE launch whose workgroups pick their body by the length of their query: the 32-bit body for
+ *                         the queries longer than bm25_long_tokens, the packed one for all others (needs bm25_post16 and a skip table at
+ *                         16384 documents); 0 = the whole batch on the 32-bit shape.  Same results
+ *   bm25_long_segs (4)    mixed launch of >= 512 queries (one workgroup per query): a LONG query's documents are cut into this many ranges, each
+ *                         a workgroup of its own, merged afterwards (one 45-token question in one workgroup is the launch's tail); 1 = no cut
  *   bm25_split_finish (0) 1: the exact re-score + rank of the scan's final lists as ONE batch-wide kernel behind the scan instead of
  *                         each workgroup's tail (measured +15 %: the tail overlaps the CU's other workgroup; a parity arm)
  *   bm25_post16 (1)       packed shape: read 4-byte postings {15-bit document offset in the tile, 16-bit payload} (built when an
@@ -407,6 +412,7 @@ int erh_dense_exhaustive_count(erh_handle *h, int32_t *count);
  *   dense_grouped_launches                             calls whose block groups ran as one launch per stage (dense_group_launch)
  *   dense_candidates_last_call                         candidates the last dense pipeline's scan handed to its final kernel, summed over
  *                                                      its queries (read back from the device: synchronises; not reset by erh_reset_stats)
+ *   bm25_mixed_launches                                BM25 scans launched with both bodies (bm25_mixed: a batch with queries longer than bm25_long_tokens)
  *   bm25_redo_segments                                 (query, segment) pairs the fixed-point scan handed to the exact block scan (device counter)
  * Reading a device counter synchronises the device.  Unknown name: ERH_ERR_INVALID. */
 int erh_get_stat(erh_handle *h, const char *name, int64_t *value);

@@ -457,7 +457,9 @@ def test_dense_clustered_corpus_exact(engine, b, k):
 def test_bm25_reference_question_lengths_full_size(engine, sparse_data):
     """configs[2]-sized corpus, 1024 queries with the length distribution of the reference's 103 real questions (4 ... 45 tokens).  On the
     packed 16-bit shape alone a handful of the longest queries cannot shrink their candidate lists and fall back to the exact block scan
-    (bm25_long_tokens = 0: `bm25_redo_segments` > 0, 3 x the time); by default such a batch scans with 32-bit sums: no redo, same lists.  The longest queries and a sample of the others against the oracle, ids and scores bit for bit."""
+    (bm25_long_tokens = 0: `bm25_redo_segments` > 0, 3 x the time); by default the long queries' workgroups run the 32-bit body beside the packed
+    ones in one launch (bm25_mixed; 0: the whole batch with 32-bit sums): no redo, same lists.  The longest queries and a sample of the others
+    against the oracle, ids and scores bit for bit."""
     indptr, doc, tf, lens, _, flat = sparse_data
     idx = host_index(sparse_data, BM25S)
     engine.set_bm25(idx)
@@ -469,7 +471,26 @@ def test_bm25_reference_question_lengths_full_size(engine, sparse_data):
     try:
         engine.reset_stats()
         ids, sc, ln = engine.bm25_topk(*csr, 192)
-        assert engine.stat("bm25_redo_segments") == 0
+        assert engine.stat("bm25_redo_segments") == 0 and engine.stat("bm25_mixed_launches") == 1
+        engine.set_option("bm25_long_segs", 1)                     # the long queries in one workgroup each
+        engine.reset_stats()
+        ids2, sc2, ln2 = engine.bm25_topk(*csr, 192)
+        assert engine.stat("bm25_redo_segments") == 0 and engine.stat("bm25_mixed_launches") == 1
+        assert np.array_equal(ln, ln2) and np.array_equal(ids, ids2) and np.array_equal(sc.view(np.uint64), sc2.view(np.uint64))
+        engine.set_option("bm25_long_segs", 4)
+        engine.set_option("bm25_mixed", 0)
+        engine.reset_stats()
+        ids1, sc1, ln1 = engine.bm25_topk(*csr, 192)
+        assert engine.stat("bm25_redo_segments") == 0 and engine.stat("bm25_mixed_launches") == 0
+        assert np.array_equal(ln, ln1) and np.array_equal(ids, ids1) and np.array_equal(sc.view(np.uint64), sc1.view(np.uint64))
+        # fewer queries than workgroup slots: several document-range segments per query, both bodies cutting at the same documents
+        few = [int(i) for i in np.argsort(-ql)[:12]] + list(range(5, 1024, 11))[:88]
+        csr_few = queries_to_csr([qs[i] for i in few])
+        engine.set_option("bm25_mixed", 1)
+        engine.reset_stats()
+        idf, scf, lnf = engine.bm25_topk(*csr_few, 192)
+        assert engine.stat("bm25_mixed_launches") == 1 and engine.stat("bm25_redo_segments") == 0
+        assert np.array_equal(lnf, ln[few]) and np.array_equal(idf, ids[few]) and np.array_equal(scf.view(np.uint64), sc[few].view(np.uint64))
         engine.set_option("bm25_long_tokens", 0)
         engine.reset_stats()
         ids0, sc0, ln0 = engine.bm25_topk(*csr, 192)
@@ -477,6 +498,8 @@ def test_bm25_reference_question_lengths_full_size(engine, sparse_data):
         assert np.array_equal(ln, ln0) and np.array_equal(ids, ids0) and np.array_equal(sc.view(np.uint64), sc0.view(np.uint64))
     finally:
         engine.set_option("bm25_long_tokens", 28)
+        engine.set_option("bm25_mixed", 1)
+        engine.set_option("bm25_long_segs", 4)
     sample = sorted(set(list(np.argsort(-ql)[:10]) + list(range(0, 1024, 73))))
     for b in sample:
         want = sparse_oracle_topk(idx, qs[b], 192)

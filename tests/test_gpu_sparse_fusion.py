@@ -27,7 +27,7 @@ def bm25_kernel(request, engine):
     engine.set_option("bm25_small", request.param[3])       # shape of the approximate scan for batches of >= 8 queries
     engine.set_option("bm25_post16", request.param[4])      # packed shape: 4-byte or 8-byte postings
     engine.set_option("bm25_split_finish", request.param[5] if len(request.param) > 5 else 0)   # exact re-score + rank in a kernel of its own
-    yield request.param[:5]
+    yield tuple(request.param) + ((0,) if len(request.param) == 5 else ())
     engine.set_option("bm25_split_finish", 0)
     engine.set_option("bm25_ascan", 1)
     engine.set_option("bm25_wscan", 0)
@@ -127,6 +127,63 @@ def test_bm25_near_tie_flood(engine, bm25_kernel, variant):
                 assert ln[b] == len(want)
                 assert list(ids[b, :ln[b]]) == [w[0] for w in want], f"k={k} query {b}: ids differ"
                 assert list(sc[b, :ln[b]]) == [w[1] for w in want], f"k={k} query {b}: scores differ"
+
+
+@pytest.mark.parametrize("variant", [OKAPI, BM25S])
+def test_bm25_mixed_launch_cuts_long_queries(engine, variant):
+    """>= 512 queries (one workgroup per query), a few of them longer than bm25_long_tokens: ONE launch whose workgroups pick their body by the
+    length of their query, and a long query's documents cut into bm25_long_segs ranges -- items query | segment << 24 built on the host, the
+    long queries' partial lists merged into the caller's rows.  Half of the long queries ask for a document that exists 2000 times (spread over
+    the whole corpus): every one of their segments floods its list and goes through the exact block scan before the merge.  Every arm --
+    cut / not cut / the whole batch on the 32-bit shape / always packed -- gives the same lists; the long queries and a sample of the others
+    against the oracle, ids and scores bit for bit; with and without a dir filter."""
+    rng = np.random.default_rng(77)
+    n, vocab, b, k = 70000, 5000, 520, 60
+    flat, lens = synth.token_corpus(n, vocab, seed=41, mean_len=20)
+    docs = [list(map(int, d)) for d in synth.split_docs(flat, lens)]
+    base = [list(map(int, rng.integers(0, vocab, size=int(rng.integers(12, 20))))) for _ in range(5)]
+    for i in range(0, n, 7):                                          # 10000 copies of five documents, everywhere in the corpus
+        docs[i] = base[(i // 7) % 5]
+    idx = build_bm25_index(docs, variant)
+    engine.set_bm25(idx)
+    dir_id = np.repeat(np.arange(3), [30000, 25000, 15000]).astype(np.int16)
+    engine.set_doc_meta(n, None, dir_id)
+    ora = _oracle_for(variant, docs)
+    short_lengths = [L for L in synth.REF_QUESTION_LENGTHS if L <= 28]
+    qs = [list(map(int, q)) for q in synth.token_queries(flat, lens, vocab, b, seed=42, lengths=short_lengths)]
+    long_at = [int(i) for i in rng.choice(b, size=20, replace=False)]
+    for j, i in enumerate(long_at):
+        L = int(rng.integers(29, 46))
+        src = base[j % 5] if j < 10 else docs[int(rng.integers(0, n))]
+        qs[i] = [src[int(t)] for t in rng.integers(0, len(src), L)]
+    csr = queries_to_csr([idx.tokens_to_ids(q) for q in qs])
+    filt = (np.arange(b) % 4 - 1).astype(np.int16)                   # none, 0, 1, 2
+    try:
+        for f in (None, filt):
+            got = {}
+            for name, opts in (("cut", (28, 1, 2)), ("cut3", (28, 1, 3)), ("mixed", (28, 1, 1)), ("wide", (28, 0, 2)), ("packed", (0, 1, 2))):
+                engine.set_option("bm25_long_tokens", opts[0])
+                engine.set_option("bm25_mixed", opts[1])
+                engine.set_option("bm25_long_segs", opts[2])
+                engine.reset_stats()
+                got[name] = engine.bm25_topk(*csr, k, filter_dir=f)
+                assert engine.stat("bm25_mixed_launches") == (1 if name in ("cut", "cut3", "mixed") else 0), name
+                if name == "cut" and f is None:
+                    assert engine.stat("bm25_redo_segments") >= 20, "the flooding long queries were meant to reach the exact scan in both ranges"
+            ids, sc, ln = got["cut"]
+            for other in ("cut3", "mixed", "wide", "packed"):
+                assert np.array_equal(ln, got[other][2]) and np.array_equal(ids, got[other][0]), other
+                assert np.array_equal(sc.view(np.uint64), got[other][1].view(np.uint64)), other
+            for i in sorted(set(long_at + list(range(0, b, 29)))):
+                mask = None if f is None or f[i] < 0 else dir_id == f[i]
+                want = bm25_filter(_oracle_scores(ora, variant, qs[i]), k, mask)
+                assert list(ids[i, :ln[i]]) == [w[0] for w in want], (i, len(qs[i]))
+                assert list(sc[i, :ln[i]]) == [w[1] for w in want], (i, len(qs[i]))
+    finally:
+        engine.set_option("bm25_long_tokens", 28)
+        engine.set_option("bm25_mixed", 1)
+        engine.set_option("bm25_long_segs", 4)
+        engine.set_doc_meta(n, None, None)
 
 
 def test_bm25_okapi_negative_idf_floor(engine, bm25_kernel):
@@ -450,8 +507,9 @@ def test_bm25_dir_filter_as_tile_range(engine, bm25_kernel, variant):
 @pytest.mark.parametrize("variant", [BM25S, OKAPI], ids=["bm25s", "okapi"])
 def test_bm25_reference_question_lengths(engine, bm25_kernel, variant):
     """Queries as long as the reference's real questions (synth.REF_QUESTION_LENGTHS: 4 ... 45 tokens, tokens repeated when the target
-    document is short) in ONE batch: a batch whose longest query exceeds bm25_long_tokens leaves the packed 16-bit shape for the 32-bit
-    one (and with the option at 0 -- always packed -- or 8 the lists are the same); every arm, with and without a dir filter, against
+    document is short) in ONE batch: in a batch whose longest query exceeds bm25_long_tokens the long queries' workgroups run the 32-bit
+    body and the others the packed one in ONE launch (bm25_mixed; with it off the whole batch leaves the packed 16-bit shape for the 32-bit
+    one), and with bm25_long_tokens at 0 -- always packed -- or 8 the lists are the same; every arm, with and without a dir filter, against
     the oracle -- ids and scores bit for bit."""
     rng = np.random.default_rng(88)
     n, vocab, b, k = 30000, 3000, 103, 60
@@ -470,13 +528,18 @@ def test_bm25_reference_question_lengths(engine, bm25_kernel, variant):
     try:
         for f in (None, filt):
             got = {}
-            for long_tokens in (28, 0, 8):
+            # the one-launch-two-bodies path exists for the packed shape on 4-byte postings with the tail inside the scan kernel
+            can_mix = bm25_kernel[0] == 1 and bm25_kernel[3] == 2 and bm25_kernel[4] == 1 and bm25_kernel[5] == 0
+            for long_tokens, mixed in ((28, 1), (28, 0), (0, 1), (8, 1), (8, 0)):
                 engine.set_option("bm25_long_tokens", long_tokens)
-                got[long_tokens] = engine.bm25_topk(*queries_to_csr([idx.tokens_to_ids(list(map(int, q))) for q in qs]), k, filter_dir=f)
-            ids, sc, ln = got[28]
-            for other in (0, 8):
-                assert np.array_equal(ln, got[other][2]) and np.array_equal(ids, got[other][0])
-                assert np.array_equal(sc.view(np.uint64), got[other][1].view(np.uint64))
+                engine.set_option("bm25_mixed", mixed)
+                engine.reset_stats()
+                got[long_tokens, mixed] = engine.bm25_topk(*queries_to_csr([idx.tokens_to_ids(list(map(int, q))) for q in qs]), k, filter_dir=f)
+                assert engine.stat("bm25_mixed_launches") == (1 if can_mix and mixed and long_tokens else 0), (long_tokens, mixed)
+            ids, sc, ln = got[28, 1]
+            for other in ((28, 0), (0, 1), (8, 1), (8, 0)):
+                assert np.array_equal(ln, got[other][2]) and np.array_equal(ids, got[other][0]), other
+                assert np.array_equal(sc.view(np.uint64), got[other][1].view(np.uint64)), other
             for i in range(b):
                 mask = None if f is None or f[i] < 0 else dir_id == f[i]
                 want = bm25_filter(ora.get_scores(list(map(int, qs[i]))), k, mask)
@@ -484,4 +547,5 @@ def test_bm25_reference_question_lengths(engine, bm25_kernel, variant):
                 assert list(sc[i, :ln[i]]) == [w[1] for w in want], (i, len(qs[i]))
     finally:
         engine.set_option("bm25_long_tokens", 28)
+        engine.set_option("bm25_mixed", 1)
         engine.set_doc_meta(n, None, None)
