@@ -119,6 +119,7 @@ int erh_set_option(erh_handle *h, const char *name, int64_t value) {
     if (!strcmp(name, "dense_gemv")) { h->opt_dense_gemv = value != 0; return ERH_OK; }
     if (!strcmp(name, "dense_gemv_kb")) { if (value != 16 && value != 32) return h->fail(ERH_ERR_INVALID, "dense_gemv_kb"); h->opt_gemv_kb = (int)value; return ERH_OK; }
     if (!strcmp(name, "dense_gemv_pipe")) { if (value < -1 || value > 1) return h->fail(ERH_ERR_INVALID, "dense_gemv_pipe"); h->opt_gemv_pipe = (int)value; return ERH_OK; }
+    if (!strcmp(name, "dense_gemv_nt")) { if (value < -1 || value > 1) return h->fail(ERH_ERR_INVALID, "dense_gemv_nt"); h->opt_gemv_nt = (int)value; return ERH_OK; }
     if (!strcmp(name, "dense_gemv_wgs")) { if (value < 1 || value > 5) return h->fail(ERH_ERR_INVALID, "dense_gemv_wgs"); h->opt_gemv_wgs = (int)value; return ERH_OK; }
     if (!strcmp(name, "dense_small_single_stage")) { h->opt_small_single = value != 0; return ERH_OK; }
     if (!strcmp(name, "dense_persist")) { h->opt_dense_persist = value != 0; return ERH_OK; }
@@ -1042,9 +1043,11 @@ int erh_hybrid_topk(erh_handle *h, const void *q, int q_dtype, int q_is_device, 
         if (rc != ERH_OK) { if (st_sparse != st) (void)hipStreamSynchronize(st_sparse); return rc; }
     }
     h->fork_after_scan = (ov == 2);
+    h->sparse_beside = (ov == 1);
     rc = dense_topk_routed(h, qd, q_dtype, normalize_q, B, k_dense, filter_dense, filt_d, ERH_DENSE_EXACT, h->hy_dids.as<int32_t>(),
                            h->hy_dsc.as<double>(), h->hy_dlen.as<int32_t>(), st);
     h->fork_after_scan = false;
+    h->sparse_beside = false;
     if (ov == 2) {                                   // fork behind the dense scan: the sparse route runs beside the selection kernels
         if (rc != ERH_OK) return rc;
         HIPCHK(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));

@@ -33,7 +33,14 @@ constexpr int kGvThreads = 256;             // 4 waves per workgroup, each with 
 // PIPE: the chunk-side loads of the NEXT 16 steps are issued before the matrix instructions of the current 16 run (two
 // register sets of 16 fragments, walked over the flattened (row group, half of K) sequence), so a wave's load and compute
 // phases overlap -- with four column groups only four waves fit a CU and nothing else would cover the HBM latency.
-template <bool STORE, int kGvKB, int G, bool PIPE>
+// NT: the chunk-side loads carry the non-temporal hint (the matrix is read once per call and is far larger than L2 + MALL).
+template <bool NT>
+__device__ __forceinline__ half8 gv_load(const _Float16 *p) {
+    if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const half8 *>(p));
+    else return *reinterpret_cast<const half8 *>(p);
+}
+
+template <bool STORE, int kGvKB, int G, bool PIPE, bool NT = false>
 __global__ __launch_bounds__(kGvThreads) void dense_gemv_kernel(
     const _Float16 *__restrict__ X, int64_t N, int d, int64_t c0, int64_t c1,
     const _Float16 *__restrict__ Q, int B,
@@ -87,7 +94,7 @@ __global__ __launch_bounds__(kGvThreads) void dense_gemv_kernel(
             constexpr int HB = 16;
             if (!primed) {
 #pragma unroll
-                for (int u = 0; u < HB; ++u) pa[0][u] = *reinterpret_cast<const half8 *>(src + 32 * u);
+                for (int u = 0; u < HB; ++u) pa[0][u] = gv_load<NT>(src + 32 * u);
                 primed = true;
             }
             for (int j0 = 0; j0 < steps; j0 += HB) {
@@ -104,7 +111,7 @@ __global__ __launch_bounds__(kGvThreads) void dense_gemv_kernel(
                 if (cur == 0) {
                     if (fetch) {
 #pragma unroll
-                        for (int u = 0; u < HB; ++u) pa[1][u] = *reinterpret_cast<const half8 *>(nsrc + 32 * u);
+                        for (int u = 0; u < HB; ++u) pa[1][u] = gv_load<NT>(nsrc + 32 * u);
                     }
 #pragma unroll
                     for (int u = 0; u < HB; ++u) {
@@ -115,7 +122,7 @@ __global__ __launch_bounds__(kGvThreads) void dense_gemv_kernel(
                 } else {
                     if (fetch) {
 #pragma unroll
-                        for (int u = 0; u < HB; ++u) pa[0][u] = *reinterpret_cast<const half8 *>(nsrc + 32 * u);
+                        for (int u = 0; u < HB; ++u) pa[0][u] = gv_load<NT>(nsrc + 32 * u);
                     }
 #pragma unroll
                     for (int u = 0; u < HB; ++u) {
@@ -131,7 +138,7 @@ __global__ __launch_bounds__(kGvThreads) void dense_gemv_kernel(
             half8 a[kGvKB];
 #pragma unroll
             for (int u = 0; u < kGvKB; ++u)
-                if (j0 + u < steps) a[u] = *reinterpret_cast<const half8 *>(src + 32 * (j0 + u));
+                if (j0 + u < steps) a[u] = gv_load<NT>(src + 32 * (j0 + u));
 #pragma unroll
             for (int u = 0; u < kGvKB; ++u)
                 if (j0 + u < steps) {
@@ -188,7 +195,7 @@ int dense_gemv_max_queries() { return 64; }
 static hipError_t gemv_launch(bool store, const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1, const _Float16 *Q,
                               int B, const float *tau, const int16_t *filter_dir, const int16_t *dir_id, ErhCand *cand,
                               uint32_t *cand_cnt, int cap, uint32_t *overflow, float *S0, int ld_s0, int n_cus, int kb, int wgs,
-                              int pipe_opt, hipStream_t st) {
+                              int pipe_opt, hipStream_t st, int nt = 0) {
     if (c1 <= c0) return hipSuccess;
     const int groups = B <= 16 ? 1 : B <= 32 ? 2 : 4;                    // column groups of 16 queries
     // software-pipelined loads (two sets of 16 fragments): default for 2 / 4 column groups, where few waves fit a CU
@@ -205,14 +212,19 @@ static hipError_t gemv_launch(bool store, const _Float16 *X, int64_t N, int d, i
 #define ERH_GV_LAUNCH(ST, KB, G, P)                                                                                    \
     hipLaunchKernelGGL((dense_gemv_kernel<ST, KB, G, P>), dim3((unsigned)grid), dim3(kGvThreads), lds, st, X, N, d, c0, c1, Q, \
                        B, tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow, S0, ld_s0)
+#define ERH_GV_LAUNCH_NT(KB, G, P)                                                                                     \
+    hipLaunchKernelGGL((dense_gemv_kernel<false, KB, G, P, true>), dim3((unsigned)grid), dim3(kGvThreads), lds, st, X, N, d, c0, c1, Q, \
+                       B, tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow, S0, ld_s0)
 #define ERH_GV_PICK(G)                                                                                                 \
     do {                                                                                                               \
-        if (pipe) { if (store) ERH_GV_LAUNCH(true, 16, G, true); else ERH_GV_LAUNCH(false, 16, G, true); }             \
+        if (nt && !store) { if (pipe) ERH_GV_LAUNCH_NT(16, G, true); else if (kb == 16) ERH_GV_LAUNCH_NT(16, G, false); else ERH_GV_LAUNCH_NT(32, G, false); } \
+        else if (pipe) { if (store) ERH_GV_LAUNCH(true, 16, G, true); else ERH_GV_LAUNCH(false, 16, G, true); }             \
         else if (kb == 16) { if (store) ERH_GV_LAUNCH(true, 16, G, false); else ERH_GV_LAUNCH(false, 16, G, false); }  \
         else { if (store) ERH_GV_LAUNCH(true, 32, G, false); else ERH_GV_LAUNCH(false, 32, G, false); }                \
     } while (0)
     if (groups == 1) ERH_GV_PICK(1); else if (groups == 2) ERH_GV_PICK(2); else ERH_GV_PICK(4);
 #undef ERH_GV_PICK
+#undef ERH_GV_LAUNCH_NT
 #undef ERH_GV_LAUNCH
     return hipGetLastError();
 }
@@ -222,7 +234,9 @@ hipError_t dense_gemv_init() {
 #define ERH_GV_FNS(G)                                                                                                  \
     (const void *)dense_gemv_kernel<false, 32, G, false>, (const void *)dense_gemv_kernel<true, 32, G, false>,         \
     (const void *)dense_gemv_kernel<false, 16, G, false>, (const void *)dense_gemv_kernel<true, 16, G, false>,         \
-    (const void *)dense_gemv_kernel<false, 16, G, true>, (const void *)dense_gemv_kernel<true, 16, G, true>
+    (const void *)dense_gemv_kernel<false, 16, G, true>, (const void *)dense_gemv_kernel<true, 16, G, true>,           \
+    (const void *)dense_gemv_kernel<false, 32, G, false, true>, (const void *)dense_gemv_kernel<false, 16, G, false, true>, \
+    (const void *)dense_gemv_kernel<false, 16, G, true, true>
     const void *fns[] = {ERH_GV_FNS(1), ERH_GV_FNS(2), ERH_GV_FNS(4)};
 #undef ERH_GV_FNS
     for (const void *f : fns) {
@@ -237,9 +251,9 @@ hipError_t dense_gemv_init() {
 hipError_t launch_dense_gemv_append(const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1, const _Float16 *Q, int B,
                                     const float *tau, const int16_t *filter_dir, const int16_t *dir_id, ErhCand *cand,
                                     uint32_t *cand_cnt, int cap, uint32_t *overflow, int n_cus, int kb, int wgs, int pipe,
-                                    hipStream_t st) {
+                                    hipStream_t st, int nt) {
     return gemv_launch(false, X, N, d, c0, c1, Q, B, tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow, nullptr, 0,
-                       n_cus, kb, wgs, pipe, st);
+                       n_cus, kb, wgs, pipe, st, nt);
 }
 
 // Seed prefix of the same small batch: S0[q][chunk - c0] for chunks [c0, c0 + nc), q < B.

@@ -236,6 +236,13 @@ struct erh_handle {
     int opt_dense_readahead = 1;           // cfg 2 only: fragments of the next K-step are read before its barrier
     int opt_small_single = 1;              // small batches: skip the refinement boundaries when the lists can take it
     int opt_gemv_pipe = -1;                  // ... software-pipelined loads: -1 by batch (2 / 4 column groups), 0 off, 1 on
+    // ... its chunk loads with the non-temporal hint: -1 by call (on up to 32 queries unless the sparse route of a fused call runs beside
+    // the stream), 0 off, 1 on.  Interleaved A/B (profiles/r06r_ab_gemv_nt_*.log): dense calls of 1 / 2 / 4 / 8 / 12 / 24 queries -7 ... -11 % scan
+    // (-6 ... -9 % wall; 0.353 ... 0.373 ms whatever the batch, where the plain loads swing between 0.357 and 0.417), 16 / 32: +2 / -2 %,
+    // 48 / 64 (four column groups): +4 / +1 %; beside the BM25 scan of a fused single query: +2 ... +8 % (the side stream's postings and
+    // the hinted stream fight over the same queues) -- there the plain loads stay.
+    int opt_gemv_nt = -1;
+    bool sparse_beside = false;              // erh_hybrid_topk, hybrid_overlap 1: the sparse route runs on the side stream beside this dense pipeline
     int opt_gemv_kb = 32, opt_gemv_wgs = 2;  // skinny-GEMM stream: steps whose loads are in flight together, workgroups per CU at most
     int opt_dense_gemv = 1;                // batches of <= 16 queries: skinny-GEMM stream instead of the padded 256-query scan
     int opt_n0_auto = 0;                   // seed prefix snapped down to a whole number of scan rounds (less seed work, more candidates: a wash at 1M chunks)

@@ -100,7 +100,7 @@ hipError_t dense_gemv_init();
 hipError_t launch_dense_gemv_append(const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1, const _Float16 *Q, int B,
                                     const float *tau, const int16_t *filter_dir, const int16_t *dir_id, ErhCand *cand,
                                     uint32_t *cand_cnt, int cap, uint32_t *overflow, int n_cus, int kb, int wgs,
-                                    int pipe, hipStream_t st);
+                                    int pipe, hipStream_t st, int nt = 0 /* chunk loads with the non-temporal hint (option dense_gemv_nt) */);
 hipError_t launch_dense_gemv_store(const _Float16 *X, int64_t N, int d, int64_t c0, int nc, const _Float16 *Q, int B,
                                    float *S0, int ld_s0, int n_cus, int kb, int wgs, int pipe, hipStream_t st);
 

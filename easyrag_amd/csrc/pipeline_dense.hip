@@ -19,7 +19,8 @@ static hipError_t scan_append(erh_handle *h, const _Float16 *X, int64_t N, int d
     // small batches: the skinny-GEMM stream (dense_gemv.hip) instead of a 256-query tile that is mostly padding
     if (h->opt_dense_gemv && h->opt_dense_ablate == 0 && B <= erh::dense_gemv_max_queries()) {
         hipError_t e = erh::launch_dense_gemv_append(X, N, d, c0, c1, Q16, B, tau, filt, dir, cand, cnt, cap, flags,
-                                                     h->n_cus, h->opt_gemv_kb, h->opt_gemv_wgs, h->opt_gemv_pipe, st);
+                                                     h->n_cus, h->opt_gemv_kb, h->opt_gemv_wgs, h->opt_gemv_pipe, st,
+                                                     h->opt_gemv_nt >= 0 ? h->opt_gemv_nt : (!h->sparse_beside && B <= 32) ? 1 : 0);
         if (e != hipErrorInvalidValue) { h->stats.dense_scan_gemv += (c1 > c0); return e; }
         (void)hipGetLastError();
     }
