@@ -590,16 +590,19 @@ __device__ __forceinline__ float erh_max4(float a, float b, float c, float d) {
 // (s, s+1) of one operand = the two 64-byte halves of the same 128-byte lines, issued back to back so that the second half
 // hits in L1.  Used by dense_scan_pp3_kernel (and by the lean kernel of the measurement builds).
 #define ERH_PP2_GLDS(SRC, DST) __builtin_amdgcn_global_load_lds((const void *)(SRC), ERH_LDS_PTR(DST), 16, 0, 0)
+// the chunk side: kPpAuxX is a constant of the kernel that expands the macro -- 2 = the non-temporal hint (dense_scan_pp3_kernel VAR bit 6:
+// a launch in which every chunk row is read by ONE workgroup, i.e. one query tile per matrix), 0 = the default policy
+#define ERH_PP2_GLDS_X(SRC, DST) __builtin_amdgcn_global_load_lds((const void *)(SRC), ERH_LDS_PTR(DST), 16, 0, kPpAuxX)
 #define ERH_PP2_ISSUE_A()                                                                             \
     do {                                                                                              \
         if (a_left > 0) {                                                                             \
             if (!(PABL & kPpNoDmaA)) {                                                                \
                 int d1_ = a_dst + pp::A_BYTES;                                                        \
                 if (d1_ == kABytes) d1_ = 0;                                                          \
-                ERH_PP2_GLDS(pa[0], my_dst + a_dst);                                                  \
-                ERH_PP2_GLDS(pa[0] + 32, my_dst + d1_);                                               \
-                ERH_PP2_GLDS(pa[1], my_dst + a_dst + 8192);                                           \
-                ERH_PP2_GLDS(pa[1] + 32, my_dst + d1_ + 8192);                                        \
+                ERH_PP2_GLDS_X(pa[0], my_dst + a_dst);                                                  \
+                ERH_PP2_GLDS_X(pa[0] + 32, my_dst + d1_);                                               \
+                ERH_PP2_GLDS_X(pa[1], my_dst + a_dst + 8192);                                           \
+                ERH_PP2_GLDS_X(pa[1] + 32, my_dst + d1_ + 8192);                                        \
             }                                                                                         \
             ka += 2;                                                                                  \
             int64_t inc_ = 64;                                                                        \
@@ -702,6 +705,7 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp3_kernel(
     const erh::ErhSeedIo sio /* VAR bit 4: this launch is the sample pass (kernels.h) */,
     const erh::ErhGroupIo gio /* VAR bit 5 */) {
     constexpr bool GROUPED = (VAR & 32) != 0;
+    constexpr int kPpAuxX = (VAR & 64) ? 2 : 0;                        // chunk-side LDS-DMA: non-temporal when each chunk row has one reader
     const int g_qt = GROUPED ? gio.wg_view[blockIdx.x] : 0;
     const erh::ErhDenseView *const gv = GROUPED ? gio.views + g_qt : nullptr;
     constexpr bool GSEED = GROUPED && (VAR & 16) != 0;                 // the grouped sample pass: rows [0, seed_rows) of the tile's view
@@ -784,10 +788,10 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp3_kernel(
             if (!(PABL & kPpNoDmaA)) {                                                                \
                 int d1_ = a_dst + pp::A_BYTES;                                                        \
                 if (d1_ == kABytes) d1_ = 0;                                                          \
-                ERH_PP2_GLDS(pa[0], my_dst + a_dst);                                                  \
-                ERH_PP2_GLDS(pa[0] + 4096, my_dst + a_dst + 8192);                                    \
-                ERH_PP2_GLDS(pa[0] + 8192, my_dst + d1_);                                             \
-                ERH_PP2_GLDS(pa[0] + 12288, my_dst + d1_ + 8192);                                     \
+                ERH_PP2_GLDS_X(pa[0], my_dst + a_dst);                                                  \
+                ERH_PP2_GLDS_X(pa[0] + 4096, my_dst + a_dst + 8192);                                    \
+                ERH_PP2_GLDS_X(pa[0] + 8192, my_dst + d1_);                                             \
+                ERH_PP2_GLDS_X(pa[0] + 12288, my_dst + d1_ + 8192);                                     \
             }                                                                                         \
             ka += 2;                                                                                  \
             int64_t inc_ = 16384;                                          /* halves: the next pair's block */ \
@@ -827,10 +831,10 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp3_kernel(
             if (!(PABL & kPpNoDmaA)) {                                                                \
                 int d1_ = a_dst + pp::A_BYTES;                                                        \
                 if (d1_ == kABytes) d1_ = 0;                                                          \
-                if ((PART) == 0) ERH_PP2_GLDS(pa[0], my_dst + a_dst);                                 \
-                if ((PART) == 1) ERH_PP2_GLDS(pa[0] + 32, my_dst + d1_);                              \
-                if ((PART) == 2) ERH_PP2_GLDS(pa[1], my_dst + a_dst + 8192);                          \
-                if ((PART) == 3) ERH_PP2_GLDS(pa[1] + 32, my_dst + d1_ + 8192);                       \
+                if ((PART) == 0) ERH_PP2_GLDS_X(pa[0], my_dst + a_dst);                                 \
+                if ((PART) == 1) ERH_PP2_GLDS_X(pa[0] + 32, my_dst + d1_);                              \
+                if ((PART) == 2) ERH_PP2_GLDS_X(pa[1], my_dst + a_dst + 8192);                          \
+                if ((PART) == 3) ERH_PP2_GLDS_X(pa[1] + 32, my_dst + d1_ + 8192);                       \
             }                                                                                         \
             if ((PART) == 3) {                                                                        \
                 ka += 2;                                                                              \
@@ -1119,6 +1123,7 @@ __global__ __launch_bounds__(pp::NT) void dense_scan_pp3_kernel(
 #undef ERH_PP3_WAIT
 }
 #undef ERH_PP2_GLDS
+#undef ERH_PP2_GLDS_X
 #undef ERH_PP2_ISSUE_A
 #undef ERH_PP2_ISSUE_B
 
@@ -1651,6 +1656,9 @@ hipError_t launch_pp(const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1
     // lean: bit 0 = lean-issue kernel, bits 1-2 = its VAR, bits 8.. = rot_stages (see dense_scan_pp2_kernel)
     const int var = (lean >> 1) & 3, rot = lean >> 8;
     const bool halfq = (lean & 8) && B <= pp::BN / 2 && Bpad == pp::BN;
+    // lean bit 4: chunk-side LDS-DMA with the non-temporal hint -- only where every chunk row has ONE reader (one query tile), on the
+    // row-major plain variant of the strict ping-pong kernel
+    const bool nt_x = (lean & 16) && (lean & 8) && n_qt == 1 && var == 0 && !seed && pabl == 0;
 #define ERH_LAUNCH_PP2(A, V)                                                                               \
     hipLaunchKernelGGL((dense_scan_pp2_kernel<A, V>), grid, block, pp::LDS_BYTES, st, X, N, d, c0, c1, Q, Bpad, B, \
                        tau, filter_dir, dir_id, cand, cand_cnt, cap, overflow, dbg, rot)
@@ -1661,6 +1669,8 @@ hipError_t launch_pp(const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1
     do {                                                                                                   \
         if (seed) {                                        /* the sample pass: row-major operands, full kernel only */ \
             if (halfq) ERH_LAUNCH_PP3V(0, 24); else ERH_LAUNCH_PP3V(0, 16);                                \
+        } else if (nt_x) {                                                                                 \
+            if (halfq) ERH_LAUNCH_PP3V(0, 72); else ERH_LAUNCH_PP3V(0, 64);                                \
         } else if (halfq && pp3_halfq_ok(A)) {             /* 65 ... 128 queries: the nt = 1 half of the tile is not computed */ \
             if (var & 2) ERH_LAUNCH_PP3V(pp3_halfq_mask(A), 10); else ERH_LAUNCH_PP3V(pp3_halfq_mask(A), 8); \
         } else if (var & 2)                                                                                \
@@ -1746,6 +1756,7 @@ hipError_t dense_scan_init() {
     ERH_SET_PP3(0, 8) ERH_SET_PP3(0, 10) ERH_SET_PP3(0, 16) ERH_SET_PP3(0, 24)
     ERH_SET_PP3(0, 32) ERH_SET_PP3(0, 40)              // the grouped launch (several matrices, one per query tile), whole / half query tile
     ERH_SET_PP3(0, 48) ERH_SET_PP3(0, 56)              // ... and its sample pass
+    ERH_SET_PP3(0, 64) ERH_SET_PP3(0, 72) ERH_SET_PP3(0, 96) ERH_SET_PP3(0, 104)   // chunk-side loads with the non-temporal hint (one query tile per matrix)
     e = hipFuncSetAttribute((const void *)dense_scan_pp5_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, pp::LDS_BYTES);
     if (e != hipSuccess) return e;
 #ifdef ERH_MEASURE
@@ -1800,7 +1811,7 @@ hipError_t launch_dense_scan_store_grouped(const ErhGroupIo &gio, int n_qt, int 
 
 hipError_t launch_dense_scan_pp_grouped(const ErhGroupIo &gio, int grid, int d, const _Float16 *Q, int Bpad, const float *tau,
                                         ErhCand *cand, uint32_t *cand_cnt, int cap, uint32_t *overflow, int halfq, hipStream_t st,
-                                        const ErhSeedIo *sio) {
+                                        const ErhSeedIo *sio, int nt) {
     if (grid <= 0) return hipSuccess;
     if (d % (2 * pp::BK) != 0 || d / pp::BK < 8) return hipErrorInvalidValue;
     erh::ErhSeedIo sio_v{};
@@ -1810,6 +1821,7 @@ hipError_t launch_dense_scan_pp_grouped(const ErhGroupIo &gio, int grid, int d, 
                        (int64_t)0, d, (int64_t)0, (int64_t)0, Q, Bpad, Bpad, tau, (const int16_t *)nullptr, (const int16_t *)nullptr, cand, \
                        cand_cnt, cap, overflow, (unsigned long long *)nullptr, 0, (uint32_t *)nullptr, sio_v, gio)
     if (sio_v.mode == 1) { if (halfq) ERH_LAUNCH_PP3G(56); else ERH_LAUNCH_PP3G(48); }
+    else if (nt) { if (halfq) ERH_LAUNCH_PP3G(104); else ERH_LAUNCH_PP3G(96); }
     else if (halfq) ERH_LAUNCH_PP3G(40);
     else ERH_LAUNCH_PP3G(32);
 #undef ERH_LAUNCH_PP3G

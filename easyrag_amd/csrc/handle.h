@@ -242,6 +242,10 @@ struct erh_handle {
     // 48 / 64 (four column groups): +4 / +1 %; beside the BM25 scan of a fused single query: +2 ... +8 % (the side stream's postings and
     // the hinted stream fight over the same queues) -- there the plain loads stay.
     int opt_gemv_nt = -1;
+    // 256 x 256 ping-pong scan at ONE query tile per matrix (<= 256 queries, the grouped launch): chunk-side LDS-DMA with the non-temporal hint
+    // (dense_scan_pp3_kernel VAR bit 6).  Measured (profiles/r06v_ab_scan_nt_*.log): +2.2 % scan at 256 queries, +5.5 % at 128, +0.8 % grouped -- the
+    // second 64-byte half of a line no longer finds the first one's fill in L1.  Off; kept as an arm.
+    int opt_dense_scan_nt = 0;
     bool sparse_beside = false;              // erh_hybrid_topk, hybrid_overlap 1: the sparse route runs on the side stream beside this dense pipeline
     int opt_gemv_kb = 32, opt_gemv_wgs = 2;  // skinny-GEMM stream: steps whose loads are in flight together, workgroups per CU at most
     int opt_dense_gemv = 1;                // batches of <= 16 queries: skinny-GEMM stream instead of the padded 256-query scan

@@ -52,7 +52,8 @@ hipError_t launch_dense_scan_pp_grouped(const ErhGroupIo &gio, int grid, int d, 
                                         int halfq /* every tile holds at most 128 queries: the other half of the tile is not computed */,
                                         hipStream_t st,
                                         const ErhSeedIo *sio = nullptr /* the grouped SAMPLE PASS: rows [0, seed_rows) of every view, the cells' two best
-                                                                          scores to sio->seed_top[q][sio->n_cells][2] (n_cells: the largest of the views) */);
+                                                                          scores to sio->seed_top[q][sio->n_cells][2] (n_cells: the largest of the views) */,
+                                        int nt = 0 /* main scan: chunk-side loads with the non-temporal hint (every view's rows have one reader) */);
 // chunk streams (co-resident workgroups per query tile) of the ping-pong scan on n_cus CUs, 0 if the shape does not qualify
 int dense_scan_pp_streams(int n_cus, int Bpad);
 hipError_t dense_scan_init();

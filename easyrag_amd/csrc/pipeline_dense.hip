@@ -62,7 +62,7 @@ static hipError_t scan_append(erh_handle *h, const _Float16 *X, int64_t N, int d
                                                  cand, cnt, cap, flags, h->n_cus, h->opt_dense_ablate,
                                                  h->opt_debug_counters ? h->dbg.as<unsigned long long>() : nullptr,
                                                  (h->opt_dense_pp >= 2 && own)
-                                                     ? (1 | (var << 1) | (h->opt_dense_pp >= 3 ? 8 : 0) | (dense_rot_stages(h, d, Bpad) << 8)) : 0,
+                                                     ? (1 | (var << 1) | (h->opt_dense_pp >= 3 ? 8 : 0) | (h->opt_dense_scan_nt ? 16 : 0) | (dense_rot_stages(h, d, Bpad) << 8)) : 0,
                                                  sync, nullptr, st);
         if (e != hipErrorInvalidValue) { h->stats.dense_scan_pp3 += (c1 > c0); return e; }
         (void)hipGetLastError();
@@ -675,7 +675,7 @@ static int dense_topk_grouped(erh_handle *h, const void *q_dev, int q_dtype, int
     if (P.grid > 0) {
         ProfScope ps(h, st, ERH_K_DENSE_SCAN, scan_rows * d * 2.0 + (double)Bpad * d * 2.0, 2.0 * scan_rows * 256.0 * d);
         HIPCHK(h, erh::launch_dense_scan_pp_grouped(gio, P.grid, d, h->Q16.as<_Float16>(), Bpad, h->tau.as<float>(), h->cand.as<ErhCand>(),
-                                                    h->cand_cnt.as<uint32_t>(), cap, flags, P.halfq ? 1 : 0, st));
+                                                    h->cand_cnt.as<uint32_t>(), cap, flags, P.halfq ? 1 : 0, st, nullptr, h->opt_dense_scan_nt));
         h->stats.dense_scan_pp3 += 1;
     }
     if (h->fork_after_scan) HIPCHK(h, hipEventRecord(h->ev_fork, st));

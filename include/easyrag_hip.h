@@ -312,6 +312,8 @@ int erh_reset_kernel_time(erh_handle *h);
  *   dense_var, dense_rot, dense_sync   schedule variants of the ping-pong kernels (measured, off: see DESIGN.md, dead ends)
  *   dense_gemv (1)        batches of at most 16 queries stream the chunk matrix through a 16x16x32 skinny-GEMM kernel
  *                         (the reference's one-query-at-a-time call pattern) instead of the padded 256-query scan
+ *   dense_scan_nt (0)     256 x 256 ping-pong scan at one query tile per matrix (<= 256 queries, the grouped launch): chunk-side LDS-DMA with
+ *                         the non-temporal hint.  Measured +2 % (256 queries), +5.5 % (128), +0.8 % (grouped): off; a parity arm
  *   dense_gemv_nt (-1)    that stream's chunk loads with the non-temporal hint: -1 on for calls of up to 32 queries unless the sparse
  *                         route of a fused call runs beside it (hybrid_overlap 1), 0 off, 1 on.  Same results
  *   bm25_ascan (1)        fixed-point BM25 scan + exact re-score: the postings are scattered into integer LDS sums in any order
