@@ -96,6 +96,7 @@ hipError_t launch_dense_naive(const _Float16 *Q, int B, const _Float16 *X, int64
                               float *out, hipStream_t st);
 
 // ---- dense_gemv.hip: append scan for batches of at most dense_gemv_max_queries() queries ----------------------------
+void dense_finalize_set_wgs(int v);
 int dense_gemv_max_queries();
 hipError_t dense_gemv_init();
 hipError_t launch_dense_gemv_append(const _Float16 *X, int64_t N, int d, int64_t c0, int64_t c1, const _Float16 *Q, int B,

@@ -460,6 +460,19 @@ __global__ __launch_bounds__(256) void scatter_topk_rows_kernel(const int32_t *_
 // score, and only entries >= p - margin (about k of them) are gathered into LDS and sorted.
 constexpr int kFinBuf = 2048;
 
+// Product of two fp16 values as fp32, straight from the packed halves: v_fma_mix_f32 widens both factors inside the instruction
+// (op_sel picks the half, op_sel_hi marks the source as fp16) and adds +0 -- one VALU instruction where v_cvt_f32_f16 + v_mul_f32 take
+// two.  The product has 22 significant bits, so it is exact either way; the +0 can only turn a -0 product into +0, which adds
+// the same nothing to the fp64 sum (the sum starts at +0 and +0 + -0 = +0: it is never -0).  HI: the dword's upper half.
+template <bool HI>
+__device__ __forceinline__ float fin_mul_f16(uint32_t x2, uint32_t q2) {
+    float p;
+    if constexpr (HI) asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "=v"(p) : "v"(x2), "v"(q2));
+    else asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[1,1,0]" : "=v"(p) : "v"(x2), "v"(q2));
+    return p;
+}
+typedef uint32_t fin_u4 __attribute__((ext_vector_type(4)));
+
 // 512 threads (a 256-VGPR budget): two workgroups per CU, and room to fetch the next pair of rows while the current
 // pair is accumulated -- the row gathers (2 KiB each, anywhere in HBM) are what this kernel waits for.
 constexpr int kFinThreads = 512;
@@ -467,9 +480,13 @@ constexpr int kFinSlots = 1024;                      // pivot granularity: strid
 
 // QR = rounds of 512 row elements held in registers (d <= 512 * QR runs entirely from them); with QR <= 2 the kernel
 // fits 128 VGPRs, i.e. TWO workgroups per CU (at 144 registers only one fits, and the row gathers of one workgroup do
-// not keep a CU's memory queue busy).
+// not keep a CU's memory queue busy).  Round 6: with the products from v_fma_mix_f32 (fin_mul_f16: no fp32 copy of the query
+// fragments) the QR <= 2 kernels fit 80 VGPRs = THREE workgroups per CU (launch bound 6 waves per SIMD; 32 bytes of scratch
+// outside the row loop): 1024 queries 0.207 -> 0.194 ms of the select class against two workgroups of the same code (-6.4 %,
+// interleaved: profiles/r06x_ab_fin_wgs_*.log; option dense_fin_wgs = 2 is that arm), 0.198 -> 0.194 against the 112-VGPR kernel
+// of the rounds before; 256 queries +-0.
 template <int QR>
-__global__ __launch_bounds__(kFinThreads, (QR <= 2) ? 4 : 2) void dense_finalize_kernel(
+__global__ __launch_bounds__(kFinThreads, (QR <= 2) ? 6 : 2) void dense_finalize_kernel(
     int k, int mode, const float *__restrict__ qnorm, float xnorm_max, int d,
     const _Float16 *__restrict__ X, const _Float16 *__restrict__ Q16,
     const ErhCand *__restrict__ cand, const uint32_t *__restrict__ cand_cnt, int cap,
@@ -641,13 +658,15 @@ __global__ __launch_bounds__(kFinThreads, (QR <= 2) ? 4 : 2) void dense_finalize
 #pragma unroll
         for (int t = 0; t < QR; ++t) {
             if (512 * t + 8 * lane < d) {
+                const fin_u4 q2 = __builtin_bit_cast(fin_u4, qreg[t]);
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
 #pragma unroll
                     for (int r = 0; r < RW; ++r) {
                         // the product of two fp16 values has 22 significant bits: exact in fp32 (and far from its
                         // subnormal range), so widening the PRODUCT gives the same double as multiplying widened factors
-                        const float p32 = (float)xa[r][t][u] * (float)qreg[t][u];
+                        const fin_u4 x2 = __builtin_bit_cast(fin_u4, xa[r][t]);
+                        const float p32 = (u & 1) ? fin_mul_f16<true>(x2[u >> 1], q2[u >> 1]) : fin_mul_f16<false>(x2[u >> 1], q2[u >> 1]);
                         acc[r] = acc[r] + (double)p32;
                     }
             }
@@ -995,6 +1014,10 @@ hipError_t launch_cand_refine(int B, int k, const float *qnorm, float xnorm_max,
 // four -0.5 %, eight +2.7 %, sixteen +11 % (profiles/r05m_ab_fin_split.log): the redundant pivot / sort stage of 16 x B workgroups costs more
 // than the shared row gathers save as soon as the queries alone spread over the chip.
 int dense_finalize_split_max() { return 2; }
+// option dense_fin_wgs: workgroups of the final kernel per CU -- 3 (what 80 VGPRs and ~40 KiB of LDS allow) or 2 (an A/B arm: 16 KiB of unused
+// dynamic LDS per workgroup keep the third one out)
+static int g_fin_wgs = 3;
+void dense_finalize_set_wgs(int v) { g_fin_wgs = v <= 2 ? 2 : 3; }
 
 hipError_t launch_dense_finalize(int B, int k, int mode, const float *qnorm, float xnorm_max, int d,
                                  const _Float16 *X, const _Float16 *Q16,
@@ -1011,7 +1034,7 @@ hipError_t launch_dense_finalize(int B, int k, int mode, const float *qnorm, flo
     ErhGroupIo gv{};
     if (gio) gv = *gio;
 #define ERH_FIN_LAUNCH(QR)                                                                                  \
-    hipLaunchKernelGGL(dense_finalize_kernel<QR>, dim3(B * G), dim3(kFinThreads), 0, st, k, mode, qnorm, xnorm_max, d, X, Q16, \
+    hipLaunchKernelGGL(dense_finalize_kernel<QR>, dim3(B * G), dim3(kFinThreads), g_fin_wgs == 2 ? 16384 : 0, st, k, mode, qnorm, xnorm_max, d, X, Q16, \
                        cand, cand_cnt, cap, out_ids, out_scores, out_len, diag_maxerr, diag_uncert, bad, N, pos_mul, \
                        pos_inv, tau_verify, G, ws_s64, ws_sync, gv)
     if (d <= 512) ERH_FIN_LAUNCH(1);
