@@ -324,6 +324,38 @@ def test_dense_sample_pass_matches_oracle(engine, b, k):
         assert np.array_equal(sc[i].view(np.uint64), osc.view(np.uint64)), f"query {i}: fp64 scores differ"
 
 
+@pytest.mark.parametrize("b,k", [(1, 288), (7, 100), (24, 288), (40, 60), (100, 100), (256, 100)])
+def test_dense_cache_policy_and_occupancy_arms(engine, b, k):
+    """Round 6 arms that must never change a result: the skinny-GEMM stream's chunk loads with / without the non-temporal hint
+    (dense_gemv_nt; default: by call), the 256 x 256 scan's chunk-side LDS-DMA with it (dense_scan_nt; incl. the half-tile variant at
+    65 ... 128 queries), two / three workgroups of the final kernel per CU (dense_fin_wgs).  Every arm equals the default bit for bit,
+    the default equals the oracle (ids + pinned-order fp64 scores)."""
+    n, d = 150_000, 512
+    x = synth.dense_corpus(n, d, seed=611)
+    q16 = to_f16_unit(synth.dense_queries(x, b, seed=612 + b))
+    engine.set_dense(x)
+    try:
+        ids, sc, ln = engine.dense_topk(q16, k)
+        diag = engine.dense_diag()
+        assert diag["uncertified"] == 0 and diag["max_abs_err"] <= diag["margin"] and diag["exhaustive"] == 0
+        for name, value, reset in (("dense_gemv_nt", 0, -1), ("dense_gemv_nt", 1, -1), ("dense_scan_nt", 1, 0), ("dense_fin_wgs", 2, 3)):
+            engine.set_option(name, value)
+            try:
+                ids1, sc1, ln1 = engine.dense_topk(q16, k)
+            finally:
+                engine.set_option(name, reset)
+            assert np.array_equal(ids, ids1) and np.array_equal(sc.view(np.uint64), sc1.view(np.uint64)) and np.array_equal(ln, ln1), (name, value)
+    finally:
+        engine.set_option("dense_gemv_nt", -1)
+        engine.set_option("dense_scan_nt", 0)
+        engine.set_option("dense_fin_wgs", 3)
+    assert np.all(ln == k)
+    for i in sorted(set([0, b // 2, b - 1])):
+        oid, osc = dense_exact_topk(x, q16[i], k)
+        assert np.array_equal(ids[i], oid), f"query {i}: ids differ"
+        assert np.array_equal(sc[i].view(np.uint64), osc.view(np.uint64)), f"query {i}: fp64 scores differ"
+
+
 def test_dense_sample_pass_with_a_cell_full_of_copies(engine):
     """Eight copies of the chunk a query asks for, planted in ONE cell of the sampled rows (stored rows 0-3 and 8-11 of tile 0:
     one lane of one wave holds them; dense_shuffle = 0 keeps the caller's order).  The cell shows the sample only two of them

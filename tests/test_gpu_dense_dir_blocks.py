@@ -79,6 +79,11 @@ def test_blocks_mixed_batch_against_oracle(blocks_opts):
     assert engine.dense_diag()["uncertified"] == 0
     _same(plain, routed)
     _check_oracle(x, q16, k, dir_id, filt, routed, range(b))
+    engine.set_option("dense_scan_nt", 1)                          # the grouped scan's chunk-side loads with the non-temporal hint: an arm, same lists
+    try:
+        _same(routed, engine.dense_topk(q16, k, filter_dir=filt))
+    finally:
+        engine.set_option("dense_scan_nt", 0)
     # device outputs: complete after dense_check, identical
     import torch
     out = engine.dense_topk(torch.from_numpy(q16).cuda(), k, device_out=True, filter_dir=filt)
