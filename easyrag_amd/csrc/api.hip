@@ -120,7 +120,7 @@ int erh_set_option(erh_handle *h, const char *name, int64_t value) {
     if (!strcmp(name, "dense_gemv_kb")) { if (value != 16 && value != 32) return h->fail(ERH_ERR_INVALID, "dense_gemv_kb"); h->opt_gemv_kb = (int)value; return ERH_OK; }
     if (!strcmp(name, "dense_gemv_pipe")) { if (value < -1 || value > 1) return h->fail(ERH_ERR_INVALID, "dense_gemv_pipe"); h->opt_gemv_pipe = (int)value; return ERH_OK; }
     if (!strcmp(name, "dense_gemv_nt")) { if (value < -1 || value > 1) return h->fail(ERH_ERR_INVALID, "dense_gemv_nt"); h->opt_gemv_nt = (int)value; return ERH_OK; }
-    if (!strcmp(name, "dense_fin_wgs")) { if (value < 2 || value > 3) return h->fail(ERH_ERR_INVALID, "dense_fin_wgs"); erh::dense_finalize_set_wgs((int)value); return ERH_OK; }
+    if (!strcmp(name, "dense_fin_wgs")) { if (value < 2 || value > 4) return h->fail(ERH_ERR_INVALID, "dense_fin_wgs"); erh::dense_finalize_set_wgs((int)value); return ERH_OK; }
     if (!strcmp(name, "dense_scan_nt")) { h->opt_dense_scan_nt = value != 0; return ERH_OK; }
     if (!strcmp(name, "dense_gemv_wgs")) { if (value < 1 || value > 5) return h->fail(ERH_ERR_INVALID, "dense_gemv_wgs"); h->opt_gemv_wgs = (int)value; return ERH_OK; }
     if (!strcmp(name, "dense_small_single_stage")) { h->opt_small_single = value != 0; return ERH_OK; }

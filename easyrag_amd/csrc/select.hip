@@ -481,12 +481,15 @@ constexpr int kFinSlots = 1024;                      // pivot granularity: strid
 // QR = rounds of 512 row elements held in registers (d <= 512 * QR runs entirely from them); with QR <= 2 the kernel
 // fits 128 VGPRs, i.e. TWO workgroups per CU (at 144 registers only one fits, and the row gathers of one workgroup do
 // not keep a CU's memory queue busy).  Round 6: with the products from v_fma_mix_f32 (fin_mul_f16: no fp32 copy of the query
-// fragments) the QR <= 2 kernels fit 80 VGPRs = THREE workgroups per CU (launch bound 6 waves per SIMD; 32 bytes of scratch
-// outside the row loop): 1024 queries 0.207 -> 0.194 ms of the select class against two workgroups of the same code (-6.4 %,
-// interleaved: profiles/r06x_ab_fin_wgs_*.log; option dense_fin_wgs = 2 is that arm), 0.198 -> 0.194 against the 112-VGPR kernel
-// of the rounds before; 256 queries +-0.
+// fragments), two rows per wave and iteration instead of three (as many again in flight) and the pivot's maxima in r_idx's
+// storage the QR <= 2 kernels fit 64 VGPRs and 36 KiB of LDS = FOUR workgroups per CU (launch bound 8 waves per SIMD; 24 bytes of
+// scratch outside the row loop) -- at 1024 queries every CU's four queries are resident at once instead of two and two (or three and
+// one: the last round gathered with a quarter of the chip's waves).  Select class per 1024 queries, interleaved
+// (profiles/r06zd_ab_fin_wgs4_*.log; option dense_fin_wgs = 2 / 3 keeps the others out with unused dynamic LDS): 0.200 / 0.194 / 0.177 ms
+// at 2 / 3 / 4 workgroups (-11.5 %; 0.198 with the 112-VGPR kernel of the rounds before), the filtered 1024-query step 1.289 -> 1.263;
+// 256 and 512 queries (one / two queries per CU) +-0.
 template <int QR>
-__global__ __launch_bounds__(kFinThreads, (QR <= 2) ? 6 : 2) void dense_finalize_kernel(
+__global__ __launch_bounds__(kFinThreads, (QR <= 2) ? 8 : 2) void dense_finalize_kernel(
     int k, int mode, const float *__restrict__ qnorm, float xnorm_max, int d,
     const _Float16 *__restrict__ X, const _Float16 *__restrict__ Q16,
     const ErhCand *__restrict__ cand, const uint32_t *__restrict__ cand_cnt, int cap,
@@ -501,9 +504,10 @@ __global__ __launch_bounds__(kFinThreads, (QR <= 2) ? 6 : 2) void dense_finalize
     const erh::ErhGroupIo gio /* views != null: the grouped call (G == 1) -- matrix and placement of the query's tile, results to the
                                  caller's row, block rows mapped to document ids */) {
     __shared__ __attribute__((aligned(16))) uint64_t buf[kFinBuf];
-    __shared__ uint32_t tmax[kFinSlots];
     __shared__ double r_s64[erh::kDenseRescoreMax];
     __shared__ int32_t r_idx[erh::kDenseRescoreMax];
+    static_assert(erh::kDenseRescoreMax >= kFinSlots, "the pivot's maxima live in r_idx's storage");
+    uint32_t *const tmax = reinterpret_cast<uint32_t *>(r_idx);         // (dead before r_idx is written: 36 KiB of LDS = four workgroups per CU)
     __shared__ float r_s32[erh::kDenseRescoreMax];
     __shared__ int32_t r_pos[erh::kDenseRescoreMax];                    // stored position of the candidate (row of X)
     __shared__ int s_cnt, s_m, s_lvl, s_last;
@@ -618,7 +622,7 @@ __global__ __launch_bounds__(kFinThreads, (QR <= 2) ? 6 : 2) void dense_finalize
     // registers (rounds of 512 elements, up to 4 = d <= 2048; longer rows reload them).
     const int lane = tid & 63, wave = tid >> 6;
     const _Float16 *qrow = Q16 + (int64_t)q * d;
-    constexpr int RW = (QR == 1) ? 4 : (QR == 2) ? 3 : 2;               // rows per wave iteration (as many again are in flight)
+    constexpr int RW = (QR == 1) ? 3 : 2;               // rows per wave iteration (as many again are in flight)
     constexpr int kWaves = kFinThreads / 64;
     half8 qreg[QR];
 #pragma unroll
@@ -1014,10 +1018,10 @@ hipError_t launch_cand_refine(int B, int k, const float *qnorm, float xnorm_max,
 // four -0.5 %, eight +2.7 %, sixteen +11 % (profiles/r05m_ab_fin_split.log): the redundant pivot / sort stage of 16 x B workgroups costs more
 // than the shared row gathers save as soon as the queries alone spread over the chip.
 int dense_finalize_split_max() { return 2; }
-// option dense_fin_wgs: workgroups of the final kernel per CU -- 3 (what 80 VGPRs and ~40 KiB of LDS allow) or 2 (an A/B arm: 16 KiB of unused
-// dynamic LDS per workgroup keep the third one out)
-static int g_fin_wgs = 3;
-void dense_finalize_set_wgs(int v) { g_fin_wgs = v <= 2 ? 2 : 3; }
+// option dense_fin_wgs: workgroups of the final kernel per CU -- 4 (what 64 VGPRs and 36 KiB of LDS allow) or 3 / 2 (A/B arms: unused
+// dynamic LDS per workgroup keeps the others out)
+static int g_fin_wgs = 4;
+void dense_finalize_set_wgs(int v) { g_fin_wgs = v <= 2 ? 2 : v == 3 ? 3 : 4; }
 
 hipError_t launch_dense_finalize(int B, int k, int mode, const float *qnorm, float xnorm_max, int d,
                                  const _Float16 *X, const _Float16 *Q16,
@@ -1034,7 +1038,7 @@ hipError_t launch_dense_finalize(int B, int k, int mode, const float *qnorm, flo
     ErhGroupIo gv{};
     if (gio) gv = *gio;
 #define ERH_FIN_LAUNCH(QR)                                                                                  \
-    hipLaunchKernelGGL(dense_finalize_kernel<QR>, dim3(B * G), dim3(kFinThreads), g_fin_wgs == 2 ? 16384 : 0, st, k, mode, qnorm, xnorm_max, d, X, Q16, \
+    hipLaunchKernelGGL(dense_finalize_kernel<QR>, dim3(B * G), dim3(kFinThreads), g_fin_wgs == 2 ? 20480 : g_fin_wgs == 3 ? 4608 : 0, st, k, mode, qnorm, xnorm_max, d, X, Q16, \
                        cand, cand_cnt, cap, out_ids, out_scores, out_len, diag_maxerr, diag_uncert, bad, N, pos_mul, \
                        pos_inv, tau_verify, G, ws_s64, ws_sync, gv)
     if (d <= 512) ERH_FIN_LAUNCH(1);

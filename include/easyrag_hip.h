@@ -314,8 +314,8 @@ int erh_reset_kernel_time(erh_handle *h);
  *                         (the reference's one-query-at-a-time call pattern) instead of the padded 256-query scan
  *   dense_scan_nt (0)     256 x 256 ping-pong scan at one query tile per matrix (<= 256 queries, the grouped launch): chunk-side LDS-DMA with
  *                         the non-temporal hint.  Measured +2 % (256 queries), +5.5 % (128), +0.8 % (grouped): off; a parity arm
- *   dense_fin_wgs (3)     workgroups of the final kernel per CU (3: what its 80 VGPRs and 40 KiB of LDS allow; 2: the A/B arm, -6 % select time
- *                         at 1024 queries).  Process-wide.  Same results
+ *   dense_fin_wgs (4)     workgroups of the final kernel per CU (4: what its 64 VGPRs and 36 KiB of LDS allow; 3 / 2: A/B arms -- select time
+ *                         per 1024 queries 0.177 / 0.194 / 0.200 ms at 4 / 3 / 2).  Process-wide.  Same results
  *   dense_gemv_nt (-1)    that stream's chunk loads with the non-temporal hint: -1 on for calls of up to 32 queries unless the sparse
  *                         route of a fused call runs beside it (hybrid_overlap 1), 0 off, 1 on.  Same results
  *   bm25_ascan (1)        fixed-point BM25 scan + exact re-score: the postings are scattered into integer LDS sums in any order

@@ -338,7 +338,7 @@ def test_dense_cache_policy_and_occupancy_arms(engine, b, k):
         ids, sc, ln = engine.dense_topk(q16, k)
         diag = engine.dense_diag()
         assert diag["uncertified"] == 0 and diag["max_abs_err"] <= diag["margin"] and diag["exhaustive"] == 0
-        for name, value, reset in (("dense_gemv_nt", 0, -1), ("dense_gemv_nt", 1, -1), ("dense_scan_nt", 1, 0), ("dense_fin_wgs", 2, 3)):
+        for name, value, reset in (("dense_gemv_nt", 0, -1), ("dense_gemv_nt", 1, -1), ("dense_scan_nt", 1, 0), ("dense_fin_wgs", 2, 4), ("dense_fin_wgs", 3, 4)):
             engine.set_option(name, value)
             try:
                 ids1, sc1, ln1 = engine.dense_topk(q16, k)
@@ -348,7 +348,7 @@ def test_dense_cache_policy_and_occupancy_arms(engine, b, k):
     finally:
         engine.set_option("dense_gemv_nt", -1)
         engine.set_option("dense_scan_nt", 0)
-        engine.set_option("dense_fin_wgs", 3)
+        engine.set_option("dense_fin_wgs", 4)
     assert np.all(ln == k)
     for i in sorted(set([0, b // 2, b - 1])):
         oid, osc = dense_exact_topk(x, q16[i], k)
