@@ -179,6 +179,21 @@ def test_bm25_mixed_launch_cuts_long_queries(engine, variant):
                 want = bm25_filter(_oracle_scores(ora, variant, qs[i]), k, mask)
                 assert list(ids[i, :ln[i]]) == [w[0] for w in want], (i, len(qs[i]))
                 assert list(sc[i, :ln[i]]) == [w[1] for w in want], (i, len(qs[i]))
+        # every query of the batch long: the item list is B x bm25_long_segs, nothing takes the packed body, every row comes from the merge
+        all_long = [[docs[int(t)][int(u) % len(docs[int(t)])] for u in rng.integers(0, 1000, int(rng.integers(29, 46)))] for t in rng.integers(0, n, 512)]
+        csr_l = queries_to_csr([idx.tokens_to_ids(q) for q in all_long])
+        engine.set_option("bm25_long_tokens", 28)
+        engine.set_option("bm25_mixed", 1)
+        engine.set_option("bm25_long_segs", 2)
+        engine.reset_stats()
+        a = engine.bm25_topk(*csr_l, k)
+        assert engine.stat("bm25_mixed_launches") == 1
+        engine.set_option("bm25_mixed", 0)
+        b_ = engine.bm25_topk(*csr_l, k)
+        assert np.array_equal(a[2], b_[2]) and np.array_equal(a[0], b_[0]) and np.array_equal(a[1].view(np.uint64), b_[1].view(np.uint64))
+        for i in (0, 255, 511):
+            want = bm25_filter(_oracle_scores(ora, variant, all_long[i]), k, None)
+            assert list(a[0][i, :a[2][i]]) == [w[0] for w in want] and list(a[1][i, :a[2][i]]) == [w[1] for w in want], i
     finally:
         engine.set_option("bm25_long_tokens", 28)
         engine.set_option("bm25_mixed", 1)
