@@ -1,6 +1,6 @@
 #!/bin/bash
 set -u
-OUT=gpurun_out/r06p
+OUT=gpurun_out/r06zj
 mkdir -p $OUT
 export TMPDIR=/tmp
 for what in filtered hybrid; do
