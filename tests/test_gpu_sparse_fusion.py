@@ -48,6 +48,17 @@ def _oracle_scores(ora, variant, q):
     return ora.get_scores(q)
 
 
+_HOST_CACHE = {}
+
+
+def _cached(key, fn):
+    """Host-side work that is a pure function of a test's seeds (the token lists, the oracle object, the host-built index, the oracle's
+    answer for one query): evaluated once and shared by the nine kernel arms of a parametrized test -- the arms differ on the device only."""
+    if key not in _HOST_CACHE:
+        _HOST_CACHE[key] = fn()
+    return _HOST_CACHE[key]
+
+
 @pytest.mark.parametrize("variant", [OKAPI, BM25S])
 @pytest.mark.parametrize("n_docs,vocab,seed", [(60, 10, 0), (3000, 500, 1), (40000, 2000, 2)])
 def test_bm25_scores_and_topk_match_oracle(engine, bm25_kernel, variant, n_docs, vocab, seed):
@@ -483,9 +494,9 @@ def test_bm25_dir_filter_as_tile_range(engine, bm25_kernel, variant):
     oracle's masked walk, and as the scan over all tiles (bm25_dir_range = 0)."""
     n_docs, vocab = 90000, 3000
     flat, lens = synth.token_corpus(n_docs, vocab, seed=17, mean_len=14)
-    docs = [list(map(int, d)) for d in synth.split_docs(flat, lens)]
-    ora = _oracle_for(variant, docs)
-    idx = build_bm25_index(docs, variant)
+    docs = _cached(("tile_range", "docs"), lambda: [list(map(int, d)) for d in synth.split_docs(flat, lens)])
+    ora = _cached(("tile_range", "ora", variant), lambda: _oracle_for(variant, docs))
+    idx = _cached(("tile_range", "idx", variant), lambda: build_bm25_index(docs, variant))
     engine.set_bm25(idx)
     dir_id = np.zeros(n_docs, np.int16)
     dir_id[20000:52000] = 1                       # ends inside a tile
@@ -509,7 +520,7 @@ def test_bm25_dir_filter_as_tile_range(engine, bm25_kernel, variant):
             ids, sc, ln = got[1]
             for b, q in enumerate(queries):
                 mask = None if filt[b] < 0 else dir_id == filt[b]
-                want = bm25_filter(_oracle_scores(ora, variant, q), 50, mask)
+                want = _cached(("tile_range", "want", variant, B, b), lambda: bm25_filter(_oracle_scores(ora, variant, q), 50, mask))
                 assert ln[b] == len(want), (B, b)
                 assert list(ids[b, :ln[b]]) == [w[0] for w in want] and list(sc[b, :ln[b]]) == [w[1] for w in want], (B, b)
                 if filt[b] in (4, 9):
@@ -529,12 +540,12 @@ def test_bm25_reference_question_lengths(engine, bm25_kernel, variant):
     rng = np.random.default_rng(88)
     n, vocab, b, k = 30000, 3000, 103, 60
     flat, lens = synth.token_corpus(n, vocab, seed=31, mean_len=30)
-    docs = [list(map(int, t)) for t in synth.split_docs(flat, lens)]
-    idx = build_bm25_index(docs, variant)
+    docs = _cached(("ref_lengths", "docs"), lambda: [list(map(int, t)) for t in synth.split_docs(flat, lens)])
+    idx = _cached(("ref_lengths", "idx", variant), lambda: build_bm25_index(docs, variant))
     engine.set_bm25(idx)
     dir_id = np.repeat(np.arange(3), [12000, 10000, 8000]).astype(np.int16)
     engine.set_doc_meta(n, None, dir_id)
-    ora = _oracle_for(variant, docs)
+    ora = _cached(("ref_lengths", "ora", variant), lambda: _oracle_for(variant, docs))
     qs = synth.token_queries(flat, lens, vocab, b, seed=32, lengths=sorted(synth.REF_QUESTION_LENGTHS))
     for i, L in enumerate(sorted(synth.REF_QUESTION_LENGTHS)):       # every length of the reference's questions, the 45-token one included
         tgt = docs[int(rng.integers(0, n))]
@@ -557,7 +568,7 @@ def test_bm25_reference_question_lengths(engine, bm25_kernel, variant):
                 assert np.array_equal(sc.view(np.uint64), got[other][1].view(np.uint64)), other
             for i in range(b):
                 mask = None if f is None or f[i] < 0 else dir_id == f[i]
-                want = bm25_filter(ora.get_scores(list(map(int, qs[i]))), k, mask)
+                want = _cached(("ref_lengths", "want", variant, f is None, i), lambda: bm25_filter(ora.get_scores(list(map(int, qs[i]))), k, mask))
                 assert list(ids[i, :ln[i]]) == [w[0] for w in want], (i, len(qs[i]))
                 assert list(sc[i, :ln[i]]) == [w[1] for w in want], (i, len(qs[i]))
     finally:
