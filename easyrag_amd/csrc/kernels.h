@@ -107,7 +107,7 @@ hipError_t launch_dense_gemv_store(const _Float16 *X, int64_t N, int d, int64_t 
                                    float *S0, int ld_s0, int n_cus, int kb, int wgs, int pipe, hipStream_t st);
 
 // ---- select.hip ------------------------------------------------------------------------------
-constexpr int kDenseN0Max = 32768;    // seed prefix: one fp32 score row must fit LDS for the k-th select
+constexpr int kDenseN0Max = 32768;    // longest seed prefix (one fp32 score row per query in S0; until round 6 it also had to fit LDS for the full-sort fall-back)
 constexpr int kDenseCapMax = 16384;   // candidates per query that the LDS sort can hold (64-bit keys)
 constexpr int kDenseRescoreMax = 1024;
 hipError_t select_init();

@@ -143,9 +143,8 @@ __global__ __launch_bounds__(256) void row_norm_max_kernel(const _Float16 *__res
 // k-th value, and only ~k*(1+k/2048) keys are >= p.  Those are compacted and sorted.
 // Fast kernel (`seed_select_kernel`): the row is read twice from memory -- thread maxima, then the gather above the pivot
 // (it was written by the store kernel a moment ago and sits in L2 / Infinity Cache); 36 KiB of LDS, two workgroups per CU.
-// Inputs that defeat the pivot (more than kSeedBuf keys >= p, or fewer than k threads holding a valid key) are
-// flagged in need_full[q] and redone by `seed_select_full_kernel`, which stages the whole row in LDS and sorts it
-// (it returns at once for every other query).
+// Inputs that defeat the pivot (more than kSeedBuf keys >= p, or fewer than k threads holding a valid key) take the kernel's own
+// fall-back: a radix select of the rank-th largest key over the row itself (round 6; a second, full-sort kernel before).
 constexpr int kSeedBuf = 4096;
 
 __device__ __forceinline__ uint32_t seed_key(const float *__restrict__ row, int i, int n0, int fd,
@@ -230,7 +229,7 @@ __global__ __launch_bounds__(kSelThreads) void seed_select_kernel(
     float *__restrict__ tau, ErhCand *__restrict__ cand, uint32_t *__restrict__ cand_cnt, int cap,
     uint32_t *__restrict__ bad, uint32_t *__restrict__ need_full,
     const erh::ErhDenseView *__restrict__ views /* null, or the grouped call's table: prefix length and rank per query tile */) {
-    __shared__ int s_nvalid, s_cnt, s_cnt2, s_keep;
+    __shared__ int s_nvalid, s_cnt, s_cnt2, s_keep, s_bin, s_need;
     __shared__ uint32_t tmax[kSelThreads];
     __shared__ uint64_t buf[kSeedBuf];
     const int q = blockIdx.x, tid = threadIdx.x;
@@ -302,39 +301,44 @@ __global__ __launch_bounds__(kSelThreads) void seed_select_kernel(
                 return;
             }
         }
-        if (full_sort) {                             // uniform: leave this query to seed_select_full_kernel
-            if (tid == 0) need_full[q] = 1u;
+        if (full_sort) {
+            // uniform, rare (a filter that leaves few strides a valid score, a tie cluster above the pivot): the rank-th largest key of the
+            // WHOLE prefix by a radix select over the row itself -- four passes of eight bits, the row read from L2 each time, a 256-bin
+            // histogram in the (now dead) gather buffer -- then every score >= that - margin is emitted.  Same threshold, same candidates
+            // as sorting the row would give.  (Until round 6 a second kernel with the whole row in 128 KiB of LDS did this; it was launched
+            // behind every seed select -- 5 us + a launch boundary per dense call of < 512 queries -- and returned at once almost always.)
+            uint32_t *const hist = reinterpret_cast<uint32_t *>(buf);
+            uint32_t prefix = 0u, mask = 0u;
+            int need = rank;
+            for (int shift = 24; shift >= 0; shift -= 8) {
+                __syncthreads();                                          // (everyone has read s_bin / s_need of the pass before)
+                if (tid < 256) hist[tid] = 0u;
+                __syncthreads();
+                seed_visit(row, n0, fd, dir_id, c0, [&](uint32_t key, float, int) {
+                    if (key != 0u && (key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+                });
+                __syncthreads();
+                if (tid == 0) {                                           // from the top bin down: the bin that holds the need-th key
+                    int above = 0, b = 255;
+                    for (; b > 0; --b) {
+                        if (above + (int)hist[b] >= need) break;
+                        above += (int)hist[b];
+                    }
+                    s_bin = b;
+                    s_need = need - above;
+                }
+                __syncthreads();
+                prefix |= (uint32_t)s_bin << shift;
+                mask |= 255u << shift;
+                need = s_need;
+            }
+            const float prune = erh_ord2f(prefix) - margin_of(qnorm[q], xnorm_max, d);
+            __syncthreads();                                              // (s_cnt is still 0: seed_emit counts from there)
+            seed_emit(row, n0, c0, fd, dir_id, prune, q, tau, cand, cand_cnt, cap, bad, &s_cnt);
             return;
         }
     }
     seed_emit(row, n0, c0, fd, dir_id, -INFINITY, q, tau, cand, cand_cnt, cap, bad, &s_cnt);   // fewer than k valid rows: all of them
-}
-
-// Full-sort fallback for the queries flagged by seed_select_kernel.  dynamic LDS = 64 + np2*4 bytes.
-__global__ __launch_bounds__(kSelThreads) void seed_select_full_kernel(
-    const float *__restrict__ S0, int ld_s0, int n0, int np2, int64_t c0, int k, int rank,
-    const float *__restrict__ qnorm, float xnorm_max, int d,
-    const int16_t *__restrict__ filter_dir, const int16_t *__restrict__ dir_id,
-    float *__restrict__ tau, ErhCand *__restrict__ cand, uint32_t *__restrict__ cand_cnt, int cap,
-    uint32_t *__restrict__ bad, const uint32_t *__restrict__ need_full, const erh::ErhDenseView *__restrict__ views) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int q = blockIdx.x, tid = threadIdx.x;
-    if (!need_full[q]) return;                       // uniform
-    if (views) {
-        const erh::ErhDenseView &v = views[q >> 8];
-        n0 = v.n0; rank = v.rank;
-        np2 = erh_next_pow2(n0 < 2 ? 2 : n0);           // (<= the launch's np2, which was sized for the longest prefix)
-    }
-    int &s_cnt = *reinterpret_cast<int *>(smem);
-    uint32_t *keys = reinterpret_cast<uint32_t *>(smem + 64);
-    const float *row = S0 + (int64_t)q * ld_s0;
-    const int fd = filter_dir ? (int)filter_dir[q] : -1;
-    if (tid == 0) s_cnt = 0;
-    for (int i = tid; i < np2; i += kSelThreads) keys[i] = seed_key(row, i, n0, fd, dir_id, c0);
-    erh_bitonic_desc<uint32_t>(keys, np2);
-    const float prune = erh_ord2f(keys[rank - 1]) - margin_of(qnorm[q], xnorm_max, d);
-    __syncthreads();
-    seed_emit(row, n0, c0, fd, dir_id, prune, q, tau, cand, cand_cnt, cap, bad, &s_cnt);
 }
 
 // Threshold from the sample pass of the ping-pong scan (round 4; kernels.h: ErhSeedIo): per query n_vals scores -- the two
@@ -915,9 +919,6 @@ static int pow2_ge(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
 hipError_t select_init() {
     hipError_t e;
-    e = hipFuncSetAttribute((const void *)seed_select_full_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            kDenseN0Max * 4 + 64);
-    if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void *)cand_refine_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kDenseCapMax * 8 + 64);
     if (e != hipSuccess) return e;
     return hipSuccess;
@@ -982,9 +983,6 @@ hipError_t launch_seed_select(const float *S0, int ld_s0, int n0, int64_t c0, in
     const int np2 = pow2_ge(n0 < 2 ? 2 : n0);         // (grouped call: n0 = the longest prefix of the table; every tile uses its own)
     if (rank < 1 || rank > k) rank = k;
     hipLaunchKernelGGL(seed_select_kernel, dim3(B), dim3(kSelThreads), 0, st,
-                       S0, ld_s0, n0, np2, c0, k, rank, qnorm, xnorm_max, d, filter_dir, dir_id, tau, cand, cand_cnt, cap,
-                       bad, need_full, views);
-    hipLaunchKernelGGL(seed_select_full_kernel, dim3(B), dim3(kSelThreads), (size_t)np2 * 4 + 64, st,
                        S0, ld_s0, n0, np2, c0, k, rank, qnorm, xnorm_max, d, filter_dir, dir_id, tau, cand, cand_cnt, cap,
                        bad, need_full, views);
     return hipGetLastError();

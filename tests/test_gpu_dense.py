@@ -213,6 +213,42 @@ def test_dense_seed_full_sort_fallback(engine):
         engine.set_option("dense_n1", 131072)
 
 
+@pytest.mark.parametrize("b,k", [(3, 40), (70, 100), (256, 288)])
+def test_dense_seed_fallback_on_a_tie_cluster_in_the_prefix(engine, b, k):
+    """6000 chunks equal to the query INSIDE the seed prefix: more than 4096 prefix scores lie above the thread-maxima pivot, the
+    gather buffer of the seed select overflows and the kernel takes its own fall-back (round 6: a radix select of the rank-th largest
+    key over the row, where a second full-sort kernel used to be launched behind every seed select).  Speculative and guaranteed
+    first thresholds, the skinny-GEMM stream and the 256-query tile, with and without a filter that halves the cluster: the lowest
+    indices of the tie block come back, ids and fp64 scores equal to the oracle."""
+    rng = np.random.default_rng(61)
+    n, d = 40000, 128
+    x = to_f16_unit(rng.standard_normal((n, d)))
+    hot = to_f16_unit(rng.standard_normal((1, d)))[0]
+    x[1000:7000] = hot
+    q16 = to_f16_unit(np.repeat(hot[None, :].astype(np.float32), b, axis=0) + (np.arange(b)[:, None] % 2) * 0.02 * rng.standard_normal((b, d)))
+    dir_id = (np.arange(n) % 2).astype(np.int16)
+    engine.set_option("dense_shuffle", 0)            # the cluster stays where it was put: inside the first 16384 stored rows
+    engine.set_option("dense_n0", 16384)
+    try:
+        engine.set_dense(x)
+        engine.set_doc_meta(n, None, dir_id)
+        for spec in (1, 0):
+            engine.set_option("dense_speculate", spec)
+            for filt in (None, (np.arange(b) % 3 - 1).astype(np.int16)):
+                ids, sc, ln = engine.dense_topk(q16, k, filter_dir=filt)
+                for i in sorted(set([0, 1, b // 2, b - 1])):
+                    mask = None if filt is None or filt[i] < 0 else dir_id == filt[i]
+                    oid, osc = dense_exact_topk(x, q16[i], k, mask)
+                    assert ln[i] == len(oid), (spec, i)
+                    assert np.array_equal(ids[i, :ln[i]], oid), (spec, i)
+                    assert np.array_equal(sc[i, :ln[i]].view(np.uint64), osc.view(np.uint64)), (spec, i)
+    finally:
+        engine.set_option("dense_speculate", 1)
+        engine.set_option("dense_shuffle", 1)
+        engine.set_option("dense_n0", 32768)
+        engine.set_doc_meta(n, None, None)
+
+
 def test_dense_corpus_sorted_by_topic(engine):
     """A corpus ordered by topic: the queries' topic fills the LAST 60 % of the rows, so a threshold seeded from the
     first rows of the caller's order would admit tens of thousands of candidates per query (more than the candidate
